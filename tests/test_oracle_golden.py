@@ -1,0 +1,139 @@
+"""CPU: the oracle against the golden vectors captured from the reference's own code (tests/golden/*.npz)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import agent_oracle as ao
+from oracle.gp_oracle import F64, GPHyper, OracleGP
+from tests.helpers import GOLDEN, fs_params, load_params
+
+TIGHT = dict(rtol=1e-13, atol=1e-14)
+
+
+def g(name):
+    return np.load(os.path.join(GOLDEN, name))
+
+
+@pytest.mark.parametrize("tag,pname", [("pendulum1D", "params_pendulum1D_samples"), ("car_residual", "params_car_residual")])
+def test_env_maps(tag, pname):
+    d = g(f"env_{tag}.npz")
+    p = load_params(pname)
+    env = ao.make_oracle_env(p)
+    X, Y = env.initial_training_data()
+    np.testing.assert_allclose(X.numpy(), d["X_train"], **TIGHT)
+    np.testing.assert_allclose(Y.numpy(), d["Y_train"], equal_nan=True, **TIGHT)
+    xu, dg = torch.tensor(d["xu"]), torch.tensor(d["dg"])
+    np.testing.assert_allclose(env.get_prior_data(X).numpy(), d["prior_data"], **TIGHT)
+    np.testing.assert_allclose(env.unknown_dyn(X).numpy(), d["unknown_dyn"], **TIGHT)
+    np.testing.assert_allclose(env.known_dyn(xu).numpy(), d["known_dyn"], **TIGHT)
+    np.testing.assert_allclose(env.get_f_known_jacobian(xu).numpy(), d["f_jac"], **TIGHT)
+    np.testing.assert_allclose(env.get_g_xu_hat(xu).numpy(), d["g_xu_hat"], **TIGHT)
+    np.testing.assert_allclose(env.transform_sensitivity(dg, xu).numpy(), d["transform"], **TIGHT)
+    np.testing.assert_allclose(env.B_d.numpy(), d["B_d"])
+    assert list(d["pad_g"]) == env.pad_g and list(d["g_idx"]) == env.g_idx_inputs
+    np.testing.assert_allclose(env.discrete_dyn(torch.tensor(d["one_xu"])).numpy(), d["discrete_dyn"], **TIGHT)
+
+
+def test_tightenings():
+    d = g("tightenings.npz")
+    for tag, pname, H in [("P17", "params_pendulum1D_samples", 17), ("P30", "params_pendulum1D_samples", 30),
+                          ("C50", "params_car_residual", 50)]:
+        p = load_params(pname)
+        p["optimizer"]["H"] = H
+        te, ci = ao.get_reachable_set_ball(p, np.ones(H + 1))
+        np.testing.assert_allclose(np.stack(te), d[f"{tag}_tilde_eps"], **TIGHT)
+        np.testing.assert_allclose(np.array(ci), d[f"{tag}_ci"], **TIGHT)
+
+
+@pytest.mark.parametrize("tag,pname", [("pendulum1D", "params_pendulum1D_samples"), ("car_residual", "params_car_residual")])
+def test_agent_plumbing(tag, pname):
+    d = g(f"agent_plumbing_{tag}.npz")
+    p = load_params(pname)
+    p["agent"]["num_dyn_samples"] = int(d["Ns"])
+    p["agent"]["true_dyn_as_sample"] = False
+    p["optimizer"]["H"] = int(d["H"])
+    p["common"]["num_MPC_itrs"] = int(d["n_mpc"])
+    p["optimizer"]["SEMPC"]["max_sqp_iter"] = int(d["n_itr"])
+    env = ao.make_oracle_env(p)
+    torch.manual_seed(123456)
+    T = 1 + env.g_nx + env.g_nu
+    z = ao.random_vector_within_bounds(p, env.g_ny, T)
+    np.testing.assert_array_equal(z.numpy(), d["epistimic_random_vector"])      # same generator stream, bit-exact
+    agent = ao.OracleAgent(p, env, z)
+    np.testing.assert_array_equal(agent.Dyn_gp_X_train_batch.numpy(), d["X_train_batch"])
+    np.testing.assert_array_equal(agent.Dyn_gp_Y_train_batch.numpy(), d["Y_train_batch"])
+    np.testing.assert_array_equal(agent.get_batch_x_hat(d["x_h"], d["u_h"]).numpy(), d["batch_x_hat"])
+    bxd = agent.get_batch_x_hat_u_diff(d["x_h"], d["u_diff"])
+    np.testing.assert_array_equal(bxd.numpy(), d["batch_x_hat_u_diff"])
+    gp_val, y_grad, u_grad = agent.dyn_fg_jacobians(bxd, 0, injected_sample=torch.tensor(d["y_inj"]))
+    for a, b in [(gp_val, d["gp_val"]), (y_grad, d["y_grad"]), (u_grad, d["u_grad"])]:
+        assert a.dtype == np.float64 and a.shape == b.shape
+        np.testing.assert_allclose(a, b, **TIGHT)
+    g_xu = env.get_g_xu_hat(bxd)
+    agent.update_hallucinated_Dyn_dataset(g_xu, torch.tensor(d["y_inj"]))
+    np.testing.assert_array_equal(agent.Hallcinated_X_train.numpy(), d["hall_X_0"])
+    np.testing.assert_array_equal(agent.Hallcinated_Y_train.numpy(), d["hall_Y_0"])
+    p["agent"]["Dyn_gp_min_data_dist"] = float(d["min_dist_1"])
+    agent.update_hallucinated_Dyn_dataset(g_xu + 0.2, torch.tensor(d["y_inj"]) * 2)
+    np.testing.assert_array_equal(agent.Hallcinated_X_train.numpy(), d["hall_X_1"])
+    np.testing.assert_array_equal(agent.Hallcinated_Y_train.numpy(), d["hall_Y_1"])
+
+
+@pytest.mark.parametrize("tag,pname", [("R_pendulum1D", "params_pendulum1D_samples"),
+                                       ("R_pendulum1D_nofb", "params_pendulum1D_samples"),
+                                       ("I_car", "params_car_residual_fs"), ("R_car", "params_car_residual_fs")])
+def test_forward_sampling_rollouts(tag, pname):
+    """Whole rollout through the oracle's restated Agent == the reference Agent's code driven the same way."""
+    d = g(f"agent_e2e_{tag}.npz")
+    p = fs_params(pname, int(d["Ns"]), int(d["H_traj"]), nograd=bool(d["nograd"]), feedback=bool(d["feedback"]),
+                  beta=float(d["beta"]))
+    env = ao.make_oracle_env(p)
+    agent = ao.OracleAgent(p, env, torch.tensor(d["epistimic_random_vector"]))
+    X, Y = ao.forward_sampling_rollout(agent, d["u_ff"], return_samples=True)
+    np.testing.assert_allclose(X, d["X_traj"], rtol=1e-12, atol=1e-13)
+    np.testing.assert_allclose(Y, d["Y"], rtol=1e-11, atol=1e-13)
+    np.testing.assert_allclose(agent.Hallcinated_X_train.numpy(), d["hall_X"], rtol=1e-12, atol=1e-13)
+
+
+def test_joint_draw_sqp_iterations():
+    d = g("agent_e2e_J_pendulum1D.npz")
+    p = load_params("params_pendulum1D_samples")
+    Ns, H = int(d["Ns"]), int(d["H"])
+    p["agent"]["num_dyn_samples"], p["optimizer"]["H"] = Ns, H
+    p["common"]["num_MPC_itrs"], p["optimizer"]["SEMPC"]["max_sqp_iter"] = 2, 2
+    env = ao.make_oracle_env(p)
+    agent = ao.OracleAgent(p, env, torch.tensor(d["epistimic_random_vector"]))
+    K = np.array(p["optimizer"]["terminal_tightening"]["K"])
+    x_equi = np.array(p["env"]["goal_state"])
+    for it in range(2):
+        x_h = d[f"x_h_{it}"]
+        agent.train_hallucinated_dynGP(it)
+        bx = agent.get_batch_x_hat_u_diff(
+            x_h, -(x_equi - x_h.reshape(H, Ns, -1)) @ K.T + np.tile(d["u_h"][:, None, :], (Ns, 1)))
+        gp_val, y_grad, u_grad = agent.dyn_fg_jacobians(bx, it)
+        np.testing.assert_allclose(agent.model_i_call.mean.numpy(), d[f"mean_{it}"], rtol=1e-11, atol=1e-13)
+        np.testing.assert_allclose(agent.model_i_call.variance.numpy(), d[f"var_{it}"], rtol=1e-9, atol=1e-16)
+        np.testing.assert_array_equal(agent.model_i_call.root_info.jitter_added.numpy(), d[f"jitter_{it}"])
+        np.testing.assert_allclose(gp_val, d[f"gp_val_{it}"], rtol=1e-10, atol=1e-12)
+        np.testing.assert_allclose(y_grad, d[f"y_grad_{it}"], rtol=1e-10, atol=1e-12)
+        np.testing.assert_allclose(u_grad, d[f"u_grad_{it}"], rtol=1e-10, atol=1e-12)
+
+
+def test_value_only_algebra_against_reference_numpy_sampler():
+    """reference extra/conditioning_gp.py (executed as is by make_goldens.py): kernel, Cholesky conditioning and
+    jittered-Cholesky sampling of a value-only RBF GP.  The only in-reference pin of the GP algebra."""
+    d = g("conditioning_gp.npz")
+    ell = torch.tensor([[float(np.sqrt(d["kernel_parameter"]))]], dtype=F64)
+    hyper = GPHyper(ell=ell, outputscale=torch.ones(1, dtype=F64), noise_diag=torch.zeros(1, dtype=F64),
+                    jitter=0.0, use_grad=False)
+    X = torch.tensor(d["X"]).reshape(1, 1, -1, 1)
+    y = torch.tensor(d["y"]).reshape(1, 1, -1, 1)
+    gp = OracleGP(X, y, hyper)
+    for xt, fp in [(d["Xtest"], d["f_post"]), (d["Xtest2"], d["f_post2"])]:
+        post = gp(torch.tensor(xt).reshape(1, 1, -1, 1))
+        S = post.covariance_matrix[0, 0] + float(d["post_jitter"]) * torch.eye(xt.shape[0], dtype=F64)
+        L = torch.linalg.cholesky(S)
+        f = post.mean[0, 0] + L @ torch.tensor(d["random_weights"])
+        np.testing.assert_allclose(f.numpy(), fp, rtol=1e-7, atol=1e-8)
