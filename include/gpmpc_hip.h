@@ -1,0 +1,206 @@
+/*
+ * gpmpc_hip.h - C-ABI of libgpmpc_hip.so: the MI355X (gfx950) implementation of the sampling-gpmpc
+ * GP-posterior-sample rollout hot path.
+ *
+ * The reference (manish-pra/sampling-gpmpc) has no native/FFI layer: its boundary for this path is the Python
+ * object `Agent` (+ `Agent.model_i`), whose arithmetic is delegated to gpytorch.  Each entry point below replaces
+ * the stack of gpytorch/torch calls behind one reference interface; the Python facade
+ * (sampling_gpmpc_amd/agent.py, same method names and shapes as reference src/agent.py) binds them via ctypes.
+ *
+ * Conventions
+ *   - plain C, no torch types; every pointer marked [dev] is a device (HBM) pointer owned by the caller,
+ *     [host] is ordinary host memory; all floating point is IEEE binary64 (the reference runs
+ *     torch.set_default_dtype(float64), src/agent.py:15).
+ *   - no hidden allocation: callers query *_workspace_bytes() and pass the workspace.
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream); calls are asynchronous on it.
+ *   - return value: 0 = launched OK, negative = GPMPC_E_* (see gpmpc_last_error_string()).
+ *   - per-batch-element numerical status comes back in [dev] int32 `info` arrays (bit field GPMPC_INFO_*), so the
+ *     facade can reproduce gpytorch's NumericalWarning / NotPSDError behaviour.
+ *   - tensor layouts are the reference's (row-major / C-contiguous) unless a stride argument says otherwise.
+ */
+#ifndef GPMPC_HIP_H
+#define GPMPC_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GPMPC_ABI_VERSION 1
+
+#define GPMPC_MAX_NY 4   /* GP outputs            (reference agent.g_dim.ny : 1 pendulum1D, 3 car)          */
+#define GPMPC_MAX_D  4   /* GP input dimension    (g_nx + g_nu : 2 in all shipped configs)                 */
+#define GPMPC_MAX_T  5   /* label slots per point (1 value-only, 1 + D value + gradient)                   */
+#define GPMPC_MAX_NX 8   /* full state dimension  (2 pendulum1D, 4 car)                                    */
+#define GPMPC_MAX_NU 4   /* input dimension       (1 pendulum1D, 2 car)                                    */
+
+/* error codes */
+#define GPMPC_OK            0
+#define GPMPC_E_ARG        -1   /* inconsistent / unsupported argument                                     */
+#define GPMPC_E_WORKSPACE  -2   /* workspace too small                                                     */
+#define GPMPC_E_HIP        -3   /* a HIP runtime call failed (string has the hipError)                     */
+#define GPMPC_E_UNSUPPORTED -4  /* size outside what the kernels were instantiated for                     */
+
+/* info bits (per batch element) */
+#define GPMPC_INFO_TRAIN_CHOL_FAIL   0x0001 /* non-positive pivot while factorising K_oo + Sigma (A.5)      */
+#define GPMPC_INFO_ROOT_JITTER_MASK  0x000e /* (info >> 1) & 7 = highest retry level reached, 0 = none      */
+#define GPMPC_INFO_ROOT_FAIL         0x0010 /* all 3 jitter retries failed -> caller must take eigh path   */
+#define GPMPC_INFO_VAR_CLAMPED       0x0020 /* a posterior variance was raised to the 1e-10 floor (A.8)     */
+#define GPMPC_INFO_NEG_1x1           0x0040 /* 1x1 covariance negative -> sqrt gives NaN (as gpytorch)      */
+
+/* environment ids: the per-step maps of reference src/environments/{pendulum1D,car_model_residual}.py        */
+#define GPMPC_ENV_PENDULUM1D   0
+#define GPMPC_ENV_CAR_RESIDUAL 1
+
+/* rollout modes */
+#define GPMPC_MODE_INDEPENDENT   0   /* "I": every step conditions on the real data only                    */
+#define GPMPC_MODE_RECONDITIONED 1   /* "R": every step conditions on real + the sample's own previous draws */
+
+/*
+ * The GP definition: replaces reference src/GP_model.py:94-143 (BatchMultitaskGPModelWithDerivatives_fromParams:
+ * zero mean, ScaleKernel(RBFKernel[Grad]) with per-output ARD lengthscales / outputscale, and the
+ * MultitaskGaussianLikelihood(rank=0) noise of src/agent.py:235-240).
+ */
+typedef struct gpmpc_gp_desc {
+    int32_t g_ny;                 /* number of independent GP outputs                                      */
+    int32_t D;                    /* GP input dimension                                                    */
+    int32_t T;                    /* tasks: 1 (use_grad=False) or 1 + D (value + gradient)                  */
+    int32_t N_r;                  /* number of real training points (shared by all samples)                */
+    int32_t real_has_grad;        /* 0: real labels observe task 0 only (NaN elsewhere); 1: all T tasks    */
+    int32_t _pad;
+    double  ell[GPMPC_MAX_NY][GPMPC_MAX_D];   /* Dyn_gp_lengthscale.both[o][d]                              */
+    double  outputscale[GPMPC_MAX_NY];        /* Dyn_gp_outputscale.both[o]                                 */
+    double  noise[GPMPC_MAX_T];               /* task_noises.val[t] * multiplier + Dyn_gp_noise             */
+    double  jitter;                           /* Dyn_gp_jitter (gpytorch.settings.cholesky_jitter)          */
+    double  var_floor;                        /* gpytorch.settings.min_variance (1e-10 for FP64)            */
+} gpmpc_gp_desc_t;
+
+/*
+ * The per-step environment maps + feedback law of the forward-sampling loop: replaces, fused into the rollout
+ * kernel, reference src/environments/pendulum1D.py:165-188 / car_model_residual.py:132-161,211-224 as composed by
+ * src/agent.py:532-557 (dyn_fg_jacobians, value column) and benchmarking/simulate_forward_sampling_car.py:121-136.
+ */
+typedef struct gpmpc_env_desc {
+    int32_t env_id;               /* GPMPC_ENV_*                                                           */
+    int32_t nx, nu;
+    int32_t use_feedback;         /* u = u_ff + K (x - x_goal)   (agent.feedback.use)                       */
+    double  dt;
+    double  p0, p1;               /* pendulum1D: l, g ; car: lf, lr (only used by the true plant, not here) */
+    double  K[GPMPC_MAX_NU][GPMPC_MAX_NX];    /* optimizer.terminal_tightening.K                            */
+    double  x_goal[GPMPC_MAX_NX];             /* env.goal_state                                             */
+} gpmpc_env_desc_t;
+
+/* ------------------------------------------------------------------------------------------------------------ */
+int         gpmpc_abi_version(void);
+const char* gpmpc_last_error_string(void);
+/* fills name (<= cap bytes), CU count, LDS bytes per workgroup of device `dev`; used by bench.py for the roofline */
+int         gpmpc_device_info(int dev, char* name /*[host]*/, int cap, int* cu_count, int* lds_bytes);
+/* runs a one-wave kernel checking the cross-lane primitives (DPP reduction, readlane broadcast, small Cholesky)
+ * against in-kernel references; synchronises `stream`.  0 = OK. */
+int         gpmpc_selftest(void* stream);
+
+/*
+ * gpmpc_plan_build - factorise the shared real-data block once.
+ * Replaces: the train-side half of gpytorch's ExactGP prediction strategy that the reference re-does from scratch
+ * on every call (src/agent.py:241-250 builds the model, src/agent.py:640 triggers K_oo + Sigma -> Cholesky -> alpha;
+ * SURVEY.md App. A.3-A.5), restricted to the real data, which are identical for every sample
+ * (src/agent.py:204-214 tiles them Ns times).
+ *   X_r   [dev] (N_r, D)            Dyn_gp_X_train
+ *   Y_r   [dev] (g_ny, N_r, T)      Dyn_gp_Y_train (NaN in unobserved slots)
+ *   plan  [dev] gpmpc_plan_bytes()  out: per output L_rr, L_rr^-1 (transposed), w_r = L^-1 y, alpha_r
+ *   info  [dev] (g_ny) int32        out: GPMPC_INFO_TRAIN_CHOL_FAIL
+ */
+size_t gpmpc_plan_bytes(const gpmpc_gp_desc_t* gp);
+int    gpmpc_plan_build(const gpmpc_gp_desc_t* gp, const double* X_r, const double* Y_r,
+                        void* plan, int32_t* info, void* stream);
+
+/*
+ * gpmpc_rollout - H-step forward rollout of Ns sampled dynamics functions, whole horizon in one launch.
+ * Replaces: the loop of reference benchmarking/simulate_forward_sampling_car.py:117-138 (and the equivalent loops
+ * simulate_true_reachable_set.py:179-258, src/agent.py:362-415), i.e. per step: train_hallucinated_dynGP
+ * (src/agent.py:216-272) -> get_batch_x_hat_u_diff (480-501) -> dyn_fg_jacobians value column (532-557) ->
+ * sample_gp (629-708: model_i(x), .sample(base_samples), optional variance-is-zero replacement, beta clip) ->
+ * update_hallucinated_Dyn_dataset (164-198, min-dist filter off) -> state hand-over.
+ *   mode          GPMPC_MODE_*                  (I: use_model_without_derivatives=True as shipped; R otherwise)
+ *   hall_tasks    label slots observed at appended points: T (sample_gp path) or 1 (value-only, src/agent.py:402)
+ *   var_zero_thr  Dyn_gp_variance_is_zero (< 0 disables, src/agent.py:646)
+ *   beta          Dyn_gp_beta (clip to mean +- beta sqrt(var), src/agent.py:701-708)
+ *   x0      [dev] (Ns, nx) if x0_per_sample else (nx)
+ *   u_ff    [dev] (H, nu)                       open-loop input sequence (input_traj[-1] of the reference's data.pkl)
+ *   z       [dev] base samples; element (t, s, o, b) at z[t*z_step_stride + ((s*g_ny)+o)*T + b]
+ *                 (the reference's epistimic_random_vector[t][1] slab: pass &erv[0][1] and
+ *                  z_step_stride = n_itrs*Ns*g_ny*T)
+ *   X_traj  [dev] (Ns, nx, H+1)                 out: the reachable tube (reference X_traj, :115,133,138)
+ *   Y       [dev] (Ns, g_ny, H, T) or NULL      out: the clipped samples (what the reference appends as labels)
+ *   Xi      [dev] (Ns, H, D) or NULL            out: GP inputs per step (the reference's Hallcinated_X_train rows)
+ *   info    [dev] (Ns) int32                    out: OR of GPMPC_INFO_* over steps and outputs
+ *   ws      [dev] gpmpc_rollout_workspace_bytes(...) scratch (per-sample factor storage when it exceeds LDS)
+ */
+size_t gpmpc_rollout_workspace_bytes(const gpmpc_gp_desc_t* gp, int32_t mode, int32_t hall_tasks,
+                                     int64_t Ns, int32_t H);
+int    gpmpc_rollout(const gpmpc_gp_desc_t* gp, const gpmpc_env_desc_t* env, const void* plan,
+                     const double* X_r, int32_t mode, int32_t hall_tasks, double var_zero_thr, double beta,
+                     int64_t Ns, int32_t H,
+                     const double* x0, int32_t x0_per_sample, const double* u_ff,
+                     const double* z, int64_t z_step_stride,
+                     double* X_traj, double* Y, double* Xi, int32_t* info,
+                     void* ws, size_t ws_bytes, void* stream);
+
+/*
+ * gpmpc_joint_sample - joint posterior draw at m test points per (sample, output), conditioning on the shared
+ * real data plus per-sample hallucinated data.
+ * Replaces: reference src/agent.py:629-708 (sample_gp): model_i(x_input) [gpytorch ExactGP eval call, SURVEY App.
+ * A.4-A.6], .sample(base_samples) [A.7 root with jitter-on-failure], .variance [A.8], the optional
+ * variance-is-zero replacement and the beta clip.  The min-data-distance overwrite (src/agent.py:666-698) stays in
+ * the facade (disabled in every shipped config).
+ *   X_h     [dev] (Ns, g_ny, n_h, D)   Hallcinated_X_train (NULL if n_h == 0)
+ *   Y_h     [dev] (Ns, g_ny, n_h, T)   Hallcinated_Y_train
+ *   h_slots [dev] (n_ho) int32         observed hallucinated label slots, ascending, slot = point*T + task
+ *                                      (gpytorch "mask" policy collapsed over the batch, A.4)
+ *   X_s     [dev] (Ns, g_ny, m, D)     test inputs (g_xu_hat)
+ *   z       [dev] (Ns, g_ny, m, T)     base samples
+ *   mean, var, y [dev] (Ns, g_ny, m, T) out (var floored; y post-processed as above)
+ *   covar   [dev] (Ns, g_ny, m*T, m*T) or NULL   out: posterior covariance (for the eigh fallback / debugging)
+ *   info    [dev] (Ns, g_ny) int32
+ */
+size_t gpmpc_joint_workspace_bytes(const gpmpc_gp_desc_t* gp, int64_t Ns, int32_t n_ho, int32_t m);
+int    gpmpc_joint_sample(const gpmpc_gp_desc_t* gp, const void* plan, const double* X_r,
+                          int64_t Ns, int32_t n_h, const double* X_h, const double* Y_h,
+                          const int32_t* h_slots, int32_t n_ho,
+                          int32_t m, const double* X_s, const double* z,
+                          double var_zero_thr, double beta, int32_t apply_clip,
+                          double* mean, double* var, double* y, double* covar, int32_t* info,
+                          void* ws, size_t ws_bytes, void* stream);
+
+/*
+ * gpmpc_assemble_jacobians - full-state value and Jacobians from the GP sample.
+ * Replaces: reference src/agent.py:532-557 (dyn_fg_jacobians: env.get_f_known_jacobian, env.transform_sensitivity,
+ * scatter into pad_g columns, B_d matmul, split) for the two environments.
+ *   xu      [dev] (Ns, nx, H, nx+nu)   batch_x_hat (row 0 of dim 1 is read; rows are replicas)
+ *   y       [dev] (Ns, g_ny, H, T)     GP sample
+ *   gp_val  [dev] (Ns, nx, H, 1), y_grad [dev] (Ns, nx, H, nx), u_grad [dev] (Ns, nx, H, nu)   out
+ */
+int    gpmpc_assemble_jacobians(const gpmpc_gp_desc_t* gp, const gpmpc_env_desc_t* env,
+                                int64_t Ns, int32_t H, const double* xu, const double* y,
+                                double* gp_val, double* y_grad, double* u_grad, void* stream);
+
+/*
+ * gpmpc_pack_plin - stage parameter vectors for the acados OCP.
+ * Replaces: the O(Ns^2) np.concatenate loop of reference src/solver.py:98-131.  Per stage:
+ * for each sample [A_i row-major (nx*nx), B_i row-major (nx*nu), x_hat_i (nx), f_i (nx)], then
+ * [u_hat (nu), xg (1), w (1), tilde_eps (nx+nu+1)].
+ *   y_grad, u_grad, gp_val as above; x_h [dev] (H, Ns*nx); u_h [dev] (H, nu); xg [dev] (H); w [dev] (H);
+ *   tilde_eps [dev] (H, nx+nu+1);  p_lin [dev] (H, Ns*(nx*nx+nx*nu+2*nx) + 2*nu... see gpmpc_plin_len)
+ */
+int64_t gpmpc_plin_len(int32_t nx, int32_t nu, int64_t Ns);
+int     gpmpc_pack_plin(int32_t nx, int32_t nu, int64_t Ns, int32_t H,
+                        const double* y_grad, const double* u_grad, const double* gp_val,
+                        const double* x_h, const double* u_h, const double* xg, const double* w,
+                        const double* tilde_eps, double* p_lin, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GPMPC_HIP_H */

@@ -1,0 +1,371 @@
+"""``Agent``: the reference's hot-path API (reference ``src/agent.py``), backed by libgpmpc_hip.so.
+
+Same constructor, attribute names, method names, argument meaning, shapes, dtypes and return TYPES as the reference
+class, so that reference ``src/DEMPC.py`` / ``src/solver.py`` / the benchmarking scripts can consume it unchanged
+(SURVEY.md section 8b lists every use).  What differs is underneath:
+
+* the GP is never rebuilt: ``train_hallucinated_dynGP`` only re-points ``model_i`` at (shared real-data plan,
+  current hallucinated tensors); the real data are factorised once (``gpmpc_plan_build``) and never tiled;
+* ``sample_gp`` is ONE kernel launch (``gpmpc_joint_sample``: posterior, root with gpytorch's jitter chain, sample,
+  variance-is-zero replacement, beta clip);
+* ``dyn_fg_jacobians`` assembles value and Jacobians on the device (``gpmpc_assemble_jacobians``) and returns the
+  three float64 numpy arrays the solver indexes;
+* whole forward-sampling rollouts run in one launch through ``sampling_gpmpc_amd.rollout``.
+
+Host-only logic (base-sample generation, tensor reshapes, tightenings, dataset bookkeeping) works without a GPU;
+every method that needs GP arithmetic raises ``GpmpcError`` when no HIP device / library is present.
+"""
+from __future__ import annotations
+
+import warnings
+from typing import Optional
+
+import numpy as np
+import torch
+
+from . import _lib
+from .gp_model import GPHyperParams, HipGPModel, RealDataPlan
+from .reachable_set import get_reachable_set_ball
+
+F64 = torch.float64
+
+
+def random_vector_within_bounds(params, g_ny: int, T: int, device="cpu", mode: Optional[str] = None) -> torch.Tensor:
+    """Base samples ``(n_mpc, n_itrs, Ns, g_ny, H, T)``: i.i.d. N(0,1) vectors of shape (g_ny, H, T), the WHOLE vector
+    redrawn until every entry lies in [-beta, beta] (reference ``src/agent.py:76-104``).
+
+    mode "reference": one ``torch.normal`` call per candidate on the global CPU generator, call for call what the
+    reference does, so a seeded run reproduces its stream exactly (the reference draws on its compute device; CUDA
+    generator streams are not reproducible on ROCm, so the draw is pinned to the CPU generator here).
+    mode "vectorized": same distribution, candidates drawn in blocks (for Ns in the 1e5 range).
+    """
+    H = params["optimizer"]["H"]
+    n_dyn = params["agent"]["num_dyn_samples"]
+    beta = params["agent"]["Dyn_gp_beta"]
+    n_mpc = params["common"]["num_MPC_itrs"]
+    n_itrs = params["optimizer"]["SEMPC"]["max_sqp_iter"]
+    total = n_mpc * n_itrs * n_dyn
+    if mode is None:
+        mode = params["agent"].get("base_sample_generator", "reference" if total <= 200_000 else "vectorized")
+    out = torch.empty(n_mpc, n_itrs, n_dyn, g_ny, H, T, dtype=F64)
+    if mode == "reference":
+        for j in range(n_mpc):
+            for i in range(n_itrs):
+                k = 0
+                while k < n_dyn:
+                    w = torch.normal(0, 1, size=(1, g_ny, H, T), dtype=F64)
+                    if torch.all(w >= -beta) and torch.all(w <= beta):
+                        out[j, i, k] = w[0]
+                        k += 1
+    elif mode == "vectorized":
+        flat = out.view(total, g_ny * H * T)
+        filled = 0
+        while filled < total:
+            cand = torch.randn(max(1024, int(1.5 * (total - filled))), g_ny * H * T, dtype=F64)
+            cand = cand[(cand.abs() <= beta).all(dim=1)]
+            n = min(cand.shape[0], total - filled)
+            flat[filled:filled + n] = cand[:n]
+            filled += n
+    else:
+        raise ValueError(f"unknown base_sample_generator {mode!r}")
+    return out.to(device)
+
+
+class Agent(object):
+    def __init__(self, params, env_model) -> None:
+        self.my_key = 0
+        self.params = params
+        self.env_model = env_model
+        ag = params["agent"]
+        self.g_nx, self.g_nu, self.g_ny = ag["g_dim"]["nx"], ag["g_dim"]["nu"], ag["g_dim"]["ny"]
+        self.ns = ag["num_dyn_samples"]
+        self.nx, self.nu = ag["dim"]["nx"], ag["dim"]["nu"]
+        self.in_dim_x = self.g_nx + self.g_nu
+        self.in_dim_y = 1 if params["env"]["use_model_without_derivatives"] else 1 + self.in_dim_x
+        self.batch_shape = torch.Size([self.ns, self.g_ny])
+        self.mean_shift_val = ag.get("mean_shift_val")
+        self.converged = False
+
+        if params["common"]["use_cuda"] and torch.cuda.is_available():
+            self.use_cuda, self.torch_device = True, torch.device("cuda")
+        else:
+            self.use_cuda, self.torch_device = False, torch.device("cpu")
+        # unlike the reference no global torch.set_default_device side effect is installed
+
+        self.model_i = None
+        self.model_i_call = None
+        self.model_i_samples = None
+        self.likelihood = None
+        self.mpc_iter = 0
+        self._plans = {}          # T -> RealDataPlan (real block factorised once per label layout)
+        self._ws_cache = {}
+        self._reset_hallucinated()
+
+        X, Y = env_model.initial_training_data()
+        self.Dyn_gp_X_train = X.to(self.torch_device)
+        self.Dyn_gp_Y_train = Y.to(self.torch_device)
+        if self.in_dim_y == 1:
+            self.Dyn_gp_Y_train = self.Dyn_gp_Y_train[:, :, [0]]
+        self.real_data_batch()
+        self.planned_measure_loc = np.array([2])
+        self.epistimic_random_vector = self.random_vector_within_bounds()
+        if "terminal_tightening" in params["optimizer"]:
+            self.tilde_eps_list, self.ci_list = get_reachable_set_ball(params, np.ones(params["optimizer"]["H"] + 1))
+
+    # ---------------------------------------------------------------------------------------------------------
+    # host-side bookkeeping
+    # ---------------------------------------------------------------------------------------------------------
+    def _reset_hallucinated(self):
+        self.Hallcinated_X_train = torch.empty(self.ns, self.g_ny, 0, self.in_dim_x, dtype=F64, device=self.torch_device)
+        self.Hallcinated_Y_train = torch.empty(self.ns, self.g_ny, 0, self.in_dim_y, dtype=F64, device=self.torch_device)
+
+    def random_vector_within_bounds(self):
+        return random_vector_within_bounds(self.params, self.g_ny, self.in_dim_y, device=self.torch_device)
+
+    def real_data_batch(self):
+        """reference ``src/agent.py:204-214`` tiles the real data Ns times; here the batch tensors are stride-0
+        expanded VIEWS of the shared data (same shapes and values, no memory)."""
+        self.Dyn_gp_X_train_batch = self.Dyn_gp_X_train.reshape(1, 1, *self.Dyn_gp_X_train.shape).expand(
+            self.ns, self.g_ny, -1, -1)
+        self.Dyn_gp_Y_train_batch = self.Dyn_gp_Y_train.unsqueeze(0).expand(self.ns, -1, -1, -1)
+
+    def update_current_location(self, loc):
+        self.current_location = loc
+
+    def update_current_state(self, state):
+        self.current_state = state
+        self.update_current_location(state[: self.nx])
+
+    def mpc_iteration(self, i):
+        self.mpc_iter = i
+
+    def get_next_to_go_loc(self):
+        return self.planned_measure_loc
+
+    def concatenate_real_hallucinated_data(self):
+        return (torch.concat([self.Dyn_gp_X_train_batch, self.Hallcinated_X_train], dim=2),
+                torch.concat([self.Dyn_gp_Y_train_batch, self.Hallcinated_Y_train], dim=2))
+
+    def update_hallucinated_Dyn_dataset(self, newX, newY):
+        """Append sampled points; optional min-distance filter (reference ``src/agent.py:164-202``)."""
+        min_distance = self.params["agent"]["Dyn_gp_min_data_dist"]
+        newX = newX.to(self.torch_device)
+        newY = newY.to(self.torch_device)
+        if min_distance >= 0.0:
+            X_cond, _ = self.concatenate_real_hallucinated_data()
+            dist_norm = torch.linalg.vector_norm(newX[:, :, None, :, :] - X_cond[:, :, :, None, :], dim=-1)
+            filt = torch.any(dist_norm <= min_distance, dim=2)                     # (Ns, g_ny, m)
+            newY = torch.where(filt.unsqueeze(-1), torch.full_like(newY, float("nan")), newY)
+            keep = ~torch.any(torch.all(filt, dim=0), dim=0)                       # filtered in ALL samples -> drop
+            newX, newY = newX[:, :, keep, :], newY[:, :, keep, :]
+        self.Hallcinated_X_train = torch.cat([self.Hallcinated_X_train, newX], 2)
+        self.Hallcinated_Y_train = torch.cat([self.Hallcinated_Y_train, newY], 2)
+
+    def get_batch_x_hat_u_diff(self, x_h, u_h):
+        """x_h (H, Ns*nx), u_h (H, Ns, nu) -> (Ns, nx, H, nx+nu), state row replicated nx times (:480-501)."""
+        H = self.params["optimizer"]["H"]
+        x_h = torch.as_tensor(x_h, dtype=F64)
+        u_h = torch.as_tensor(u_h, dtype=F64)
+        xb = x_h.transpose(0, 1).reshape(self.ns, self.nx, H).transpose(1, 2)
+        ub = u_h.transpose(0, 1).reshape(self.ns, H, self.nu)
+        ret = torch.cat([xb, ub], 2)
+        return torch.stack([ret] * self.nx, dim=1).to(self.torch_device)
+
+    def get_batch_x_hat(self, x_h, u_h):
+        """x_h (H, Ns*nx), u_h (H, nu) shared by all samples -> (Ns, nx, H, nx+nu)   (:503-527)."""
+        H = self.params["optimizer"]["H"]
+        x_h = torch.as_tensor(x_h, dtype=F64)
+        u_h = torch.as_tensor(u_h, dtype=F64)
+        xb = x_h.transpose(0, 1).reshape(self.ns, self.nx, H).transpose(1, 2)
+        ub = torch.ones(self.ns, H, 1, dtype=F64) * u_h
+        ret = torch.cat([xb, ub], 2)
+        return torch.stack([ret] * self.nx, dim=1).to(self.torch_device)
+
+    # ---------------------------------------------------------------------------------------------------------
+    # GP (device)
+    # ---------------------------------------------------------------------------------------------------------
+    def _plan(self, use_grad: bool) -> RealDataPlan:
+        T = 1 + self.in_dim_x if use_grad else 1
+        plan = self._plans.get(T)
+        if plan is None:
+            _lib.require_hip_device(self.torch_device)
+            hyper = GPHyperParams.from_params(self.params, use_grad)
+            Y = self.Dyn_gp_Y_train if use_grad else self.Dyn_gp_Y_train[:, :, [0]]
+            if use_grad and Y.shape[-1] != T:
+                raise RuntimeError("value+gradient model requested but the agent was built value-only "
+                                   "(env.use_model_without_derivatives)")
+            plan = RealDataPlan(self.Dyn_gp_X_train, Y, hyper)
+            self._plans[T] = plan
+        return plan
+
+    def env_desc(self, use_feedback: Optional[bool] = None):
+        p = self.params
+        fb = p["agent"]["feedback"]["use"] if use_feedback is None else use_feedback
+        tt = p["optimizer"].get("terminal_tightening", {})
+        K = tt.get("K") if fb else None
+        p0, p1 = self.env_model.env_params
+        return _lib.make_env_desc(self.env_model.env_id, self.nx, self.nu, fb, p["optimizer"]["dt"], p0, p1, K,
+                                  p["env"]["goal_state"])
+
+    def train_hallucinated_dynGP(self, sqp_iter, use_model_without_derivatives=False):
+        """(Re)define ``model_i`` on real + hallucinated data (reference ``src/agent.py:216-272``), including the
+        order quirk: the model sees the PRE-reset hallucinated set; the set is emptied afterwards when sqp_iter==0."""
+        plan = self._plan(use_grad=not use_model_without_derivatives)
+        if use_model_without_derivatives:      # real data only (reference :221-226)
+            hx = torch.empty(self.ns, self.g_ny, 0, self.in_dim_x, dtype=F64, device=self.torch_device)
+            hy = torch.empty(self.ns, self.g_ny, 0, 1, dtype=F64, device=self.torch_device)
+        else:
+            hx, hy = self.Hallcinated_X_train, self.Hallcinated_Y_train
+        self.model_i = HipGPModel(plan, hx, hy, self.batch_shape, self._ws_cache)
+        self.likelihood = plan.hyper
+        if sqp_iter == 0:
+            self._reset_hallucinated()
+
+    def train_forward_sampling_dynGP(self):
+        """real + forward-sampling + hallucinated data (reference ``src/agent.py:283-329``)."""
+        plan = self._plan(use_grad=True)
+        hx = torch.concat([self.FS_X_train_batch, self.Hallcinated_X_train], dim=2)
+        hy = torch.concat([self.FS_Y_train_batch, self.Hallcinated_Y_train], dim=2)
+        self.model_i = HipGPModel(plan, hx, hy, self.batch_shape, self._ws_cache)
+        self.likelihood = plan.hyper
+
+    def sample_gp(self, x_input, base_samples=None):
+        """Joint posterior draw + post-processing (reference ``src/agent.py:629-730``) in one kernel launch."""
+        ag = self.params["agent"]
+        self.model_i_call = self.model_i(x_input)
+        y = self.model_i_call._sample(base_samples, clip=(ag["Dyn_gp_min_data_dist"] < 0.0),
+                                      beta=ag["Dyn_gp_beta"], var_zero_thr=ag["Dyn_gp_variance_is_zero"])
+        if ag["Dyn_gp_min_data_dist"] >= 0.0:
+            # overwrite by the closest observed training label when a test input is too close to it (:666-698),
+            # then clip (:701-708).  Off in every shipped config; plain device tensor ops.
+            y_train, x_train = self.model_i.train_targets, self.model_i.train_inputs[0]
+            m = x_input.shape[2]
+            dn = torch.linalg.vector_norm(x_input[:, :, None, :, :] - x_train[:, :, :, None, :], dim=-1)
+            isnan = torch.any(torch.isnan(y_train), dim=3).unsqueeze(-1).expand(-1, -1, -1, m)
+            dn = torch.where(isnan, torch.full_like(dn, float("inf")), dn)
+            too_small = torch.any(dn <= ag["Dyn_gp_min_data_dist"], dim=2).unsqueeze(-1)
+            idx = torch.argmin(dn, dim=2)                                          # (Ns, g_ny, m)
+            closest = torch.gather(y_train, 2, idx.unsqueeze(-1).expand(-1, -1, -1, y_train.shape[-1]))
+            y = torch.where(too_small, closest, y)
+            assert not torch.any(torch.isnan(y))
+            mean, sd = self.model_i_call.mean, ag["Dyn_gp_beta"] * torch.sqrt(self.model_i_call.variance)
+            y = torch.min(torch.max(y, mean - sd), mean + sd)
+        self.model_i_samples = y
+        return y
+
+    def get_batch_gp_sensitivities(self, xu_hat, sqp_iter):
+        """GP value+gradient sample at the linearisation points (reference ``src/agent.py:566-627``)."""
+        ag = self.params["agent"]
+        H = self.params["optimizer"]["H"]
+        g_xu_hat = self.env_model.get_g_xu_hat(xu_hat).contiguous()
+        update = True
+        if (ag["true_dyn_as_sample"] or ag["mean_as_dyn_sample"]) and self.ns == 1:
+            y = torch.zeros((1, self.g_ny, H, self.in_dim_y), dtype=F64, device=self.torch_device)
+            update = False
+        elif (ag["true_dyn_as_sample"] and ag["mean_as_dyn_sample"]) and self.ns == 2:
+            y = torch.zeros((2, self.g_ny, H, self.in_dim_y), dtype=F64, device=self.torch_device)
+            update = False
+        else:
+            y = self.sample_gp(g_xu_hat, base_samples=self.epistimic_random_vector[self.mpc_iter][sqp_iter])
+        if not update:
+            self.model_i_call = self.model_i(g_xu_hat)
+        idx = 0
+        if ag["true_dyn_as_sample"]:
+            t = self.env_model.get_prior_data(g_xu_hat[idx, 0, :, :])
+            if self.in_dim_y == 1:
+                t = t[:, :, [0]]
+            y[idx, :, :, :] = t
+            idx += 1
+        if ag["mean_as_dyn_sample"]:
+            y[[idx], :, :, :] = self.model_i_call.mean[[idx], :, :, :]
+            idx += 1
+        if update:
+            self.update_hallucinated_Dyn_dataset(g_xu_hat, y)
+        return y
+
+    def dyn_fg_jacobians(self, xu_hat, sqp_iter):
+        """Full-state value and Jacobians ``f + B_d g`` at the linearisation points (reference ``src/agent.py:532-564``).
+        Returns numpy float64 ``gp_val (Ns,nx,H,1)``, ``y_grad (Ns,nx,H,nx)``, ``u_grad (Ns,nx,H,nu)``."""
+        lib = _lib.load()
+        xu_hat = xu_hat.to(device=self.torch_device, dtype=F64).contiguous()
+        ns, nH = xu_hat.shape[0], xu_hat.shape[2]
+        y = self.get_batch_gp_sensitivities(xu_hat, sqp_iter).contiguous()
+        dev = _lib.require_hip_device(self.torch_device)
+        gp_val = torch.empty(ns, self.nx, nH, 1, dtype=F64, device=dev)
+        y_grad = torch.empty(ns, self.nx, nH, self.nx, dtype=F64, device=dev)
+        u_grad = torch.empty(ns, self.nx, nH, self.nu, dtype=F64, device=dev)
+        plan = self.model_i.plan
+        _lib.check(lib.gpmpc_assemble_jacobians(plan.desc, self.env_desc(), ns, nH, _lib.dptr(xu_hat), _lib.dptr(y),
+                                                _lib.dptr(gp_val), _lib.dptr(y_grad), _lib.dptr(u_grad),
+                                                _lib.current_stream_ptr()), "gpmpc_assemble_jacobians")
+        self._last_device_jacobians = (gp_val, y_grad, u_grad)
+        out = (gp_val.cpu().numpy(), y_grad.cpu().numpy(), u_grad.cpu().numpy())
+        if not (np.isfinite(out[0]).all() and np.isfinite(out[1]).all() and np.isfinite(out[2]).all()):
+            print("Nan/inf in y_sample")
+        return out
+
+    def pack_p_lin(self, x_h, u_h, xg, w, K=None):
+        """Stage parameter vectors for the acados OCP in the layout of reference ``src/solver.py:98-131``, packed on
+        the device from the Jacobians of the last ``dyn_fg_jacobians`` call.  Returns numpy (H, len)."""
+        lib = _lib.load()
+        gp_val, y_grad, u_grad = self._last_device_jacobians
+        dev = gp_val.device
+        H = gp_val.shape[2]
+        if K is not None:                      # feedback: y_grad + u_grad @ K   (reference src/solver.py:90)
+            y_grad = (y_grad + u_grad @ torch.as_tensor(K, dtype=F64, device=dev)).contiguous()
+        t = lambda a: torch.as_tensor(np.asarray(a), dtype=F64).to(dev).contiguous()
+        x_h_d, u_h_d, xg_d, w_d = t(x_h), t(u_h), t(np.asarray(xg).reshape(-1)[:H]), t(np.asarray(w).reshape(-1)[:H])
+        te = t(np.stack(self.tilde_eps_list)[:H])
+        n = lib.gpmpc_plin_len(self.nx, self.nu, self.ns)
+        p_lin = torch.empty(H, n, dtype=F64, device=dev)
+        _lib.check(lib.gpmpc_pack_plin(self.nx, self.nu, self.ns, H, _lib.dptr(y_grad), _lib.dptr(u_grad),
+                                       _lib.dptr(gp_val), _lib.dptr(x_h_d), _lib.dptr(u_h_d), _lib.dptr(xg_d),
+                                       _lib.dptr(w_d), _lib.dptr(te), _lib.dptr(p_lin), _lib.current_stream_ptr()),
+                   "gpmpc_pack_plin")
+        return p_lin.cpu().numpy()
+
+    # ---------------------------------------------------------------------------------------------------------
+    # forward sampling with rejection (reference src/agent.py:331-443)
+    # ---------------------------------------------------------------------------------------------------------
+    def prepare_dynamics_set(self, X_soln, U_soln, X_kp1):
+        """Propagate every sampled dynamics along the shifted solution, reject the samples that leave the
+        ``ci_list`` tube, replace their hallucinated data by randomly chosen survivors'."""
+        n_sample = self.ns
+        tight = self.params["agent"]["tight"]
+        B_d_norm = np.sqrt(self.params["optimizer"]["terminal_tightening"]["P"][1][1])
+        var_eps = (tight["dyn_eps"] + tight["w_bound"]) * B_d_norm
+        dev = _lib.require_hip_device(self.torch_device)
+        self.FS_X_train_batch = torch.empty(n_sample, self.g_ny, 0, self.in_dim_x, dtype=F64, device=dev)
+        self.FS_Y_train_batch = torch.empty(n_sample, self.g_ny, 0, self.in_dim_y, dtype=F64, device=dev)
+        X_soln = torch.as_tensor(X_soln, dtype=F64).reshape(X_soln.shape[0], n_sample, self.nx).to(dev)
+        X_kp1 = torch.as_tensor(X_kp1, dtype=F64).transpose(0, 1).to(dev)
+        U_soln = torch.as_tensor(U_soln, dtype=F64).to(dev)
+        diff = X_soln[1, :, :] - X_kp1
+        samples_left = torch.prod(torch.abs(diff) - var_eps < 0, dim=1)
+        xu_init = torch.cat([X_kp1, U_soln[[1]]], dim=-1)
+        xu_hat = torch.tile(xu_init, dims=(n_sample, self.nx, 1, 1))
+        for i in range(1, X_soln.shape[0] - 1):
+            g_xu_hat = self.env_model.get_g_xu_hat(xu_hat).contiguous()
+            Y_sample = self.model_i(g_xu_hat).sample()
+            g_val = Y_sample[:, :, :].squeeze()[:, : self.g_ny]
+            f_val = self.env_model.known_dyn(xu_hat).squeeze()
+            x_next = f_val + torch.matmul(self.env_model.B_d, g_val.t()).t()
+            diff = X_soln[i + 1, :, :] - x_next
+            samples_left = samples_left * torch.prod(torch.abs(diff) - self.ci_list[i] < 0, dim=1)
+            if i == X_soln.shape[0] - 2:
+                break
+            self.FS_X_train_batch = torch.cat([self.FS_X_train_batch, g_xu_hat], dim=2)
+            Y_sample = Y_sample.clone()
+            Y_sample[:, :, :, 1:] = float("nan")
+            self.FS_Y_train_batch = torch.cat([self.FS_Y_train_batch, Y_sample], dim=2)
+            self.train_forward_sampling_dynGP()
+            xu_hat = torch.cat([torch.stack([x_next] * self.nx, dim=1)[:, :, None, :],
+                                torch.tile(U_soln[[i + 1]], dims=(n_sample, self.nx, 1, 1))], dim=-1)
+        if torch.sum(samples_left) > 0:
+            n_rep = int(torch.sum(samples_left == 0).item())
+            remaining = torch.arange(n_sample)[(samples_left > 0).cpu()].numpy()
+            dead = samples_left == 0
+            self.Hallcinated_X_train[dead] = self.Hallcinated_X_train[np.random.choice(remaining, n_rep).tolist()]
+            self.Hallcinated_Y_train[dead] = self.Hallcinated_Y_train[np.random.choice(remaining, n_rep).tolist()]
+        self.train_hallucinated_dynGP(sqp_iter=self.params["optimizer"]["SEMPC"]["max_sqp_iter"])
+        return

@@ -1,0 +1,154 @@
+// gpmpc_assemble_jacobians / gpmpc_pack_plin: the elementwise tail of the SQP linearisation (gfx950).
+// HBM-bound streaming kernels: one thread per output row, contiguous stores.
+#include "gpmpc_host.hpp"
+
+namespace gpmpc {
+
+// Replaces reference src/agent.py:532-557 for the two environments:
+//   y_full[row] = [f | df/dx | df/du](row) + sum_o B_d[row][o] * scatter_{pad_g}(transform(y[o]))
+template <int T>
+__global__ __launch_bounds__(256) void jacobians_kernel(GpParams gp, EnvParams env, long Ns, int H,
+                                                        const double* __restrict__ xu, const double* __restrict__ y,
+                                                        double* __restrict__ gp_val, double* __restrict__ y_grad,
+                                                        double* __restrict__ u_grad) {
+    constexpr int I1 = (T == 1) ? 0 : 1, I2 = (T == 1) ? 0 : 2;   // value-only model: one column feeds all pads
+    const int nx = env.nx, nu = env.nu, W = 1 + nx + nu;
+    const long total = Ns * nx * H;
+    for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+        const int h = (int)(e % H);
+        const int row = (int)((e / H) % nx);
+        const long s = e / ((long)H * nx);
+        const double* xr = xu + ((s * nx + 0) * H + h) * (nx + nu);      // replica 0 of the state row
+        double out[1 + GPMPC_MAX_NX + GPMPC_MAX_NU];
+        for (int c = 0; c < W; ++c) out[c] = 0.0;
+        if (env.env_id == GPMPC_ENV_PENDULUM1D) {
+            // known part: theta+ = theta + omega dt ; omega+ = omega          (pendulum1D.py:137-188)
+            if (row == 0) {
+                out[0] = xr[0] + xr[1] * env.dt;
+                out[1] = 1.0;
+                out[2] = env.dt;
+            } else {
+                out[0] = xr[1];
+                out[2] = 1.0;
+                const double* yo = y + ((s * gp.g_ny + 0) * H + h) * T;  // B_d = [0,1]^T, pad_g = [0,1,3]
+                out[0] += yo[0];
+                out[1] += yo[I1];                                        // T == 1: the value is broadcast (quirk K)
+                out[3] += yo[I2];
+            }
+        } else {
+            // known part: identity on (X,Y,phi,v), dv+/da = dt                (car_model_residual.py:101-161)
+            out[0] = xr[row] + ((row == 3) ? xr[5] * env.dt : 0.0);
+            out[1 + row] = 1.0;
+            if (row == 3) out[6] = env.dt;
+            if (row < 3) {
+                // transform_sensitivity (211-224): [g, dg/dphi, dg/ddelta] -> [v g, v dg/dphi, g, v dg/ddelta]
+                // scattered to pad_g = [0,3,4,5]; B_d = I_{4x3}
+                const double* yo = y + ((s * gp.g_ny + row) * H + h) * T;
+                const double v = xr[3];
+                const double y0 = yo[0], y1 = yo[I1], y2 = yo[I2];
+                out[0] += v * y0;
+                out[3] += v * y1;
+                out[4] += y0;
+                out[5] += v * y2;
+            }
+        }
+        gp_val[e] = out[0];
+        for (int c = 0; c < nx; ++c) y_grad[e * nx + c] = out[1 + c];
+        for (int c = 0; c < nu; ++c) u_grad[e * nu + c] = out[1 + nx + c];
+    }
+}
+
+// Replaces the O(Ns^2) host loop of reference src/solver.py:98-131.
+__global__ __launch_bounds__(256) void plin_kernel(int nx, int nu, long Ns, int H, const double* __restrict__ y_grad,
+                                                   const double* __restrict__ u_grad, const double* __restrict__ gp_val,
+                                                   const double* __restrict__ x_h, const double* __restrict__ u_h,
+                                                   const double* __restrict__ xg, const double* __restrict__ w,
+                                                   const double* __restrict__ tilde_eps, double* __restrict__ p_lin) {
+    const long per = (long)nx * nx + (long)nx * nu + 2L * nx;
+    const long tail = nu + 2 + (nx + nu + 1);
+    const long len = Ns * per + tail;
+    const long total = len * H;
+    for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+        const int h = (int)(e / len);
+        const long k = e - (long)h * len;
+        double v;
+        if (k < Ns * per) {
+            const long i = k / per;
+            const int r = (int)(k - i * per);
+            if (r < nx * nx) {
+                const int a = r / nx, b = r - a * nx;
+                v = y_grad[((i * nx + a) * H + h) * nx + b];
+            } else if (r < nx * nx + nx * nu) {
+                const int rr = r - nx * nx;
+                const int a = rr / nu, b = rr - a * nu;
+                v = u_grad[((i * nx + a) * H + h) * nu + b];
+            } else if (r < nx * nx + nx * nu + nx) {
+                v = x_h[(long)h * Ns * nx + i * nx + (r - nx * nx - nx * nu)];
+            } else {
+                v = gp_val[(i * nx + (r - nx * nx - nx * nu - nx)) * H + h];
+            }
+        } else {
+            const int r = (int)(k - Ns * per);
+            if (r < nu) v = u_h[(long)h * nu + r];
+            else if (r == nu) v = xg[h];
+            else if (r == nu + 1) v = w[h];
+            else v = tilde_eps[(long)h * (nx + nu + 1) + (r - nu - 2)];
+        }
+        p_lin[e] = v;
+    }
+}
+
+static unsigned stream_grid(long total) {
+    long g = (total + 255) / 256;
+    if (g > 2048) g = 2048;            // ~8 workgroups per CU, grid-stride for the rest
+    if (g < 1) g = 1;
+    return (unsigned)g;
+}
+
+}  // namespace gpmpc
+
+using namespace gpmpc;
+
+extern "C" {
+
+int gpmpc_assemble_jacobians(const gpmpc_gp_desc_t* gp, const gpmpc_env_desc_t* env, int64_t Ns, int32_t H,
+                             const double* xu, const double* y, double* gp_val, double* y_grad, double* u_grad,
+                             void* stream) {
+    if (int rc = check_gp(gp)) return rc;
+    if (int rc = check_env(gp, env)) return rc;
+    if (!xu || !y || !gp_val || !y_grad || !u_grad) return fail(GPMPC_E_ARG, "gpmpc_assemble_jacobians: NULL pointer");
+    if (Ns < 1 || H < 1) return fail(GPMPC_E_ARG, "gpmpc_assemble_jacobians: bad sizes");
+    GpParams g = make_gp_params(gp);
+    EnvParams e = make_env_params(env);
+    const long total = Ns * env->nx * H;
+    hipStream_t st = (hipStream_t)stream;
+    if (gp->T == 1)
+        hipLaunchKernelGGL(jacobians_kernel<1>, dim3(stream_grid(total)), dim3(256), 0, st, g, e, (long)Ns, H, xu, y,
+                           gp_val, y_grad, u_grad);
+    else if (gp->T == 3)
+        hipLaunchKernelGGL(jacobians_kernel<3>, dim3(stream_grid(total)), dim3(256), 0, st, g, e, (long)Ns, H, xu, y,
+                           gp_val, y_grad, u_grad);
+    else
+        return fail(GPMPC_E_UNSUPPORTED, "jacobians: only T = 1 and T = 3 are instantiated");
+    GPMPC_HIP_CHECK(hipGetLastError());
+    return GPMPC_OK;
+}
+
+int64_t gpmpc_plin_len(int32_t nx, int32_t nu, int64_t Ns) {
+    return Ns * ((int64_t)nx * nx + (int64_t)nx * nu + 2 * nx) + nu + 2 + (nx + nu + 1);
+}
+
+int gpmpc_pack_plin(int32_t nx, int32_t nu, int64_t Ns, int32_t H, const double* y_grad, const double* u_grad,
+                    const double* gp_val, const double* x_h, const double* u_h, const double* xg, const double* w,
+                    const double* tilde_eps, double* p_lin, void* stream) {
+    if (!y_grad || !u_grad || !gp_val || !x_h || !u_h || !xg || !w || !tilde_eps || !p_lin)
+        return fail(GPMPC_E_ARG, "gpmpc_pack_plin: NULL pointer");
+    if (nx < 1 || nu < 1 || Ns < 1 || H < 1) return fail(GPMPC_E_ARG, "gpmpc_pack_plin: bad sizes");
+    const long total = gpmpc_plin_len(nx, nu, Ns) * H;
+    hipLaunchKernelGGL(plin_kernel, dim3(stream_grid(total)), dim3(256), 0, (hipStream_t)stream, nx, nu, (long)Ns, H,
+                       y_grad, u_grad, gp_val, x_h, u_h, xg, w, tilde_eps, p_lin);
+    GPMPC_HIP_CHECK(hipGetLastError());
+    return GPMPC_OK;
+}
+
+}  // extern "C"

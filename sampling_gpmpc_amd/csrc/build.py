@@ -1,0 +1,61 @@
+#!/usr/bin/env python3
+"""Build libgpmpc_hip.so for gfx950 in-tree with hipcc (cross-compiles without a GPU).
+
+    python sampling_gpmpc_amd/csrc/build.py [--force] [--verbose]
+"""
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+SOURCES = ["capi.hip", "rollout.hip", "joint.hip", "assemble.hip"]
+HEADERS = ["gpmpc_device.hpp", "gpmpc_host.hpp", os.path.join(REPO, "include", "gpmpc_hip.h")]
+OUT = os.path.join(os.path.dirname(HERE), "libgpmpc_hip.so")
+OBJDIR = os.path.join(HERE, "build")
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fgpu-rdc" if False else "-fno-gpu-rdc",
+         "-ffp-contract=on", "-I", os.path.join(REPO, "include"), "-I", HERE]
+
+
+def _mtime(p):
+    return os.path.getmtime(p) if os.path.exists(p) else 0.0
+
+
+def build(force=False, verbose=False):
+    os.makedirs(OBJDIR, exist_ok=True)
+    hdr_t = max(_mtime(h if os.path.isabs(h) else os.path.join(HERE, h)) for h in HEADERS)
+    hdr_t = max(hdr_t, _mtime(os.path.abspath(__file__)))
+    jobs = []
+    for src in SOURCES:
+        s = os.path.join(HERE, src)
+        o = os.path.join(OBJDIR, src.replace(".hip", ".o"))
+        if force or _mtime(o) < max(_mtime(s), hdr_t):
+            jobs.append((s, o))
+    def cc(job):
+        s, o = job
+        cmd = [HIPCC, "-x", "hip", "-c", s, "-o", o] + FLAGS
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"hipcc failed for {s}:\n{r.stdout}\n{r.stderr}")
+        if verbose and r.stderr.strip():
+            print(r.stderr)
+    with ThreadPoolExecutor(max_workers=4) as ex:
+        list(ex.map(cc, jobs))
+    objs = [os.path.join(OBJDIR, s.replace(".hip", ".o")) for s in SOURCES]
+    if jobs or not os.path.exists(OUT):
+        cmd = [HIPCC, "-shared", "-fPIC", "--offload-arch=gfx950", "-o", OUT] + objs
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
+    return OUT
+
+
+if __name__ == "__main__":
+    out = build(force="--force" in sys.argv, verbose="--verbose" in sys.argv or "-v" in sys.argv)
+    print(out)

@@ -1,0 +1,202 @@
+// libgpmpc_hip.so - C-ABI basics, the shared real-data plan, device self test.  gfx950 only.
+#include "gpmpc_host.hpp"
+
+namespace gpmpc {
+
+std::string& last_error() {
+    static thread_local std::string s;
+    return s;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// plan: factorise K_rr + Sigma_r once per output (shared by all samples).  One workgroup per output; the matrix
+// lives in LDS (n_r <= 143 -> <= 160 KiB).  Right-looking Cholesky; then L^-1 column by column (thread per column).
+// ---------------------------------------------------------------------------------------------------------------
+template <int D>
+__global__ __launch_bounds__(256) void plan_kernel(GpParams gp, const double* __restrict__ X_r,
+                                                   const double* __restrict__ Y_r, double* __restrict__ plan,
+                                                   int* __restrict__ info) {
+    extern __shared__ __attribute__((aligned(16))) double A[];
+    __shared__ int s_fail;
+    const int o = blockIdx.x;
+    const int n = gp.n_r;
+    const int Tr = gp.real_has_grad ? gp.T : 1;
+    const int tid = threadIdx.x, nt = blockDim.x;
+    const double* inv_l2 = gp.inv_l2[o];
+    if (tid == 0) s_fail = 0;
+
+    for (int e = tid; e < n * n; e += nt) {
+        const int s1 = e / n, s2 = e - s1 * n;
+        const int i1 = s1 / Tr, a1 = s1 - i1 * Tr;
+        const int i2 = s2 / Tr, a2 = s2 - i2 * Tr;
+        double q[D];
+        const double k = kern_scalar<D>(X_r + i1 * D, X_r + i2 * D, inv_l2, gp.os[o], q);
+        double v = kern_entry<D>(q, k, inv_l2, a1, a2);
+        if (s1 == s2) v += gp.noise[a1];
+        A[e] = v;
+    }
+    __syncthreads();
+
+    for (int j = 0; j < n; ++j) {
+        const double d = A[j * n + j];
+        if (!(d > 0.0)) {
+            if (tid == 0) s_fail = 1;
+            break;                                   // uniform: every thread reads the same d
+        }
+        const double sj = sqrt(d);
+        __syncthreads();
+        for (int i = j + 1 + tid; i < n; i += nt) A[i * n + j] /= sj;
+        if (tid == 0) A[j * n + j] = sj;
+        __syncthreads();
+        // trailing update: A[i][k] -= L[i][j] L[k][j]   for j < k <= i
+        const int m = n - j - 1;
+        for (int e = tid; e < m * m; e += nt) {
+            const int ii = e / m, kk = e - ii * m;
+            if (kk <= ii) {
+                const int i = j + 1 + ii, k = j + 1 + kk;
+                A[i * n + k] -= A[i * n + j] * A[k * n + j];
+            }
+        }
+        __syncthreads();
+    }
+    __syncthreads();
+    double* L = plan + o * gp.plan_stride;
+    double* LinvT = L + (long)n * n;
+    double* w = LinvT + (long)n * n;
+    double* alpha = w + n;
+    if (s_fail) {
+        if (tid == 0) info[o] = GPMPC_INFO_TRAIN_CHOL_FAIL;
+        for (long e = tid; e < gp.plan_stride; e += nt) L[e] = __builtin_nan("");
+        return;
+    }
+    if (tid == 0) info[o] = 0;
+    for (int e = tid; e < n * n; e += nt) {
+        const int i = e / n, k = e - i * n;
+        L[e] = (k <= i) ? A[e] : 0.0;
+    }
+    // column c of L^-1:  x_c = 1/L_cc ; x_i = -(sum_{k=c}^{i-1} L_ik x_k) / L_ii   (stored LinvT[c*n + i])
+    for (int c = tid; c < n; c += nt) {
+        double* x = LinvT + (long)c * n;
+        for (int i = 0; i < c; ++i) x[i] = 0.0;
+        x[c] = 1.0 / A[c * n + c];
+        for (int i = c + 1; i < n; ++i) {
+            double s = 0.0;
+            for (int k = c; k < i; ++k) s += A[i * n + k] * x[k];
+            x[i] = -s / A[i * n + i];
+        }
+    }
+    __syncthreads();
+    __threadfence_block();
+    for (int i = tid; i < n; i += nt) {                 // w = L^-1 y
+        double s = 0.0;
+        for (int j = 0; j <= i; ++j) {
+            const int pj = j / Tr, aj = j - pj * Tr;
+            s += LinvT[(long)j * n + i] * Y_r[((long)o * gp.N_r + pj) * gp.T + aj];
+        }
+        w[i] = s;
+    }
+    __syncthreads();
+    __threadfence_block();
+    for (int j = tid; j < n; j += nt) {                 // alpha = L^-T w
+        double s = 0.0;
+        for (int i = j; i < n; ++i) s += LinvT[(long)j * n + i] * w[i];
+        alpha[j] = s;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// device self test of the cross-lane primitives (run once by the test-suite / smoke on the GPU box)
+// ---------------------------------------------------------------------------------------------------------------
+__global__ void selftest_kernel(int* out) {
+    const int lane = threadIdx.x;
+    int bad = 0;
+    const double v = 1.0 + 0.25 * lane + 1e-9 * lane * lane;
+    double ref = 0.0;
+    for (int l = 0; l < 64; ++l) ref += 1.0 + 0.25 * l + 1e-9 * l * l;
+    const double s1 = wave_sum(v), s2 = wave_sum_shfl(v);
+    if (fabs(s1 - ref) > 1e-9 * fabs(ref)) bad |= 1;
+    if (fabs(s2 - ref) > 1e-9 * fabs(ref)) bad |= 2;
+    for (int l = 0; l < 64; l += 7) {
+        const double r = readlane_f64(v, l);
+        if (r != 1.0 + 0.25 * l + 1e-9 * l * l) bad |= 4;
+    }
+    double S[3][3] = {{4.0, 2.0, 0.6}, {2.0, 5.0, 1.0}, {0.6, 1.0, 3.0}}, L[3][3];
+    if (!chol_small<3>(S, L)) bad |= 8;
+    double err = 0.0;
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) {
+            double a = 0.0;
+            for (int k = 0; k < 3; ++k) a += L[i][k] * L[j][k];
+            err += fabs(a - S[i][j]);
+        }
+    if (err > 1e-12) bad |= 16;
+    double Sn[3][3] = {{1.0, 2.0, 0.0}, {2.0, 1.0, 0.0}, {0.0, 0.0, 1.0}}, R[3][3];
+    const int inf = root_small<3>(Sn, 1e-6, R);
+    if (!(inf & GPMPC_INFO_ROOT_FAIL)) bad |= 32;
+    const unsigned long long any = __ballot(bad != 0);
+    if (lane == 0) out[0] = (any != 0ull) ? (bad | 0x1000) : 0;
+    if (bad) atomicOr(out + 1, bad);
+}
+
+}  // namespace gpmpc
+
+using namespace gpmpc;
+
+extern "C" {
+
+int gpmpc_abi_version(void) { return GPMPC_ABI_VERSION; }
+
+const char* gpmpc_last_error_string(void) { return last_error().c_str(); }
+
+int gpmpc_device_info(int dev, char* name, int cap, int* cu_count, int* lds_bytes) {
+    hipDeviceProp_t prop;
+    GPMPC_HIP_CHECK(hipGetDeviceProperties(&prop, dev));
+    if (name && cap > 0) {
+        std::snprintf(name, cap, "%s (%s)", prop.name, prop.gcnArchName);
+    }
+    if (cu_count) *cu_count = prop.multiProcessorCount;
+    if (lds_bytes) *lds_bytes = (int)prop.sharedMemPerBlock;
+    return GPMPC_OK;
+}
+
+int gpmpc_selftest(void* stream) {
+    int* d = nullptr;
+    int h[2] = {-1, -1};
+    GPMPC_HIP_CHECK(hipMalloc(&d, 2 * sizeof(int)));
+    GPMPC_HIP_CHECK(hipMemsetAsync(d, 0, 2 * sizeof(int), (hipStream_t)stream));
+    hipLaunchKernelGGL(selftest_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, d);
+    GPMPC_HIP_CHECK(hipGetLastError());
+    GPMPC_HIP_CHECK(hipMemcpyAsync(h, d, 2 * sizeof(int), hipMemcpyDeviceToHost, (hipStream_t)stream));
+    GPMPC_HIP_CHECK(hipStreamSynchronize((hipStream_t)stream));
+    GPMPC_HIP_CHECK(hipFree(d));
+    if (h[0] != 0 || h[1] != 0) {
+        char buf[96];
+        std::snprintf(buf, sizeof(buf), "device self test failed: mask 0x%x / 0x%x", h[0], h[1]);
+        return fail(GPMPC_E_HIP, buf);
+    }
+    return GPMPC_OK;
+}
+
+size_t gpmpc_plan_bytes(const gpmpc_gp_desc_t* gp) {
+    if (check_gp(gp) != GPMPC_OK) return 0;
+    const int n_r = observed_real_slots(gp);
+    return align_up((size_t)gp->g_ny * plan_doubles_per_output(n_r) * sizeof(double), 256);
+}
+
+int gpmpc_plan_build(const gpmpc_gp_desc_t* gp, const double* X_r, const double* Y_r, void* plan, int32_t* info,
+                     void* stream) {
+    if (int rc = check_gp(gp)) return rc;
+    if (!X_r || !Y_r || !plan || !info) return fail(GPMPC_E_ARG, "gpmpc_plan_build: NULL pointer");
+    GpParams p = make_gp_params(gp);
+    const size_t lds = (size_t)p.n_r * p.n_r * sizeof(double);
+    if (lds > 160 * 1024 - 64) return fail(GPMPC_E_UNSUPPORTED, "plan: n_r too large for the LDS-resident factorisation");
+    if (gp->D != 2) return fail(GPMPC_E_UNSUPPORTED, "only D = 2 is instantiated");
+    auto kern = plan_kernel<2>;
+    GPMPC_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(kern, dim3(gp->g_ny), dim3(256), lds, (hipStream_t)stream, p, X_r, Y_r, (double*)plan,
+                       (int*)info);
+    GPMPC_HIP_CHECK(hipGetLastError());
+    return GPMPC_OK;
+}
+
+}  // extern "C"

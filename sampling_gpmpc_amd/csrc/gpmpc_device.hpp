@@ -1,0 +1,209 @@
+// Device-side building blocks shared by the gfx950 kernels of libgpmpc_hip.so.
+// Wave = 64 lanes everywhere (CDNA4); nothing here is written for 32-wide warps.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "gpmpc_hip.h"
+
+namespace gpmpc {
+
+constexpr int kWave = 64;
+
+// ---------------------------------------------------------------------------------------------------------------
+// kernel-argument copies of the C-ABI descriptors (plain data, passed by value)
+// ---------------------------------------------------------------------------------------------------------------
+struct GpParams {
+    int g_ny, D, T, N_r, real_has_grad, n_r;          // n_r = observed real label slots
+    double inv_l2[GPMPC_MAX_NY][GPMPC_MAX_D];         // 1 / ell^2
+    double os[GPMPC_MAX_NY];                          // outputscale
+    double noise[GPMPC_MAX_T];
+    double jitter, var_floor;
+    long plan_stride;                                 // doubles per output inside the plan buffer
+};
+
+struct EnvParams {
+    int env_id, nx, nu, use_feedback;
+    double dt, p0, p1;
+    double K[GPMPC_MAX_NU][GPMPC_MAX_NX];
+    double x_goal[GPMPC_MAX_NX];
+};
+
+// plan buffer layout per output o (doubles): [ L (n_r*n_r, row-major) | LinvT (n_r*n_r, LinvT[j*n_r+i]=Linv[i][j])
+//                                            | w (n_r) = L^-1 y | alpha (n_r) = L^-T w ]
+__host__ __device__ inline long plan_doubles_per_output(int n_r) { return 2L * n_r * n_r + 2L * n_r; }
+__device__ inline const double* plan_L(const double* plan, const GpParams& gp, int o) { return plan + o * gp.plan_stride; }
+__device__ inline const double* plan_LinvT(const double* plan, const GpParams& gp, int o) {
+    return plan + o * gp.plan_stride + (long)gp.n_r * gp.n_r;
+}
+__device__ inline const double* plan_w(const double* plan, const GpParams& gp, int o) {
+    return plan + o * gp.plan_stride + 2L * gp.n_r * gp.n_r;
+}
+__device__ inline const double* plan_alpha(const double* plan, const GpParams& gp, int o) {
+    return plan + o * gp.plan_stride + 2L * gp.n_r * gp.n_r + gp.n_r;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// cross-lane helpers (wave64)
+// ---------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ double readlane_f64(double v, int lane) {
+    // v_readlane_b32 x2 -> SGPR pair: the broadcast value feeds v_fma_f64 as a scalar operand
+    int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
+    int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+    return __hiloint2double(hi, lo);
+}
+
+template <int CTRL, int ROW_MASK, int BANK_MASK>
+__device__ __forceinline__ double dpp_f64(double v) {
+    // lanes whose source is out of range / masked off receive +0.0 (old = 0, bound_ctrl = 0)
+    int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, ROW_MASK, BANK_MASK, false);
+    int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, ROW_MASK, BANK_MASK, false);
+    return __hiloint2double(hi, lo);
+}
+
+// Sum over the 64 lanes of a wave; the result is returned (uniform) to every lane.
+// DPP ladder: row_shr 1,2,3 -> row_shr 4 -> row_shr 8 -> row_bcast15 -> row_bcast31, total lands in lane 63.
+__device__ __forceinline__ double wave_sum(double v) {
+    double t = v + dpp_f64<0x111, 0xf, 0xf>(v);          // row_shr:1
+    t += dpp_f64<0x112, 0xf, 0xf>(v);                    // row_shr:2
+    t += dpp_f64<0x113, 0xf, 0xf>(v);                    // row_shr:3
+    t += dpp_f64<0x114, 0xf, 0xe>(t);                    // row_shr:4  bank_mask 0xe
+    t += dpp_f64<0x118, 0xf, 0xc>(t);                    // row_shr:8  bank_mask 0xc
+    t += dpp_f64<0x142, 0xa, 0xf>(t);                    // row_bcast:15 row_mask 0xa
+    t += dpp_f64<0x143, 0xc, 0xf>(t);                    // row_bcast:31 row_mask 0xc
+    return readlane_f64(t, 63);
+}
+
+// portable butterfly (ds_bpermute based) - used by the self test to cross-check the DPP ladder
+__device__ __forceinline__ double wave_sum_shfl(double v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+    return v;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// RBF(+gradient) kernel block, SURVEY.md App. A.2.  r = x - x' (x: first argument / row, x': second / column)
+//   q[d] = r_d / l_d^2, k = outputscale * exp(-1/2 sum r_d q_d)
+//   cov(task_a(x), task_b(x')):  (0,0) k ; (0,b) +k q_b ; (a,0) -k q_a ; (a,b) k (delta_ab / l_a^2 - q_a q_b)
+// ---------------------------------------------------------------------------------------------------------------
+template <int D>
+__device__ __forceinline__ double kern_entry(const double (&q)[D], double k, const double* inv_l2, int a, int b) {
+    if (a == 0) return (b == 0) ? k : k * q[b - 1];
+    if (b == 0) return -k * q[a - 1];
+    double v = -q[a - 1] * q[b - 1];
+    if (a == b) v += inv_l2[a - 1];
+    return k * v;
+}
+
+template <int D>
+__device__ __forceinline__ double kern_scalar(const double* x, const double* xp, const double* inv_l2, double os,
+                                              double (&q)[D]) {
+    double s = 0.0;
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+        const double r = x[d] - xp[d];
+        q[d] = r * inv_l2[d];
+        s += r * q[d];
+    }
+    return os * exp(-0.5 * s);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// small dense Cholesky (LAPACK dpotrf lower semantics: fail on pivot <= 0 or NaN), T x T, in registers
+// ---------------------------------------------------------------------------------------------------------------
+template <int T>
+__device__ __forceinline__ bool chol_small(const double (&S)[T][T], double (&L)[T][T]) {
+#pragma unroll
+    for (int j = 0; j < T; ++j) {
+        double d = S[j][j];
+#pragma unroll
+        for (int k = 0; k < j; ++k) d -= L[j][k] * L[j][k];
+        if (!(d > 0.0)) return false;
+        d = sqrt(d);
+        L[j][j] = d;
+        const double inv = 1.0 / d;
+#pragma unroll
+        for (int i = j + 1; i < T; ++i) {
+            double s = S[i][j];
+#pragma unroll
+            for (int k = 0; k < j; ++k) s -= L[i][k] * L[j][k];
+            L[i][j] = s * inv;
+        }
+#pragma unroll
+        for (int i = 0; i < j; ++i) L[i][j] = 0.0;
+    }
+    return true;
+}
+
+// Root of a T x T posterior covariance, SURVEY.md App. A.7:
+//   1x1 -> sqrt (no jitter; NaN if negative);  else Cholesky, on failure up to 3 retries adding jitter*10^i (total)
+//   to the diagonal.  Returns info bits (GPMPC_INFO_ROOT_*).  The whole-batch eigh fallback is the caller's job.
+template <int T>
+__device__ __forceinline__ int root_small(const double (&S)[T][T], double jitter, double (&R)[T][T]) {
+    if constexpr (T == 1) {
+        R[0][0] = sqrt(S[0][0]);
+        return (S[0][0] < 0.0) ? GPMPC_INFO_NEG_1x1 : 0;
+    } else {
+        if (chol_small<T>(S, R)) return 0;
+        double A[T][T];
+#pragma unroll
+        for (int i = 0; i < T; ++i)
+#pragma unroll
+            for (int j = 0; j < T; ++j) A[i][j] = S[i][j];
+        double prev = 0.0, jn = jitter;
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+            const double add = jn - prev;            // the library accumulates increments on a cloned matrix
+#pragma unroll
+            for (int i = 0; i < T; ++i) A[i][i] += add;
+            prev = jn;
+            if (chol_small<T>(A, R)) return (t + 1) << 1;
+            jn *= 10.0;
+        }
+        return (3 << 1) | GPMPC_INFO_ROOT_FAIL;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// environment maps fused into the rollout
+// ---------------------------------------------------------------------------------------------------------------
+// u = u_ff + K (x - x_goal), written as the reference does: -((x_goal - x) @ K^T) + u_ff
+__device__ __forceinline__ void apply_feedback(const EnvParams& e, const double* x, const double* u_ff, double* u) {
+    for (int i = 0; i < e.nu; ++i) {
+        double acc = 0.0;
+        if (e.use_feedback) {
+            for (int j = 0; j < e.nx; ++j) acc += (e.x_goal[j] - x[j]) * e.K[i][j];
+            u[i] = -acc + u_ff[i];
+        } else {
+            u[i] = u_ff[i];
+        }
+    }
+}
+
+// GP input selection: pendulum1D g_idx_inputs = [0, 2] (theta, u); car g_idx_inputs = [2, 4] (phi, delta)
+__device__ __forceinline__ void gp_input(const EnvParams& e, const double* x, const double* u, double* xi) {
+    if (e.env_id == GPMPC_ENV_PENDULUM1D) {
+        xi[0] = x[0];
+        xi[1] = u[0];
+    } else {
+        xi[0] = x[2];
+        xi[1] = u[0];
+    }
+}
+
+// x+ = f(x,u) + B_d(x) g   with g[o] = value component of output o's sample
+__device__ __forceinline__ void env_step(const EnvParams& e, const double* x, const double* u, const double* g,
+                                         double* xn) {
+    if (e.env_id == GPMPC_ENV_PENDULUM1D) {
+        xn[0] = x[0] + x[1] * e.dt;          // known_dyn: theta + omega dt
+        xn[1] = x[1] + g[0];                 // omega + B_d g, B_d = [0, 1]^T
+    } else {
+        const double v = x[3];
+        xn[0] = x[0] + v * g[0];             // transform_sensitivity multiplies the value by v, B_d = I_{4x3}
+        xn[1] = x[1] + v * g[1];
+        xn[2] = x[2] + v * g[2];
+        xn[3] = (x[3] + u[1] * e.dt);        // known_dyn: v + a dt
+    }
+}
+
+}  // namespace gpmpc

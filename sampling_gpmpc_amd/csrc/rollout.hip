@@ -1,0 +1,474 @@
+// gpmpc_rollout: whole-horizon rollout of Ns sampled dynamics functions in ONE launch (gfx950).
+//
+// Mapping: one workgroup per sample, one 64-lane wave per GP output ("chain").  Each chain keeps the Cholesky
+// factor of its own growing training set in append-row form:
+//
+//      L = [ L_rr   0   ]     L_rr  : shared real-data block, factorised once by gpmpc_plan_build (HBM, L2 resident)
+//          [ L_hr  L_hh ]     L_hr  : rows v_r(x_j)^T  of the sample's own previous draws      (n_h x n_r)
+//                             L_hh  : lower-triangular Schur factor of those draws            (n_h x n_h)
+//
+// Per step and chain: kernel row vs real data -> v_r = L_rr^-1 k_r (dense product with the precomputed inverse)
+// -> rhs = k_h - L_hr v_r -> v_h = L_hh^-1 rhs (column-oriented substitution, rows in registers, the pivot value
+// travels through v_readlane as a scalar operand) -> mu = v^T w, S = k** - v^T v (DPP wave reductions) -> T x T
+// root with gpytorch's jitter-on-failure chain -> y = mu + R z -> clip -> append [v^T, chol(S + noise)] and w.
+// The per-sample factor lives in LDS when it fits (FAC_LDS) and in an HBM workspace otherwise; both are laid out
+// column-major so that lane == row gives conflict-free LDS / coalesced HBM access.
+#include "gpmpc_host.hpp"
+
+namespace gpmpc {
+
+struct RolloutArgs {
+    GpParams gp;
+    EnvParams env;
+    const double* plan;
+    const double* X_r;
+    int mode, hall_tasks;
+    double var_zero_thr, beta;
+    long Ns;
+    int H;
+    const double* x0;
+    int x0_per_sample;
+    const double* u_ff;
+    const double* z;
+    long z_step_stride;
+    double* X_traj;
+    double* Y;
+    double* Xi;
+    int* info;
+    double* ws;
+    long ws_chain_stride;   // doubles per chain in the HBM workspace
+    int nh_max;             // hallucinated slots allocated per chain
+    int lds_shared;         // doubles of block-shared LDS
+    int lds_per_wave;       // doubles of per-wave LDS
+};
+
+__device__ __forceinline__ void wave_lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+__device__ __forceinline__ long col_ofs(int p, int nh_max) { return (long)p * nh_max - ((long)p * (p - 1)) / 2; }
+
+template <int T, int RPL, bool FAC_LDS>
+__global__ __launch_bounds__(64 * GPMPC_MAX_NY) void rollout_kernel(const RolloutArgs a) {
+    constexpr int D = 2;
+    constexpr int NS = T * (T + 1) / 2;
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    __shared__ int s_info;
+
+    const GpParams& gp = a.gp;
+    const EnvParams& env = a.env;
+    const long s = blockIdx.x;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int o = wave;
+    const int H = a.H, nx = env.nx, nu = env.nu;
+    const int n_r = gp.n_r, Tr = gp.real_has_grad ? T : 1;
+    const int nh_max = a.nh_max, Th = a.hall_tasks;
+    const bool recond = (a.mode == GPMPC_MODE_RECONDITIONED);
+
+    double* xbuf = smem;                          // [nx][H+1]
+    double* Xh = xbuf + nx * (H + 1);             // [H][D]   GP inputs of every step
+    double* ybuf = Xh + H * D;                    // [2][MAX_NY] value samples, double-buffered over t parity
+    double* wb = smem + a.lds_shared + (long)wave * a.lds_per_wave;
+    double* kr = wb;                              // [T][n_r]
+    double* vr = kr + T * n_r;                    // [T][n_r]
+    double* wh = vr + T * n_r;                    // [nh_max]
+    double* invd = wh + nh_max;                   // [nh_max]
+    double* yout = invd + nh_max;                 // [H][T]
+    double* fac = FAC_LDS ? (yout + H * T) : (a.ws + (s * gp.g_ny + o) * a.ws_chain_stride);
+    double* LhrT = fac;                           // [n_r][nh_max]   LhrT[i*nh_max + slot] = L_hr[slot][i]
+    double* Lhh = fac + (long)n_r * nh_max;       // packed lower, column-major: (slot,p) at col_ofs(p)+slot-p
+
+    const double* LinvT = plan_LinvT(a.plan, gp, o);
+    const double* w_r = plan_w(a.plan, gp, o);
+    double il2[D];
+#pragma unroll
+    for (int d = 0; d < D; ++d) il2[d] = gp.inv_l2[o][d];
+    const double os = gp.os[o];
+
+    if (threadIdx.x == 0) s_info = 0;
+    double x[GPMPC_MAX_NX];
+    for (int d = 0; d < nx; ++d) x[d] = a.x0[(a.x0_per_sample ? s * nx : 0) + d];
+    int info_acc = 0;
+    int n_h = 0;
+    __syncthreads();
+
+    for (int t = 0; t < H; ++t) {
+        double u[GPMPC_MAX_NU], xi[D];
+        apply_feedback(env, x, a.u_ff + (long)t * nu, u);
+        gp_input(env, x, u, xi);
+        if (threadIdx.x == 0) {
+            for (int d = 0; d < nx; ++d) xbuf[d * (H + 1) + t] = x[d];
+            for (int d = 0; d < D; ++d) Xh[t * D + d] = xi[d];
+        }
+
+        // ---- kernel row block against the real data ------------------------------------------------------
+        for (int sl = lane; sl < n_r; sl += kWave) {
+            const int i = sl / Tr, ar = sl - i * Tr;
+            double q[D];
+            const double k = kern_scalar<D>(a.X_r + i * D, xi, il2, os, q);
+#pragma unroll
+            for (int b = 0; b < T; ++b) kr[b * n_r + sl] = kern_entry<D>(q, k, il2, ar, b);
+        }
+        wave_lds_sync();
+
+        // ---- v_r = L_rr^-1 k_r ; partial sums of mu and v^T v -------------------------------------------
+        double pm[T], pss[NS];
+#pragma unroll
+        for (int b = 0; b < T; ++b) pm[b] = 0.0;
+#pragma unroll
+        for (int e = 0; e < NS; ++e) pss[e] = 0.0;
+        for (int i = lane; i < n_r; i += kWave) {
+            double acc[T];
+#pragma unroll
+            for (int b = 0; b < T; ++b) acc[b] = 0.0;
+            for (int j = 0; j <= i; ++j) {
+                const double l = LinvT[(long)j * n_r + i];
+#pragma unroll
+                for (int b = 0; b < T; ++b) acc[b] += l * kr[b * n_r + j];
+            }
+            const double wi = w_r[i];
+            int e = 0;
+#pragma unroll
+            for (int b = 0; b < T; ++b) {
+                vr[b * n_r + i] = acc[b];
+                pm[b] += acc[b] * wi;
+#pragma unroll
+                for (int c = 0; c <= b; ++c) pss[e++] += acc[b] * acc[c];
+            }
+        }
+        wave_lds_sync();
+
+        // ---- rows of the sample's own previous draws: rhs = k_h - L_hr v_r --------------------------------
+        double rhs[RPL][T];
+#pragma unroll
+        for (int r = 0; r < RPL; ++r)
+#pragma unroll
+            for (int b = 0; b < T; ++b) rhs[r][b] = 0.0;
+        if (n_h > 0) {
+#pragma unroll
+            for (int r = 0; r < RPL; ++r) {
+                const int slot = lane + kWave * r;
+                if (slot < n_h) {
+                    const int j = slot / Th, ah = slot - j * Th;
+                    double q[D];
+                    const double k = kern_scalar<D>(Xh + j * D, xi, il2, os, q);
+                    double acc[T];
+#pragma unroll
+                    for (int b = 0; b < T; ++b) acc[b] = kern_entry<D>(q, k, il2, ah, b);
+                    for (int i = 0; i < n_r; ++i) {
+                        const double l = LhrT[(long)i * nh_max + slot];
+#pragma unroll
+                        for (int b = 0; b < T; ++b) acc[b] -= l * vr[b * n_r + i];
+                    }
+#pragma unroll
+                    for (int b = 0; b < T; ++b) rhs[r][b] = acc[b];
+                }
+            }
+
+            // ---- v_h = L_hh^-1 rhs: column-oriented forward substitution, next column prefetched ------------
+            double lnext[RPL];
+#pragma unroll
+            for (int r = 0; r < RPL; ++r) {
+                const int slot = lane + kWave * r;
+                lnext[r] = (slot > 0 && slot < n_h) ? Lhh[slot] : 0.0;
+            }
+            for (int p = 0; p < n_h; ++p) {
+                double lcur[RPL];
+#pragma unroll
+                for (int r = 0; r < RPL; ++r) lcur[r] = lnext[r];
+                if (p + 1 < n_h) {
+                    const long co = col_ofs(p + 1, nh_max) - (p + 1);
+#pragma unroll
+                    for (int r = 0; r < RPL; ++r) {
+                        const int slot = lane + kWave * r;
+                        lnext[r] = (slot > p + 1 && slot < n_h) ? Lhh[co + slot] : 0.0;
+                    }
+                }
+                const int owner = p & 63, bank = p >> 6;
+                const double dinv = invd[p];
+                double vp[T];
+#pragma unroll
+                for (int b = 0; b < T; ++b) {
+                    double val = rhs[0][b];
+#pragma unroll
+                    for (int r = 1; r < RPL; ++r) val = (bank == r) ? rhs[r][b] : val;
+                    vp[b] = readlane_f64(val, owner) * dinv;
+                }
+#pragma unroll
+                for (int r = 0; r < RPL; ++r)
+#pragma unroll
+                    for (int b = 0; b < T; ++b) rhs[r][b] = fma(-lcur[r], vp[b], rhs[r][b]);
+                if (lane == owner) {
+#pragma unroll
+                    for (int r = 0; r < RPL; ++r)
+#pragma unroll
+                        for (int b = 0; b < T; ++b) rhs[r][b] = (bank == r) ? vp[b] : rhs[r][b];
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < RPL; ++r) {
+                const int slot = lane + kWave * r;
+                if (slot < n_h) {
+                    const double wi = wh[slot];
+                    int e = 0;
+#pragma unroll
+                    for (int b = 0; b < T; ++b) {
+                        pm[b] += rhs[r][b] * wi;
+#pragma unroll
+                        for (int c = 0; c <= b; ++c) pss[e++] += rhs[r][b] * rhs[r][c];
+                    }
+                }
+            }
+        }
+
+        // ---- posterior mean / covariance of the T label slots at the test point ---------------------------
+        double mu[T], S[T][T];
+        {
+            int e = 0;
+#pragma unroll
+            for (int b = 0; b < T; ++b) {
+                mu[b] = wave_sum(pm[b]);
+#pragma unroll
+                for (int c = 0; c <= b; ++c) {
+                    const double kss = (b == c) ? ((b == 0) ? os : os * il2[b - 1]) : 0.0;
+                    const double v = kss - wave_sum(pss[e++]);
+                    S[b][c] = v;
+                    S[c][b] = v;
+                }
+            }
+        }
+        double var[T];
+        bool all_zero = (a.var_zero_thr >= 0.0);
+#pragma unroll
+        for (int b = 0; b < T; ++b) {
+            var[b] = S[b][b];
+            if (var[b] < gp.var_floor) {
+                var[b] = gp.var_floor;
+                info_acc |= GPMPC_INFO_VAR_CLAMPED;
+            }
+            all_zero = all_zero && (var[b] <= a.var_zero_thr);
+        }
+
+        // ---- sample: y = mu + R z, post-processing of sample_gp -------------------------------------------
+        double R[T][T];
+        info_acc |= root_small<T>(S, gp.jitter, R);
+        const double* zt = a.z + (long)t * a.z_step_stride + (s * gp.g_ny + o) * T;
+        double y[T];
+#pragma unroll
+        for (int b = 0; b < T; ++b) {
+            double acc = 0.0;
+#pragma unroll
+            for (int c = 0; c <= b; ++c) acc += R[b][c] * zt[c];
+            double yb = acc + mu[b];
+            if (all_zero) yb = mu[b];
+            const double sd = a.beta * sqrt(var[b]);
+            yb = fmax(yb, mu[b] - sd);
+            yb = fmin(yb, mu[b] + sd);
+            y[b] = yb;
+        }
+
+        // ---- append the draw to the chain's own training set (A.9) ----------------------------------------
+        if (recond && t + 1 < H) {
+            double C[T][T], wn[T];
+            bool ok = true;
+            if (Th == T) {
+                double Sn[T][T];
+#pragma unroll
+                for (int b = 0; b < T; ++b)
+#pragma unroll
+                    for (int c = 0; c < T; ++c) Sn[b][c] = S[b][c] + ((b == c) ? gp.noise[b] : 0.0);
+                ok = chol_small<T>(Sn, C);
+#pragma unroll
+                for (int b = 0; b < T; ++b) {
+                    double acc = y[b] - mu[b];
+#pragma unroll
+                    for (int c = 0; c < b; ++c) acc -= C[b][c] * wn[c];
+                    wn[b] = acc / C[b][b];
+                }
+            } else {   // value-only label at the appended point (reference src/agent.py:402)
+                const double d0 = S[0][0] + gp.noise[0];
+                ok = (d0 > 0.0);
+                C[0][0] = sqrt(d0);
+                wn[0] = (y[0] - mu[0]) / C[0][0];
+            }
+            if (!ok) info_acc |= GPMPC_INFO_TRAIN_CHOL_FAIL;
+            const int base = n_h;
+            for (int i = lane; i < n_r; i += kWave)
+                for (int c = 0; c < Th; ++c) LhrT[(long)i * nh_max + base + c] = vr[c * n_r + i];
+#pragma unroll
+            for (int r = 0; r < RPL; ++r) {
+                const int slot = lane + kWave * r;
+                if (slot < n_h) {
+                    const long co = col_ofs(slot, nh_max) - slot;
+#pragma unroll
+                    for (int c = 0; c < T; ++c)
+                        if (c < Th) Lhh[co + base + c] = rhs[r][c];
+                }
+            }
+            if (lane == 0) {
+#pragma unroll
+                for (int c = 0; c < T; ++c) {
+                    if (c < Th) {
+#pragma unroll
+                        for (int e = 0; e < T; ++e)
+                            if (e <= c) Lhh[col_ofs(base + e, nh_max) + (c - e)] = C[c][e];
+                        invd[base + c] = 1.0 / C[c][c];
+                        wh[base + c] = wn[c];
+                    }
+                }
+            }
+            n_h += Th;
+        }
+
+        // ---- hand the value samples of all outputs to every chain, advance the state ----------------------
+        double* yb_t = ybuf + (t & 1) * GPMPC_MAX_NY;
+        if (lane == 0) {
+            yb_t[o] = y[0];
+#pragma unroll
+            for (int b = 0; b < T; ++b) yout[t * T + b] = y[b];
+        }
+        __syncthreads();
+        double g[GPMPC_MAX_NY], xn[GPMPC_MAX_NX];
+        for (int oo = 0; oo < gp.g_ny; ++oo) g[oo] = yb_t[oo];
+        env_step(env, x, u, g, xn);
+        for (int d = 0; d < nx; ++d) x[d] = xn[d];
+    }
+
+    if (threadIdx.x == 0)
+        for (int d = 0; d < nx; ++d) xbuf[d * (H + 1) + H] = x[d];
+    if (info_acc) atomicOr(&s_info, info_acc);
+    __syncthreads();
+    for (int e = threadIdx.x; e < nx * (H + 1); e += blockDim.x) a.X_traj[s * nx * (H + 1) + e] = xbuf[e];
+    if (a.Y)
+        for (int e = lane; e < H * T; e += kWave) a.Y[(s * gp.g_ny + o) * H * T + e] = yout[e];
+    if (a.Xi)
+        for (int e = threadIdx.x; e < H * D; e += blockDim.x) a.Xi[s * H * D + e] = Xh[e];
+    if (threadIdx.x == 0) a.info[s] = s_info;
+}
+
+struct RolloutPlan {
+    int nh_max, rpl, lds_shared, lds_per_wave;
+    long chain_doubles;
+    bool fac_lds;
+    size_t lds_bytes;
+};
+
+static bool force_global_factor() {
+    const char* e = std::getenv("GPMPC_FORCE_GLOBAL_FACTOR");
+    return e && e[0] == '1';
+}
+
+static int plan_rollout(const gpmpc_gp_desc_t* gp, int nx, int mode, int hall_tasks, int H, RolloutPlan* rp) {
+    const int n_r = observed_real_slots(gp);
+    const int T = gp->T;
+    int nh_max = (mode == GPMPC_MODE_RECONDITIONED) ? hall_tasks * (H - 1) : 0;
+    if (nh_max < 1) nh_max = 1;
+    rp->nh_max = nh_max;
+    rp->rpl = (nh_max + 63) / 64;
+    if (rp->rpl > 4) return fail(GPMPC_E_UNSUPPORTED, "rollout: more than 256 hallucinated label slots per chain");
+    if (rp->rpl == 3) rp->rpl = 4;
+    rp->chain_doubles = (long)n_r * nh_max + ((long)nh_max * (nh_max + 1)) / 2;
+    rp->lds_shared = nx * (H + 1) + H * gp->D + 2 * GPMPC_MAX_NY;
+    rp->lds_shared = (rp->lds_shared + 1) & ~1;
+    const int vec = 2 * T * n_r + 2 * nh_max + H * T;
+    const long with_fac = vec + rp->chain_doubles;
+    const size_t bytes_fac = ((size_t)rp->lds_shared + (size_t)gp->g_ny * ((with_fac + 1) & ~1L)) * sizeof(double);
+    rp->fac_lds = (mode == GPMPC_MODE_RECONDITIONED) && bytes_fac <= (size_t)(160 * 1024 - 256) && !force_global_factor();
+    rp->lds_per_wave = (int)(((rp->fac_lds ? with_fac : (long)vec) + 1) & ~1L);
+    rp->lds_bytes = ((size_t)rp->lds_shared + (size_t)gp->g_ny * rp->lds_per_wave) * sizeof(double);
+    if (rp->lds_bytes > (size_t)(160 * 1024 - 256)) return fail(GPMPC_E_UNSUPPORTED, "rollout: horizon too long for LDS vectors");
+    return GPMPC_OK;
+}
+
+template <int T, int RPL>
+static int launch_rollout(const RolloutArgs& args, const RolloutPlan& rp, int g_ny, hipStream_t stream) {
+    const dim3 grid((unsigned)args.Ns), block(64 * g_ny);
+    if (rp.fac_lds) {
+        auto k = rollout_kernel<T, RPL, true>;
+        GPMPC_HIP_CHECK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)rp.lds_bytes));
+        hipLaunchKernelGGL(k, grid, block, rp.lds_bytes, stream, args);
+    } else {
+        auto k = rollout_kernel<T, RPL, false>;
+        GPMPC_HIP_CHECK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)rp.lds_bytes));
+        hipLaunchKernelGGL(k, grid, block, rp.lds_bytes, stream, args);
+    }
+    GPMPC_HIP_CHECK(hipGetLastError());
+    return GPMPC_OK;
+}
+
+}  // namespace gpmpc
+
+using namespace gpmpc;
+
+extern "C" {
+
+size_t gpmpc_rollout_workspace_bytes(const gpmpc_gp_desc_t* gp, int32_t mode, int32_t hall_tasks, int64_t Ns,
+                                     int32_t H) {
+    if (check_gp(gp) != GPMPC_OK) return 0;
+    RolloutPlan rp;
+    if (plan_rollout(gp, GPMPC_MAX_NX, mode, hall_tasks, H, &rp) != GPMPC_OK) return 0;
+    if (mode != GPMPC_MODE_RECONDITIONED) return 256;
+    return align_up((size_t)Ns * gp->g_ny * rp.chain_doubles * sizeof(double), 256) + 256;
+}
+
+int gpmpc_rollout(const gpmpc_gp_desc_t* gp, const gpmpc_env_desc_t* env, const void* plan, const double* X_r,
+                  int32_t mode, int32_t hall_tasks, double var_zero_thr, double beta, int64_t Ns, int32_t H,
+                  const double* x0, int32_t x0_per_sample, const double* u_ff, const double* z,
+                  int64_t z_step_stride, double* X_traj, double* Y, double* Xi, int32_t* info, void* ws,
+                  size_t ws_bytes, void* stream) {
+    if (int rc = check_gp(gp)) return rc;
+    if (int rc = check_env(gp, env)) return rc;
+    if (!plan || !X_r || !x0 || !u_ff || !z || !X_traj || !info) return fail(GPMPC_E_ARG, "gpmpc_rollout: NULL pointer");
+    if (Ns < 1 || H < 1) return fail(GPMPC_E_ARG, "gpmpc_rollout: Ns and H must be >= 1");
+    if (mode != GPMPC_MODE_INDEPENDENT && mode != GPMPC_MODE_RECONDITIONED) return fail(GPMPC_E_ARG, "bad mode");
+    if (mode == GPMPC_MODE_RECONDITIONED && !(hall_tasks == gp->T || hall_tasks == 1))
+        return fail(GPMPC_E_ARG, "hall_tasks must be T or 1");
+    if (mode == GPMPC_MODE_INDEPENDENT) hall_tasks = gp->T;
+    RolloutPlan rp;
+    if (int rc = plan_rollout(gp, env->nx, mode, hall_tasks, H, &rp)) return rc;
+
+    RolloutArgs args;
+    args.gp = make_gp_params(gp);
+    args.env = make_env_params(env);
+    args.plan = (const double*)plan;
+    args.X_r = X_r;
+    args.mode = mode;
+    args.hall_tasks = hall_tasks;
+    args.var_zero_thr = var_zero_thr;
+    args.beta = beta;
+    args.Ns = Ns;
+    args.H = H;
+    args.x0 = x0;
+    args.x0_per_sample = x0_per_sample;
+    args.u_ff = u_ff;
+    args.z = z;
+    args.z_step_stride = z_step_stride;
+    args.X_traj = X_traj;
+    args.Y = Y;
+    args.Xi = Xi;
+    args.info = (int*)info;
+    args.ws = (double*)ws;
+    args.ws_chain_stride = rp.chain_doubles;
+    args.nh_max = rp.nh_max;
+    args.lds_shared = rp.lds_shared;
+    args.lds_per_wave = rp.lds_per_wave;
+    if (mode == GPMPC_MODE_RECONDITIONED && !rp.fac_lds) {
+        const size_t need = (size_t)Ns * gp->g_ny * rp.chain_doubles * sizeof(double);
+        if (!ws || ws_bytes < need) return fail(GPMPC_E_WORKSPACE, "gpmpc_rollout: workspace too small");
+    }
+    hipStream_t st = (hipStream_t)stream;
+    const int T = gp->T;
+    if (T == 1) {
+        if (rp.rpl == 1) return launch_rollout<1, 1>(args, rp, gp->g_ny, st);
+        if (rp.rpl == 2) return launch_rollout<1, 2>(args, rp, gp->g_ny, st);
+        return launch_rollout<1, 4>(args, rp, gp->g_ny, st);
+    } else if (T == 3) {
+        if (rp.rpl == 1) return launch_rollout<3, 1>(args, rp, gp->g_ny, st);
+        if (rp.rpl == 2) return launch_rollout<3, 2>(args, rp, gp->g_ny, st);
+        return launch_rollout<3, 4>(args, rp, gp->g_ny, st);
+    }
+    return fail(GPMPC_E_UNSUPPORTED, "rollout: only T = 1 and T = 3 (D = 2) are instantiated");
+}
+
+}  // extern "C"

@@ -1,0 +1,269 @@
+"""``model_i``: the batched exact GP of the reference, backed by the HIP kernels.
+
+Mirrors the surface reference callers use on ``BatchMultitaskGPModelWithDerivatives_fromParams``
+(reference ``src/GP_model.py:94-143``) and on the object ``model_i(x)`` returns:
+
+* ``model_i.train_inputs[0]`` / ``model_i.train_targets`` / ``model_i.batch_shape`` / ``model_i.eval()``
+  (reference ``src/visu.py:483-484``, ``benchmarking/simulate_true_reachable_set.py:183``,
+  ``benchmarking/robust_tube_based_GPMPC_koller.py:184-191``)
+* ``model_i(x)`` -> ``.mean``, ``.variance``, ``.sample(base_samples)``, ``.confidence_region()``
+  (reference ``src/agent.py:640-641,648,701-706``, ``src/solver.py:254-259``)
+
+Differences by design: the real data are NOT tiled ``Ns`` times (they are shared by every sample; the tiled view
+is materialised only if somebody reads ``train_inputs``), nothing is autograd-capable, and the arithmetic runs in
+``libgpmpc_hip.so`` (``gpmpc_plan_build`` + ``gpmpc_joint_sample``).  No gpytorch, no CPU fallback.
+"""
+from __future__ import annotations
+
+import warnings
+from dataclasses import dataclass
+from typing import Optional
+
+import torch
+
+from . import _lib
+
+F64 = torch.float64
+
+
+class NumericalWarning(RuntimeWarning):
+    """Same role as gpytorch.utils.warnings.NumericalWarning (jitter added / variance clamped)."""
+
+
+class NotPSDError(RuntimeError):
+    """Factorisation of the training covariance failed (gpytorch raises NotPSDError after its jitter retries)."""
+
+
+@dataclass
+class GPHyperParams:
+    """Hyper-parameters injected from the YAML exactly as reference ``src/GP_model.py:121-143`` does."""
+    g_ny: int
+    D: int
+    T: int
+    ell: list            # [g_ny][D]   agent.Dyn_gp_lengthscale.both
+    outputscale: list    # [g_ny]      agent.Dyn_gp_outputscale.both
+    noise: list          # [T]         task_noises.val * multiplier + Dyn_gp_noise
+    jitter: float        # agent.Dyn_gp_jitter
+    use_grad: bool
+
+    @staticmethod
+    def from_params(params: dict, use_grad: bool) -> "GPHyperParams":
+        ag = params["agent"]
+        g_ny = ag["g_dim"]["ny"]
+        D = ag["g_dim"]["nx"] + ag["g_dim"]["nu"]
+        ell = torch.tensor(ag["Dyn_gp_lengthscale"]["both"], dtype=F64).reshape(g_ny, D).tolist()
+        osc = torch.tensor(ag["Dyn_gp_outputscale"]["both"], dtype=F64).reshape(g_ny).tolist()
+        vals = ag["Dyn_gp_task_noises"]["val"] if use_grad else [ag["Dyn_gp_task_noises"]["val"][0]]
+        noise = [v * ag["Dyn_gp_task_noises"]["multiplier"] + ag["Dyn_gp_noise"] for v in vals]
+        T = 1 + D if use_grad else 1
+        return GPHyperParams(g_ny, D, T, ell, osc, noise, float(ag["Dyn_gp_jitter"]), use_grad)
+
+
+class RealDataPlan:
+    """The shared real-data block, factorised once on the device (``gpmpc_plan_build``)."""
+
+    def __init__(self, X_r: torch.Tensor, Y_r: torch.Tensor, hyper: GPHyperParams):
+        dev = _lib.require_hip_device(X_r.device)
+        lib = _lib.load()
+        self.hyper = hyper
+        self.X_r = X_r.to(dtype=F64).contiguous()                 # (N_r, D)
+        self.Y_r = Y_r.to(dtype=F64).contiguous()                 # (g_ny, N_r, T)
+        N_r = self.X_r.shape[0]
+        nan = torch.isnan(self.Y_r)
+        if hyper.T == 1:
+            has_grad = False
+            if bool(nan.any()):
+                raise NotImplementedError("NaN value labels in the real data are not supported")
+        else:
+            grad_nan = nan[:, :, 1:]
+            if bool(nan[:, :, 0].any()) or not (bool(grad_nan.all()) or not bool(grad_nan.any())):
+                raise NotImplementedError("real-data label mask must be 'value only' or 'all tasks' (uniform)")
+            has_grad = not bool(grad_nan.any())
+        self.real_has_grad = has_grad
+        self.desc = _lib.make_gp_desc(hyper.g_ny, hyper.D, hyper.T, N_r, has_grad, hyper.ell, hyper.outputscale,
+                                      hyper.noise, hyper.jitter)
+        nbytes = lib.gpmpc_plan_bytes(self.desc)
+        if nbytes == 0:
+            _lib.check(-1, "gpmpc_plan_bytes")
+        self.buf = torch.empty(nbytes // 8, dtype=F64, device=dev)
+        info = torch.zeros(hyper.g_ny, dtype=torch.int32, device=dev)
+        _lib.check(lib.gpmpc_plan_build(self.desc, _lib.dptr(self.X_r), _lib.dptr(self.Y_r), _lib.dptr(self.buf),
+                                        _lib.dptr(info), _lib.current_stream_ptr()), "gpmpc_plan_build")
+        if int(info.max().item()) != 0:
+            raise NotPSDError("Cholesky of the real-data covariance K_rr + Sigma failed")
+        self.n_r = N_r * hyper.T if has_grad else N_r
+
+
+class HipPosterior:
+    """What ``model_i(x)`` returns: a lazily evaluated joint posterior at the ``m`` test points of every chain."""
+
+    def __init__(self, model: "HipGPModel", x: torch.Tensor):
+        self._model = model
+        self._x = x.to(dtype=F64).contiguous()
+        assert self._x.dim() == 4 and tuple(self._x.shape[:2]) == tuple(model.batch_shape)
+        self._mean = self._var = self._covar = None
+        self.last_info = None
+
+    # -- one kernel launch ----------------------------------------------------------------------------------
+    def _run(self, z: Optional[torch.Tensor], clip: bool, beta: float = 0.0, var_zero_thr: float = -1.0,
+             want_covar: bool = False):
+        mdl = self._model
+        lib = _lib.load()
+        hy = mdl.hyper
+        Ns, g_ny, m, _ = self._x.shape
+        dev = self._x.device
+        shape = (Ns, g_ny, m, hy.T)
+        if z is None:
+            z = torch.zeros(shape, dtype=F64, device=dev)
+        z = z.to(device=dev, dtype=F64).contiguous()
+        if tuple(z.shape) != shape:
+            raise RuntimeError(f"base_samples shape {tuple(z.shape)} does not match the mean shape {shape}")
+        mean, var, y = (torch.empty(shape, dtype=F64, device=dev) for _ in range(3))
+        covar = torch.empty((Ns, g_ny, m * hy.T, m * hy.T), dtype=F64, device=dev) if want_covar else None
+        info = torch.zeros((Ns, g_ny), dtype=torch.int32, device=dev)
+        n_ho = int(mdl.h_slots.numel())
+        ws_bytes = lib.gpmpc_joint_workspace_bytes(mdl.plan.desc, Ns, n_ho, m)
+        ws = mdl._workspace(ws_bytes)
+        rc = lib.gpmpc_joint_sample(
+            mdl.plan.desc, _lib.dptr(mdl.plan.buf), _lib.dptr(mdl.plan.X_r), Ns, mdl.n_h,
+            _lib.dptr(mdl.hall_X) if mdl.n_h else None, _lib.dptr(mdl.hall_Y) if mdl.n_h else None,
+            _lib.dptr(mdl.h_slots) if n_ho else None, n_ho, m, _lib.dptr(self._x), _lib.dptr(z),
+            float(var_zero_thr), float(beta), int(bool(clip)), _lib.dptr(mean), _lib.dptr(var), _lib.dptr(y),
+            _lib.dptr(covar), _lib.dptr(info), _lib.dptr(ws), ws.numel() * 8, _lib.current_stream_ptr())
+        _lib.check(rc, "gpmpc_joint_sample")
+        self._mean, self._var = mean, var
+        if want_covar:
+            self._covar = covar
+        bits = _or_reduce(info)
+        self.last_info = info
+        if bits & _lib.INFO_TRAIN_CHOL_FAIL:
+            raise NotPSDError("Cholesky of the training covariance (real + hallucinated data) failed")
+        if bits & _lib.INFO_VAR_CLAMPED:
+            warnings.warn("Negative variance values detected; rounding them up to 1e-10.", NumericalWarning)
+        if bits & _lib.INFO_ROOT_JITTER_MASK:
+            warnings.warn(f"posterior covariance not p.d. - added jitter of up to "
+                          f"{hy.jitter * 10 ** (((bits & _lib.INFO_ROOT_JITTER_MASK) >> 1) - 1):.1e} to the diagonal",
+                          NumericalWarning)
+        return y, bits
+
+    # -- distribution surface -----------------------------------------------------------------------------------
+    @property
+    def mean(self) -> torch.Tensor:
+        if self._mean is None:
+            self._run(None, clip=False)
+        return self._mean
+
+    @property
+    def variance(self) -> torch.Tensor:
+        if self._var is None:
+            self._run(None, clip=False)
+        return self._var
+
+    @property
+    def stddev(self) -> torch.Tensor:
+        return self.variance.sqrt()
+
+    @property
+    def covariance_matrix(self) -> torch.Tensor:
+        if self._covar is None:
+            self._run(None, clip=False, want_covar=True)
+        return self._covar
+
+    def confidence_region(self):
+        s2 = self.stddev * 2
+        return self.mean - s2, self.mean + s2
+
+    def sample(self, base_samples: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """``y = mean + R z``.  ``base_samples`` has the mean's shape ``(Ns, g_ny, m, T)``;
+        None draws z internally like gpytorch does (``randn``, device generator)."""
+        return self._sample(base_samples, clip=False)
+
+    def _sample(self, base_samples, clip, beta=0.0, var_zero_thr=-1.0):
+        Ns, g_ny, m, _ = self._x.shape
+        T = self._model.hyper.T
+        if base_samples is None:
+            base_samples = torch.randn(Ns, g_ny, m, T, dtype=F64, device=self._x.device)
+        y, bits = self._run(base_samples, clip, beta, var_zero_thr)
+        if bits & _lib.INFO_ROOT_FAIL:
+            # gpytorch: NotPSDError inside root_decomposition -> eigh root for the WHOLE batch (A.7 step 4).
+            # Off the default path; uses the device eigensolver (rocSOLVER via torch.linalg.eigh).
+            warnings.warn("Cholesky of the posterior covariance failed after 3 jitter retries; using the "
+                          "eigendecomposition root for the whole batch", NumericalWarning)
+            S = self.covariance_matrix
+            evals, evecs = torch.linalg.eigh(S)
+            R = evecs * evals.clamp_min(0.0).sqrt().unsqueeze(-2)
+            z = base_samples.to(device=S.device, dtype=F64).reshape(Ns, g_ny, m * T, 1)
+            y = ((R @ z).squeeze(-1) + self._mean.reshape(Ns, g_ny, m * T)).reshape(Ns, g_ny, m, T)
+            if var_zero_thr >= 0.0:
+                zero = torch.all(self._var <= var_zero_thr, dim=-1, keepdim=True)
+                y = torch.where(zero, self._mean, y)
+            if clip:
+                sd = beta * torch.sqrt(self._var)
+                y = torch.min(torch.max(y, self._mean - sd), self._mean + sd)
+        return y
+
+
+def _or_reduce(info: torch.Tensor) -> int:
+    """bitwise OR over an int32 tensor (tiny; one device->host sync)."""
+    if info.numel() == 0:
+        return 0
+    v = info.flatten()
+    # OR == max per bit: one small reduction per flag bit, a single transfer
+    packed = torch.stack([(v & b).max() for b in (0x1, 0x2, 0x4, 0x8, 0x10, 0x20, 0x40)])
+    bits = 0
+    for x in packed.tolist():
+        bits |= int(x)
+    return bits
+
+
+class HipGPModel:
+    """Conditioning set = shared real data (factorised plan) + per-sample hallucinated data."""
+
+    def __init__(self, plan: RealDataPlan, hall_X: torch.Tensor, hall_Y: torch.Tensor, batch_shape,
+                 ws_cache: Optional[dict] = None):
+        self.plan = plan
+        self.hyper = plan.hyper
+        self.batch_shape = torch.Size(batch_shape)
+        Ns, g_ny = self.batch_shape
+        dev = plan.X_r.device
+        self.hall_X = hall_X.to(device=dev, dtype=F64).contiguous()      # (Ns, g_ny, n_h, D)
+        self.hall_Y = hall_Y.to(device=dev, dtype=F64).contiguous()      # (Ns, g_ny, n_h, T)
+        self.n_h = int(self.hall_X.shape[2])
+        assert tuple(self.hall_X.shape[:2]) == (Ns, g_ny) and self.hall_Y.shape[-1] == self.hyper.T
+        if self.n_h:
+            # gpytorch "mask" policy: a label slot that is NaN in ANY batch element is dropped for the whole batch
+            nan_any = torch.isnan(self.hall_Y).reshape(Ns * g_ny, self.n_h * self.hyper.T).any(dim=0)
+            self.h_slots = torch.nonzero(~nan_any).flatten().to(torch.int32).contiguous()
+        else:
+            self.h_slots = torch.empty(0, dtype=torch.int32, device=dev)
+        self._ws_cache = ws_cache if ws_cache is not None else {}
+        self.use_grad = self.hyper.use_grad
+
+    def _workspace(self, nbytes: int) -> torch.Tensor:
+        buf = self._ws_cache.get("joint")
+        if buf is None or buf.numel() * 8 < nbytes:
+            buf = torch.empty((nbytes + 7) // 8, dtype=F64, device=self.plan.X_r.device)
+            self._ws_cache["joint"] = buf
+        return buf
+
+    # -- reference attribute surface ---------------------------------------------------------------------------
+    @property
+    def train_inputs(self):
+        Ns, g_ny = self.batch_shape
+        Xr = self.plan.X_r.reshape(1, 1, *self.plan.X_r.shape).expand(Ns, g_ny, -1, -1)
+        return (torch.cat([Xr, self.hall_X], dim=2),)
+
+    @property
+    def train_targets(self):
+        Ns, _ = self.batch_shape
+        Yr = self.plan.Y_r.unsqueeze(0).expand(Ns, -1, -1, -1)
+        return torch.cat([Yr, self.hall_Y], dim=2)
+
+    def eval(self):
+        return self
+
+    def cuda(self):
+        return self
+
+    def __call__(self, x: torch.Tensor) -> HipPosterior:
+        return HipPosterior(self, x.to(self.plan.X_r.device))

@@ -1,0 +1,144 @@
+"""Whole-horizon rollouts of the sampled dynamics in one kernel launch (``gpmpc_rollout``).
+
+Drivers with the loop structure of the reference's harnesses:
+
+* ``forward_sampling_rollout``  - reference ``benchmarking/simulate_forward_sampling_car.py:108-138``
+  (mode "I" when ``env.use_model_without_derivatives`` is True as shipped, mode "R" otherwise);
+* ``true_reachable_set_rollout`` - the sampling loop of reference ``benchmarking/simulate_true_reachable_set.py:
+  179-258`` for the residual environments (open-loop inputs, internally drawn base samples, variance-is-zero
+  replacement), expressed on the same kernel.
+
+Both return ``X_traj (Ns, nx, H+1)`` float64 - the array the reference pickles (``data_X_traj_<idx>.pkl``).
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import numpy as np
+import torch
+
+from . import _lib
+from .agent import Agent
+
+F64 = torch.float64
+
+
+class RolloutResult:
+    def __init__(self, X_traj, Y, Xi, info):
+        self.X_traj, self.Y, self.Xi, self.info = X_traj, Y, Xi, info
+
+
+def rollout_device(agent: Agent, u_ff, z: torch.Tensor, z_step_stride: int, *, H: int, mode: int,
+                   use_model_without_derivatives: bool, use_feedback: Optional[bool] = None,
+                   x0=None, hall_tasks: Optional[int] = None, var_zero_thr: Optional[float] = None,
+                   beta: Optional[float] = None, want_samples: bool = True, sample_slice=None) -> RolloutResult:
+    """Launch ``gpmpc_rollout`` for the samples of ``agent`` (or a contiguous ``sample_slice`` of them) and return
+    device tensors.  ``z`` element (t, s, o, b) is read at ``z[t*z_step_stride + ((s*g_ny)+o)*T + b]``."""
+    lib = _lib.load()
+    dev = _lib.require_hip_device(agent.torch_device)
+    p = agent.params
+    plan = agent._plan(use_grad=not use_model_without_derivatives)
+    T = plan.hyper.T
+    lo, hi = (0, agent.ns) if sample_slice is None else sample_slice
+    Ns = hi - lo
+    nx, g_ny, D = agent.nx, agent.g_ny, agent.in_dim_x
+    u_ff_d = torch.as_tensor(np.asarray(u_ff), dtype=F64).reshape(H, agent.nu).to(dev).contiguous()
+    if x0 is None:
+        x0_d = torch.as_tensor(np.asarray(p["env"]["start"], dtype=np.float64)[:nx]).to(dev).contiguous()
+        per_sample = 0
+    else:
+        x0_d = torch.as_tensor(x0, dtype=F64).to(dev).contiguous()
+        per_sample = int(x0_d.dim() == 2)
+        if per_sample:
+            x0_d = x0_d[lo:hi].contiguous()
+    if hall_tasks is None:
+        hall_tasks = T
+    if var_zero_thr is None:
+        var_zero_thr = p["agent"]["Dyn_gp_variance_is_zero"]
+    if beta is None:
+        beta = p["agent"]["Dyn_gp_beta"]
+    X_traj = torch.empty(Ns, nx, H + 1, dtype=F64, device=dev)
+    Y = torch.empty(Ns, g_ny, H, T, dtype=F64, device=dev) if want_samples else None
+    Xi = torch.empty(Ns, H, D, dtype=F64, device=dev) if want_samples else None
+    info = torch.zeros(Ns, dtype=torch.int32, device=dev)
+    ws_bytes = lib.gpmpc_rollout_workspace_bytes(plan.desc, mode, hall_tasks, Ns, H)
+    ws = agent._ws_cache.get("rollout")
+    if ws is None or ws.numel() * 8 < ws_bytes:
+        ws = torch.empty((ws_bytes + 7) // 8, dtype=F64, device=dev)
+        agent._ws_cache["rollout"] = ws
+    assert z.is_cuda and z.dtype == F64
+    z_ptr = z.data_ptr() + 8 * lo * g_ny * T
+    rc = lib.gpmpc_rollout(plan.desc, agent.env_desc(use_feedback), _lib.dptr(plan.buf), _lib.dptr(plan.X_r),
+                           mode, hall_tasks, float(var_zero_thr), float(beta), Ns, H,
+                           _lib.dptr(x0_d), per_sample, _lib.dptr(u_ff_d), z_ptr, int(z_step_stride),
+                           _lib.dptr(X_traj), _lib.dptr(Y), _lib.dptr(Xi), _lib.dptr(info),
+                           _lib.dptr(ws), ws.numel() * 8, _lib.current_stream_ptr())
+    _lib.check(rc, "gpmpc_rollout")
+    return RolloutResult(X_traj, Y, Xi, info)
+
+
+def forward_sampling_rollout(agent: Agent, u_ff, x0=None, return_samples: bool = False, check: bool = True):
+    """The reference forward-sampling loop, one launch.
+
+    ``agent.epistimic_random_vector`` must have the layout the reference script relies on: ``optimizer.H == 1``,
+    ``num_MPC_itrs >= H_traj``, ``max_sqp_iter >= 2``; step ``t`` uses the slab ``[t][1]``.
+    Side effect (as in the reference): ``agent.Hallcinated_{X,Y}_train`` end up holding the H appended points.
+    """
+    p = agent.params
+    u_ff = np.asarray(u_ff, dtype=np.float64)
+    H = u_ff.shape[0]
+    erv = agent.epistimic_random_vector
+    if p["optimizer"]["H"] != 1 or erv.shape[0] < H or erv.shape[1] < 2:
+        raise ValueError("forward sampling needs optimizer.H == 1, num_MPC_itrs >= H_traj and max_sqp_iter >= 2 "
+                         "(reference simulate_forward_sampling_car.py indexes epistimic_random_vector[H_idx][1])")
+    nograd = bool(p["env"]["use_model_without_derivatives"])
+    mode = _lib.MODE_INDEPENDENT if nograd else _lib.MODE_RECONDITIONED
+    T = 1 if nograd else 1 + agent.in_dim_x
+    erv = erv.to(device=agent.torch_device, dtype=F64).contiguous()
+    n_itrs = erv.shape[1]
+    per_slab = agent.ns * agent.g_ny * 1 * T
+    z = erv.reshape(-1)[per_slab:]                       # starts at [0][1]
+    res = rollout_device(agent, u_ff, z, n_itrs * per_slab, H=H, mode=mode,
+                         use_model_without_derivatives=nograd, x0=x0)
+    if check:
+        _raise_on_info(res.info)
+    # dataset side effect of the reference loop (appended at every step, also in mode I where it is never used)
+    agent.Hallcinated_X_train = torch.cat(
+        [agent.Hallcinated_X_train, res.Xi.unsqueeze(1).expand(-1, agent.g_ny, -1, -1)], dim=2)
+    agent.Hallcinated_Y_train = torch.cat([agent.Hallcinated_Y_train, res.Y], dim=2)
+    agent.model_i_samples = res.Y[:, :, [H - 1], :]
+    X = res.X_traj.cpu().numpy()
+    if return_samples:
+        return X, res.Y.cpu().numpy()
+    return X
+
+
+def true_reachable_set_rollout(agent: Agent, u_seq, z: Optional[torch.Tensor] = None, x0=None,
+                               return_samples: bool = False):
+    """Sequential re-conditioned rollout with open-loop inputs and internally drawn base samples
+    (reference ``simulate_true_reachable_set.py:179-258``: ``.sample()`` without base samples, variance-is-zero
+    replacement, beta clip, conditioning on the sampled values, state hand-over)."""
+    u_seq = np.asarray(u_seq, dtype=np.float64)
+    H = u_seq.shape[0]
+    T = 1 + agent.in_dim_x
+    dev = _lib.require_hip_device(agent.torch_device)
+    if z is None:
+        z = torch.randn(H, agent.ns, agent.g_ny, T, dtype=F64, device=dev)
+    z = z.to(device=dev, dtype=F64).contiguous()
+    res = rollout_device(agent, u_seq, z.reshape(-1), agent.ns * agent.g_ny * T, H=H,
+                         mode=_lib.MODE_RECONDITIONED, use_model_without_derivatives=False, use_feedback=False, x0=x0)
+    _raise_on_info(res.info)
+    X = res.X_traj.cpu().numpy()
+    if return_samples:
+        return X, res.Y.cpu().numpy()
+    return X
+
+
+def _raise_on_info(info: torch.Tensor):
+    from .gp_model import NotPSDError, _or_reduce
+    bits = _or_reduce(info)
+    if bits & _lib.INFO_TRAIN_CHOL_FAIL:
+        raise NotPSDError("rollout: Cholesky of a chain's training covariance failed")
+    if bits & _lib.INFO_ROOT_FAIL:
+        raise NotPSDError("rollout: posterior root failed after 3 jitter retries (eigh fallback is only "
+                          "available through Agent.sample_gp)")
