@@ -1,0 +1,181 @@
+#!/usr/bin/env python3
+"""bench.py - sampled trajectory-steps/sec of the GP-posterior-sample rollout on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+A "step" is one pass of the hot path over one batch: the full H-step re-conditioned rollout of the rank's Ns sampled
+dynamics functions (one gpmpc_rollout launch) plus, for N > 1, the RCCL all-gather that assembles the reachable tube
+X_traj (N*Ns, nx, H+1) on every rank.  Workload at every N: BASELINE.json configs[1] per GPU - pendulum1D
+(params_pendulum1D_samples), Ns = 1024 samples per GPU, H = 30, sequential re-conditioned rollout (mode R, T = 3
+value+gradient labels) - i.e. weak scaling over samples.  Inputs (training grid, base samples z, input sequence)
+are synthetic and resident in HBM before the timed region.
+
+Prints ONE JSON line on rank 0 (see the keys below).  `roofline` is for the dominant kernel (rollout_kernel):
+algorithmic FP64 FLOP per launch (2.55e4 FLOP per trajectory-step for this config) divided by
+the launch duration measured with HIP events on the launch stream.  `cpu_baseline` times the CPU oracle (the
+reference-faithful from-scratch algorithm, torch CPU FP64) on rank 0 at N = 1 on a bounded sample of the same
+workload.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+import numpy as np
+import torch
+
+FLOP_PER_TRAJ_STEP = {"pendulum1D_R_H30": 2.55e4}     # SURVEY.md section 8(d), append-row algorithm
+MIN_HBM_BYTES_PER_TRAJ_STEP = {"pendulum1D_R_H30": 80}
+FP64_PEAK_TFLOPS = 78.6                                # MI355X FP64 vector == matrix peak (vendor figure)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--ns", type=int, default=1024, help="samples per GPU (BASELINE configs[1]: 1024)")
+    ap.add_argument("--horizon", type=int, default=30)
+    ap.add_argument("--cpu-sample", type=int, default=256, help="samples of the CPU-oracle baseline (0 = skip)")
+    return ap.parse_args()
+
+
+def cpu_baseline(Ns_cpu, H, u_ff):
+    """Time the oracle (reference-faithful: Ns-tiled real data, dense kernel rebuild, from-scratch Cholesky per step)."""
+    from oracle import agent_oracle as ao
+    from tests.helpers import fs_params
+    import sampling_gpmpc_amd as sg
+    p = fs_params("params_pendulum1D_samples", Ns_cpu, H)
+    p["agent"]["base_sample_generator"] = "vectorized"
+    torch.manual_seed(99)
+    erv = sg.random_vector_within_bounds(p, 1, 3)
+    agent = ao.OracleAgent(p, ao.make_oracle_env(p), erv)
+    t0 = time.perf_counter()
+    X = ao.forward_sampling_rollout(agent, u_ff)
+    dt = time.perf_counter() - t0
+    assert np.isfinite(X).all()
+    return Ns_cpu * H / dt, dt
+
+
+def main():
+    a = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if a.gpus != world:
+        if world == 1 and a.gpus > 1:
+            raise SystemExit("launch N > 1 with torch.distributed.run (one process per GPU)")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device (no CPU fallback for the product path)")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_
+        dist = dist_
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    import sampling_gpmpc_amd as sg
+    from sampling_gpmpc_amd import _lib
+    from sampling_gpmpc_amd.rollout import RolloutRunner
+    from tests.helpers import fs_params, synthetic_u_ff
+
+    Ns, H = a.ns, a.horizon
+    p = fs_params("params_pendulum1D_samples", Ns, H)
+    p["common"]["use_cuda"] = True
+    p["agent"]["base_sample_generator"] = "vectorized"
+    torch.manual_seed(123456 + rank)            # every rank owns different samples (global sample id = rank*Ns + s)
+    agent = sg.Agent(p, sg.make_env(p))
+    u_ff = synthetic_u_ff(1, H)
+    erv = agent.epistimic_random_vector         # (H, 2, Ns, 1, 1, 3) on the device
+    per_slab = Ns * 3
+    z = erv.reshape(-1)[per_slab:]
+    runner = RolloutRunner(agent, u_ff, z, erv.shape[1] * per_slab, H, _lib.MODE_RECONDITIONED, False)
+    tube = torch.empty(world * Ns, agent.nx, H + 1, dtype=torch.float64, device="cuda") if world > 1 else None
+
+    def step():
+        X = runner.launch()
+        if world > 1:
+            dist.all_gather_into_tensor(tube, X)
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        step()
+    fence()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(a.steps)]
+    t0 = time.perf_counter()
+    for k in range(a.steps):
+        ev[k][0].record()
+        X = runner.launch()
+        ev[k][1].record()
+        if world > 1:
+            dist.all_gather_into_tensor(tube, X)
+    fence()
+    wall = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([wall], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        wall = float(t.item())
+    kern_ms = float(np.mean([s.elapsed_time(e) for s, e in ev]))
+    bits = int(runner.info.max().item())
+    assert torch.isfinite(runner.X_traj).all() and not (bits & (_lib.INFO_TRAIN_CHOL_FAIL | _lib.INFO_ROOT_FAIL)), bits
+
+    if rank == 0:
+        name, cus, _ = _lib.device_info(local_rank)
+        units = world * Ns * H                                  # sampled trajectory-steps per step
+        flop = FLOP_PER_TRAJ_STEP["pendulum1D_R_H30"] * Ns * H  # per launch (one GPU)
+        achieved = flop / (kern_ms * 1e-3) / 1e12
+        out = {
+            "metric": "sampled trajectory-steps/sec (Ns*H per wall second)",
+            "value": units * a.steps / wall,
+            "unit": "trajectory-steps/s",
+            "n_gpus": world,
+            "steps": a.steps,
+            "warmup": a.warmup,
+            "ms_per_step": wall / a.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {"workload": "BASELINE configs[1]: params_pendulum1D_samples, sequential re-conditioned rollout "
+                                   "(mode R, value+gradient labels T=3), Ns=%d per GPU, H=%d" % (Ns, H),
+                       "Ns_per_gpu": Ns, "H": H, "Ns_total": world * Ns,
+                       "parallelism": "samples sharded over %d GPU(s), RCCL all-gather of X_traj per rollout" % world,
+                       "device": name, "cus": cus},
+            "roofline": {"bound": "mfma", "achieved": achieved, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved / FP64_PEAK_TFLOPS, "traffic": None,
+                         "kernel": "rollout_kernel<T=3>", "kernel_ms": kern_ms,
+                         "flop_per_launch": flop,
+                         "note": "FP64 (vector FMA; FP64 MFMA peak is the same 78.6 TFLOP/s on MI355X); algorithmic "
+                                 "FLOP = 2.55e4 per trajectory-step (SURVEY 8d) x Ns x H; min HBM traffic 80 B per "
+                                 "trajectory-step, i.e. the kernel is latency/FLOP bound, not HBM bound"},
+        }
+        if world == 1 and a.cpu_sample > 0:
+            v, dt = cpu_baseline(a.cpu_sample, H, u_ff)
+            out["cpu_baseline"] = {"value": v, "unit": "trajectory-steps/s", "cores": torch.get_num_threads(),
+                                   "kind": "port",
+                                   "sample": "same workload, Ns=%d of %d samples, full H=%d horizon, %.1f s of CPU work "
+                                             "(oracle: reference-faithful from-scratch batched Cholesky per step, torch "
+                                             "CPU FP64; gpytorch itself is not installable on the box)" % (a.cpu_sample, Ns, H, dt),
+                                   "host_cpus": os.cpu_count()}
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -142,3 +142,43 @@ def _raise_on_info(info: torch.Tensor):
     if bits & _lib.INFO_ROOT_FAIL:
         raise NotPSDError("rollout: posterior root failed after 3 jitter retries (eigh fallback is only "
                           "available through Agent.sample_gp)")
+
+
+class RolloutRunner:
+    """Preallocated, allocation-free repeated launches of one rollout configuration (used by bench.py and by
+    ``sampling_gpmpc_amd.distributed``): every buffer lives in HBM before the first launch."""
+
+    def __init__(self, agent: Agent, u_ff, z: torch.Tensor, z_step_stride: int, H: int, mode: int,
+                 use_model_without_derivatives: bool, x0=None, want_samples: bool = False):
+        self.lib = _lib.load()
+        dev = _lib.require_hip_device(agent.torch_device)
+        p = agent.params
+        self.agent, self.H, self.mode = agent, H, mode
+        self.plan = agent._plan(use_grad=not use_model_without_derivatives)
+        T = self.plan.hyper.T
+        self.Ns = agent.ns
+        self.u_ff = torch.as_tensor(np.asarray(u_ff), dtype=F64).reshape(H, agent.nu).to(dev).contiguous()
+        x0 = p["env"]["start"] if x0 is None else x0
+        self.x0 = torch.as_tensor(np.asarray(x0, dtype=np.float64)[: agent.nx]).to(dev).contiguous()
+        self.z = z.to(device=dev, dtype=F64).contiguous()
+        self.z_step_stride = int(z_step_stride)
+        self.X_traj = torch.empty(self.Ns, agent.nx, H + 1, dtype=F64, device=dev)
+        self.Y = torch.empty(self.Ns, agent.g_ny, H, T, dtype=F64, device=dev) if want_samples else None
+        self.Xi = torch.empty(self.Ns, H, agent.in_dim_x, dtype=F64, device=dev) if want_samples else None
+        self.info = torch.zeros(self.Ns, dtype=torch.int32, device=dev)
+        nbytes = self.lib.gpmpc_rollout_workspace_bytes(self.plan.desc, mode, T, self.Ns, H)
+        self.ws = torch.empty((nbytes + 7) // 8, dtype=F64, device=dev)
+        self.env = agent.env_desc()
+        self.beta = float(p["agent"]["Dyn_gp_beta"])
+        self.var_zero = float(p["agent"]["Dyn_gp_variance_is_zero"])
+        self._args = (self.plan.desc, self.env, _lib.dptr(self.plan.buf), _lib.dptr(self.plan.X_r), mode, T,
+                      self.var_zero, self.beta, self.Ns, H, _lib.dptr(self.x0), 0, _lib.dptr(self.u_ff),
+                      self.z.data_ptr(), self.z_step_stride, _lib.dptr(self.X_traj), _lib.dptr(self.Y),
+                      _lib.dptr(self.Xi), _lib.dptr(self.info), _lib.dptr(self.ws), self.ws.numel() * 8)
+
+    def launch(self, stream_ptr: Optional[int] = None):
+        st = _lib.current_stream_ptr() if stream_ptr is None else stream_ptr
+        rc = self.lib.gpmpc_rollout(*self._args, st)
+        if rc != 0:
+            _lib.check(rc, "gpmpc_rollout")
+        return self.X_traj
