@@ -14,40 +14,26 @@
 // The per-sample factor lives in LDS when it fits (FAC_LDS) and in an HBM workspace otherwise; both are laid out
 // column-major so that lane == row gives conflict-free LDS / coalesced HBM access.
 #include "gpmpc_host.hpp"
+#include "rollout_args.hpp"
 
 namespace gpmpc {
 
-struct RolloutArgs {
-    GpParams gp;
-    EnvParams env;
-    const double* plan;
-    const double* X_r;
-    int mode, hall_tasks;
-    double var_zero_thr, beta;
-    long Ns;
-    int H;
-    const double* x0;
-    int x0_per_sample;
-    const double* u_ff;
-    const double* z;
-    long z_step_stride;
-    double* X_traj;
-    double* Y;
-    double* Xi;
-    int* info;
-    double* ws;
-    long ws_chain_stride;   // doubles per chain in the HBM workspace
-    int nh_max;             // hallucinated slots allocated per chain
-    int lds_shared;         // doubles of block-shared LDS
-    int lds_per_wave;       // doubles of per-wave LDS
-};
+
+// Debug only (not part of the public ABI): per-phase shader-cycle totals of block 0 / wave 0, read back through
+// gpmpc_debug_read_phases().  Compiled in always; costs one s_memtime per phase.
+__device__ long long g_phase_cycles[16];
+#define GPMPC_PHASE(idx)                                                  \
+    do {                                                                  \
+        const long long _now = __builtin_readcyclecounter();              \
+        ph[idx] += _now - tph;                                            \
+        tph = _now;                                                       \
+    } while (0)
 
 __device__ __forceinline__ void wave_lds_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
 }
 
-__device__ __forceinline__ long col_ofs(int p, int nh_max) { return (long)p * nh_max - ((long)p * (p - 1)) / 2; }
 
 template <int T, int RPL, bool FAC_LDS>
 __global__ __launch_bounds__(64 * GPMPC_MAX_NY) void rollout_kernel(const RolloutArgs a) {
@@ -75,12 +61,18 @@ __global__ __launch_bounds__(64 * GPMPC_MAX_NY) void rollout_kernel(const Rollou
     double* wh = vr + T * n_r;                    // [nh_max]
     double* invd = wh + nh_max;                   // [nh_max]
     double* yout = invd + nh_max;                 // [H][T]
-    double* fac = FAC_LDS ? (yout + H * T) : (a.ws + (s * gp.g_ny + o) * a.ws_chain_stride);
+    double* LinvT = yout + H * T;                 // [n_r][n_r] staged copy of the plan's L_rr^-1 (transposed)
+    double* w_r = LinvT + n_r * n_r;              // [n_r]
+    double* fac = FAC_LDS ? (w_r + n_r) : (a.ws + (s * gp.g_ny + o) * a.ws_chain_stride);
     double* LhrT = fac;                           // [n_r][nh_max]   LhrT[i*nh_max + slot] = L_hr[slot][i]
     double* Lhh = fac + (long)n_r * nh_max;       // packed lower, column-major: (slot,p) at col_ofs(p)+slot-p
 
-    const double* LinvT = plan_LinvT(a.plan, gp, o);
-    const double* w_r = plan_w(a.plan, gp, o);
+    {
+        const double* gL = plan_LinvT(a.plan, gp, o);
+        const double* gw = plan_w(a.plan, gp, o);
+        for (int e = lane; e < n_r * n_r; e += kWave) LinvT[e] = gL[e];
+        for (int e = lane; e < n_r; e += kWave) w_r[e] = gw[e];
+    }
     double il2[D];
 #pragma unroll
     for (int d = 0; d < D; ++d) il2[d] = gp.inv_l2[o][d];
@@ -93,6 +85,8 @@ __global__ __launch_bounds__(64 * GPMPC_MAX_NY) void rollout_kernel(const Rollou
     int n_h = 0;
     __syncthreads();
 
+    long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    long long tph = __builtin_readcyclecounter();
     for (int t = 0; t < H; ++t) {
         double u[GPMPC_MAX_NU], xi[D];
         apply_feedback(env, x, a.u_ff + (long)t * nu, u);
@@ -111,6 +105,7 @@ __global__ __launch_bounds__(64 * GPMPC_MAX_NY) void rollout_kernel(const Rollou
             for (int b = 0; b < T; ++b) kr[b * n_r + sl] = kern_entry<D>(q, k, il2, ar, b);
         }
         wave_lds_sync();
+        GPMPC_PHASE(0);
 
         // ---- v_r = L_rr^-1 k_r ; partial sums of mu and v^T v -------------------------------------------
         double pm[T], pss[NS];
@@ -122,8 +117,9 @@ __global__ __launch_bounds__(64 * GPMPC_MAX_NY) void rollout_kernel(const Rollou
             double acc[T];
 #pragma unroll
             for (int b = 0; b < T; ++b) acc[b] = 0.0;
+#pragma unroll 4
             for (int j = 0; j <= i; ++j) {
-                const double l = LinvT[(long)j * n_r + i];
+                const double l = LinvT[j * n_r + i];
 #pragma unroll
                 for (int b = 0; b < T; ++b) acc[b] += l * kr[b * n_r + j];
             }
@@ -138,6 +134,7 @@ __global__ __launch_bounds__(64 * GPMPC_MAX_NY) void rollout_kernel(const Rollou
             }
         }
         wave_lds_sync();
+        GPMPC_PHASE(1);
 
         // ---- rows of the sample's own previous draws: rhs = k_h - L_hr v_r --------------------------------
         double rhs[RPL][T];
@@ -156,6 +153,7 @@ __global__ __launch_bounds__(64 * GPMPC_MAX_NY) void rollout_kernel(const Rollou
                     double acc[T];
 #pragma unroll
                     for (int b = 0; b < T; ++b) acc[b] = kern_entry<D>(q, k, il2, ah, b);
+#pragma unroll 4
                     for (int i = 0; i < n_r; ++i) {
                         const double l = LhrT[(long)i * nh_max + slot];
 #pragma unroll
@@ -166,6 +164,7 @@ __global__ __launch_bounds__(64 * GPMPC_MAX_NY) void rollout_kernel(const Rollou
                 }
             }
 
+            GPMPC_PHASE(2);
             // ---- v_h = L_hh^-1 rhs: column-oriented forward substitution, next column prefetched ------------
             double lnext[RPL];
 #pragma unroll
@@ -222,6 +221,7 @@ __global__ __launch_bounds__(64 * GPMPC_MAX_NY) void rollout_kernel(const Rollou
             }
         }
 
+        GPMPC_PHASE(3);
         // ---- posterior mean / covariance of the T label slots at the test point ---------------------------
         double mu[T], S[T][T];
         {
@@ -250,6 +250,7 @@ __global__ __launch_bounds__(64 * GPMPC_MAX_NY) void rollout_kernel(const Rollou
             all_zero = all_zero && (var[b] <= a.var_zero_thr);
         }
 
+        GPMPC_PHASE(4);
         // ---- sample: y = mu + R z, post-processing of sample_gp -------------------------------------------
         double R[T][T];
         info_acc |= root_small<T>(S, gp.jitter, R);
@@ -268,6 +269,7 @@ __global__ __launch_bounds__(64 * GPMPC_MAX_NY) void rollout_kernel(const Rollou
             y[b] = yb;
         }
 
+        GPMPC_PHASE(5);
         // ---- append the draw to the chain's own training set (A.9) ----------------------------------------
         if (recond && t + 1 < H) {
             double C[T][T], wn[T];
@@ -321,6 +323,7 @@ __global__ __launch_bounds__(64 * GPMPC_MAX_NY) void rollout_kernel(const Rollou
             n_h += Th;
         }
 
+        GPMPC_PHASE(6);
         // ---- hand the value samples of all outputs to every chain, advance the state ----------------------
         double* yb_t = ybuf + (t & 1) * GPMPC_MAX_NY;
         if (lane == 0) {
@@ -333,7 +336,10 @@ __global__ __launch_bounds__(64 * GPMPC_MAX_NY) void rollout_kernel(const Rollou
         for (int oo = 0; oo < gp.g_ny; ++oo) g[oo] = yb_t[oo];
         env_step(env, x, u, g, xn);
         for (int d = 0; d < nx; ++d) x[d] = xn[d];
+        GPMPC_PHASE(7);
     }
+    if (blockIdx.x == 0 && threadIdx.x == 0)
+        for (int i = 0; i < 8; ++i) g_phase_cycles[i] = ph[i];
 
     if (threadIdx.x == 0)
         for (int d = 0; d < nx; ++d) xbuf[d * (H + 1) + H] = x[d];
@@ -371,7 +377,7 @@ static int plan_rollout(const gpmpc_gp_desc_t* gp, int nx, int mode, int hall_ta
     rp->chain_doubles = (long)n_r * nh_max + ((long)nh_max * (nh_max + 1)) / 2;
     rp->lds_shared = nx * (H + 1) + H * gp->D + 2 * GPMPC_MAX_NY;
     rp->lds_shared = (rp->lds_shared + 1) & ~1;
-    const int vec = 2 * T * n_r + 2 * nh_max + H * T;
+    const int vec = 2 * T * n_r + 2 * nh_max + H * T + n_r * n_r + n_r;
     const long with_fac = vec + rp->chain_doubles;
     const size_t bytes_fac = ((size_t)rp->lds_shared + (size_t)gp->g_ny * ((with_fac + 1) & ~1L)) * sizeof(double);
     rp->fac_lds = (mode == GPMPC_MODE_RECONDITIONED) && bytes_fac <= (size_t)(160 * 1024 - 256) && !force_global_factor();
@@ -403,13 +409,19 @@ using namespace gpmpc;
 
 extern "C" {
 
+// debug helper, deliberately not declared in include/gpmpc_hip.h
+int gpmpc_debug_read_phases(long long* out /*[host] 16*/) {
+    GPMPC_HIP_CHECK(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_phase_cycles), 16 * sizeof(long long)));
+    return GPMPC_OK;
+}
+
 size_t gpmpc_rollout_workspace_bytes(const gpmpc_gp_desc_t* gp, int32_t mode, int32_t hall_tasks, int64_t Ns,
                                      int32_t H) {
     if (check_gp(gp) != GPMPC_OK) return 0;
     RolloutPlan rp;
     if (plan_rollout(gp, GPMPC_MAX_NX, mode, hall_tasks, H, &rp) != GPMPC_OK) return 0;
     if (mode != GPMPC_MODE_RECONDITIONED) return 256;
-    return align_up((size_t)Ns * gp->g_ny * rp.chain_doubles * sizeof(double), 256) + 256;
+    return align_up((size_t)Ns * gp->g_ny * rp.chain_doubles * sizeof(double), 256) + 256;   // >= the tuned path's need
 }
 
 int gpmpc_rollout(const gpmpc_gp_desc_t* gp, const gpmpc_env_desc_t* env, const void* plan, const double* X_r,
@@ -458,6 +470,7 @@ int gpmpc_rollout(const gpmpc_gp_desc_t* gp, const gpmpc_env_desc_t* env, const 
         if (!ws || ws_bytes < need) return fail(GPMPC_E_WORKSPACE, "gpmpc_rollout: workspace too small");
     }
     hipStream_t st = (hipStream_t)stream;
+    if (rollout_fast_eligible(gp, env, mode, hall_tasks, H)) return rollout_fast_launch(gp, env, args, ws, ws_bytes, st);
     const int T = gp->T;
     if (T == 1) {
         if (rp.rpl == 1) return launch_rollout<1, 1>(args, rp, gp->g_ny, st);

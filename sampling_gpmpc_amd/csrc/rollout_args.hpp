@@ -1,0 +1,41 @@
+// Kernel-argument block shared by the rollout kernels (generic: rollout.hip, tuned: rollout_fast.hip).
+#pragma once
+#include "gpmpc_device.hpp"
+
+namespace gpmpc {
+
+struct RolloutArgs {
+    GpParams gp;
+    EnvParams env;
+    const double* plan;
+    const double* X_r;
+    int mode, hall_tasks;
+    double var_zero_thr, beta;
+    long Ns;
+    int H;
+    const double* x0;
+    int x0_per_sample;
+    const double* u_ff;
+    const double* z;
+    long z_step_stride;
+    double* X_traj;
+    double* Y;
+    double* Xi;
+    int* info;
+    double* ws;
+    long ws_chain_stride;   // doubles per chain in the HBM workspace
+    int nh_max;             // hallucinated slots allocated per chain
+    int lds_shared;         // doubles of block-shared LDS
+    int lds_per_wave;       // doubles of per-wave LDS
+};
+
+// packed lower-triangular, column-major: element (row, col) at col_ofs(col) + row - col, rows col..nh_max-1
+__host__ __device__ __forceinline__ long col_ofs(int p, int nh_max) { return (long)p * nh_max - ((long)p * (p - 1)) / 2; }
+
+// tuned path (rollout_fast.hip)
+bool rollout_fast_eligible(const gpmpc_gp_desc_t* gp, const gpmpc_env_desc_t* env, int mode, int hall_tasks, int H);
+size_t rollout_fast_workspace_bytes(const gpmpc_gp_desc_t* gp, int64_t Ns, int H);
+int rollout_fast_launch(const gpmpc_gp_desc_t* gp, const gpmpc_env_desc_t* env, RolloutArgs& args, void* ws,
+                        size_t ws_bytes, hipStream_t st);
+
+}  // namespace gpmpc
