@@ -207,6 +207,9 @@ def test_joint_draw_against_reference_golden(sg):
         np.testing.assert_allclose(gp_val[same], d[f"gp_val_{it}"][same], rtol=1e-5, atol=2e-6)
         np.testing.assert_allclose(y_grad[same], d[f"y_grad_{it}"][same], rtol=1e-4, atol=2e-5)
         np.testing.assert_allclose(u_grad[same], d[f"u_grad_{it}"][same], rtol=1e-4, atol=2e-5)
+        # the next SQP iteration conditions on THIS iteration's draws: continue from the reference's own labels so
+        # that a different coin flip above does not leak into the next comparison
+        agent.Hallcinated_Y_train = torch.tensor(d[f"y_{it}"]).to(agent.torch_device)
 
 
 @pytest.mark.parametrize("pname,Ns,H,iters", [("params_pendulum1D_samples", 16, 30, 2),
@@ -363,3 +366,23 @@ def test_true_reachable_set_rollout_against_oracle(sg):
     Xo, Yo = ao.forward_sampling_rollout(oagent, u, return_samples=True)
     print(f"true-RS rollout rel err {relerr(X, Xo):.2e}")
     np.testing.assert_allclose(X, Xo, rtol=RTOL_TRAJ, atol=1e-9)
+
+
+def test_sharded_rollout_single_rank_rccl(sg):
+    """The N > 1 code path (shard_range + rollout on the slice + all-gather over RCCL) with a world of one rank."""
+    import torch.distributed as dist
+    from sampling_gpmpc_amd.distributed import sharded_forward_sampling_rollout
+    from sampling_gpmpc_amd.rollout import forward_sampling_rollout
+    Ns, H = 64, 8
+    p = fs_params("params_pendulum1D_samples", Ns, H)
+    agent, _ = make_agents(sg, p)
+    u_ff = synthetic_u_ff(1, H)
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29531")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        tube = sharded_forward_sampling_rollout(agent, u_ff)
+    finally:
+        dist.destroy_process_group()
+    X = forward_sampling_rollout(agent, u_ff)
+    np.testing.assert_array_equal(tube.cpu().numpy(), X)

@@ -1,0 +1,145 @@
+"""CPU: host-side logic of the product package (no GPU, no oracle in the product path) against the goldens, the
+C-ABI surface of the built library, and the loud-failure contract."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+import sampling_gpmpc_amd as sg
+from sampling_gpmpc_amd import _lib
+from tests.helpers import GOLDEN, REPO, load_params
+
+
+def g(name):
+    return np.load(os.path.join(GOLDEN, name))
+
+
+@pytest.mark.parametrize("tag,pname", [("pendulum1D", "params_pendulum1D_samples"), ("car_residual", "params_car_residual")])
+def test_env_plugins_match_reference(tag, pname):
+    d = g(f"env_{tag}.npz")
+    p = load_params(pname)
+    p["common"]["use_cuda"] = False
+    env = sg.make_env(p)
+    X, Y = env.initial_training_data()
+    xu, dg = torch.tensor(d["xu"]), torch.tensor(d["dg"])
+    checks = [(X, d["X_train"]), (Y, d["Y_train"]), (env.get_prior_data(X), d["prior_data"]),
+              (env.unknown_dyn(X), d["unknown_dyn"]), (env.known_dyn(xu), d["known_dyn"]),
+              (env.get_f_known_jacobian(xu), d["f_jac"]), (env.get_g_xu_hat(xu), d["g_xu_hat"]),
+              (env.transform_sensitivity(dg, xu), d["transform"]), (env.B_d, d["B_d"]),
+              (env.discrete_dyn(torch.tensor(d["one_xu"])), d["discrete_dyn"])]
+    for a, b in checks:
+        np.testing.assert_allclose(a.numpy(), b, rtol=1e-13, atol=1e-14, equal_nan=True)
+    assert env.pad_g == list(d["pad_g"]) and env.g_idx_inputs == list(d["g_idx"])
+
+
+def test_tightenings_match_reference():
+    d = g("tightenings.npz")
+    for tag, pname, H in [("P17", "params_pendulum1D_samples", 17), ("P30", "params_pendulum1D_samples", 30),
+                          ("C50", "params_car_residual", 50)]:
+        p = load_params(pname)
+        p["optimizer"]["H"] = H
+        te, ci = sg.get_reachable_set_ball(p, np.ones(H + 1))
+        np.testing.assert_allclose(np.stack(te), d[f"{tag}_tilde_eps"], rtol=1e-13, atol=1e-15)
+        np.testing.assert_allclose(ci, d[f"{tag}_ci"], rtol=1e-13)
+
+
+@pytest.mark.parametrize("tag,pname", [("pendulum1D", "params_pendulum1D_samples"), ("car_residual", "params_car_residual")])
+def test_agent_host_plumbing_matches_reference(tag, pname):
+    """Seeded base samples (bit-exact stream), real-data batch views, x_hat reshapes, hallucinated-set update."""
+    d = g(f"agent_plumbing_{tag}.npz")
+    p = load_params(pname)
+    p["common"]["use_cuda"] = False
+    p["agent"]["num_dyn_samples"] = int(d["Ns"])
+    p["agent"]["true_dyn_as_sample"] = False
+    p["optimizer"]["H"] = int(d["H"])
+    p["common"]["num_MPC_itrs"] = int(d["n_mpc"])
+    p["optimizer"]["SEMPC"]["max_sqp_iter"] = int(d["n_itr"])
+    torch.manual_seed(123456)
+    env = sg.make_env(p)
+    agent = sg.Agent(p, env)
+    np.testing.assert_array_equal(agent.epistimic_random_vector.numpy(), d["epistimic_random_vector"])
+    np.testing.assert_array_equal(agent.Dyn_gp_X_train_batch.numpy(), d["X_train_batch"])
+    np.testing.assert_array_equal(agent.Dyn_gp_Y_train_batch.numpy(), d["Y_train_batch"])
+    np.testing.assert_array_equal(agent.get_batch_x_hat(d["x_h"], d["u_h"]).numpy(), d["batch_x_hat"])
+    bxd = agent.get_batch_x_hat_u_diff(d["x_h"], d["u_diff"])
+    np.testing.assert_array_equal(bxd.numpy(), d["batch_x_hat_u_diff"])
+    g_xu = env.get_g_xu_hat(bxd)
+    y = torch.tensor(d["y_inj"])
+    agent.update_hallucinated_Dyn_dataset(g_xu, y)
+    np.testing.assert_array_equal(agent.Hallcinated_X_train.numpy(), d["hall_X_0"])
+    np.testing.assert_array_equal(agent.Hallcinated_Y_train.numpy(), d["hall_Y_0"])
+    p["agent"]["Dyn_gp_min_data_dist"] = float(d["min_dist_1"])
+    agent.update_hallucinated_Dyn_dataset(g_xu + 0.2, y * 2)
+    np.testing.assert_array_equal(agent.Hallcinated_X_train.numpy(), d["hall_X_1"])
+    np.testing.assert_array_equal(agent.Hallcinated_Y_train.numpy(), d["hall_Y_1"])
+    assert len(agent.tilde_eps_list) == int(d["H"]) + 1 and len(agent.ci_list) == int(d["H"])
+    assert agent.get_next_to_go_loc().tolist() == [2]
+
+
+def test_vectorized_base_samples_respect_the_truncation():
+    p = load_params("params_pendulum1D_samples")
+    p["agent"]["num_dyn_samples"], p["optimizer"]["H"] = 500, 30
+    p["common"]["num_MPC_itrs"], p["optimizer"]["SEMPC"]["max_sqp_iter"] = 2, 1
+    torch.manual_seed(0)
+    z = sg.random_vector_within_bounds(p, 1, 3, mode="vectorized")
+    assert tuple(z.shape) == (2, 1, 500, 1, 30, 3)
+    assert float(z.abs().max()) <= p["agent"]["Dyn_gp_beta"]
+    assert abs(float(z.mean())) < 0.02 and 0.85 < float(z.std()) < 1.0
+
+
+def test_library_exports_every_declared_symbol():
+    """Every function include/gpmpc_hip.h declares is exported by the built .so and bound by the ctypes layer."""
+    hdr = open(os.path.join(REPO, "include", "gpmpc_hip.h")).read()
+    declared = set(re.findall(r"\b(gpmpc_[a-z_]+)\s*\(", hdr))
+    assert declared, "no declarations parsed"
+    assert declared == set(_lib.SYMBOLS), declared ^ set(_lib.SYMBOLS)
+    lib = _lib.load()
+    raw = ctypes.CDLL(_lib.LIB_PATH)
+    for name in declared:
+        assert hasattr(raw, name), f"{name} not exported"
+    assert lib.gpmpc_abi_version() == _lib.ABI_VERSION
+    assert lib.gpmpc_plin_len(4, 2, 10) == 10 * (16 + 8 + 8) + 2 + 2 + 7
+
+
+def test_argument_validation_without_a_gpu():
+    """Host-side argument checks run before any device work and report through gpmpc_last_error_string."""
+    lib = _lib.load()
+    bad = _lib.make_gp_desc(1, 2, 2, 36, False, [[1.0, 1.0]], [1.0], [1e-6, 1e-6], 1e-6)   # T must be 1 or 1+D
+    assert lib.gpmpc_plan_bytes(bad) == 0
+    assert b"T must be" in lib.gpmpc_last_error_string()
+    ok = _lib.make_gp_desc(1, 2, 3, 36, False, [[1.84, 1.92]], [0.03], [4.8e-6, 2.27e-6, 4.8e-6], 1e-6)
+    assert lib.gpmpc_plan_bytes(ok) >= (2 * 36 * 36 + 72) * 8
+    assert lib.gpmpc_rollout_workspace_bytes(ok, _lib.MODE_RECONDITIONED, 3, 1024, 30) >= 1024 * (36 * 87 + 87 * 44) * 8
+    assert lib.gpmpc_joint_workspace_bytes(ok, 16, 0, 30) > 0
+    env = _lib.make_env_desc(_lib.ENV_CAR_RESIDUAL, 4, 2, True, 0.06, 1.1, 1.7, [[0] * 4] * 2, [0] * 4)
+    rc = lib.gpmpc_rollout(ok, env, 1, 1, _lib.MODE_RECONDITIONED, 3, -1.0, 2.5, 4, 5, 1, 0, 1, 1, 0, 1, None, None, 1,
+                           None, 0, None)
+    assert rc == -1 and b"car_residual needs" in lib.gpmpc_last_error_string()
+
+
+def test_product_path_fails_loudly_without_hip_device():
+    if torch.cuda.is_available():
+        pytest.skip("a HIP device is visible")
+    p = load_params("params_pendulum1D_samples")
+    p["agent"]["num_dyn_samples"], p["optimizer"]["H"] = 4, 3
+    p["common"]["num_MPC_itrs"] = 1
+    agent = sg.Agent(p, sg.make_env(p))
+    with pytest.raises(_lib.GpmpcError):
+        agent.train_hallucinated_dynGP(0)
+    from sampling_gpmpc_amd.rollout import forward_sampling_rollout
+    p["optimizer"]["H"], p["common"]["num_MPC_itrs"], p["optimizer"]["SEMPC"]["max_sqp_iter"] = 1, 3, 2
+    agent = sg.Agent(p, sg.make_env(p))
+    with pytest.raises(_lib.GpmpcError):
+        forward_sampling_rollout(agent, np.zeros((3, 1)))
+
+
+def test_product_package_never_imports_the_oracle():
+    pkg = os.path.join(REPO, "sampling_gpmpc_amd")
+    for root, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp")):
+                src = open(os.path.join(root, f)).read()
+                assert "import oracle" not in src and "from oracle" not in src, os.path.join(root, f)
