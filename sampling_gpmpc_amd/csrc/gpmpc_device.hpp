@@ -164,6 +164,83 @@ __device__ __forceinline__ int root_small(const double (&S)[T][T], double jitter
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// fast FP64 reciprocal square root: v_rsq_f64 seed + 2 Newton steps (~1 ulp); sqrt(x) = x * rsqrt(x) with one
+// Heron correction.  Used for the T x T pivots (the generic sqrt/div sequences are ~5x longer and sit on the
+// per-step critical path of a single wave).
+// ---------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ double rsqrt_fast(double x) {
+    double y = __builtin_amdgcn_rsq(x);
+    const double h = 0.5 * x;
+    double e = fma(-h * y, y, 0.5);
+    y = fma(y, e, y);
+    e = fma(-h * y, y, 0.5);
+    y = fma(y, e, y);
+    return y;
+}
+// returns sqrt(x), writes 1/sqrt(x)
+__device__ __forceinline__ double sqrt_rsqrt_fast(double x, double& inv) {
+    const double y = rsqrt_fast(x);
+    double s = x * y;
+    const double d = fma(-s, s, x);
+    s = fma(d, 0.5 * y, s);
+    inv = y;
+    return s;
+}
+
+// Cholesky of a T x T matrix with rsqrt pivots; also returns 1/L_jj.  Same failure rule as chol_small.
+template <int T>
+__device__ __forceinline__ bool chol_small_fast(const double (&S)[T][T], double (&L)[T][T], double (&linv)[T]) {
+#pragma unroll
+    for (int j = 0; j < T; ++j) {
+        double d = S[j][j];
+#pragma unroll
+        for (int k = 0; k < j; ++k) d = fma(-L[j][k], L[j][k], d);
+        if (!(d > 0.0)) return false;
+        double inv;
+        L[j][j] = sqrt_rsqrt_fast(d, inv);
+        linv[j] = inv;
+#pragma unroll
+        for (int i = j + 1; i < T; ++i) {
+            double s = S[i][j];
+#pragma unroll
+            for (int k = 0; k < j; ++k) s = fma(-L[i][k], L[j][k], s);
+            L[i][j] = s * inv;
+        }
+#pragma unroll
+        for (int i = 0; i < j; ++i) L[i][j] = 0.0;
+    }
+    return true;
+}
+
+template <int T>
+__device__ __forceinline__ int root_small_fast(const double (&S)[T][T], double jitter, double (&R)[T][T]) {
+    double linv[T];
+    if constexpr (T == 1) {
+        R[0][0] = sqrt(S[0][0]);
+        return (S[0][0] < 0.0) ? GPMPC_INFO_NEG_1x1 : 0;
+    } else {
+        if (chol_small_fast<T>(S, R, linv)) return 0;
+        double A[T][T];
+#pragma unroll
+        for (int i = 0; i < T; ++i)
+#pragma unroll
+            for (int j = 0; j < T; ++j) A[i][j] = S[i][j];
+        double prev = 0.0, jn = jitter;
+#pragma unroll 1
+        for (int t = 0; t < 3; ++t) {
+            const double add = jn - prev;
+#pragma unroll
+            for (int i = 0; i < T; ++i) A[i][i] += add;
+            prev = jn;
+            if (chol_small_fast<T>(A, R, linv)) return (t + 1) << 1;
+            jn *= 10.0;
+        }
+        return (3 << 1) | GPMPC_INFO_ROOT_FAIL;
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // environment maps fused into the rollout
 // ---------------------------------------------------------------------------------------------------------------

@@ -2,18 +2,21 @@
 // appended slots, value-only real labels on an N_r = 36 / 45 grid).  gfx950, wave64.
 //
 // One wave per (sample, output) chain; a workgroup holds WAVES = G_NY * SPW chains (pendulum1D: 4 independent samples,
-// car: the 3 outputs of one sample, which meet at one barrier per step).  Per chain:
+// car: the 3 outputs of one sample, which meet at one barrier per step).  With one wave per SIMD every instruction of
+// the chain costs ~4-7 cycles, so the kernel is organised around INSTRUCTION COUNT:
 //
-//   registers : the chain's rows of L_hr (row = lane, lane+64; NR doubles each), the running right-hand side,
-//               1/L_pp and w_p of the lane's own rows
-//   LDS       : L_rr^-1 (shared by the workgroup's chains of the same output), k_r / v_r broadcast buffers, and
-//               - when it fits (LHH_LDS) - the chain's L_hh; otherwise L_hh streams from an HBM/L2 workspace
+//   registers : this lane's row of L_rr^-1 (NR doubles, loaded once), this lane's bank-0 row of L_hr (rows 0..63 of the
+//               chain's appended slots), the running right-hand sides, 1/L_pp and w_p of the lane's own rows
+//   LDS       : k_r / v_r broadcast buffers laid out for ds_read_b128 (two doubles per instruction), the bank-1 rows
+//               of L_hr (rows 64..), and - when it fits (LHH_LDS) - the chain's L_hh; otherwise L_hh streams from an
+//               HBM/L2 workspace
 //
-// L_hh is stored column-major and COLUMN-SCALED (L''[i][p] = L[i][p] / L[p][p]): the forward substitution
-//   rhs_i -= L''[i][p] * rhs_p     (p = 0 .. n_h-1)
-// then has a dependency chain of exactly v_readlane -> v_fma_f64 per pivot (no divide, no LDS access on the chain);
-// v_p = rhs_p / L_pp is formed once after the loop.  Columns are prefetched PF pivots ahead into a register ring, and
-// the pivot loop is split at the 64-row bank boundary so no per-pivot select is needed.
+// L_hh is stored ROW-major (row r = its r entries, 16-byte aligned) and COLUMN-SCALED (L''[r][p] = L[r][p] / L[p][p]):
+//   * lane == row reads its own row two pivots per ds_read_b128 with immediate offsets (no per-pivot address math);
+//   * the forward substitution  rhs_r -= L''[r][p] * rhs_p  has a dependency chain of v_readlane -> v_fma_f64 per
+//     pivot (no divide, no LDS access on the chain); v_p = rhs_p / L_pp is formed once after the loop;
+//   * appending a row is one coalesced ds_write_b64 per lane (lane p owns the new row's entry in column p);
+//   * the storage is zero-initialised, so not-yet-appended rows read as zero; finished rows (r <= p) are masked.
 #include "gpmpc_host.hpp"
 #include "rollout_args.hpp"
 
@@ -21,82 +24,122 @@ namespace gpmpc {
 
 __device__ long long g_fast_phase_cycles[16];
 
-template <int T, int NR, int G_NY, int ENV, bool LHH_LDS>
-__global__ __launch_bounds__(256, 1) void rollout_fast_kernel(const RolloutArgs a) {
-    constexpr int D = 2;
-    constexpr int NS = T * (T + 1) / 2;
-    constexpr int NX = (ENV == GPMPC_ENV_PENDULUM1D) ? 2 : 4;
-    constexpr int NU = (ENV == GPMPC_ENV_PENDULUM1D) ? 1 : 2;
-    constexpr int PF = LHH_LDS ? 4 : 8;
-    extern __shared__ __attribute__((aligned(16))) double smem[];
-    __shared__ int s_info[4];
-
-    const GpParams& gp = a.gp;
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int spw = (blockDim.x >> 6) / G_NY;           // samples per workgroup
-    const int sw = wave / G_NY, o = wave - sw * G_NY;
-    const long s = (long)blockIdx.x * spw + sw;
-    const bool valid = s < a.Ns;
-    const int H = a.H, nh_max = a.nh_max;
-
-    // ---- LDS carve ---------------------------------------------------------------------------------------------
-    double* LinvT_all = smem;                                   // [G_NY][NR*NR]
-    double* wr_all = LinvT_all + G_NY * NR * NR;                // [G_NY][NR]
-    double* ybuf_all = wr_all + G_NY * NR;                      // [spw][2][G_NY]
-    double* wb = smem + a.lds_shared + (long)wave * a.lds_per_wave;
-    double* krs = wb;                                           // [T][NR]
-    double* vrs = krs + T * NR;                                 // [T][NR]
-    double* Xh = vrs + T * NR;                                  // [H][D]
-    double* xbuf = Xh + H * D;                                  // [NX][H+1]
-    double* yout = xbuf + NX * (H + 1);                         // [H][T]
-    double* Lhh = LHH_LDS ? (yout + H * T) : (a.ws + (s * G_NY + o) * a.ws_chain_stride);
-    const double* LinvT = LinvT_all + o * NR * NR;
-    const double* w_r = wr_all + o * NR;
-    double* ybuf = ybuf_all + sw * 2 * G_NY;
-
-    for (int e = threadIdx.x; e < G_NY * NR * NR; e += blockDim.x) {
-        const int oo = e / (NR * NR);
-        LinvT_all[e] = plan_LinvT(a.plan, gp, oo)[e - oo * NR * NR];
-    }
-    for (int e = threadIdx.x; e < G_NY * NR; e += blockDim.x) {
-        const int oo = e / NR;
-        wr_all[e] = plan_w(a.plan, gp, oo)[e - oo * NR];
-    }
-    if (threadIdx.x < 4) s_info[threadIdx.x] = 0;
-    __syncthreads();
-    if (!valid) return;                                 // whole workgroups are valid when G_NY > 1 (spw == 1)
-
-    for (long e = lane; e < a.ws_chain_stride; e += kWave) Lhh[e] = 0.0;   // see the substitution loop
-    double il2[D];
-#pragma unroll
-    for (int d = 0; d < D; ++d) il2[d] = gp.inv_l2[o][d];
-    const double os = gp.os[o];
-    double xr[D];                                       // this lane's real training input
-#pragma unroll
-    for (int d = 0; d < D; ++d) xr[d] = (lane < NR) ? a.X_r[lane * D + d] : 0.0;
-    const double w_lane = (lane < NR) ? w_r[lane] : 0.0;
-
-    double x[NX];
-#pragma unroll
-    for (int d = 0; d < NX; ++d) x[d] = valid ? a.x0[(a.x0_per_sample ? s * NX : 0) + d] : 0.0;
-
-    double Lhr0[NR], Lhr1[NR];                          // rows lane / lane+64 of L_hr
-#pragma unroll
-    for (int i = 0; i < NR; ++i) {
-        Lhr0[i] = 0.0;
-        Lhr1[i] = 0.0;
-    }
-    double dinv0 = 0.0, dinv1 = 0.0, wown0 = 0.0, wown1 = 0.0;
-    int info_acc = 0;
-    int n_h = 0;
-    long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    long long tph = __builtin_readcyclecounter();
+#ifdef GPMPC_PHASE_TIMERS
+#define FPHASE_DECL                                   \
+    long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};       \
+    long long tph = __builtin_readcyclecounter()
 #define FPHASE(idx)                                              \
     do {                                                         \
         const long long _n = __builtin_readcyclecounter();       \
         ph[idx] += _n - tph;                                     \
         tph = _n;                                                \
     } while (0)
+#define FPHASE_STORE                                             \
+    if (blockIdx.x == 0 && threadIdx.x == 0)                     \
+        for (int i = 0; i < 8; ++i) g_fast_phase_cycles[i] = ph[i]
+#else
+#define FPHASE_DECL
+#define FPHASE(idx)
+#define FPHASE_STORE
+#endif
+
+typedef double double2_t __attribute__((ext_vector_type(2)));
+
+// row-major, every row start 16-byte aligned: row r holds r entries in a slot of r rounded up to even
+__host__ __device__ __forceinline__ int lhh_rowofs(int r) {
+    const int h = r >> 1;
+    return (r & 1) ? 2 * h * (h + 1) : 2 * h * h;
+}
+// + slack for the look-ahead reads of the last row (8 pivots ahead of a pivot index rounded up to 8)
+__host__ __device__ __forceinline__ long lhh_doubles(int nh_max) {
+    const int r = nh_max - 1, cap = r + (r & 1);
+    int slack = ((nh_max + 7) & ~7) + 8 - cap;
+    slack = (slack < 0) ? 0 : ((slack + 1) & ~1);
+    return lhh_rowofs(nh_max) + slack;
+}
+
+__device__ __forceinline__ void wave_sync_lds() {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+template <int T, int NR, int G_NY, int ENV, bool LHH_LDS>
+__global__ __launch_bounds__(256, 1) void rollout_fast_kernel(const RolloutArgs a) {
+    constexpr int D = 2;
+    constexpr int NS = T * (T + 1) / 2;
+    constexpr int NX = (ENV == GPMPC_ENV_PENDULUM1D) ? 2 : 4;
+    constexpr int NU = (ENV == GPMPC_ENV_PENDULUM1D) ? 1 : 2;
+    constexpr int NRP = (NR + 1) & ~1;                            // broadcast-buffer row length (even -> b128 aligned)
+    constexpr int NRS = ((NRP / 2) & 1) ? NRP : NRP + 2;          // row stride of lane==row tables: 16-byte slots, odd count
+    constexpr int NPAIR = NR / 2;
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    __shared__ int s_info[4];
+
+    const GpParams& gp = a.gp;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int spw = (blockDim.x >> 6) / G_NY;
+    const int sw = wave / G_NY, o = wave - sw * G_NY;
+    const long s = (long)blockIdx.x * spw + sw;
+    const bool valid = s < a.Ns;
+    const int H = a.H, nh_max = a.nh_max;
+    const int nb1 = (nh_max > kWave) ? nh_max - kWave : 0;        // rows kept in bank 1
+
+    // ---- LDS carve (all offsets even => 16-byte aligned) -----------------------------------------------------------
+    double* Linv_all = smem;                                      // [G_NY][NR][NRS]  L_rr^-1 rows, shared by the workgroup
+    double* ybuf_all = Linv_all + G_NY * NR * NRS;                // [spw][2][G_NY] (+pad)
+    double* wb = smem + a.lds_shared + (long)wave * a.lds_per_wave;
+    double* kvs = wb;                                             // [T][NRP]  k_r, then (after phase B) v_r: one buffer
+    double* Lhr1 = kvs + T * NRP;                                 // [nb1][NRS]
+    double* Lhh = LHH_LDS ? (Lhr1 + nb1 * NRS) : (a.ws + (s * G_NY + o) * a.ws_chain_stride);
+    double* ybuf = ybuf_all + sw * 2 * G_NY;
+
+    for (int e = threadIdx.x; e < G_NY * NR * NRS; e += blockDim.x) {
+        const int oo = e / (NR * NRS), rem = e - oo * NR * NRS;
+        const int i = rem / NRS, j = rem - i * NRS;
+        Linv_all[e] = (j < NR) ? plan_LinvT(a.plan, gp, oo)[j * NR + i] : 0.0;
+    }
+    if constexpr (G_NY > 1) {
+        if (threadIdx.x < 4) s_info[threadIdx.x] = 0;
+    }
+    __syncthreads();
+    if (!valid) return;                                           // whole workgroups are valid when G_NY > 1 (spw == 1)
+
+    for (long e = lane; e < a.ws_chain_stride; e += kWave) Lhh[e] = 0.0;
+    for (int e = lane; e < nb1 * NRS; e += kWave) Lhr1[e] = 0.0;
+
+    double il2[D];
+#pragma unroll
+    for (int d = 0; d < D; ++d) il2[d] = gp.inv_l2[o][d];
+    const double os = gp.os[o];
+    double xr[D];
+#pragma unroll
+    for (int d = 0; d < D; ++d) xr[d] = (lane < NR) ? a.X_r[lane * D + d] : 0.0;
+    const double w_lane = (lane < NR) ? plan_w(a.plan, gp, o)[lane] : 0.0;
+    // lane == row of L_rr^-1 (lanes >= NR read row 0 and discard the result)
+    const double2_t* linvrow = reinterpret_cast<const double2_t*>(Linv_all + ((long)o * NR + ((lane < NR) ? lane : 0)) * NRS);
+
+    double x[NX];
+#pragma unroll
+    for (int d = 0; d < NX; ++d) x[d] = a.x0[(a.x0_per_sample ? s * NX : 0) + d];
+
+    double Lhr0[NR];                                              // bank-0 row (`lane`) of L_hr
+#pragma unroll
+    for (int i = 0; i < NR; ++i) Lhr0[i] = 0.0;
+    double xh0[D], xh1[D];                                        // GP input of the point this lane's rows belong to
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+        xh0[d] = 0.0;
+        xh1[d] = 0.0;
+    }
+    double dinv0 = 0.0, dinv1 = 0.0, wown0 = 0.0, wown1 = 0.0;
+    int info_acc = 0;
+    int n_h = 0;
+    // this lane's L_hh rows (clamped into the allocation; non-existent rows are discarded by ex0 / ex1 below)
+    const double2_t* row0 = reinterpret_cast<const double2_t*>(Lhh + lhh_rowofs(min(lane, nh_max - 1)));
+    const double2_t* row1 = reinterpret_cast<const double2_t*>(Lhh + lhh_rowofs(min(lane + kWave, nh_max - 1)));
+    const double2_t* lhr1row = reinterpret_cast<const double2_t*>(Lhr1 + (long)min(lane, max(nb1 - 1, 0)) * NRS);
+    const int a0t = lane - (lane / T) * T, a1t = (lane + kWave) - ((lane + kWave) / T) * T;   // task of this lane's rows
+    FPHASE_DECL;
 
 #pragma unroll 1
     for (int t = 0; t < H; ++t) {
@@ -115,21 +158,16 @@ __global__ __launch_bounds__(256, 1) void rollout_fast_kernel(const RolloutArgs 
                     u[i] = uf[i];
                 }
             }
-            if (ENV == GPMPC_ENV_PENDULUM1D) {
-                xi[0] = x[0];
-                xi[1] = u[0];
-            } else {
-                xi[0] = x[2];
-                xi[1] = u[0];
-            }
+            xi[0] = (ENV == GPMPC_ENV_PENDULUM1D) ? x[0] : x[2];
+            xi[1] = u[0];
         }
-        if (lane == 0) {
-            if (o == 0) {
+        if (lane == 0 && o == 0) {
 #pragma unroll
-                for (int d = 0; d < NX; ++d) xbuf[d * (H + 1) + t] = x[d];
+            for (int d = 0; d < NX; ++d) a.X_traj[(s * NX + d) * (H + 1) + t] = x[d];
+            if (a.Xi) {
+#pragma unroll
+                for (int d = 0; d < D; ++d) a.Xi[(s * H + t) * D + d] = xi[d];
             }
-#pragma unroll
-            for (int d = 0; d < D; ++d) Xh[t * D + d] = xi[d];
         }
 
         // ---- kernel row against the real data (lane = real point) ---------------------------------------------
@@ -138,44 +176,48 @@ __global__ __launch_bounds__(256, 1) void rollout_fast_kernel(const RolloutArgs 
             const double k = kern_scalar<D>(xr, xi, il2, os, q);
             if (lane < NR) {
 #pragma unroll
-                for (int b = 0; b < T; ++b) krs[b * NR + lane] = kern_entry<D>(q, k, il2, 0, b);
+                for (int b = 0; b < T; ++b) kvs[b * NRP + lane] = kern_entry<D>(q, k, il2, 0, b);
             }
         }
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        __builtin_amdgcn_wave_barrier();
+        wave_sync_lds();
         FPHASE(0);
 
-        // ---- v_r = L_rr^-1 k_r (lane = row) ---------------------------------------------------------------------
+        // ---- v_r = L_rr^-1 k_r (lane = row; own row and the broadcast k_r both two entries per ds_read_b128) ----
         double vr[T];
 #pragma unroll
         for (int b = 0; b < T; ++b) vr[b] = 0.0;
-        {
-            const int li = (lane < NR) ? lane : 0;
 #pragma unroll
-            for (int j = 0; j < NR; ++j) {
-                const double l = LinvT[j * NR + li];     // zero above the diagonal
+        for (int jp = 0; jp < NPAIR; ++jp) {
+            const double2_t l = linvrow[jp];
 #pragma unroll
-                for (int b = 0; b < T; ++b) vr[b] = fma(l, krs[b * NR + j], vr[b]);
-                if ((j & 7) == 7) __builtin_amdgcn_sched_barrier(0);   // keep <= 32 LDS loads in flight (VGPR budget)
-            }
-            if (lane >= NR) {
-#pragma unroll
-                for (int b = 0; b < T; ++b) vr[b] = 0.0;
+            for (int b = 0; b < T; ++b) {
+                const double2_t kk = *reinterpret_cast<const double2_t*>(kvs + b * NRP + 2 * jp);
+                vr[b] = fma(l.x, kk.x, vr[b]);
+                vr[b] = fma(l.y, kk.y, vr[b]);
             }
         }
+        if (NR & 1) {
+            const double l = reinterpret_cast<const double*>(linvrow)[NR - 1];
+#pragma unroll
+            for (int b = 0; b < T; ++b) vr[b] = fma(l, kvs[b * NRP + NR - 1], vr[b]);
+        }
+        if (lane >= NR) {
+#pragma unroll
+            for (int b = 0; b < T; ++b) vr[b] = 0.0;
+        }
         double pm[T], pss[NS];
+        wave_sync_lds();                                          // every lane has consumed k_r: the buffer becomes v_r
         {
             int e = 0;
 #pragma unroll
             for (int b = 0; b < T; ++b) {
-                if (lane < NR) vrs[b * NR + lane] = vr[b];
+                if (lane < NR) kvs[b * NRP + lane] = vr[b];
                 pm[b] = vr[b] * w_lane;
 #pragma unroll
                 for (int c = 0; c <= b; ++c) pss[e++] = vr[b] * vr[c];
             }
         }
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        __builtin_amdgcn_wave_barrier();
+        wave_sync_lds();
         FPHASE(1);
 
         double v0[T], v1[T];                             // rows lane / lane+64 of v_h
@@ -185,116 +227,140 @@ __global__ __launch_bounds__(256, 1) void rollout_fast_kernel(const RolloutArgs 
             v1[b] = 0.0;
         }
         if (n_h > 0) {
-            // ---- rhs = k_h - L_hr v_r -----------------------------------------------------------------------------
             const bool two = n_h > kWave;
+            const bool ex0 = lane < n_h, ex1 = lane + kWave < n_h;
+            // ---- rhs = k_h - L_hr v_r -----------------------------------------------------------------------------
             {
-                const int j0 = (lane < n_h) ? lane / T : 0, a0 = lane - (lane / T) * T;
                 double q[D];
-                const double k = kern_scalar<D>(Xh + j0 * D, xi, il2, os, q);
+                const double k = kern_scalar<D>(xh0, xi, il2, os, q);
 #pragma unroll
-                for (int b = 0; b < T; ++b) v0[b] = (lane < n_h) ? kern_entry<D>(q, k, il2, a0, b) : 0.0;
+                for (int b = 0; b < T; ++b) v0[b] = ex0 ? kern_entry<D>(q, k, il2, a0t, b) : 0.0;
             }
             if (two) {
-                const int sl = lane + kWave;
-                const int j1 = (sl < n_h) ? sl / T : 0, a1 = sl - (sl / T) * T;
                 double q[D];
-                const double k = kern_scalar<D>(Xh + j1 * D, xi, il2, os, q);
+                const double k = kern_scalar<D>(xh1, xi, il2, os, q);
 #pragma unroll
-                for (int b = 0; b < T; ++b) v1[b] = (sl < n_h) ? kern_entry<D>(q, k, il2, a1, b) : 0.0;
-            }
-            if (two) {
+                for (int b = 0; b < T; ++b) v1[b] = ex1 ? kern_entry<D>(q, k, il2, a1t, b) : 0.0;
 #pragma unroll
-                for (int i = 0; i < NR; ++i) {
+                for (int ip = 0; ip < NPAIR; ++ip) {
+                    const double2_t l1 = lhr1row[ip];
 #pragma unroll
                     for (int b = 0; b < T; ++b) {
-                        const double vb = vrs[b * NR + i];
-                        v0[b] = fma(-Lhr0[i], vb, v0[b]);
-                        v1[b] = fma(-Lhr1[i], vb, v1[b]);
+                        const double2_t vv = *reinterpret_cast<const double2_t*>(kvs + b * NRP + 2 * ip);
+                        v0[b] = fma(-Lhr0[2 * ip], vv.x, v0[b]);
+                        v0[b] = fma(-Lhr0[2 * ip + 1], vv.y, v0[b]);
+                        v1[b] = fma(-l1.x, vv.x, v1[b]);
+                        v1[b] = fma(-l1.y, vv.y, v1[b]);
                     }
-                    if ((i & 7) == 7) __builtin_amdgcn_sched_barrier(0);
+                }
+                if (NR & 1) {
+                    const double l1 = reinterpret_cast<const double*>(lhr1row)[NR - 1];
+#pragma unroll
+                    for (int b = 0; b < T; ++b) {
+                        const double vv = kvs[b * NRP + NR - 1];
+                        v0[b] = fma(-Lhr0[NR - 1], vv, v0[b]);
+                        v1[b] = fma(-l1, vv, v1[b]);
+                    }
                 }
             } else {
 #pragma unroll
-                for (int i = 0; i < NR; ++i) {
+                for (int ip = 0; ip < NPAIR; ++ip) {
 #pragma unroll
-                    for (int b = 0; b < T; ++b) v0[b] = fma(-Lhr0[i], vrs[b * NR + i], v0[b]);
-                    if ((i & 7) == 7) __builtin_amdgcn_sched_barrier(0);
+                    for (int b = 0; b < T; ++b) {
+                        const double2_t vv = *reinterpret_cast<const double2_t*>(kvs + b * NRP + 2 * ip);
+                        v0[b] = fma(-Lhr0[2 * ip], vv.x, v0[b]);
+                        v0[b] = fma(-Lhr0[2 * ip + 1], vv.y, v0[b]);
+                    }
+                }
+                if (NR & 1) {
+#pragma unroll
+                    for (int b = 0; b < T; ++b) v0[b] = fma(-Lhr0[NR - 1], kvs[b * NRP + NR - 1], v0[b]);
                 }
             }
             FPHASE(2);
 
-            // ---- forward substitution with column-scaled L_hh ------------------------------------------------------
-            // L_hh storage is zero-initialised and its diagonal slots are never written, so a load of column p with
-            // the row clamped into [p, nh_max-1] returns L''[row][p] for p < row < n_h and exactly 0.0 otherwise:
-            // no select, no branch, every load unconditional (the compiler keeps them in flight across pivots).
-            // Pivots beyond n_h are harmless no-ops (their broadcast value and their column are both zero).
-            const int rmax = nh_max - 1;
-            auto colA = [&](int p) -> long { return col_ofs(p, nh_max) - p; };     // element (row, p) at colA(p) + row
-            auto ld0 = [&](int p) -> double {                                       // L''[lane][p]
-                const int pc = min(p, rmax);
-                return Lhh[colA(pc) + min(max(lane, pc), rmax)];
-            };
-            auto ld1 = [&](int p) -> double {                                       // L''[lane+64][p]
-                const int pc = min(p, rmax);
-                return Lhh[colA(pc) + min(max(lane + kWave, pc), rmax)];
-            };
+            // ---- forward substitution (see the header comment) -----------------------------------------------------
+            // ring of 4 row pairs per bank = 8 pivots of look-ahead; reads past a row / the allocation land in the
+            // slack or in later rows and are masked (finished rows) or multiplied by a zero pivot value.  All T pivot
+            // values are broadcast (v_readlane) before the FMAs that consume them, so the SGPR write latency overlaps.
             if (!two) {
-                double r0[PF];
+                double2_t ra[4];
 #pragma unroll
-                for (int k = 0; k < PF; ++k) r0[k] = ld0(k);
+                for (int k = 0; k < 4; ++k) ra[k] = row0[k];
 #pragma unroll 1
-                for (int p0 = 0; p0 < n_h; p0 += PF) {
+                for (int p0 = 0; p0 < n_h; p0 += 8) {
 #pragma unroll
-                    for (int k = 0; k < PF; ++k) {
-                        const int p = p0 + k;
-                        const double la = r0[k];
-                        r0[k] = ld0(p + PF);
+                    for (int k = 0; k < 4; ++k) {
+                        const double2_t la2 = ra[k];
+                        ra[k] = row0[(p0 >> 1) + 4 + k];
 #pragma unroll
-                        for (int b = 0; b < T; ++b) v0[b] = fma(-la, readlane_f64(v0[b], p), v0[b]);
+                        for (int h = 0; h < 2; ++h) {
+                            const int p = p0 + 2 * k + h;
+                            double sp[T];
+#pragma unroll
+                            for (int b = 0; b < T; ++b) sp[b] = readlane_f64(v0[b], p);
+                            const double la = (lane > p) ? (h ? la2.y : la2.x) : 0.0;
+#pragma unroll
+                            for (int b = 0; b < T; ++b) v0[b] = fma(-la, sp[b], v0[b]);
+                        }
                     }
                 }
             } else {
-                double r0[PF], r1[PF];
+                double2_t ra[4], rb[4];
 #pragma unroll
-                for (int k = 0; k < PF; ++k) {
-                    r0[k] = ld0(k);
-                    r1[k] = ld1(k);
+                for (int k = 0; k < 4; ++k) {
+                    ra[k] = row0[k];
+                    rb[k] = row1[k];
                 }
 #pragma unroll 1
-                for (int p0 = 0; p0 < kWave; p0 += PF) {                // pivots owned by bank 0
+                for (int p0 = 0; p0 < kWave; p0 += 8) {                  // pivots owned by bank 0
 #pragma unroll
-                    for (int k = 0; k < PF; ++k) {
-                        const int p = p0 + k;
-                        const double la = r0[k], lb = r1[k];
-                        r0[k] = ld0(p + PF);
-                        r1[k] = ld1(p + PF);
+                    for (int k = 0; k < 4; ++k) {
+                        const double2_t la2 = ra[k], lb2 = rb[k];
+                        ra[k] = row0[(p0 >> 1) + 4 + k];
+                        rb[k] = row1[(p0 >> 1) + 4 + k];
 #pragma unroll
-                        for (int b = 0; b < T; ++b) {
-                            const double sp = readlane_f64(v0[b], p);
-                            v0[b] = fma(-la, sp, v0[b]);
-                            v1[b] = fma(-lb, sp, v1[b]);
+                        for (int h = 0; h < 2; ++h) {
+                            const int p = p0 + 2 * k + h;
+                            double sp[T];
+#pragma unroll
+                            for (int b = 0; b < T; ++b) sp[b] = readlane_f64(v0[b], p);
+                            const double la = (lane > p) ? (h ? la2.y : la2.x) : 0.0;
+                            const double lb = h ? lb2.y : lb2.x;
+#pragma unroll
+                            for (int b = 0; b < T; ++b) {
+                                v0[b] = fma(-la, sp[b], v0[b]);
+                                v1[b] = fma(-lb, sp[b], v1[b]);
+                            }
                         }
                     }
                 }
 #pragma unroll 1
-                for (int p0 = kWave; p0 < n_h; p0 += PF) {               // pivots owned by bank 1
+                for (int p0 = kWave; p0 < n_h; p0 += 8) {                 // pivots owned by bank 1
 #pragma unroll
-                    for (int k = 0; k < PF; ++k) {
-                        const int p = p0 + k;
-                        const double lb = r1[k];
-                        r1[k] = ld1(p + PF);
+                    for (int k = 0; k < 4; ++k) {
+                        const double2_t lb2 = rb[k];
+                        rb[k] = row1[(p0 >> 1) + 4 + k];
 #pragma unroll
-                        for (int b = 0; b < T; ++b) v1[b] = fma(-lb, readlane_f64(v1[b], p - kWave), v1[b]);
+                        for (int h = 0; h < 2; ++h) {
+                            const int p = p0 + 2 * k + h;
+                            double sp[T];
+#pragma unroll
+                            for (int b = 0; b < T; ++b) sp[b] = readlane_f64(v1[b], p - kWave);
+                            const double lb = (lane + kWave > p) ? (h ? lb2.y : lb2.x) : 0.0;
+#pragma unroll
+                            for (int b = 0; b < T; ++b) v1[b] = fma(-lb, sp[b], v1[b]);
+                        }
                     }
                 }
             }
-            // v = rhs / L_pp  (own rows); partial sums
+            // v = rhs / L_pp (own rows; rows that do not exist yet are dropped); partial sums
             {
                 int e = 0;
 #pragma unroll
                 for (int b = 0; b < T; ++b) {
-                    v0[b] *= dinv0;
-                    v1[b] *= dinv1;
+                    v0[b] = ex0 ? v0[b] * dinv0 : 0.0;
+                    v1[b] = ex1 ? v1[b] * dinv1 : 0.0;
                 }
 #pragma unroll
                 for (int b = 0; b < T; ++b) {
@@ -335,63 +401,62 @@ __global__ __launch_bounds__(256, 1) void rollout_fast_kernel(const RolloutArgs 
             all_zero = all_zero && (var[b] <= a.var_zero_thr);
         }
         double R[T][T];
-        info_acc |= root_small<T>(S, gp.jitter, R);
+        info_acc |= root_small_fast<T>(S, gp.jitter, R);
         const double* zt = a.z + (long)t * a.z_step_stride + (s * G_NY + o) * T;
         double y[T];
 #pragma unroll
         for (int b = 0; b < T; ++b) {
             double acc = 0.0;
 #pragma unroll
-            for (int c = 0; c <= b; ++c) acc += R[b][c] * (valid ? zt[c] : 0.0);
+            for (int c = 0; c <= b; ++c) acc = fma(R[b][c], zt[c], acc);
             double yb = acc + mu[b];
             if (all_zero) yb = mu[b];
-            const double sd = a.beta * sqrt(var[b]);
-            yb = fmax(yb, mu[b] - sd);
-            yb = fmin(yb, mu[b] + sd);
+            // clip to mu +- beta sqrt(var): the square root is only needed when the clip is active
+            const double dlt = yb - mu[b];
+            if (dlt * dlt > a.beta * a.beta * var[b]) {
+                const double sd = a.beta * sqrt(var[b]);
+                yb = fmin(fmax(yb, mu[b] - sd), mu[b] + sd);
+            }
             y[b] = yb;
+        }
+        if (lane == 0 && a.Y) {
+#pragma unroll
+            for (int b = 0; b < T; ++b) a.Y[((s * G_NY + o) * H + t) * T + b] = y[b];
         }
         FPHASE(5);
 
         // ---- append [v^T, chol(S + noise)] and w to the chain's factor (A.9) -------------------------------------
         if (t + 1 < H) {
-            double C[T][T], wn[T], Sn[T][T];
+            double C[T][T], wn[T], Sn[T][T], cinv[T];
 #pragma unroll
             for (int b = 0; b < T; ++b)
 #pragma unroll
                 for (int c = 0; c < T; ++c) Sn[b][c] = S[b][c] + ((b == c) ? gp.noise[b] : 0.0);
-            if (!chol_small<T>(Sn, C)) info_acc |= GPMPC_INFO_TRAIN_CHOL_FAIL;
-            double cinv[T];
+            if (!chol_small_fast<T>(Sn, C, cinv)) info_acc |= GPMPC_INFO_TRAIN_CHOL_FAIL;
 #pragma unroll
             for (int b = 0; b < T; ++b) {
-                cinv[b] = 1.0 / C[b][b];
                 double acc = y[b] - mu[b];
 #pragma unroll
-                for (int c = 0; c < b; ++c) acc -= C[b][c] * wn[c];
+                for (int c = 0; c < b; ++c) acc = fma(-C[b][c], wn[c], acc);
                 wn[b] = acc * cinv[b];
             }
             const int base = n_h;
-            // (1) columns of the old slots get T new rows:  L''[base+c][slot] = v_slot[c] / L_slot,slot
-            if (lane < n_h) {
-                const long co = col_ofs(lane, nh_max) - lane;
+            // (1) new rows base+c of L'': lane p owns the entry in column p:  L''[base+c][p] = v_p[c] / L_pp
 #pragma unroll
-                for (int c = 0; c < T; ++c) Lhh[co + base + c] = v0[c] * dinv0;
-            }
-            if (lane + kWave < n_h) {
-                const long co = col_ofs(lane + kWave, nh_max) - (lane + kWave);
-#pragma unroll
-                for (int c = 0; c < T; ++c) Lhh[co + base + c] = v1[c] * dinv1;
-            }
-            // (2) the new T x T diagonal block, column-scaled
-            if (lane == 0) {
-#pragma unroll
-                for (int c = 0; c < T; ++c)
+            for (int c = 0; c < T; ++c) {
+                double* rowc = Lhh + lhh_rowofs(base + c);
+                if (lane < base) rowc[lane] = v0[c] * dinv0;
+                if (lane + kWave < base) rowc[lane + kWave] = v1[c] * dinv1;
+                // (2) the new diagonal block, column-scaled
+                if (lane == 0) {
 #pragma unroll
                     for (int e = 0; e < T; ++e)
-                        if (e < c) Lhh[col_ofs(base + e, nh_max) + (c - e)] = C[c][e] * cinv[e];
+                        if (e < c) rowc[base + e] = C[c][e] * cinv[e];
+                }
             }
-            // (3) the lanes that own the new rows: 1/L_pp, w_p and the L_hr row (= v_r^T) into registers
+            // (3) owners of the new rows: 1/L_pp, w_p, the point's GP input, and the L_hr row (= v_r^T)
             {
-                const int a0 = lane - base;                               // task index if this lane's bank-0 row is new
+                const int a0 = lane - base;
                 const int a1 = lane + kWave - base;
                 const bool new0 = (a0 >= 0 && a0 < T), new1 = (a1 >= 0 && a1 < T);
 #pragma unroll
@@ -405,22 +470,28 @@ __global__ __launch_bounds__(256, 1) void rollout_fast_kernel(const RolloutArgs 
                         wown1 = wn[c];
                     }
                 }
-                if (base < kWave) {                                       // uniform: some new row lives in bank 0
+#pragma unroll
+                for (int d = 0; d < D; ++d) {
+                    xh0[d] = new0 ? xi[d] : xh0[d];
+                    xh1[d] = new1 ? xi[d] : xh1[d];
+                }
+                if (base < kWave) {                                       // uniform: a new row lives in bank 0 (registers)
                     const int ac = new0 ? a0 : 0;
 #pragma unroll
-                    for (int i = 0; i < NR; ++i) {
-                        const double val = vrs[ac * NR + i];
-                        Lhr0[i] = new0 ? val : Lhr0[i];
-                        if ((i & 7) == 7) __builtin_amdgcn_sched_barrier(0);
+                    for (int ip = 0; ip < NPAIR; ++ip) {
+                        const double2_t vv = *reinterpret_cast<const double2_t*>(kvs + ac * NRP + 2 * ip);
+                        Lhr0[2 * ip] = new0 ? vv.x : Lhr0[2 * ip];
+                        Lhr0[2 * ip + 1] = new0 ? vv.y : Lhr0[2 * ip + 1];
+                    }
+                    if (NR & 1) {
+                        const double vv = kvs[ac * NRP + NR - 1];
+                        Lhr0[NR - 1] = new0 ? vv : Lhr0[NR - 1];
                     }
                 }
-                if (base + T > kWave) {                                   // uniform: some new row lives in bank 1
-                    const int ac = new1 ? a1 : 0;
+                if (base + T > kWave) {                                   // uniform: a new row lives in bank 1 (LDS)
 #pragma unroll
-                    for (int i = 0; i < NR; ++i) {
-                        const double val = vrs[ac * NR + i];
-                        Lhr1[i] = new1 ? val : Lhr1[i];
-                        if ((i & 7) == 7) __builtin_amdgcn_sched_barrier(0);
+                    for (int c = 0; c < T; ++c) {
+                        if (base + c >= kWave && lane < NR) Lhr1[(long)(base + c - kWave) * NRS + lane] = vr[c];
                     }
                 }
             }
@@ -429,13 +500,10 @@ __global__ __launch_bounds__(256, 1) void rollout_fast_kernel(const RolloutArgs 
         FPHASE(6);
 
         // ---- state hand-over ---------------------------------------------------------------------------------------
-        if (lane == 0) {
-#pragma unroll
-            for (int b = 0; b < T; ++b) yout[t * T + b] = y[b];
-        }
         double g[G_NY];
         if (G_NY == 1) {
             g[0] = y[0];
+            wave_sync_lds();                       // the appended rows are read by other lanes in the next step
         } else {
             double* yb_t = ybuf + (t & 1) * G_NY;
             if (lane == 0) yb_t[o] = y[0];
@@ -459,28 +527,16 @@ __global__ __launch_bounds__(256, 1) void rollout_fast_kernel(const RolloutArgs 
 
     if (lane == 0 && o == 0) {
 #pragma unroll
-        for (int d = 0; d < NX; ++d) xbuf[d * (H + 1) + H] = x[d];
+        for (int d = 0; d < NX; ++d) a.X_traj[(s * NX + d) * (H + 1) + H] = x[d];
     }
-    if (info_acc && lane == 0) atomicOr(&s_info[sw], info_acc);
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    if (G_NY > 1) __syncthreads();
-    if (valid) {
-        if (o == 0)
-            for (int e = lane; e < NX * (H + 1); e += kWave) a.X_traj[s * NX * (H + 1) + e] = xbuf[e];
-        if (a.Y)
-            for (int e = lane; e < H * T; e += kWave) a.Y[(s * G_NY + o) * H * T + e] = yout[e];
-        if (a.Xi && o == 0)
-            for (int e = lane; e < H * D; e += kWave) a.Xi[s * H * D + e] = Xh[e];
-        if (G_NY == 1) {
-            if (lane == 0) a.info[s] = info_acc;
-        } else {
-            if (o == 0 && lane == 0) a.info[s] = s_info[sw];
-        }
+    if constexpr (G_NY == 1) {
+        if (lane == 0) a.info[s] = info_acc;
+    } else {
+        if (info_acc && lane == 0) atomicOr(&s_info[sw], info_acc);
+        __syncthreads();
+        if (o == 0 && lane == 0) a.info[s] = s_info[sw];
     }
-    if (blockIdx.x == 0 && threadIdx.x == 0)
-        for (int i = 0; i < 8; ++i) g_fast_phase_cycles[i] = ph[i];
-#undef FPHASE
+    FPHASE_STORE;
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -509,18 +565,23 @@ bool rollout_fast_eligible(const gpmpc_gp_desc_t* gp, const gpmpc_env_desc_t* en
 }
 
 static void fast_plan(const gpmpc_gp_desc_t* gp, int nx, int H, bool force_global, FastPlan* fp) {
-    const int NR = gp->N_r, T = 3, D = 2, G = gp->g_ny;
+    const int NR = gp->N_r, T = 3, G = gp->g_ny;
+    (void)nx;
+    (void)H;
+    const int NRP = (NR + 1) & ~1;
+    const int NRS = ((NRP / 2) & 1) ? NRP : NRP + 2;
     const int nh_max = 3 * (H - 1);
-    fp->chain_doubles = ((long)nh_max * (nh_max + 1)) / 2;
-    const int vec = 2 * T * NR + H * D + nx * (H + 1) + H * T;
-    const size_t budget = 160 * 1024 - 512;
-    int max_spw = (G == 1) ? 4 : 1;
+    const int nb1 = nh_max > 64 ? nh_max - 64 : 0;
+    fp->chain_doubles = lhh_doubles(nh_max);
+    const long vec = (long)T * NRP + (long)nb1 * NRS;
+    const size_t budget = 160 * 1024 - 64;
+    const int max_spw = (G == 1) ? 4 : 1;
+    auto shared_doubles = [&](int spw) { return (G * NR * NRS + ((G > 1) ? spw * 2 * G : 0) + 1) & ~1; };
     fp->lhh_lds = false;
     fp->spw = max_spw;
     for (int spw = max_spw; spw >= 1 && !force_global; --spw) {
-        const int shared = G * NR * NR + G * NR + spw * 2 * G;
         const long per = vec + fp->chain_doubles;
-        const size_t bytes = ((size_t)((shared + 1) & ~1) + (size_t)spw * G * ((per + 1) & ~1L)) * sizeof(double);
+        const size_t bytes = ((size_t)shared_doubles(spw) + (size_t)spw * G * ((per + 1) & ~1L)) * sizeof(double);
         if (bytes <= budget) {
             fp->lhh_lds = true;
             fp->spw = spw;
@@ -528,16 +589,14 @@ static void fast_plan(const gpmpc_gp_desc_t* gp, int nx, int H, bool force_globa
         }
     }
     fp->waves = fp->spw * G;
-    const int shared = G * NR * NR + G * NR + fp->spw * 2 * G;
-    fp->lds_shared = (shared + 1) & ~1;
+    fp->lds_shared = shared_doubles(fp->spw);
     const long per = vec + (fp->lhh_lds ? fp->chain_doubles : 0);
     fp->lds_per_wave = (int)((per + 1) & ~1L);
     fp->lds_bytes = ((size_t)fp->lds_shared + (size_t)fp->waves * fp->lds_per_wave) * sizeof(double);
 }
 
 size_t rollout_fast_workspace_bytes(const gpmpc_gp_desc_t* gp, int64_t Ns, int H) {
-    const int nh_max = 3 * (H - 1);
-    return (size_t)Ns * gp->g_ny * (((size_t)nh_max * (nh_max + 1)) / 2) * sizeof(double);
+    return (size_t)Ns * gp->g_ny * (size_t)lhh_doubles(3 * (H - 1)) * sizeof(double);
 }
 
 template <int NR, int G_NY, int ENV>
