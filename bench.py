@@ -133,6 +133,11 @@ def main():
     if rank == 0:
         name, cus, _ = _lib.device_info(local_rank)
         units = world * Ns * H                                  # sampled trajectory-steps per step
+        traffic, traffic_src = None, None
+        tf = os.path.join(REPO, "profiles", "latest_traffic.json")
+        if os.path.exists(tf) and Ns == 1024 and H == 30:     # PMC counters cannot be read in-process: last profiled run
+            tj = json.load(open(tf))
+            traffic, traffic_src = tj["hbm_bytes_per_launch_gfx950_corrected"], tj["source"]
         flop = FLOP_PER_TRAJ_STEP["pendulum1D_R_H30"] * Ns * H  # per launch (one GPU)
         achieved = flop / (kern_ms * 1e-3) / 1e12
         out = {
@@ -154,7 +159,8 @@ def main():
                        "parallelism": "samples sharded over %d GPU(s), RCCL all-gather of X_traj per rollout" % world,
                        "device": name, "cus": cus},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / FP64_PEAK_TFLOPS, "traffic": None,
+                         "frac": achieved / FP64_PEAK_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
+                         "algorithmic_hbm_bytes_per_launch": MIN_HBM_BYTES_PER_TRAJ_STEP["pendulum1D_R_H30"] * Ns * H,
                          "kernel": "rollout_kernel<T=3>", "kernel_ms": kern_ms,
                          "flop_per_launch": flop,
                          "note": "FP64 (vector FMA; FP64 MFMA peak is the same 78.6 TFLOP/s on MI355X); algorithmic "

@@ -21,6 +21,11 @@ if os.environ.get("GPMPC_PHASE_TIMERS") == "1":      # debug build: per-phase s_
     FLAGS.append("-DGPMPC_PHASE_TIMERS")
 
 
+# Per-file code-generation flags.  rollout_fast.hip runs at one wave per SIMD: machine-LICM hoists ~100 registers of
+# constants/addresses out of the time-step loop, which starves the scheduler of VGPRs and serialises the LDS loads.
+EXTRA_FLAGS = {"rollout_fast.hip": os.environ.get("GPMPC_FAST_FLAGS", "-mllvm -disable-machine-licm").split()}
+
+
 def _mtime(p):
     return os.path.getmtime(p) if os.path.exists(p) else 0.0
 
@@ -37,7 +42,7 @@ def build(force=False, verbose=False):
             jobs.append((s, o))
     def cc(job):
         s, o = job
-        cmd = [HIPCC, "-x", "hip", "-c", s, "-o", o] + FLAGS
+        cmd = [HIPCC, "-x", "hip", "-c", s, "-o", o] + FLAGS + EXTRA_FLAGS.get(os.path.basename(s), [])
         if verbose:
             print(" ".join(cmd), flush=True)
         r = subprocess.run(cmd, capture_output=True, text=True)
