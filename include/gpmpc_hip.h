@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define GPMPC_ABI_VERSION 1
+#define GPMPC_ABI_VERSION 2
 
 #define GPMPC_MAX_NY 4   /* GP outputs            (reference agent.g_dim.ny : 1 pendulum1D, 3 car)          */
 #define GPMPC_MAX_D  4   /* GP input dimension    (g_nx + g_nu : 2 in all shipped configs)                 */
@@ -69,6 +69,9 @@ typedef struct gpmpc_gp_desc {
     int32_t T;                    /* tasks: 1 (use_grad=False) or 1 + D (value + gradient)                  */
     int32_t N_r;                  /* number of real training points (shared by all samples)                */
     int32_t real_has_grad;        /* 0: real labels observe task 0 only (NaN elsewhere); 1: all T tasks    */
+    int32_t grid_n0, grid_n1;     /* > 0: X_r is the tensor-product grid meshgrid(axis0[n0], axis1[n1], "ij") the  */
+                                  /* reference builds (pendulum1D.py:36-47, car_model_residual.py:37-50), row    */
+                                  /* i = a*n1 + c; enables the separable-kernel fast path.  0/0: unstructured.    */
     int32_t _pad;
     double  ell[GPMPC_MAX_NY][GPMPC_MAX_D];   /* Dyn_gp_lengthscale.both[o][d]                              */
     double  outputscale[GPMPC_MAX_NY];        /* Dyn_gp_outputscale.both[o]                                 */

@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libgpmpc_hip.so")
 
 MAX_NY, MAX_D, MAX_T, MAX_NX, MAX_NU = 4, 4, 5, 8, 4
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 ENV_PENDULUM1D, ENV_CAR_RESIDUAL = 0, 1
 MODE_INDEPENDENT, MODE_RECONDITIONED = 0, 1
@@ -29,7 +29,7 @@ INFO_NEG_1x1 = 0x0040
 
 class GpDesc(C.Structure):
     _fields_ = [("g_ny", C.c_int32), ("D", C.c_int32), ("T", C.c_int32), ("N_r", C.c_int32),
-                ("real_has_grad", C.c_int32), ("_pad", C.c_int32),
+                ("real_has_grad", C.c_int32), ("grid_n0", C.c_int32), ("grid_n1", C.c_int32), ("_pad", C.c_int32),
                 ("ell", (C.c_double * MAX_D) * MAX_NY), ("outputscale", C.c_double * MAX_NY),
                 ("noise", C.c_double * MAX_T), ("jitter", C.c_double), ("var_floor", C.c_double)]
 
@@ -115,9 +115,11 @@ def current_stream_ptr() -> int:
     return torch.cuda.current_stream().cuda_stream
 
 
-def make_gp_desc(g_ny, D, T, N_r, real_has_grad, ell, outputscale, noise, jitter, var_floor=1e-10) -> GpDesc:
+def make_gp_desc(g_ny, D, T, N_r, real_has_grad, ell, outputscale, noise, jitter, var_floor=1e-10,
+                 grid=(0, 0)) -> GpDesc:
     d = GpDesc()
     d.g_ny, d.D, d.T, d.N_r, d.real_has_grad = int(g_ny), int(D), int(T), int(N_r), int(bool(real_has_grad))
+    d.grid_n0, d.grid_n1 = int(grid[0]), int(grid[1])
     for o in range(g_ny):
         for k in range(D):
             d.ell[o][k] = float(ell[o][k])

@@ -10,7 +10,7 @@ from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 REPO = os.path.dirname(os.path.dirname(HERE))
-SOURCES = ["capi.hip", "rollout.hip", "rollout_fast.hip", "joint.hip", "assemble.hip"]
+SOURCES = ["capi.hip", "rollout.hip", "rollout_fast.hip", "rollout_indep.hip", "joint.hip", "assemble.hip"]
 HEADERS = ["gpmpc_device.hpp", "gpmpc_host.hpp", "rollout_args.hpp", os.path.join(REPO, "include", "gpmpc_hip.h")]
 OUT = os.path.join(os.path.dirname(HERE), "libgpmpc_hip.so")
 OBJDIR = os.path.join(HERE, "build")

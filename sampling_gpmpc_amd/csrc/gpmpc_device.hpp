@@ -15,6 +15,7 @@ constexpr int kWave = 64;
 // ---------------------------------------------------------------------------------------------------------------
 struct GpParams {
     int g_ny, D, T, N_r, real_has_grad, n_r;          // n_r = observed real label slots
+    int grid_n0, grid_n1;                             // tensor-product training grid (0/0 = unstructured)
     double inv_l2[GPMPC_MAX_NY][GPMPC_MAX_D];         // 1 / ell^2
     double os[GPMPC_MAX_NY];                          // outputscale
     double noise[GPMPC_MAX_T];

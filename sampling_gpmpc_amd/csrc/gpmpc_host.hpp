@@ -34,6 +34,8 @@ inline int check_gp(const gpmpc_gp_desc_t* gp) {
     if (!(gp->T == 1 || gp->T == gp->D + 1)) return fail(GPMPC_E_ARG, "T must be 1 or 1+D");
     if (gp->N_r < 1) return fail(GPMPC_E_ARG, "N_r must be >= 1");
     if (gp->real_has_grad && gp->T == 1) return fail(GPMPC_E_ARG, "real_has_grad needs T = 1+D");
+    if ((gp->grid_n0 || gp->grid_n1) && ((long)gp->grid_n0 * gp->grid_n1 != gp->N_r || gp->D != 2))
+        return fail(GPMPC_E_ARG, "grid_n0 * grid_n1 must equal N_r (D = 2)");
     return GPMPC_OK;
 }
 
@@ -46,6 +48,8 @@ inline GpParams make_gp_params(const gpmpc_gp_desc_t* gp) {
     p.N_r = gp->N_r;
     p.real_has_grad = gp->real_has_grad;
     p.n_r = observed_real_slots(gp);
+    p.grid_n0 = gp->grid_n0;
+    p.grid_n1 = gp->grid_n1;
     for (int o = 0; o < gp->g_ny; ++o) {
         for (int d = 0; d < gp->D; ++d) p.inv_l2[o][d] = 1.0 / (gp->ell[o][d] * gp->ell[o][d]);
         p.os[o] = gp->outputscale[o];

@@ -471,6 +471,7 @@ int gpmpc_rollout(const gpmpc_gp_desc_t* gp, const gpmpc_env_desc_t* env, const 
     }
     hipStream_t st = (hipStream_t)stream;
     if (rollout_fast_eligible(gp, env, mode, hall_tasks, H)) return rollout_fast_launch(gp, env, args, ws, ws_bytes, st);
+    if (rollout_indep_eligible(gp, env, mode)) return rollout_indep_launch(env, args, st);
     const int T = gp->T;
     if (T == 1) {
         if (rp.rpl == 1) return launch_rollout<1, 1>(args, rp, gp->g_ny, st);

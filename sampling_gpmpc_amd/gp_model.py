@@ -80,8 +80,9 @@ class RealDataPlan:
                 raise NotImplementedError("real-data label mask must be 'value only' or 'all tasks' (uniform)")
             has_grad = not bool(grad_nan.any())
         self.real_has_grad = has_grad
+        self.grid = _detect_tensor_grid(self.X_r)
         self.desc = _lib.make_gp_desc(hyper.g_ny, hyper.D, hyper.T, N_r, has_grad, hyper.ell, hyper.outputscale,
-                                      hyper.noise, hyper.jitter)
+                                      hyper.noise, hyper.jitter, grid=self.grid)
         nbytes = lib.gpmpc_plan_bytes(self.desc)
         if nbytes == 0:
             _lib.check(-1, "gpmpc_plan_bytes")
@@ -92,6 +93,22 @@ class RealDataPlan:
         if int(info.max().item()) != 0:
             raise NotPSDError("Cholesky of the real-data covariance K_rr + Sigma failed")
         self.n_r = N_r * hyper.T if has_grad else N_r
+
+
+def _detect_tensor_grid(X: torch.Tensor):
+    """(n0, n1) if X (N, 2) is exactly meshgrid(axis0, axis1, indexing="ij") flattened row-major, else (0, 0)."""
+    if X.dim() != 2 or X.shape[1] != 2:
+        return (0, 0)
+    Xc = X.detach().cpu()
+    N = Xc.shape[0]
+    first = Xc[0, 0]
+    n1 = int((Xc[:, 0] == first).sum().item()) if N > 0 else 0
+    if n1 == 0 or N % n1 != 0:
+        return (0, 0)
+    n0 = N // n1
+    G = Xc.reshape(n0, n1, 2)
+    ok = bool((G[:, :, 0] == G[:, :1, 0]).all()) and bool((G[:, :, 1] == G[:1, :, 1]).all())
+    return (n0, n1) if ok else (0, 0)
 
 
 class HipPosterior:

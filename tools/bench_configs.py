@@ -1,0 +1,33 @@
+"""Time the other BASELINE configs (not the bench.py line): cfg3 car mode R, cfg4 car mode I (as shipped)."""
+import sys, os, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch, numpy as np
+import sampling_gpmpc_amd as sg
+from sampling_gpmpc_amd import _lib
+from sampling_gpmpc_amd.rollout import RolloutRunner
+from tests.helpers import fs_params, synthetic_u_ff
+
+def run(pname, Ns, H, nograd, reps=10):
+    p = fs_params(pname, Ns, H, nograd=nograd, beta=(3.0 if ("car" in pname and not nograd) else None))
+    p["common"]["use_cuda"] = True; p["agent"]["base_sample_generator"] = "vectorized"
+    torch.manual_seed(1)
+    agent = sg.Agent(p, sg.make_env(p)); u_ff = synthetic_u_ff(agent.nu, H); erv = agent.epistimic_random_vector
+    T = 1 if nograd else 3
+    per = Ns * agent.g_ny * T
+    mode = _lib.MODE_INDEPENDENT if nograd else _lib.MODE_RECONDITIONED
+    r = RolloutRunner(agent, u_ff, erv.reshape(-1)[per:], erv.shape[1] * per, H, mode, nograd)
+    for _ in range(2): r.launch()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps): r.launch()
+    e1.record(); torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / reps
+    ok = bool(torch.isfinite(r.X_traj).all()); bits = int(r.info.max().item())
+    print(f"{pname:28s} Ns={Ns:7d} H={H} mode={'I' if nograd else 'R'}: {ms:9.3f} ms/rollout  {Ns*H/ms*1e3/1e6:10.1f} M traj-steps/s  finite={ok} info=0x{bits:x}", flush=True)
+
+if __name__ == "__main__":
+    run("params_pendulum1D_samples", 1024, 30, False, 20)
+    run("params_car_residual_fs", 4096, 40, False, 5)
+    run("params_car_residual_fs", 32768, 40, True, 5)
+    run("params_car_residual_fs", 262144, 40, True, 3)
