@@ -186,14 +186,32 @@ __global__ __launch_bounds__(256, 1) void rollout_fast_kernel(const RolloutArgs 
         double vr[T];
 #pragma unroll
         for (int b = 0; b < T; ++b) vr[b] = 0.0;
+        {
+            // explicit load batches (JB pairs = 4*JB ds_read_b128 in flight), fenced so the scheduler neither serialises
+            // them one by one (what it does under register pressure) nor hoists the whole loop's loads at once
+            constexpr int JB = 3;
 #pragma unroll
-        for (int jp = 0; jp < NPAIR; ++jp) {
-            const double2_t l = linvrow[jp];
+            for (int jp0 = 0; jp0 < NPAIR; jp0 += JB) {
+                double2_t l[JB], kk[JB][T];
 #pragma unroll
-            for (int b = 0; b < T; ++b) {
-                const double2_t kk = *reinterpret_cast<const double2_t*>(kvs + b * NRP + 2 * jp);
-                vr[b] = fma(l.x, kk.x, vr[b]);
-                vr[b] = fma(l.y, kk.y, vr[b]);
+                for (int q = 0; q < JB; ++q) {
+                    if (jp0 + q < NPAIR) {
+                        l[q] = linvrow[jp0 + q];
+#pragma unroll
+                        for (int b = 0; b < T; ++b) kk[q][b] = *reinterpret_cast<const double2_t*>(kvs + b * NRP + 2 * (jp0 + q));
+                    }
+                }
+#pragma unroll
+                for (int q = 0; q < JB; ++q) {
+                    if (jp0 + q < NPAIR) {
+#pragma unroll
+                        for (int b = 0; b < T; ++b) {
+                            vr[b] = fma(l[q].x, kk[q][b].x, vr[b]);
+                            vr[b] = fma(l[q].y, kk[q][b].y, vr[b]);
+                        }
+                    }
+                }
+                asm volatile("" ::: "memory");
             }
         }
         if (NR & 1) {
@@ -241,40 +259,48 @@ __global__ __launch_bounds__(256, 1) void rollout_fast_kernel(const RolloutArgs 
                 const double k = kern_scalar<D>(xh1, xi, il2, os, q);
 #pragma unroll
                 for (int b = 0; b < T; ++b) v1[b] = ex1 ? kern_entry<D>(q, k, il2, a1t, b) : 0.0;
+            }
+            {
+                constexpr int IB = 3;                              // i-pairs per fenced batch
 #pragma unroll
-                for (int ip = 0; ip < NPAIR; ++ip) {
-                    const double2_t l1 = lhr1row[ip];
+                for (int ip0 = 0; ip0 < NPAIR; ip0 += IB) {
+                    double2_t vv[IB][T], l1[IB];
 #pragma unroll
-                    for (int b = 0; b < T; ++b) {
-                        const double2_t vv = *reinterpret_cast<const double2_t*>(kvs + b * NRP + 2 * ip);
-                        v0[b] = fma(-Lhr0[2 * ip], vv.x, v0[b]);
-                        v0[b] = fma(-Lhr0[2 * ip + 1], vv.y, v0[b]);
-                        v1[b] = fma(-l1.x, vv.x, v1[b]);
-                        v1[b] = fma(-l1.y, vv.y, v1[b]);
+                    for (int q = 0; q < IB; ++q) {
+                        if (ip0 + q < NPAIR) {
+#pragma unroll
+                            for (int b = 0; b < T; ++b)
+                                vv[q][b] = *reinterpret_cast<const double2_t*>(kvs + b * NRP + 2 * (ip0 + q));
+                            if (two) l1[q] = lhr1row[ip0 + q];
+                        }
                     }
+#pragma unroll
+                    for (int q = 0; q < IB; ++q) {
+                        if (ip0 + q < NPAIR) {
+#pragma unroll
+                            for (int b = 0; b < T; ++b) {
+                                v0[b] = fma(-Lhr0[2 * (ip0 + q)], vv[q][b].x, v0[b]);
+                                v0[b] = fma(-Lhr0[2 * (ip0 + q) + 1], vv[q][b].y, v0[b]);
+                            }
+                            if (two) {
+#pragma unroll
+                                for (int b = 0; b < T; ++b) {
+                                    v1[b] = fma(-l1[q].x, vv[q][b].x, v1[b]);
+                                    v1[b] = fma(-l1[q].y, vv[q][b].y, v1[b]);
+                                }
+                            }
+                        }
+                    }
+                    asm volatile("" ::: "memory");
                 }
                 if (NR & 1) {
-                    const double l1 = reinterpret_cast<const double*>(lhr1row)[NR - 1];
+                    const double l1 = two ? reinterpret_cast<const double*>(lhr1row)[NR - 1] : 0.0;
 #pragma unroll
                     for (int b = 0; b < T; ++b) {
                         const double vv = kvs[b * NRP + NR - 1];
                         v0[b] = fma(-Lhr0[NR - 1], vv, v0[b]);
                         v1[b] = fma(-l1, vv, v1[b]);
                     }
-                }
-            } else {
-#pragma unroll
-                for (int ip = 0; ip < NPAIR; ++ip) {
-#pragma unroll
-                    for (int b = 0; b < T; ++b) {
-                        const double2_t vv = *reinterpret_cast<const double2_t*>(kvs + b * NRP + 2 * ip);
-                        v0[b] = fma(-Lhr0[2 * ip], vv.x, v0[b]);
-                        v0[b] = fma(-Lhr0[2 * ip + 1], vv.y, v0[b]);
-                    }
-                }
-                if (NR & 1) {
-#pragma unroll
-                    for (int b = 0; b < T; ++b) v0[b] = fma(-Lhr0[NR - 1], kvs[b * NRP + NR - 1], v0[b]);
                 }
             }
             FPHASE(2);
@@ -401,6 +427,16 @@ __global__ __launch_bounds__(256, 1) void rollout_fast_kernel(const RolloutArgs 
             all_zero = all_zero && (var[b] <= a.var_zero_thr);
         }
         double R[T][T];
+        double C[T][T], cinv[T];
+        bool c_ok;
+        {
+            double Sn[T][T];
+#pragma unroll
+            for (int b = 0; b < T; ++b)
+#pragma unroll
+                for (int c = 0; c < T; ++c) Sn[b][c] = S[b][c] + ((b == c) ? gp.noise[b] : 0.0);
+            c_ok = chol_small_fast<T>(Sn, C, cinv);        // independent of the root below: the two chains interleave
+        }
         info_acc |= root_small_fast<T>(S, gp.jitter, R);
         const double* zt = a.z + (long)t * a.z_step_stride + (s * G_NY + o) * T;
         double y[T];
@@ -427,12 +463,8 @@ __global__ __launch_bounds__(256, 1) void rollout_fast_kernel(const RolloutArgs 
 
         // ---- append [v^T, chol(S + noise)] and w to the chain's factor (A.9) -------------------------------------
         if (t + 1 < H) {
-            double C[T][T], wn[T], Sn[T][T], cinv[T];
-#pragma unroll
-            for (int b = 0; b < T; ++b)
-#pragma unroll
-                for (int c = 0; c < T; ++c) Sn[b][c] = S[b][c] + ((b == c) ? gp.noise[b] : 0.0);
-            if (!chol_small_fast<T>(Sn, C, cinv)) info_acc |= GPMPC_INFO_TRAIN_CHOL_FAIL;
+            double wn[T];
+            if (!c_ok) info_acc |= GPMPC_INFO_TRAIN_CHOL_FAIL;
 #pragma unroll
             for (int b = 0; b < T; ++b) {
                 double acc = y[b] - mu[b];
