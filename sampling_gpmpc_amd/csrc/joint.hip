@@ -1,6 +1,8 @@
 // gpmpc_joint_sample: joint posterior draw at m test points per (sample, output) chain (mode "J", gfx950).
 //
 // One 256-thread workgroup per chain; chains are taken grid-stride so the HBM workspace is bounded by the grid.
+// The factorisation is BLOCKED (NB columns at a time): the pivot-block rows are staged in LDS, each thread keeps NB
+// register accumulators per row it owns and streams its own row from HBM/L2 once per block (NB FMAs per 8 bytes).
 // Everything is ONE left-looking factorisation over a tall matrix M whose ROWS are label slots and whose COLUMNS
 // are the conditioning slots (column-major, leading dimension = rows, so "thread = row" is coalesced):
 //
@@ -42,11 +44,120 @@ struct JointArgs {
     int ld;                 // rows of M (padded)
 };
 
-template <int T>
+// Blocked left-looking step shared by the three phases.  For the column block whose pivot rows are
+// prow0..prow0+nb-1 and for every row this thread owns (row = tid + rs*256, row >= rlo):
+//     acc[rs][q] -= sum_{k < kdone} W[row][k] * W[prow0+q][k]
+// The pivot rows are staged KC columns at a time in LDS (broadcast reads), the thread's own row streams from
+// HBM/L2 once per block (coalesced: column-major, thread == row): NB FMAs per 8-byte load.
+typedef double double2_j __attribute__((ext_vector_type(2)));
+
+__device__ long long g_joint_phase[16];
+#ifdef GPMPC_PHASE_TIMERS
+#define JPH(idx) do { const long long _n = __builtin_readcyclecounter(); jph[idx] += _n - jt; jt = _n; } while (0)
+#else
+#define JPH(idx)
+#endif
+
+template <int NB, int RPT, int KC>
+__device__ __forceinline__ void block_update(const double* __restrict__ W, int ld, int kdone, int prow0, int nb,
+                                             int rlo, int nrow, double (&acc)[RPT][NB], double (*piv)[NB]) {
+    // piv[kk][q]: the NB pivot-row entries of column k0+kk are contiguous -> NB/2 broadcast ds_read_b128 per column,
+    // shared by all RPT rows of the thread (RPT*NB FMAs per NB/2 LDS reads and RPT 8-byte global loads).
+    const int tid = threadIdx.x, nt = blockDim.x;
+    bool own[RPT];
+    const double* wr[RPT];
+#pragma unroll
+    for (int rs = 0; rs < RPT; ++rs) {
+        const int row = tid + rs * nt;
+        own[rs] = (row >= rlo && row < nrow);
+        wr[rs] = W + (own[rs] ? row : rlo);
+    }
+    for (int k0 = 0; k0 < kdone; k0 += KC) {
+        const int kc = min(KC, kdone - k0);
+        __syncthreads();
+        for (int e = tid; e < NB * KC; e += nt) {
+            const int kk = e / NB, q = e - kk * NB;
+            piv[kk][q] = (q < nb && kk < kc) ? W[(long)(k0 + kk) * ld + prow0 + q] : 0.0;
+        }
+        __syncthreads();
+        // the thread's own row entries come from HBM/L2 (latency ~1-2 us): fetch KU columns at once so that
+        // KU*RPT loads are in flight per thread, then do the KU*RPT*NB FMAs
+        constexpr int KU = 16;
+        for (int kk0 = 0; kk0 < kc; kk0 += KU) {
+            double m[KU][RPT];
+#pragma unroll
+            for (int j = 0; j < KU; ++j) {
+                const int kk = min(kk0 + j, kc - 1);                  // clamped: the padded piv columns are zero
+#pragma unroll
+                for (int rs = 0; rs < RPT; ++rs) m[j][rs] = wr[rs][(long)(k0 + kk) * ld];
+            }
+#pragma unroll
+            for (int j = 0; j < KU; ++j) {
+                if (kk0 + j < kc) {
+#pragma unroll
+                    for (int qq = 0; qq < NB / 2; ++qq) {
+                        const double2_j pp = *reinterpret_cast<const double2_j*>(&piv[kk0 + j][2 * qq]);
+#pragma unroll
+                        for (int rs = 0; rs < RPT; ++rs) {
+                            acc[rs][2 * qq] = fma(-m[j][rs], pp.x, acc[rs][2 * qq]);
+                            acc[rs][2 * qq + 1] = fma(-m[j][rs], pp.y, acc[rs][2 * qq + 1]);
+                        }
+                    }
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int rs = 0; rs < RPT; ++rs) {
+        if (!own[rs]) {
+#pragma unroll
+            for (int q = 0; q < NB; ++q) acc[rs][q] = 0.0;
+        }
+    }
+}
+
+// Factor the nb x nb diagonal block held (lower part) in blk; LAPACK failure rule; result, 1/diag and flag via LDS.
+// Executed by ONE WAVE (lane = row, the row lives in registers, row j is broadcast with v_readlane): a single thread
+// walking the block through LDS costs ~70k cycles per block (dependent ~100-cycle LDS reads), this ~5k.
+template <int NB>
+__device__ __forceinline__ void block_factor(double (*blk)[NB + 1], double* dinv, int nb, int* flag) {
+    const int lane = threadIdx.x & 63;
+    const int li = (lane < NB) ? lane : 0;
+    double r[NB];
+#pragma unroll
+    for (int k = 0; k < NB; ++k) r[k] = (lane < nb && k <= lane) ? blk[li][k] : 0.0;
+    bool bad = false;
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+        double sacc = r[j];
+#pragma unroll
+        for (int k = 0; k < NB; ++k)
+            if (k < j) sacc = fma(-r[k], readlane_f64(r[k], j), sacc);       // row j's finished entries, broadcast
+        const double d = readlane_f64(sacc, j);
+        if (j < nb) {
+            if (!(d > 0.0)) bad = true;
+            const double sd = sqrt(d), inv = 1.0 / sd;
+            r[j] = (lane == j) ? sd : ((lane > j) ? sacc * inv : 0.0);
+            if (lane == j) dinv[j] = inv;
+        }
+    }
+    if (lane < nb) {
+#pragma unroll
+        for (int k = 0; k < NB; ++k)
+            if (k <= lane) blk[li][k] = r[k];
+    }
+    if (lane == 0) *flag = bad ? 1 : 0;
+}
+
+template <int T, int NB, int RPT>
 __global__ __launch_bounds__(256) void joint_kernel(const JointArgs a) {
     constexpr int D = 2;
-    __shared__ double s_piv;
+    constexpr int KC = 64;
+    __shared__ __attribute__((aligned(16))) double piv[KC][NB];
+    __shared__ double blk[NB][NB + 1];
+    __shared__ double dinv_s[NB];
     __shared__ int s_flag;
+    __shared__ int s_info;
     const GpParams& gp = a.gp;
     const int tid = threadIdx.x, nt = blockDim.x;
     const int n_r = gp.n_r, Tr = gp.real_has_grad ? T : 1;
@@ -56,9 +167,9 @@ __global__ __launch_bounds__(256) void joint_kernel(const JointArgs a) {
     const int wrow = n_ho, trow0 = n_ho + 1, nrow = n_ho + 1 + mT;
     const long nchains = a.Ns * gp.g_ny;
 
-    double* M = a.ws + (long)blockIdx.x * a.ws_chain_stride;     // [n_o][ld]
-    double* Sm = M + (long)n_o * ld;                              // [mT][mT] column-major, lower part valid
-    double* Rm = Sm + (long)mT * mT;                              // [mT][mT] factor attempts
+    double* M = a.ws + (long)blockIdx.x * a.ws_chain_stride;     // [n_o][ld]   column-major, thread == row
+    double* Sm = M + (long)n_o * ld;                              // [mT][mT]    column-major, lower part valid
+    double* Rm = Sm + (long)mT * mT;                              // [mT][mT]    factor attempts
     double* muv = Rm + (long)mT * mT;                             // [mT]
 
     for (long chain = blockIdx.x; chain < nchains; chain += gridDim.x) {
@@ -74,9 +185,14 @@ __global__ __launch_bounds__(256) void joint_kernel(const JointArgs a) {
         for (int d = 0; d < D; ++d) il2[d] = gp.inv_l2[o][d];
         const double os = gp.os[o];
         int info_acc = 0;
+        if (tid == 0) s_info = 0;
         __syncthreads();
+#ifdef GPMPC_PHASE_TIMERS
+        long long jph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        long long jt = __builtin_readcyclecounter();
+#endif
 
-        // row descriptor: input point + task of label slot `row`
+        // row descriptor: input point + task of label slot `row` (hallucinated or test; not the w row)
         auto row_point = [&](int row, const double*& xp, int& task) {
             if (row < n_ho) {
                 const int sl = a.h_slots[row];
@@ -91,7 +207,7 @@ __global__ __launch_bounds__(256) void joint_kernel(const JointArgs a) {
             }
         };
 
-        // ---- real columns ---------------------------------------------------------------------------------
+        // ---- real columns: M[row, :n_r] = L_rr^-1 k_r(row)  (w row = w_r) ------------------------------------------
         for (int row = tid; row < nrow; row += nt) {
             if (row == wrow) {
                 for (int i = 0; i < n_r; ++i) M[(long)i * ld + row] = w_r[i];
@@ -113,71 +229,137 @@ __global__ __launch_bounds__(256) void joint_kernel(const JointArgs a) {
             }
         }
         __syncthreads();
+        JPH(0);
 
-        // ---- hallucinated columns (left-looking) -----------------------------------------------------------
-        for (int c = 0; c < n_ho; ++c) {
-            const double* xc;
-            int tc;
-            row_point(c, xc, tc);
-            const int ncol = n_r + c;
-            double val[4];                                 // rows handled by this thread: tid + r*nt (nrow <= 4*nt)
+        // ---- hallucinated columns, NB at a time -------------------------------------------------------------------
+        for (int c0 = 0; c0 < n_ho; c0 += NB) {
+            const int nb = min(NB, n_ho - c0);
+            double acc[RPT][NB];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int row = tid + r * nt;
-                val[r] = 0.0;
-                if (row >= c && row < nrow) {
-                    double kv;
+            for (int rs = 0; rs < RPT; ++rs) {
+                const int row = tid + rs * nt;
+#pragma unroll
+                for (int q = 0; q < NB; ++q) acc[rs][q] = 0.0;
+                if (row >= c0 && row < nrow) {
                     if (row == wrow) {
-                        kv = Yh[a.h_slots[c]];
+#pragma unroll
+                        for (int q = 0; q < NB; ++q)
+                            if (q < nb) acc[rs][q] = Yh[a.h_slots[c0 + q]];
                     } else {
                         const double* xp;
                         int task;
                         row_point(row, xp, task);
-                        double q[D];
-                        const double k = kern_scalar<D>(xp, xc, il2, os, q);       // r = x_row - x_c
-                        kv = kern_entry<D>(q, k, il2, task, tc);
-                        if (row == c) kv += gp.noise[tc];
-                    }
-                    double acc = 0.0;
-                    for (int k = 0; k < ncol; ++k) acc += M[(long)k * ld + row] * M[(long)k * ld + c];
-                    val[r] = kv - acc;
-                    if (row == c) {
-                        s_flag = !(val[r] > 0.0);
-                        s_piv = sqrt(val[r]);
+#pragma unroll
+                        for (int q = 0; q < NB; ++q) {
+                            if (q < nb) {
+                                const double* xc;
+                                int tc;
+                                row_point(c0 + q, xc, tc);
+                                double qq[D];
+                                const double k = kern_scalar<D>(xp, xc, il2, os, qq);       // r = x_row - x_c
+                                double kv = kern_entry<D>(qq, k, il2, task, tc);
+                                if (row == c0 + q) kv += gp.noise[tc];
+                                acc[rs][q] = kv;
+                            }
+                        }
                     }
                 }
             }
+            JPH(1);
+            block_update<NB, RPT, KC>(M, ld, n_r + c0, c0, nb, c0, nrow, acc, piv);
             __syncthreads();
-            const double piv = s_piv;
+            JPH(2);
+#pragma unroll
+            for (int rs = 0; rs < RPT; ++rs) {
+                const int row = tid + rs * nt;
+                if (row >= c0 && row < c0 + nb) {
+#pragma unroll
+                    for (int q = 0; q < NB; ++q)
+                        if (q <= row - c0) blk[row - c0][q] = acc[rs][q];
+                }
+            }
+            __syncthreads();
+            if (tid < 64) block_factor<NB>(blk, dinv_s, nb, &s_flag);
+            __syncthreads();
+            JPH(3);
             if (s_flag) info_acc |= GPMPC_INFO_TRAIN_CHOL_FAIL;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int row = tid + r * nt;
-                if (row >= c && row < nrow) M[(long)ncol * ld + row] = (row == c) ? piv : val[r] / piv;
+            for (int rs = 0; rs < RPT; ++rs) {
+                const int row = tid + rs * nt;
+                if (row >= c0 && row < nrow) {
+                    double x[NB];
+#pragma unroll
+                    for (int q = 0; q < NB; ++q) {
+                        double v = acc[rs][q];
+#pragma unroll
+                        for (int e = 0; e < NB; ++e)
+                            if (e < q) v = fma(-x[e], blk[q][e], v);
+                        x[q] = (q < nb) ? v * dinv_s[q] : 0.0;
+                        if (row < n_ho && q > row - c0) x[q] = 0.0;      // above the diagonal
+                    }
+#pragma unroll
+                    for (int q = 0; q < NB; ++q)
+                        if (q < nb) M[(long)(n_r + c0 + q) * ld + row] = x[q];
+                }
             }
             __syncthreads();
         }
 
-        // ---- posterior mean, covariance, variance ------------------------------------------------------------
-        for (int tau = tid; tau < mT; tau += nt) {
-            double acc = 0.0;
-            for (int k = 0; k < n_o; ++k) acc += M[(long)k * ld + trow0 + tau] * M[(long)k * ld + wrow];
-            muv[tau] = acc;
+        JPH(4);
+        // ---- posterior mean; covariance S = K** - V V^T (same blocked update, no factor step) ---------------------
+        {   // mu = V^T w: the same blocked update with the w row (index -1 relative to the test rows) as the only pivot
+            double accw[RPT][NB];
+#pragma unroll
+            for (int rs = 0; rs < RPT; ++rs)
+#pragma unroll
+                for (int q = 0; q < NB; ++q) accw[rs][q] = 0.0;
+            block_update<NB, RPT, KC>(M + trow0, ld, n_o, -1, 1, 0, mT, accw, piv);
+#pragma unroll
+            for (int rs = 0; rs < RPT; ++rs) {
+                const int tau = tid + rs * nt;
+                if (tau < mT) muv[tau] = -accw[rs][0];
+            }
         }
-        for (int e = tid; e < mT * mT; e += nt) {
-            const int t2 = e / mT, t1 = e - t2 * mT;      // column t2, row t1 (column-major)
-            if (t1 < t2) continue;
-            const int j1 = t1 / T, b1 = t1 - j1 * T, j2 = t2 / T, b2 = t2 - j2 * T;
-            double q[D];
-            const double k = kern_scalar<D>(Xs + (long)j1 * D, Xs + (long)j2 * D, il2, os, q);
-            double acc = 0.0;
-            for (int kk = 0; kk < n_o; ++kk) acc += M[(long)kk * ld + trow0 + t1] * M[(long)kk * ld + trow0 + t2];
-            Sm[e] = kern_entry<D>(q, k, il2, b1, b2) - acc;
+        for (int c0 = 0; c0 < mT; c0 += NB) {
+            const int nb = min(NB, mT - c0);
+            double acc[RPT][NB];
+#pragma unroll
+            for (int rs = 0; rs < RPT; ++rs) {
+                const int row = trow0 + tid + rs * nt;                 // test rows only
+#pragma unroll
+                for (int q = 0; q < NB; ++q) acc[rs][q] = 0.0;
+                const int t1 = tid + rs * nt;
+                if (t1 >= c0 && t1 < mT) {
+                    const int j1 = t1 / T, b1 = t1 - j1 * T;
+#pragma unroll
+                    for (int q = 0; q < NB; ++q) {
+                        if (q < nb) {
+                            const int t2 = c0 + q, j2 = t2 / T, b2 = t2 - j2 * T;
+                            double qq[D];
+                            const double k = kern_scalar<D>(Xs + (long)j1 * D, Xs + (long)j2 * D, il2, os, qq);
+                            acc[rs][q] = kern_entry<D>(qq, k, il2, b1, b2);
+                        }
+                    }
+                }
+                (void)row;
+            }
+            // rows are offset by trow0 inside M: shift the base pointer so that "row" == test slot index
+            block_update<NB, RPT, KC>(M + trow0, ld, n_o, c0, nb, c0, mT, acc, piv);
+#pragma unroll
+            for (int rs = 0; rs < RPT; ++rs) {
+                const int t1 = tid + rs * nt;
+                if (t1 >= c0 && t1 < mT) {
+#pragma unroll
+                    for (int q = 0; q < NB; ++q)
+                        if (q < nb) Sm[(long)(c0 + q) * mT + t1] = acc[rs][q];
+                }
+            }
         }
         __syncthreads();
 
-        // ---- root: Cholesky with jitter-on-failure (A.7) ----------------------------------------------------
-        int level = 0;                 // 0 = plain, 1..3 = retries
+        JPH(5);
+        // ---- root: blocked Cholesky of S with the jitter-on-failure chain (A.7) -----------------------------------
+        int level = 0;
         bool rooted = false;
         double jit_total = 0.0;
         if (mT == 1) {
@@ -189,34 +371,59 @@ __global__ __launch_bounds__(256) void joint_kernel(const JointArgs a) {
             __syncthreads();
         }
         while (!rooted) {
-            for (int e = tid; e < mT * mT; e += nt) {
-                const int t2 = e / mT, t1 = e - t2 * mT;
-                if (t1 >= t2) Rm[e] = Sm[e] + ((t1 == t2) ? jit_total : 0.0);
-            }
-            __syncthreads();
             bool failed = false;
-            for (int c = 0; c < mT; ++c) {
-                double val = 0.0;
-                const int row = tid;                      // mT <= 256 enforced by the host
-                if (row >= c && row < mT) {
-                    double acc = 0.0;
-                    for (int k = 0; k < c; ++k) acc += Rm[(long)k * mT + row] * Rm[(long)k * mT + c];
-                    val = Rm[(long)c * mT + row] - acc;
-                    if (row == c) {
-                        s_flag = !(val > 0.0);
-                        s_piv = sqrt(val);
+            for (int c0 = 0; c0 < mT && !failed; c0 += NB) {
+                const int nb = min(NB, mT - c0);
+                double acc[RPT][NB];
+#pragma unroll
+                for (int rs = 0; rs < RPT; ++rs) {
+                    const int t1 = tid + rs * nt;
+#pragma unroll
+                    for (int q = 0; q < NB; ++q) {
+                        acc[rs][q] = 0.0;
+                        if (q < nb && t1 >= c0 + q && t1 < mT)
+                            acc[rs][q] = Sm[(long)(c0 + q) * mT + t1] + ((t1 == c0 + q) ? jit_total : 0.0);
+                    }
+                }
+                block_update<NB, RPT, KC>(Rm, mT, c0, c0, nb, c0, mT, acc, piv);
+                __syncthreads();
+#pragma unroll
+                for (int rs = 0; rs < RPT; ++rs) {
+                    const int t1 = tid + rs * nt;
+                    if (t1 >= c0 && t1 < c0 + nb) {
+#pragma unroll
+                        for (int q = 0; q < NB; ++q)
+                            if (q <= t1 - c0) blk[t1 - c0][q] = acc[rs][q];
                     }
                 }
                 __syncthreads();
-                const double piv = s_piv;
+                if (tid < 64) block_factor<NB>(blk, dinv_s, nb, &s_flag);
+                __syncthreads();
                 if (s_flag) {
-                    failed = true;
-                    break;                                // uniform
+                    failed = true;                     // uniform
+                } else {
+#pragma unroll
+                    for (int rs = 0; rs < RPT; ++rs) {
+                        const int t1 = tid + rs * nt;
+                        if (t1 >= c0 && t1 < mT) {
+                            double x[NB];
+#pragma unroll
+                            for (int q = 0; q < NB; ++q) {
+                                double v = acc[rs][q];
+#pragma unroll
+                                for (int e = 0; e < NB; ++e)
+                                    if (e < q) v = fma(-x[e], blk[q][e], v);
+                                x[q] = (q < nb) ? v * dinv_s[q] : 0.0;
+                                if (q > t1 - c0) x[q] = 0.0;
+                            }
+#pragma unroll
+                            for (int q = 0; q < NB; ++q)
+                                if (q < nb) Rm[(long)(c0 + q) * mT + t1] = x[q];
+                        }
+                    }
                 }
-                if (row >= c && row < mT) Rm[(long)c * mT + row] = (row == c) ? piv : val / piv;
                 __syncthreads();
             }
-            __syncthreads();
             if (!failed) {
                 rooted = true;
             } else {
@@ -230,7 +437,9 @@ __global__ __launch_bounds__(256) void joint_kernel(const JointArgs a) {
         }
         info_acc |= (level << 1);
         if (!rooted) info_acc |= GPMPC_INFO_ROOT_FAIL;
+        __syncthreads();
 
+        JPH(6);
         // ---- sample + post-processing (reference src/agent.py:641-708) --------------------------------------
         const double* zc = a.z + chain * (long)mT;
         for (int j = tid; j < m; j += nt) {
@@ -276,13 +485,14 @@ __global__ __launch_bounds__(256) void joint_kernel(const JointArgs a) {
                 Cv[(long)t1 * mT + t2] = v;
             }
         }
-        // OR-reduce info over the block
+        JPH(7);
+#ifdef GPMPC_PHASE_TIMERS
+        if (blockIdx.x == 0 && tid == 0)
+            for (int i = 0; i < 8; ++i) g_joint_phase[i] = jph[i];
+#endif
+        if (info_acc) atomicOr(&s_info, info_acc);
         __syncthreads();
-        if (tid == 0) s_flag = 0;
-        __syncthreads();
-        if (info_acc) atomicOr(&s_flag, info_acc);
-        __syncthreads();
-        if (tid == 0) a.info[chain] = s_flag;
+        if (tid == 0) a.info[chain] = s_info;
         __syncthreads();
     }
 }
@@ -305,6 +515,11 @@ static long joint_grid(long nchains) {
 using namespace gpmpc;
 
 extern "C" {
+
+int gpmpc_debug_read_joint_phases(long long* out /*[host] 16*/) {
+    GPMPC_HIP_CHECK(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_joint_phase), 16 * sizeof(long long)));
+    return GPMPC_OK;
+}
 
 size_t gpmpc_joint_workspace_bytes(const gpmpc_gp_desc_t* gp, int64_t Ns, int32_t n_ho, int32_t m) {
     if (check_gp(gp) != GPMPC_OK) return 0;
@@ -354,12 +569,18 @@ int gpmpc_joint_sample(const gpmpc_gp_desc_t* gp, const void* plan, const double
     if (ws_bytes < (size_t)grid * a.ws_chain_stride * sizeof(double))
         return fail(GPMPC_E_WORKSPACE, "gpmpc_joint_sample: workspace too small");
     hipStream_t st = (hipStream_t)stream;
-    if (gp->T == 1)
-        hipLaunchKernelGGL(joint_kernel<1>, dim3((unsigned)grid), dim3(256), 0, st, a);
-    else if (gp->T == 3)
-        hipLaunchKernelGGL(joint_kernel<3>, dim3((unsigned)grid), dim3(256), 0, st, a);
-    else
+    const int nrow = n_ho + 1 + mT;
+    const bool small = nrow <= 512;                 // 2 rows per thread x 16-wide blocks, else 4 rows x 8-wide
+    const dim3 g((unsigned)grid), blk(256);
+    if (gp->T == 1) {
+        if (small) hipLaunchKernelGGL((joint_kernel<1, 16, 2>), g, blk, 0, st, a);
+        else hipLaunchKernelGGL((joint_kernel<1, 8, 4>), g, blk, 0, st, a);
+    } else if (gp->T == 3) {
+        if (small) hipLaunchKernelGGL((joint_kernel<3, 16, 2>), g, blk, 0, st, a);
+        else hipLaunchKernelGGL((joint_kernel<3, 8, 4>), g, blk, 0, st, a);
+    } else {
         return fail(GPMPC_E_UNSUPPORTED, "joint: only T = 1 and T = 3 (D = 2) are instantiated");
+    }
     GPMPC_HIP_CHECK(hipGetLastError());
     return GPMPC_OK;
 }

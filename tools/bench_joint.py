@@ -1,0 +1,46 @@
+"""Time mode J (joint-horizon draw per SQP iteration, BASELINE config 5 shape) through Agent.dyn_fg_jacobians."""
+import sys, os, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import warnings
+import torch, numpy as np
+import sampling_gpmpc_amd as sg
+from tests.helpers import load_params
+
+def run(pname, Ns, H, iters, jitter=None):
+    p = load_params(pname)
+    p["common"]["use_cuda"] = True
+    p["agent"]["num_dyn_samples"], p["optimizer"]["H"] = Ns, H
+    p["agent"]["true_dyn_as_sample"] = False
+    p["agent"]["base_sample_generator"] = "vectorized"
+    p["common"]["num_MPC_itrs"], p["optimizer"]["SEMPC"]["max_sqp_iter"] = 1, iters
+    if jitter is not None:
+        p["agent"]["Dyn_gp_jitter"] = jitter
+    torch.manual_seed(3)
+    agent = sg.Agent(p, sg.make_env(p))
+    nx, nu = agent.nx, agent.nu
+    g = torch.Generator().manual_seed(5)
+    x0 = np.array(p["env"]["start"], dtype=np.float64)
+    agent.mpc_iteration(0)
+    for it in range(iters):
+        x_h = np.tile(x0, (H, Ns)) + 0.05 * torch.randn(H, Ns * nx, generator=g, dtype=torch.float64).numpy() + 0.02 * np.arange(H)[:, None]
+        u_h = 0.3 * torch.randn(H, Ns, nu, generator=g, dtype=torch.float64).numpy()
+        agent.train_hallucinated_dynGP(it)
+        bx = agent.get_batch_x_hat_u_diff(x_h, u_h)
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            y = agent.get_batch_gp_sensitivities(bx, it)
+        torch.cuda.synchronize(); t1 = time.perf_counter()
+        n_h = agent.model_i.n_h
+        lvl = int(((agent.model_i_call.last_info >> 1) & 7).max().item())
+        if os.environ.get("GPMPC_PHASE_TIMERS") == "1":
+            import ctypes as C
+            out = (C.c_longlong * 16)(); sg._lib.load().gpmpc_debug_read_joint_phases(out)
+            names = ["realcols", "init", "update", "factor", "solve", "mean+S", "root", "sample"]
+            print("   phases(cycles):", {n: out[i] for i, n in enumerate(names)})
+        print(f"{pname:26s} Ns={Ns} H={H} k={it}: n_o={agent.model_i.plan.n_r + n_h*3:4d} m*T={H*3}: sample_gp+update {1e3*(t1-t0):8.2f} ms "
+              f"({Ns*H/(t1-t0)/1e6:7.2f} M traj-steps/s), max jitter level {lvl}, finite={bool(torch.isfinite(y).all())}", flush=True)
+
+if __name__ == "__main__":
+    run("params_pendulum1D_samples", 1024, 30, 2)
+    run("params_car_residual", 1024, 40, 4, jitter=1e-9)
