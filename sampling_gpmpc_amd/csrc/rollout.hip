@@ -409,7 +409,10 @@ using namespace gpmpc;
 
 extern "C" {
 
-// debug helper, deliberately not declared in include/gpmpc_hip.h
+// debug helpers, deliberately not declared in include/gpmpc_hip.h
+static int g_last_rollout_path = -1;     // 0 generic, 1 tuned re-conditioned (rollout_fast), 2 thread-per-sample (rollout_indep)
+int gpmpc_debug_last_rollout_path(void) { return g_last_rollout_path; }
+
 int gpmpc_debug_read_phases(long long* out /*[host] 16*/) {
     GPMPC_HIP_CHECK(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_phase_cycles), 16 * sizeof(long long)));
     return GPMPC_OK;
@@ -470,8 +473,15 @@ int gpmpc_rollout(const gpmpc_gp_desc_t* gp, const gpmpc_env_desc_t* env, const 
         if (!ws || ws_bytes < need) return fail(GPMPC_E_WORKSPACE, "gpmpc_rollout: workspace too small");
     }
     hipStream_t st = (hipStream_t)stream;
-    if (rollout_fast_eligible(gp, env, mode, hall_tasks, H)) return rollout_fast_launch(gp, env, args, ws, ws_bytes, st);
-    if (rollout_indep_eligible(gp, env, mode)) return rollout_indep_launch(env, args, st);
+    if (rollout_fast_eligible(gp, env, mode, hall_tasks, H)) {
+        g_last_rollout_path = 1;
+        return rollout_fast_launch(gp, env, args, ws, ws_bytes, st);
+    }
+    if (rollout_indep_eligible(gp, env, mode)) {
+        g_last_rollout_path = 2;
+        return rollout_indep_launch(env, args, st);
+    }
+    g_last_rollout_path = 0;
     const int T = gp->T;
     if (T == 1) {
         if (rp.rpl == 1) return launch_rollout<1, 1>(args, rp, gp->g_ny, st);

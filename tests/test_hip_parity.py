@@ -126,7 +126,9 @@ def test_rollout_against_reference_goldens(sg, tag, pname):
     ("params_pendulum1D_samples", 32, 10, False, True),       # same through the HBM-workspace factor
     ("params_pendulum1D_samples", 48, 30, False, False),      # config 2 horizon, n_h up to 87 (2 rows per lane)
     ("params_car_residual_fs", 24, 40, False, False),         # config 3 horizon, T=3, n_h up to 117, HBM factor
-    ("params_car_residual_fs", 64, 40, True, False),          # config 4 as shipped (mode I, T=1)
+    ("params_car_residual_fs", 64, 40, True, False),          # config 4 as shipped (mode I, T=1): thread-per-sample kernel
+    ("params_car_residual_fs", 300, 7, True, False),          # mode I, ragged last workgroup (300 = 256 + 44)
+    ("params_pendulum1D_samples", 40, 12, True, False),       # mode I on the 4x9 pendulum grid
 ])
 def test_rollout_against_oracle(sg, pname, Ns, H, nograd, force_global, monkeypatch):
     from sampling_gpmpc_amd.rollout import forward_sampling_rollout
@@ -389,3 +391,30 @@ def test_sharded_rollout_single_rank_rccl(sg):
         dist.destroy_process_group()
     X = forward_sampling_rollout(agent, u_ff)
     np.testing.assert_array_equal(tube.cpu().numpy(), X)
+
+
+@pytest.mark.parametrize("pname,Ns,H,nograd", [("params_pendulum1D_samples", 16, 12, False),
+                                               ("params_car_residual_fs", 9, 10, False),
+                                               ("params_car_residual_fs", 70, 9, True)])
+def test_generic_kernels_agree_with_tuned_kernels(sg, pname, Ns, H, nograd, monkeypatch):
+    """The generic rollout kernel (any T / n_r / horizon) and the tuned kernels (rollout_fast / rollout_indep) are two
+    implementations of the same arithmetic: same inputs, results equal to round-off."""
+    from sampling_gpmpc_amd.rollout import forward_sampling_rollout
+    p = fs_params(pname, Ns, H, nograd=nograd, beta=(3.0 if (not nograd and "car" in pname) else None))
+    agent, _ = make_agents(sg, p)
+    u_ff = synthetic_u_ff(agent.nu, H)
+    lib = sg._lib.load()
+    X_fast, Y_fast = forward_sampling_rollout(agent, u_ff, return_samples=True)
+    assert lib.gpmpc_debug_last_rollout_path() == (2 if nograd else 1), "tuned kernel was not selected"
+    monkeypatch.setenv("GPMPC_DISABLE_FAST_ROLLOUT", "1")
+    agent2, _ = make_agents(sg, p, erv=agent.epistimic_random_vector.cpu().numpy())
+    X_gen, Y_gen = forward_sampling_rollout(agent2, u_ff, return_samples=True)
+    assert lib.gpmpc_debug_last_rollout_path() == 0, "generic kernel was not selected"
+    po = fs_params(pname, Ns, H, nograd=nograd, beta=(3.0 if (not nograd and "car" in pname) else None))
+    oagent = ao.OracleAgent(po, ao.make_oracle_env(po), agent.epistimic_random_vector.cpu())
+    X_o = ao.forward_sampling_rollout(oagent, u_ff)
+    print(f"{pname} Ns={Ns} H={H} nograd={nograd}: tuned vs generic max abs diff {np.abs(X_fast - X_gen).max():.2e}; "
+          f"generic vs oracle rel err {relerr(X_gen, X_o):.2e}; tuned vs oracle {relerr(X_fast, X_o):.2e}")
+    assert relerr(X_gen, X_o) < RTOL_TRAJ and relerr(X_fast, X_o) < RTOL_TRAJ
+    np.testing.assert_allclose(X_fast, X_gen, rtol=1e-9, atol=1e-11)
+    np.testing.assert_allclose(Y_fast, Y_gen, rtol=1e-7, atol=1e-11)

@@ -143,3 +143,48 @@ def test_product_package_never_imports_the_oracle():
             if f.endswith((".py", ".hip", ".hpp")):
                 src = open(os.path.join(root, f)).read()
                 assert "import oracle" not in src and "from oracle" not in src, os.path.join(root, f)
+
+
+def test_tensor_grid_detection():
+    from sampling_gpmpc_amd.gp_model import _detect_tensor_grid
+    for pname, want in [("params_pendulum1D_samples", (4, 9)), ("params_car_residual", (5, 9))]:
+        p = load_params(pname)
+        p["common"]["use_cuda"] = False
+        X, _ = sg.make_env(p).initial_training_data()
+        assert _detect_tensor_grid(X) == want
+        Xb = X.clone()
+        Xb[7, 1] += 1e-9                         # not a tensor grid any more
+        assert _detect_tensor_grid(Xb) == (0, 0)
+    assert _detect_tensor_grid(torch.rand(10, 2, dtype=torch.float64)) in [(0, 0), (10, 1)]
+
+
+def test_gp_desc_layout_matches_header():
+    """ctypes mirror of gpmpc_gp_desc_t / gpmpc_env_desc_t: sizes implied by the header's field list."""
+    assert ctypes.sizeof(_lib.GpDesc) == 8 * 4 + 8 * (4 * 4 + 4 + 5 + 2)
+    assert ctypes.sizeof(_lib.EnvDesc) == 4 * 4 + 8 * (3 + 4 * 8 + 8)
+    d = _lib.make_gp_desc(3, 2, 1, 45, False, [[2.0, 1.1]] * 3, [0.05] * 3, [2e-7], 1e-20, grid=(5, 9))
+    assert (d.grid_n0, d.grid_n1, d.N_r, d.T) == (5, 9, 45, 1)
+    lib = _lib.load()
+    bad = _lib.make_gp_desc(3, 2, 1, 45, False, [[2.0, 1.1]] * 3, [0.05] * 3, [2e-7], 1e-20, grid=(5, 8))
+    assert lib.gpmpc_plan_bytes(bad) == 0 and b"grid_n0" in lib.gpmpc_last_error_string()
+
+
+def test_on_disk_formats_roundtrip(tmp_path):
+    """data_X_traj_<idx>.pkl as the reference writes it: float64 ndarray (Ns, nx, H+1), readable with plain pickle."""
+    import pickle
+    from sampling_gpmpc_amd import io_formats as io
+    rng = np.random.default_rng(0)
+    a, b = rng.normal(size=(5, 4, 9)), rng.normal(size=(3, 4, 9))
+    pa = io.save_x_traj(str(tmp_path), 400, torch.tensor(a))
+    io.save_x_traj(str(tmp_path), 401, b)
+    assert os.path.basename(pa) == "data_X_traj_400.pkl"
+    with open(pa, "rb") as f:
+        got = pickle.load(f)                      # what generate_convex_hull.py does
+    assert isinstance(got, np.ndarray) and got.dtype == np.float64
+    np.testing.assert_array_equal(got, a)
+    np.testing.assert_array_equal(io.merge_x_traj(str(tmp_path), [400, 401]), np.concatenate([a, b], axis=0))
+    erv = torch.randn(2, 2, 3, 1, 1, 3, dtype=torch.float64)
+    pe = io.save_epistemic_vector(str(tmp_path), 7, erv)
+    assert torch.equal(io.load_epistemic_vector(pe), erv)
+    with pytest.raises(ValueError):
+        io.save_x_traj(str(tmp_path), 1, np.zeros((3, 4)))
