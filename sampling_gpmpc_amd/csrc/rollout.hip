@@ -61,16 +61,18 @@ __global__ __launch_bounds__(64 * GPMPC_MAX_NY) void rollout_kernel(const Rollou
     double* wh = vr + T * n_r;                    // [nh_max]
     double* invd = wh + nh_max;                   // [nh_max]
     double* yout = invd + nh_max;                 // [H][T]
-    double* LinvT = yout + H * T;                 // [n_r][n_r] staged copy of the plan's L_rr^-1 (transposed)
-    double* w_r = LinvT + n_r * n_r;              // [n_r]
+    double* LinvT_s = yout + H * T;               // [n_r][n_r] staged copy of the plan's L_rr^-1 (transposed), if it fits
+    double* w_r = LinvT_s + (a.linv_in_lds ? n_r * n_r : 0);   // [n_r]
     double* fac = FAC_LDS ? (w_r + n_r) : (a.ws + (s * gp.g_ny + o) * a.ws_chain_stride);
     double* LhrT = fac;                           // [n_r][nh_max]   LhrT[i*nh_max + slot] = L_hr[slot][i]
     double* Lhh = fac + (long)n_r * nh_max;       // packed lower, column-major: (slot,p) at col_ofs(p)+slot-p
 
+    const double* LinvT = a.linv_in_lds ? LinvT_s : plan_LinvT(a.plan, gp, o);
     {
         const double* gL = plan_LinvT(a.plan, gp, o);
         const double* gw = plan_w(a.plan, gp, o);
-        for (int e = lane; e < n_r * n_r; e += kWave) LinvT[e] = gL[e];
+        if (a.linv_in_lds)
+            for (int e = lane; e < n_r * n_r; e += kWave) LinvT_s[e] = gL[e];
         for (int e = lane; e < n_r; e += kWave) w_r[e] = gw[e];
     }
     double il2[D];
@@ -354,7 +356,7 @@ __global__ __launch_bounds__(64 * GPMPC_MAX_NY) void rollout_kernel(const Rollou
 }
 
 struct RolloutPlan {
-    int nh_max, rpl, lds_shared, lds_per_wave;
+    int nh_max, rpl, lds_shared, lds_per_wave, linv_in_lds;
     long chain_doubles;
     bool fac_lds;
     size_t lds_bytes;
@@ -377,7 +379,9 @@ static int plan_rollout(const gpmpc_gp_desc_t* gp, int nx, int mode, int hall_ta
     rp->chain_doubles = (long)n_r * nh_max + ((long)nh_max * (nh_max + 1)) / 2;
     rp->lds_shared = nx * (H + 1) + H * gp->D + 2 * GPMPC_MAX_NY;
     rp->lds_shared = (rp->lds_shared + 1) & ~1;
-    const int vec = 2 * T * n_r + 2 * nh_max + H * T + n_r * n_r + n_r;
+    // stage L_rr^-1 per wave when it leaves room for the rest (n_r <= ~60); otherwise it is read through L2
+    rp->linv_in_lds = ((size_t)gp->g_ny * n_r * n_r * sizeof(double) <= 64 * 1024) ? 1 : 0;
+    const int vec = 2 * T * n_r + 2 * nh_max + H * T + (rp->linv_in_lds ? n_r * n_r : 0) + n_r;
     const long with_fac = vec + rp->chain_doubles;
     const size_t bytes_fac = ((size_t)rp->lds_shared + (size_t)gp->g_ny * ((with_fac + 1) & ~1L)) * sizeof(double);
     rp->fac_lds = (mode == GPMPC_MODE_RECONDITIONED) && bytes_fac <= (size_t)(160 * 1024 - 256) && !force_global_factor();
@@ -468,6 +472,7 @@ int gpmpc_rollout(const gpmpc_gp_desc_t* gp, const gpmpc_env_desc_t* env, const 
     args.nh_max = rp.nh_max;
     args.lds_shared = rp.lds_shared;
     args.lds_per_wave = rp.lds_per_wave;
+    args.linv_in_lds = rp.linv_in_lds;
     if (mode == GPMPC_MODE_RECONDITIONED && !rp.fac_lds) {
         const size_t need = (size_t)Ns * gp->g_ny * rp.chain_doubles * sizeof(double);
         if (!ws || ws_bytes < need) return fail(GPMPC_E_WORKSPACE, "gpmpc_rollout: workspace too small");

@@ -27,6 +27,7 @@ struct RolloutArgs {
     int nh_max;             // hallucinated slots allocated per chain
     int lds_shared;         // doubles of block-shared LDS
     int lds_per_wave;       // doubles of per-wave LDS
+    int linv_in_lds;        // generic kernel: L_rr^-1 staged per wave in LDS (else read from the plan in HBM/L2)
 };
 
 // packed lower-triangular, column-major: element (row, col) at col_ofs(col) + row - col, rows col..nh_max-1

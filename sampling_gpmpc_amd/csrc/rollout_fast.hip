@@ -657,6 +657,7 @@ int rollout_fast_launch(const gpmpc_gp_desc_t* gp, const gpmpc_env_desc_t* env, 
     args.nh_max = 3 * (args.H - 1);
     args.lds_shared = fp.lds_shared;
     args.lds_per_wave = fp.lds_per_wave;
+    args.linv_in_lds = 1;
     args.ws_chain_stride = fp.chain_doubles;
     if (!fp.lhh_lds) {
         if (!ws || ws_bytes < rollout_fast_workspace_bytes(gp, args.Ns, args.H))

@@ -418,3 +418,114 @@ def test_generic_kernels_agree_with_tuned_kernels(sg, pname, Ns, H, nograd, monk
     assert relerr(X_gen, X_o) < RTOL_TRAJ and relerr(X_fast, X_o) < RTOL_TRAJ
     np.testing.assert_allclose(X_fast, X_gen, rtol=1e-9, atol=1e-11)
     np.testing.assert_allclose(Y_fast, Y_gen, rtol=1e-7, atol=1e-11)
+
+
+@pytest.mark.parametrize("pname,Ns,H", [
+    ("params_pendulum1D_samples", 1, 2),        # a single sample, the shortest horizon that appends (n_h max 3)
+    ("params_pendulum1D_samples", 5, 43),       # longest horizon of the tuned kernel (n_h max 126 of 128)
+    ("params_pendulum1D_samples", 3, 45),       # beyond it: generic kernel, 4 rows per lane (n_h max 132)
+    ("params_car_residual_fs", 2, 3),
+    ("params_car_residual_fs", 1025, 2),        # many workgroups, tiny horizon
+])
+def test_rollout_edge_sizes(sg, pname, Ns, H):
+    from sampling_gpmpc_amd.rollout import forward_sampling_rollout
+    p = fs_params(pname, Ns, H, nograd=False, beta=(3.0 if "car" in pname else None))
+    if Ns > 64:
+        p["agent"]["base_sample_generator"] = "vectorized"
+    agent, oagent = make_agents(sg, p)
+    u_ff = synthetic_u_ff(agent.nu, H)
+    X, Y = forward_sampling_rollout(agent, u_ff, return_samples=True)
+    path = sg._lib.load().gpmpc_debug_last_rollout_path()
+    if Ns > 64:                                    # oracle on a subset (it is Ns-tiled and from scratch)
+        sel = slice(Ns - 24, Ns)
+        po = fs_params(pname, 24, H, nograd=False, beta=(3.0 if "car" in pname else None))
+        oagent = ao.OracleAgent(po, ao.make_oracle_env(po), agent.epistimic_random_vector[:, :, sel].cpu())
+        X, Y = X[sel], Y[sel]
+    Xo, Yo = ao.forward_sampling_rollout(oagent, u_ff, return_samples=True)
+    print(f"{pname} Ns={Ns} H={H}: kernel path {path}, rel err X {relerr(X, Xo):.2e} Y {relerr(Y, Yo):.2e}")
+    assert path == (0 if H > 43 else 1)
+    assert relerr(X, Xo) < RTOL_TRAJ
+    np.testing.assert_allclose(Y, Yo, rtol=1e-4, atol=1e-8)
+
+
+@pytest.mark.parametrize("pname", ["params_pendulum1D_samples", "params_car_residual"])
+def test_derivative_observing_real_data(sg, pname):
+    """env.train_data_has_derivatives: True - the real labels observe value AND gradient (n_r = N_r*T slots): plan,
+    joint draw and re-conditioned rollout (generic kernel) against the oracle."""
+    from sampling_gpmpc_amd.rollout import forward_sampling_rollout
+    Ns, H = 6, 5
+    p = load_params(pname)
+    p["env"]["train_data_has_derivatives"] = True
+    p["agent"]["true_dyn_as_sample"] = False
+    p["agent"]["num_dyn_samples"], p["optimizer"]["H"] = Ns, H
+    p["common"]["num_MPC_itrs"], p["optimizer"]["SEMPC"]["max_sqp_iter"] = 1, 1
+    if "car" in pname:
+        p["agent"]["Dyn_gp_jitter"] = 1e-9
+    agent, oagent = make_agents(sg, p)
+    assert agent._plan(True).real_has_grad and agent._plan(True).n_r == agent.Dyn_gp_X_train.shape[0] * 3
+    g = torch.Generator().manual_seed(4)
+    x_h = np.tile(np.array(p["env"]["start"]), (H, Ns)) + 0.05 * torch.randn(H, Ns * agent.nx, generator=g, dtype=F64).numpy()
+    u_h = 0.2 * torch.randn(H, Ns, agent.nu, generator=g, dtype=F64).numpy()
+    agent.train_hallucinated_dynGP(0)
+    oagent.train_hallucinated_dynGP(0)
+    gp_val, y_grad, u_grad = agent.dyn_fg_jacobians(agent.get_batch_x_hat_u_diff(x_h, u_h), 0)
+    ogp_val, oy_grad, ou_grad = oagent.dyn_fg_jacobians(oagent.get_batch_x_hat_u_diff(x_h, u_h), 0)
+    np.testing.assert_allclose(agent.model_i_call.mean.cpu().numpy(), oagent.model_i_call.mean.numpy(), rtol=1e-6, atol=1e-9)
+    np.testing.assert_allclose(agent.model_i_call.variance.cpu().numpy(), oagent.model_i_call.variance.numpy(),
+                               rtol=1e-3, atol=1e-13)
+    lvl = ((agent.model_i_call.last_info.cpu().numpy() >> 1) & 7).max(axis=1)
+    ojit = oagent.model_i_call.root_info.jitter_added.numpy().max(axis=1)
+    same = (lvl > 0) == (ojit > 0)
+    # with gradient labels on the grid the posterior is nearly degenerate (variances at the jitter level), so the
+    # samples carry O(sqrt(jitter)) branch/round-off noise; mean, variance above are the sharp checks
+    print(f"{pname}: derivative data, max |gp_val - oracle| = {np.abs(gp_val[same] - ogp_val[same]).max():.2e}")
+    np.testing.assert_allclose(gp_val[same], ogp_val[same], rtol=1e-5, atol=2e-4)
+    # rollout with the same data (forward-sampling layout)
+    pf = fs_params(pname if "pendulum" in pname else "params_car_residual_fs", Ns, 6, nograd=False,
+                   beta=(3.0 if "car" in pname else None))
+    pf["env"]["train_data_has_derivatives"] = True
+    agent, oagent = make_agents(sg, pf)
+    u_ff = synthetic_u_ff(agent.nu, 6)
+    X = forward_sampling_rollout(agent, u_ff)
+    assert sg._lib.load().gpmpc_debug_last_rollout_path() == 0
+    Xo = ao.forward_sampling_rollout(oagent, u_ff)
+    print(f"{pname} derivative-observing real data: rollout rel err {relerr(X, Xo):.2e}")
+    assert relerr(X, Xo) < RTOL_TRAJ
+
+
+def test_value_only_appended_labels(sg):
+    """hall_tasks = 1: the appended points observe task 0 only (reference src/agent.py:402, the forward-sampling data
+    of prepare_dynamics_set).  Oracle: the same loop with the gradient labels NaN-ed before the dataset update."""
+    from sampling_gpmpc_amd.rollout import rollout_device
+    from sampling_gpmpc_amd import _lib
+    Ns, H = 7, 8
+    p = fs_params("params_pendulum1D_samples", Ns, H)
+    agent, oagent = make_agents(sg, p)
+    u_ff = synthetic_u_ff(1, H)
+    erv = agent.epistimic_random_vector
+    per = Ns * 3
+    res = rollout_device(agent, u_ff, erv.reshape(-1)[per:], erv.shape[1] * per, H=H, mode=_lib.MODE_RECONDITIONED,
+                         use_model_without_derivatives=False, hall_tasks=1)
+    assert sg._lib.load().gpmpc_debug_last_rollout_path() == 0
+    X = res.X_traj.cpu().numpy()
+    # oracle loop (forward_sampling_rollout of oracle/agent_oracle.py with the label masking inserted)
+    K = np.array(p["optimizer"]["terminal_tightening"]["K"])
+    x_equi = np.array(p["env"]["goal_state"])
+    x_h = np.tile(np.array(p["env"]["start"], dtype=np.float64), (1, Ns))
+    Xo = np.empty((Ns, 2, H + 1))
+    orig_update = oagent.update_hallucinated_Dyn_dataset
+    def masked_update(newX, newY):
+        newY = newY.clone()
+        newY[..., 1:] = float("nan")
+        orig_update(newX, newY)
+    oagent.update_hallucinated_Dyn_dataset = masked_update
+    for t in range(H):
+        oagent.train_hallucinated_dynGP(1)
+        oagent.mpc_iteration(t)
+        bx = oagent.get_batch_x_hat_u_diff(x_h, -(x_equi - x_h.reshape(1, Ns, -1)) @ K.T + np.tile(u_ff[t].reshape(1, 1, -1), (Ns, 1)))
+        gp_val, _, _ = oagent.dyn_fg_jacobians(bx, 1)
+        Xo[:, :, t] = bx[:, 0, 0, :2].numpy()
+        x_h = gp_val[:, :, 0, 0].reshape(1, -1)
+    Xo[:, :, H] = gp_val[:, :, 0, 0]
+    print(f"value-only appended labels: rel err {relerr(X, Xo):.2e}")
+    assert relerr(X, Xo) < RTOL_TRAJ
