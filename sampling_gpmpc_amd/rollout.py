@@ -9,6 +9,11 @@ Drivers with the loop structure of the reference's harnesses:
   replacement), expressed on the same kernel.
 
 Both return ``X_traj (Ns, nx, H+1)`` float64 - the array the reference pickles (``data_X_traj_<idx>.pkl``).
+
+``forward_sampling_stepwise`` is the same harness loop driven through the ``Agent`` methods one step at a time (one
+``gpmpc_joint_sample`` + ``gpmpc_assemble_jacobians`` launch per step).  ``forward_sampling_rollout`` routes to it when
+a feature the fused kernel does not implement is switched on (``Dyn_gp_min_data_dist >= 0``: label overwrite and
+dataset filtering, ``true_dyn_as_sample`` / ``mean_as_dyn_sample`` short cuts); every shipped YAML takes the fused path.
 """
 from __future__ import annotations
 
@@ -77,6 +82,50 @@ def rollout_device(agent: Agent, u_ff, z: torch.Tensor, z_step_stride: int, *, H
     return RolloutResult(X_traj, Y, Xi, info)
 
 
+def fused_rollout_supported(agent: Agent) -> bool:
+    """True when ``gpmpc_rollout`` implements everything the configuration asks of ``sample_gp`` /
+    ``update_hallucinated_Dyn_dataset`` (reference ``src/agent.py:164-202, 566-730``)."""
+    ag = agent.params["agent"]
+    return (ag["Dyn_gp_min_data_dist"] < 0.0 and not ag.get("true_dyn_as_sample", False)
+            and not ag.get("mean_as_dyn_sample", False))
+
+
+def forward_sampling_stepwise(agent: Agent, u_ff, x0=None, return_samples: bool = False):
+    """The forward-sampling harness (reference ``benchmarking/simulate_forward_sampling_car.py:108-138``) through the
+    ``Agent`` call surface, one step per iteration: re-train on the points appended so far, draw at the current
+    state/input, hand the sampled next state over.  Slower than the fused kernel (per-step launches and two host
+    round trips, like the reference) but covers every ``sample_gp`` option."""
+    p = agent.params
+    u_ff = np.asarray(u_ff, dtype=np.float64)
+    H_traj = u_ff.shape[0]
+    ns, nx = agent.ns, agent.nx
+    nograd = bool(p["env"]["use_model_without_derivatives"])
+    start = np.asarray(p["env"]["start"] if x0 is None else x0, dtype=np.float64)
+    states = np.tile(start[:nx].reshape(1, nx), (1, ns))                         # (1, Ns*nx): the H=1 "x_h" row
+    K = np.asarray(p["optimizer"]["terminal_tightening"]["K"], dtype=np.float64)
+    x_goal = np.asarray(p["env"]["goal_state"], dtype=np.float64)
+    X_traj = np.empty((ns, nx, H_traj + 1))
+    draws = []
+    for t in range(H_traj):
+        agent.train_hallucinated_dynGP(1, use_model_without_derivatives=nograd)
+        agent.mpc_iteration(t)
+        u_t = u_ff[t].reshape(1, -1)
+        if p["agent"]["feedback"]["use"]:
+            u_fb = (states.reshape(1, ns, nx) - x_goal) @ K.T + u_t[:, None, :]     # u_ff + K (x - x_goal)
+            xu = agent.get_batch_x_hat_u_diff(states, u_fb)
+        else:
+            xu = agent.get_batch_x_hat(states, u_t)
+        gp_val, _, _ = agent.dyn_fg_jacobians(xu, 1)
+        if return_samples:
+            draws.append(agent.model_i_samples.detach().cpu().numpy())
+        X_traj[:, :, t] = states.reshape(ns, nx)
+        states = gp_val[:, :, 0, 0].reshape(1, -1)
+    X_traj[:, :, H_traj] = states.reshape(ns, nx)
+    if return_samples:
+        return X_traj, np.concatenate(draws, axis=2)
+    return X_traj
+
+
 def forward_sampling_rollout(agent: Agent, u_ff, x0=None, return_samples: bool = False, check: bool = True):
     """The reference forward-sampling loop, one launch.
 
@@ -88,6 +137,8 @@ def forward_sampling_rollout(agent: Agent, u_ff, x0=None, return_samples: bool =
     u_ff = np.asarray(u_ff, dtype=np.float64)
     H = u_ff.shape[0]
     erv = agent.epistimic_random_vector
+    if not fused_rollout_supported(agent):
+        return forward_sampling_stepwise(agent, u_ff, x0=x0, return_samples=return_samples)
     if p["optimizer"]["H"] != 1 or erv.shape[0] < H or erv.shape[1] < 2:
         raise ValueError("forward sampling needs optimizer.H == 1, num_MPC_itrs >= H_traj and max_sqp_iter >= 2 "
                          "(reference simulate_forward_sampling_car.py indexes epistimic_random_vector[H_idx][1])")

@@ -529,3 +529,56 @@ def test_value_only_appended_labels(sg):
     Xo[:, :, H] = gp_val[:, :, 0, 0]
     print(f"value-only appended labels: rel err {relerr(X, Xo):.2e}")
     assert relerr(X, Xo) < RTOL_TRAJ
+
+
+def _clamped_base_samples(p, H, seed):
+    g = torch.Generator().manual_seed(seed)
+    ag = p["agent"]
+    T = 1 if p["env"]["use_model_without_derivatives"] else 1 + ag["g_dim"]["nx"] + ag["g_dim"]["nu"]
+    return torch.randn(H, 2, ag["num_dyn_samples"], ag["g_dim"]["ny"], 1, T, generator=g, dtype=F64).clamp(-2.0, 2.0)
+
+
+@pytest.mark.parametrize("pname,nograd", [("params_pendulum1D_samples", False), ("params_car_residual_fs", False),
+                                          ("params_car_residual_fs", True)])
+def test_stepwise_harness_equals_fused_rollout(sg, pname, nograd):
+    """The per-step Agent call sequence (gpmpc_joint_sample + gpmpc_assemble_jacobians per step, the reference's loop
+    structure) and the one-launch fused rollout are the same computation."""
+    from sampling_gpmpc_amd.rollout import forward_sampling_rollout, forward_sampling_stepwise
+    Ns, H = 16, 8
+    p = fs_params(pname, Ns, H, nograd=nograd, beta=(3.0 if (not nograd and "car" in pname) else None))
+    erv = _clamped_base_samples(p, H, 11)
+    a_fused, _ = make_agents(sg, p, erv=erv)
+    a_step, _ = make_agents(sg, p, erv=erv)
+    u_ff = synthetic_u_ff(a_fused.nu, H)
+    Xf, Yf = forward_sampling_rollout(a_fused, u_ff, return_samples=True)
+    Xs, Ys = forward_sampling_stepwise(a_step, u_ff, return_samples=True)
+    print(f"{pname} nograd={nograd}: stepwise vs fused max abs diff X {np.abs(Xf - Xs).max():.2e} Y {np.abs(Yf - Ys).max():.2e}")
+    np.testing.assert_allclose(Xs, Xf, rtol=1e-8, atol=1e-10)
+    np.testing.assert_allclose(Ys, Yf, rtol=1e-6, atol=1e-10)
+    np.testing.assert_allclose(a_step.Hallcinated_X_train.cpu().numpy(), a_fused.Hallcinated_X_train.cpu().numpy(),
+                               rtol=1e-8, atol=1e-10)
+
+
+@pytest.mark.parametrize("pname,min_dist", [("params_pendulum1D_samples", 0.25), ("params_car_residual_fs", 0.05)])
+def test_forward_sampling_with_min_data_dist(sg, pname, min_dist):
+    """Dyn_gp_min_data_dist >= 0 (off in the shipped YAMLs): appended points too close to existing data get NaN labels
+    per sample, points filtered in all samples are dropped, draws too close to an observed label are overwritten
+    (reference src/agent.py:164-202, 666-698).  forward_sampling_rollout routes to the per-step harness for it."""
+    from sampling_gpmpc_amd.rollout import forward_sampling_rollout, fused_rollout_supported
+    Ns, H = 12, 8
+    p = fs_params(pname, Ns, H, nograd=False, beta=(3.0 if "car" in pname else None))
+    p["agent"]["Dyn_gp_min_data_dist"] = min_dist
+    agent, oagent = make_agents(sg, p, erv=_clamped_base_samples(p, H, 3))
+    assert not fused_rollout_supported(agent)
+    u_ff = synthetic_u_ff(agent.nu, H)
+    X, Y = forward_sampling_rollout(agent, u_ff, return_samples=True)
+    Xo, Yo = ao.forward_sampling_rollout(oagent, u_ff, return_samples=True)
+    hy, hyo = agent.Hallcinated_Y_train.cpu().numpy(), oagent.Hallcinated_Y_train.numpy()
+    assert hy.shape == hyo.shape and hy.shape[2] < H, "the filter must have dropped points in this case"
+    nan, nano = np.isnan(hy), np.isnan(hyo)
+    assert nan.any() and (nan == nano).all(), "per-sample NaN-labelled points differ"
+    print(f"{pname} min_dist={min_dist}: kept {hy.shape[2]}/{H} points, {nan[..., 0].mean():.0%} NaN-labelled; "
+          f"rel err X {relerr(X, Xo):.2e}")
+    np.testing.assert_allclose(X, Xo, rtol=RTOL_TRAJ, atol=1e-9)
+    np.testing.assert_allclose(Y, Yo, rtol=1e-5, atol=1e-9)
+    np.testing.assert_allclose(hy[~nan], hyo[~nano], rtol=1e-5, atol=1e-9)
