@@ -17,6 +17,7 @@ OBJDIR = os.path.join(HERE, "build")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fgpu-rdc" if False else "-fno-gpu-rdc",
          "-ffp-contract=on", "-I", os.path.join(REPO, "include"), "-I", HERE]
+FLAGS += os.environ.get("GPMPC_EXTRA_DEFS", "").split()   # experiment knobs, e.g. "-DGPMPC_JOINT_WPE=4"
 if os.environ.get("GPMPC_PHASE_TIMERS") == "1":      # debug build: per-phase s_memtime counters in the tuned kernel
     FLAGS.append("-DGPMPC_PHASE_TIMERS")
 

@@ -58,49 +58,88 @@ __device__ long long g_joint_phase[16];
 #define JPH(idx)
 #endif
 
-template <int NB, int RPT, int KC>
-__device__ __forceinline__ void block_update(const double* __restrict__ W, int ld, int kdone, int prow0, int nb,
+template <int NB, int RPT, int KC, int NT>
+__device__ __forceinline__ void block_update(const double* __restrict__ W, int ld, int kdone,
+                                             const double* __restrict__ P, long p_rs, long p_cs, int nb,
                                              int rlo, int nrow, double (&acc)[RPT][NB], double (*piv)[NB]) {
+    // Pivot-row entry (q, k) lives at P[q * p_rs + k * p_cs] (rows of W itself, or rows of the plan's L_rr).
     // piv[kk][q]: the NB pivot-row entries of column k0+kk are contiguous -> NB/2 broadcast ds_read_b128 per column,
     // shared by all RPT rows of the thread (RPT*NB FMAs per NB/2 LDS reads and RPT 8-byte global loads).
-    const int tid = threadIdx.x, nt = blockDim.x;
+    // Both HBM/L2 streams are software-pipelined (their ~1-2 us latency would otherwise be paid per batch):
+    //   * the thread's own row entries: KU columns per batch, the next batch is in flight while this one is consumed;
+    //   * the pivot rows of the NEXT KC-column chunk are fetched into registers while this chunk is consumed.
+    const int tid = threadIdx.x;
+    constexpr int KU = (RPT >= 4) ? 2 : 8;                       // columns per row batch
+    constexpr int PV = (NB * KC + NT - 1) / NT;
+    constexpr int RD = 2;                                        // row batches in the ring
+    static_assert(KC % (RD * KU) == 0, "the batch ring must turn a whole number of times per pivot chunk");
     bool own[RPT];
     const double* wr[RPT];
 #pragma unroll
     for (int rs = 0; rs < RPT; ++rs) {
-        const int row = tid + rs * nt;
+        const int row = tid + rs * NT;
         own[rs] = (row >= rlo && row < nrow);
         wr[rs] = W + (own[rs] ? row : rlo);
     }
-    for (int k0 = 0; k0 < kdone; k0 += KC) {
-        const int kc = min(KC, kdone - k0);
-        __syncthreads();
-        for (int e = tid; e < NB * KC; e += nt) {
-            const int kk = e / NB, q = e - kk * NB;
-            piv[kk][q] = (q < nb && kk < kc) ? W[(long)(k0 + kk) * ld + prow0 + q] : 0.0;
-        }
-        __syncthreads();
-        // the thread's own row entries come from HBM/L2 (latency ~1-2 us): fetch KU columns at once so that
-        // KU*RPT loads are in flight per thread, then do the KU*RPT*NB FMAs
-        constexpr int KU = 16;
-        for (int kk0 = 0; kk0 < kc; kk0 += KU) {
-            double m[KU][RPT];
+    // waves none of whose rows take part (rows are contiguous per wave) only help staging the pivot rows: the column
+    // blocks of the factorisation shrink the active row range, the S / root phases touch the m*T test rows only
+    bool any_own = false;
 #pragma unroll
-            for (int j = 0; j < KU; ++j) {
-                const int kk = min(kk0 + j, kc - 1);                  // clamped: the padded piv columns are zero
+    for (int rs = 0; rs < RPT; ++rs) {
+        const int w0 = (tid & ~63) + rs * NT;
+        any_own = any_own || (w0 + 63 >= rlo && w0 < nrow);
+    }
+    if (kdone > 0) {
+        // ring of RD row batches (KU columns each): RD-1 batches = (RD-1)*KU*RPT 8-byte loads stay in flight per thread
+        // while one batch is consumed; the ring runs across the pivot chunks (own-row loads do not depend on them)
+        double pv[PV], ring[RD][KU][RPT];
+        auto fetch_piv = [&](int k0) {
 #pragma unroll
-                for (int rs = 0; rs < RPT; ++rs) m[j][rs] = wr[rs][(long)(k0 + kk) * ld];
+            for (int i = 0; i < PV; ++i) {
+                const int e = tid + i * NT, kk = e / NB, q = e - kk * NB;
+                pv[i] = (e < NB * KC && q < nb && k0 + kk < kdone) ? P[q * p_rs + (long)(k0 + kk) * p_cs] : 0.0;
             }
+        };
+        auto fetch_rows = [&](int kbase, double (&m)[KU][RPT]) {
 #pragma unroll
             for (int j = 0; j < KU; ++j) {
-                if (kk0 + j < kc) {
+                const int k = min(kbase + j, kdone - 1);                  // clamped: never consumed beyond kdone
 #pragma unroll
-                    for (int qq = 0; qq < NB / 2; ++qq) {
-                        const double2_j pp = *reinterpret_cast<const double2_j*>(&piv[kk0 + j][2 * qq]);
+                for (int rs = 0; rs < RPT; ++rs) m[j][rs] = wr[rs][(long)k * ld];
+            }
+        };
+        fetch_piv(0);
+        if (any_own) {
 #pragma unroll
-                        for (int rs = 0; rs < RPT; ++rs) {
-                            acc[rs][2 * qq] = fma(-m[j][rs], pp.x, acc[rs][2 * qq]);
-                            acc[rs][2 * qq + 1] = fma(-m[j][rs], pp.y, acc[rs][2 * qq + 1]);
+            for (int r = 0; r < RD - 1; ++r) fetch_rows(r * KU, ring[r]);
+        }
+        for (int k0 = 0; k0 < kdone; k0 += KC) {
+            const int kc = min(KC, kdone - k0);
+            __syncthreads();                                             // the previous chunk's piv has been consumed
+#pragma unroll
+            for (int i = 0; i < PV; ++i) {
+                const int e = tid + i * NT, kk = e / NB, q = e - kk * NB;
+                if (e < NB * KC) piv[kk][q] = pv[i];
+            }
+            __syncthreads();
+            if (k0 + KC < kdone) fetch_piv(k0 + KC);
+            for (int kk0 = 0; kk0 < kc && any_own; kk0 += RD * KU) {
+#pragma unroll
+                for (int r = 0; r < RD; ++r) {
+                    const int kb = kk0 + r * KU;                         // this batch; uniform
+                    fetch_rows(k0 + kb + (RD - 1) * KU, ring[(r + RD - 1) % RD]);
+#pragma unroll
+                    for (int j = 0; j < KU; ++j) {
+                        if (kb + j < kc) {
+#pragma unroll
+                            for (int qq = 0; qq < NB / 2; ++qq) {
+                                const double2_j pp = *reinterpret_cast<const double2_j*>(&piv[kb + j][2 * qq]);
+#pragma unroll
+                                for (int rs = 0; rs < RPT; ++rs) {
+                                    acc[rs][2 * qq] = fma(-ring[r][j][rs], pp.x, acc[rs][2 * qq]);
+                                    acc[rs][2 * qq + 1] = fma(-ring[r][j][rs], pp.y, acc[rs][2 * qq + 1]);
+                                }
+                            }
                         }
                     }
                 }
@@ -149,8 +188,8 @@ __device__ __forceinline__ void block_factor(double (*blk)[NB + 1], double* dinv
     if (lane == 0) *flag = bad ? 1 : 0;
 }
 
-template <int T, int NB, int RPT>
-__global__ __launch_bounds__(256) void joint_kernel(const JointArgs a) {
+template <int T, int NB, int RPT, int NT, int WPE>
+__global__ __launch_bounds__(NT, WPE) void joint_kernel(const JointArgs a) {
     constexpr int D = 2;
     constexpr int KC = 64;
     __shared__ __attribute__((aligned(16))) double piv[KC][NB];
@@ -159,7 +198,8 @@ __global__ __launch_bounds__(256) void joint_kernel(const JointArgs a) {
     __shared__ int s_flag;
     __shared__ int s_info;
     const GpParams& gp = a.gp;
-    const int tid = threadIdx.x, nt = blockDim.x;
+    const int tid = threadIdx.x;
+    constexpr int nt = NT;
     const int n_r = gp.n_r, Tr = gp.real_has_grad ? T : 1;
     const int n_ho = a.n_ho, m = a.m, mT = m * T;
     const int n_o = n_r + n_ho;
@@ -261,12 +301,13 @@ __global__ __launch_bounds__(256) void joint_kernel(const JointArgs a) {
                                 if (row == c0 + q) kv += gp.noise[tc];
                                 acc[rs][q] = kv;
                             }
+                            asm volatile("" ::: "memory");      // one kernel evaluation at a time (register pressure)
                         }
                     }
                 }
             }
             JPH(1);
-            block_update<NB, RPT, KC>(M, ld, n_r + c0, c0, nb, c0, nrow, acc, piv);
+            block_update<NB, RPT, KC, NT>(M, ld, n_r + c0, M + c0, 1, ld, nb, c0, nrow, acc, piv);
             __syncthreads();
             JPH(2);
 #pragma unroll
@@ -296,6 +337,8 @@ __global__ __launch_bounds__(256) void joint_kernel(const JointArgs a) {
                             if (e < q) v = fma(-x[e], blk[q][e], v);
                         x[q] = (q < nb) ? v * dinv_s[q] : 0.0;
                         if (row < n_ho && q > row - c0) x[q] = 0.0;      // above the diagonal
+                        asm volatile("" : "+v"(x[q]) : : "memory");   // row q of blk is consumed before row q+1 is read:
+                                                                      // otherwise all 120 broadcast reads are hoisted (spills)
                     }
 #pragma unroll
                     for (int q = 0; q < NB; ++q)
@@ -313,7 +356,7 @@ __global__ __launch_bounds__(256) void joint_kernel(const JointArgs a) {
             for (int rs = 0; rs < RPT; ++rs)
 #pragma unroll
                 for (int q = 0; q < NB; ++q) accw[rs][q] = 0.0;
-            block_update<NB, RPT, KC>(M + trow0, ld, n_o, -1, 1, 0, mT, accw, piv);
+            block_update<NB, RPT, KC, NT>(M + trow0, ld, n_o, M + wrow, 1, ld, 1, 0, mT, accw, piv);
 #pragma unroll
             for (int rs = 0; rs < RPT; ++rs) {
                 const int tau = tid + rs * nt;
@@ -339,12 +382,13 @@ __global__ __launch_bounds__(256) void joint_kernel(const JointArgs a) {
                             const double k = kern_scalar<D>(Xs + (long)j1 * D, Xs + (long)j2 * D, il2, os, qq);
                             acc[rs][q] = kern_entry<D>(qq, k, il2, b1, b2);
                         }
+                        asm volatile("" ::: "memory");
                     }
                 }
                 (void)row;
             }
             // rows are offset by trow0 inside M: shift the base pointer so that "row" == test slot index
-            block_update<NB, RPT, KC>(M + trow0, ld, n_o, c0, nb, c0, mT, acc, piv);
+            block_update<NB, RPT, KC, NT>(M + trow0, ld, n_o, M + trow0 + c0, 1, ld, nb, c0, mT, acc, piv);
 #pragma unroll
             for (int rs = 0; rs < RPT; ++rs) {
                 const int t1 = tid + rs * nt;
@@ -385,7 +429,7 @@ __global__ __launch_bounds__(256) void joint_kernel(const JointArgs a) {
                             acc[rs][q] = Sm[(long)(c0 + q) * mT + t1] + ((t1 == c0 + q) ? jit_total : 0.0);
                     }
                 }
-                block_update<NB, RPT, KC>(Rm, mT, c0, c0, nb, c0, mT, acc, piv);
+                block_update<NB, RPT, KC, NT>(Rm, mT, c0, Rm + c0, 1, mT, nb, c0, mT, acc, piv);
                 __syncthreads();
 #pragma unroll
                 for (int rs = 0; rs < RPT; ++rs) {
@@ -415,6 +459,7 @@ __global__ __launch_bounds__(256) void joint_kernel(const JointArgs a) {
                                     if (e < q) v = fma(-x[e], blk[q][e], v);
                                 x[q] = (q < nb) ? v * dinv_s[q] : 0.0;
                                 if (q > t1 - c0) x[q] = 0.0;
+                                asm volatile("" : "+v"(x[q]) : : "memory");
                             }
 #pragma unroll
                             for (int q = 0; q < NB; ++q)
@@ -570,14 +615,14 @@ int gpmpc_joint_sample(const gpmpc_gp_desc_t* gp, const void* plan, const double
         return fail(GPMPC_E_WORKSPACE, "gpmpc_joint_sample: workspace too small");
     hipStream_t st = (hipStream_t)stream;
     const int nrow = n_ho + 1 + mT;
-    const bool small = nrow <= 512;                 // 2 rows per thread x 16-wide blocks, else 4 rows x 8-wide
-    const dim3 g((unsigned)grid), blk(256);
+    const bool small = nrow <= 512;                 // one row per thread x 16-wide blocks, else 4 rows x 8-wide
+    const dim3 g((unsigned)grid);
     if (gp->T == 1) {
-        if (small) hipLaunchKernelGGL((joint_kernel<1, 16, 2>), g, blk, 0, st, a);
-        else hipLaunchKernelGGL((joint_kernel<1, 8, 4>), g, blk, 0, st, a);
+        if (small) hipLaunchKernelGGL((joint_kernel<1, 16, 1, 512, 4>), g, dim3(512), 0, st, a);
+        else hipLaunchKernelGGL((joint_kernel<1, 8, 4, 256, 2>), g, dim3(256), 0, st, a);
     } else if (gp->T == 3) {
-        if (small) hipLaunchKernelGGL((joint_kernel<3, 16, 2>), g, blk, 0, st, a);
-        else hipLaunchKernelGGL((joint_kernel<3, 8, 4>), g, blk, 0, st, a);
+        if (small) hipLaunchKernelGGL((joint_kernel<3, 16, 1, 512, 4>), g, dim3(512), 0, st, a);
+        else hipLaunchKernelGGL((joint_kernel<3, 8, 4, 256, 2>), g, dim3(256), 0, st, a);
     } else {
         return fail(GPMPC_E_UNSUPPORTED, "joint: only T = 1 and T = 3 (D = 2) are instantiated");
     }

@@ -26,11 +26,20 @@ def run(pname, Ns, H, iters, jitter=None):
         u_h = 0.3 * torch.randn(H, Ns, nu, generator=g, dtype=torch.float64).numpy()
         agent.train_hallucinated_dynGP(it)
         bx = agent.get_batch_x_hat_u_diff(x_h, u_h)
-        torch.cuda.synchronize(); t0 = time.perf_counter()
+        # time the draw itself (joint kernel + post-processing) on repeats that leave the Agent state alone ...
+        g_xu = agent.env_model.get_g_xu_hat(bx).contiguous()
+        z = agent.epistimic_random_vector[agent.mpc_iter][it]
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+        best = float("inf")
         with warnings.catch_warnings():
             warnings.simplefilter("ignore")
+            for rep in range(4):
+                ev[0].record(); agent.sample_gp(g_xu, base_samples=z); ev[1].record(); torch.cuda.synchronize()
+                if rep:
+                    best = min(best, ev[0].elapsed_time(ev[1]))
+            # ... then the real call, which also appends the draw to the hallucinated data set
             y = agent.get_batch_gp_sensitivities(bx, it)
-        torch.cuda.synchronize(); t1 = time.perf_counter()
+        t0, t1 = 0.0, best * 1e-3
         n_h = agent.model_i.n_h
         lvl = int(((agent.model_i_call.last_info >> 1) & 7).max().item())
         if os.environ.get("GPMPC_PHASE_TIMERS") == "1":
@@ -38,7 +47,7 @@ def run(pname, Ns, H, iters, jitter=None):
             out = (C.c_longlong * 16)(); sg._lib.load().gpmpc_debug_read_joint_phases(out)
             names = ["realcols", "init", "update", "factor", "solve", "mean+S", "root", "sample"]
             print("   phases(cycles):", {n: out[i] for i, n in enumerate(names)})
-        print(f"{pname:26s} Ns={Ns} H={H} k={it}: n_o={agent.model_i.plan.n_r + n_h*3:4d} m*T={H*3}: sample_gp+update {1e3*(t1-t0):8.2f} ms "
+        print(f"{pname:26s} Ns={Ns} H={H} k={it}: n_o={agent.model_i.plan.n_r + n_h*3:4d} m*T={H*3}: sample_gp {1e3*(t1-t0):8.2f} ms (best of 3) "
               f"({Ns*H/(t1-t0)/1e6:7.2f} M traj-steps/s), max jitter level {lvl}, finite={bool(torch.isfinite(y).all())}", flush=True)
 
 if __name__ == "__main__":
