@@ -188,6 +188,23 @@ __device__ __forceinline__ void block_factor(double (*blk)[NB + 1], double* dinv
     if (lane == 0) *flag = bad ? 1 : 0;
 }
 
+// Row-wise forward substitution against the factorised diagonal block: x = (acc - x[:q] . blk[q][:q]) / blk[q][q] for the
+// block's nb columns; columns beyond qmax (above the diagonal for a row inside the block) are zero.
+template <int NB>
+__device__ __forceinline__ void block_solve(const double (&acc)[NB], double (&x)[NB], double (*blk)[NB + 1],
+                                            const double* dinv, int nb, int qmax) {
+#pragma unroll
+    for (int q = 0; q < NB; ++q) {
+        double v = acc[q];
+#pragma unroll
+        for (int e = 0; e < NB; ++e)
+            if (e < q) v = fma(-x[e], blk[q][e], v);
+        x[q] = (q < nb && q <= qmax) ? v * dinv[q] : 0.0;
+        // row q of blk is consumed before row q+1 is read: otherwise all NB(NB-1)/2 broadcast reads are hoisted (spills)
+        asm volatile("" : "+v"(x[q]) : : "memory");
+    }
+}
+
 template <int T, int NB, int RPT, int NT, int WPE>
 __global__ __launch_bounds__(NT, WPE) void joint_kernel(const JointArgs a) {
     constexpr int D = 2;
@@ -197,6 +214,9 @@ __global__ __launch_bounds__(NT, WPE) void joint_kernel(const JointArgs a) {
     __shared__ double dinv_s[NB];
     __shared__ int s_flag;
     __shared__ int s_info;
+    __shared__ __attribute__((aligned(16))) double colx[NB][D];   // input point / task / label of the block's NB pivot slots
+    __shared__ int colt[NB];
+    __shared__ double coly[NB];
     const GpParams& gp = a.gp;
     const int tid = threadIdx.x;
     constexpr int nt = NT;
@@ -211,6 +231,7 @@ __global__ __launch_bounds__(NT, WPE) void joint_kernel(const JointArgs a) {
     double* Sm = M + (long)n_o * ld;                              // [mT][mT]    column-major, lower part valid
     double* Rm = Sm + (long)mT * mT;                              // [mT][mT]    factor attempts
     double* muv = Rm + (long)mT * mT;                             // [mT]
+    double* yv = muv + mT;                                        // [mT]   mean + R z
 
     for (long chain = blockIdx.x; chain < nchains; chain += gridDim.x) {
         const long s = chain / gp.g_ny;
@@ -247,25 +268,71 @@ __global__ __launch_bounds__(NT, WPE) void joint_kernel(const JointArgs a) {
             }
         };
 
+        // this thread's rows: input point and task, fixed for the whole chain
+        double rowx[RPT][D];
+        int rowt[RPT];
+#pragma unroll
+        for (int rs = 0; rs < RPT; ++rs) {
+            const int row = tid + rs * nt;
+            rowt[rs] = 0;
+#pragma unroll
+            for (int d = 0; d < D; ++d) rowx[rs][d] = 0.0;
+            if (row < nrow && row != wrow) {
+                const double* xp;
+                row_point(row, xp, rowt[rs]);
+#pragma unroll
+                for (int d = 0; d < D; ++d) rowx[rs][d] = xp[d];
+            }
+        }
+
         // ---- real columns: M[row, :n_r] = L_rr^-1 k_r(row)  (w row = w_r) ------------------------------------------
-        for (int row = tid; row < nrow; row += nt) {
-            if (row == wrow) {
-                for (int i = 0; i < n_r; ++i) M[(long)i * ld + row] = w_r[i];
-                continue;
-            }
-            const double* xp;
-            int task;
-            row_point(row, xp, task);
-            for (int i = 0; i < n_r; ++i) {
-                const int pi = i / Tr, ai = i - pi * Tr;
-                double q[D];
-                const double k = kern_scalar<D>(a.X_r + pi * D, xp, il2, os, q);   // r = x_real - x_row
-                M[(long)i * ld + row] = kern_entry<D>(q, k, il2, ai, task);
-            }
-            for (int i = n_r - 1; i >= 0; --i) {          // in place: out[i] needs in[j <= i] only
-                double acc = 0.0;
-                for (int j = 0; j <= i; ++j) acc += LinvT[(long)j * n_r + i] * M[(long)j * ld + row];
-                M[(long)i * ld + row] = acc;
+        // the same blocked substitution as below, against the plan's factor L_rr (row-major) instead of rows of M
+        {
+            const double* Lrr = plan_L(a.plan, gp, o);
+            for (int cb = 0; cb < n_r; cb += NB) {
+                const int nb = min(NB, n_r - cb);
+                if (tid < NB) {
+                    const int i = min(cb + tid, n_r - 1);
+                    const int pi = i / Tr;
+                    colx[tid][0] = a.X_r[pi * D];
+                    colx[tid][1] = a.X_r[pi * D + 1];
+                    colt[tid] = i - pi * Tr;
+                    coly[tid] = w_r[i];
+                    dinv_s[tid] = 1.0 / Lrr[(long)i * n_r + i];
+                }
+                for (int e = tid; e < NB * NB; e += nt) {
+                    const int q = e / NB, c = e - q * NB;
+                    if (c < q) blk[q][c] = (q < nb) ? Lrr[(long)(cb + q) * n_r + cb + c] : 0.0;
+                }
+                __syncthreads();
+                double acc[RPT][NB];
+#pragma unroll
+                for (int rs = 0; rs < RPT; ++rs) {
+                    const int row = tid + rs * nt;
+#pragma unroll
+                    for (int q = 0; q < NB; ++q) {
+                        acc[rs][q] = 0.0;
+                        if (q < nb && row < nrow && row != wrow) {
+                            double qq[D];
+                            const double k = kern_scalar<D>(colx[q], rowx[rs], il2, os, qq);    // r = x_real - x_row
+                            acc[rs][q] = kern_entry<D>(qq, k, il2, colt[q], rowt[rs]);
+                        }
+                        asm volatile("" ::: "memory");
+                    }
+                }
+                block_update<NB, RPT, KC, NT>(M, ld, cb, Lrr + (long)cb * n_r, n_r, 1, nb, 0, nrow, acc, piv);
+#pragma unroll
+                for (int rs = 0; rs < RPT; ++rs) {
+                    const int row = tid + rs * nt;
+                    if (row < nrow) {
+                        double x[NB];
+                        block_solve<NB>(acc[rs], x, blk, dinv_s, nb, NB);
+#pragma unroll
+                        for (int q = 0; q < NB; ++q)
+                            if (q < nb) M[(long)(cb + q) * ld + row] = (row == wrow) ? coly[q] : x[q];
+                    }
+                }
+                __syncthreads();
             }
         }
         __syncthreads();
@@ -274,6 +341,22 @@ __global__ __launch_bounds__(NT, WPE) void joint_kernel(const JointArgs a) {
         // ---- hallucinated columns, NB at a time -------------------------------------------------------------------
         for (int c0 = 0; c0 < n_ho; c0 += NB) {
             const int nb = min(NB, n_ho - c0);
+            if (tid < NB) {                                   // descriptors of the block's pivot slots, shared by all rows
+                int tc = 0;
+                double x0 = 0.0, x1 = 0.0, yl = 0.0;
+                if (tid < nb) {
+                    const double* xc;
+                    row_point(c0 + tid, xc, tc);
+                    x0 = xc[0];
+                    x1 = xc[1];
+                    yl = Yh[a.h_slots[c0 + tid]];
+                }
+                colx[tid][0] = x0;
+                colx[tid][1] = x1;
+                colt[tid] = tc;
+                coly[tid] = yl;
+            }
+            __syncthreads();
             double acc[RPT][NB];
 #pragma unroll
             for (int rs = 0; rs < RPT; ++rs) {
@@ -284,20 +367,15 @@ __global__ __launch_bounds__(NT, WPE) void joint_kernel(const JointArgs a) {
                     if (row == wrow) {
 #pragma unroll
                         for (int q = 0; q < NB; ++q)
-                            if (q < nb) acc[rs][q] = Yh[a.h_slots[c0 + q]];
+                            if (q < nb) acc[rs][q] = coly[q];
                     } else {
-                        const double* xp;
-                        int task;
-                        row_point(row, xp, task);
 #pragma unroll
                         for (int q = 0; q < NB; ++q) {
                             if (q < nb) {
-                                const double* xc;
-                                int tc;
-                                row_point(c0 + q, xc, tc);
+                                const int tc = colt[q];
                                 double qq[D];
-                                const double k = kern_scalar<D>(xp, xc, il2, os, qq);       // r = x_row - x_c
-                                double kv = kern_entry<D>(qq, k, il2, task, tc);
+                                const double k = kern_scalar<D>(rowx[rs], colx[q], il2, os, qq);   // r = x_row - x_c
+                                double kv = kern_entry<D>(qq, k, il2, rowt[rs], tc);
                                 if (row == c0 + q) kv += gp.noise[tc];
                                 acc[rs][q] = kv;
                             }
@@ -329,17 +407,7 @@ __global__ __launch_bounds__(NT, WPE) void joint_kernel(const JointArgs a) {
                 const int row = tid + rs * nt;
                 if (row >= c0 && row < nrow) {
                     double x[NB];
-#pragma unroll
-                    for (int q = 0; q < NB; ++q) {
-                        double v = acc[rs][q];
-#pragma unroll
-                        for (int e = 0; e < NB; ++e)
-                            if (e < q) v = fma(-x[e], blk[q][e], v);
-                        x[q] = (q < nb) ? v * dinv_s[q] : 0.0;
-                        if (row < n_ho && q > row - c0) x[q] = 0.0;      // above the diagonal
-                        asm volatile("" : "+v"(x[q]) : : "memory");   // row q of blk is consumed before row q+1 is read:
-                                                                      // otherwise all 120 broadcast reads are hoisted (spills)
-                    }
+                    block_solve<NB>(acc[rs], x, blk, dinv_s, nb, (row < n_ho) ? row - c0 : NB);
 #pragma unroll
                     for (int q = 0; q < NB; ++q)
                         if (q < nb) M[(long)(n_r + c0 + q) * ld + row] = x[q];
@@ -451,16 +519,7 @@ __global__ __launch_bounds__(NT, WPE) void joint_kernel(const JointArgs a) {
                         const int t1 = tid + rs * nt;
                         if (t1 >= c0 && t1 < mT) {
                             double x[NB];
-#pragma unroll
-                            for (int q = 0; q < NB; ++q) {
-                                double v = acc[rs][q];
-#pragma unroll
-                                for (int e = 0; e < NB; ++e)
-                                    if (e < q) v = fma(-x[e], blk[q][e], v);
-                                x[q] = (q < nb) ? v * dinv_s[q] : 0.0;
-                                if (q > t1 - c0) x[q] = 0.0;
-                                asm volatile("" : "+v"(x[q]) : : "memory");
-                            }
+                            block_solve<NB>(acc[rs], x, blk, dinv_s, nb, t1 - c0);
 #pragma unroll
                             for (int q = 0; q < NB; ++q)
                                 if (q < nb) Rm[(long)(c0 + q) * mT + t1] = x[q];
@@ -487,6 +546,24 @@ __global__ __launch_bounds__(NT, WPE) void joint_kernel(const JointArgs a) {
         JPH(6);
         // ---- sample + post-processing (reference src/agent.py:641-708) --------------------------------------
         const double* zc = a.z + chain * (long)mT;
+        // y_raw = mean + R z: thread = test slot, the column sweep in batches of 8 independent (coalesced) loads
+        for (int tau = tid; tau < mT; tau += nt) {
+            double acc = 0.0;
+            if (rooted) {
+                for (int cb = 0; cb <= tau; cb += 8) {
+                    double r8[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) r8[u] = Rm[(long)min(cb + u, mT - 1) * mT + tau];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u)
+                        if (cb + u <= tau) acc += r8[u] * zc[cb + u];
+                }
+            } else {
+                acc = __builtin_nan("");
+            }
+            yv[tau] = acc + muv[tau];
+        }
+        __syncthreads();
         for (int j = tid; j < m; j += nt) {
             double vv[T], mm[T], yy[T];
             bool all_zero = (a.var_zero_thr >= 0.0);
@@ -501,13 +578,7 @@ __global__ __launch_bounds__(NT, WPE) void joint_kernel(const JointArgs a) {
                 vv[b] = v;
                 mm[b] = muv[tau];
                 all_zero = all_zero && (v <= a.var_zero_thr);
-                double acc = 0.0;
-                if (rooted) {
-                    for (int c = 0; c <= tau; ++c) acc += Rm[(long)c * mT + tau] * zc[c];
-                } else {
-                    acc = __builtin_nan("");
-                }
-                yy[b] = acc + mm[b];
+                yy[b] = yv[tau];
             }
 #pragma unroll
             for (int b = 0; b < T; ++b) {
@@ -547,7 +618,7 @@ static long joint_chain_doubles(int n_r, int n_ho, int m, int T, int* ld_out) {
     int ld = n_ho + 1 + mT;
     ld = (ld + 3) & ~3;
     if (ld_out) *ld_out = ld;
-    return (long)(n_r + n_ho) * ld + 2L * mT * mT + mT + 4;
+    return (long)(n_r + n_ho) * ld + 2L * mT * mT + 2L * mT + 4;
 }
 
 static long joint_grid(long nchains) {
