@@ -317,7 +317,7 @@ __global__ __launch_bounds__(NT, WPE) void joint_kernel(const JointArgs a) {
                             const double k = kern_scalar<D>(colx[q], rowx[rs], il2, os, qq);    // r = x_real - x_row
                             acc[rs][q] = kern_entry<D>(qq, k, il2, colt[q], rowt[rs]);
                         }
-                        asm volatile("" ::: "memory");
+                        if ((q & 3) == 3) asm volatile("" ::: "memory");
                     }
                 }
                 block_update<NB, RPT, KC, NT>(M, ld, cb, Lrr + (long)cb * n_r, n_r, 1, nb, 0, nrow, acc, piv);
@@ -379,7 +379,7 @@ __global__ __launch_bounds__(NT, WPE) void joint_kernel(const JointArgs a) {
                                 if (row == c0 + q) kv += gp.noise[tc];
                                 acc[rs][q] = kv;
                             }
-                            asm volatile("" ::: "memory");      // one kernel evaluation at a time (register pressure)
+                            if ((q & 3) == 3) asm volatile("" ::: "memory");   // four kernel evaluations in flight (registers)
                         }
                     }
                 }
@@ -450,7 +450,7 @@ __global__ __launch_bounds__(NT, WPE) void joint_kernel(const JointArgs a) {
                             const double k = kern_scalar<D>(Xs + (long)j1 * D, Xs + (long)j2 * D, il2, os, qq);
                             acc[rs][q] = kern_entry<D>(qq, k, il2, b1, b2);
                         }
-                        asm volatile("" ::: "memory");
+                        if ((q & 3) == 3) asm volatile("" ::: "memory");
                     }
                 }
                 (void)row;
@@ -622,7 +622,7 @@ static long joint_chain_doubles(int n_r, int n_ho, int m, int T, int* ld_out) {
 }
 
 static long joint_grid(long nchains) {
-    const long cap = 256L * 8;
+    const long cap = 256L * 16;
     return nchains < cap ? nchains : cap;
 }
 
@@ -686,17 +686,24 @@ int gpmpc_joint_sample(const gpmpc_gp_desc_t* gp, const void* plan, const double
         return fail(GPMPC_E_WORKSPACE, "gpmpc_joint_sample: workspace too small");
     hipStream_t st = (hipStream_t)stream;
     const int nrow = n_ho + 1 + mT;
-    const bool small = nrow <= 512;                 // one row per thread x 16-wide blocks, else 4 rows x 8-wide
+    // one label row per thread and a workgroup just wide enough for the rows (more chains per CU when they are short:
+    // iteration 0 of config 5 has 121 rows); beyond 512 rows four rows per thread on 8-wide blocks
     const dim3 g((unsigned)grid);
+#define GPMPC_JOINT_LAUNCH(TT)                                                                              \
+    do {                                                                                                    \
+        if (nrow <= 128) hipLaunchKernelGGL((joint_kernel<TT, 16, 1, 128, 4>), g, dim3(128), 0, st, a);      \
+        else if (nrow <= 256) hipLaunchKernelGGL((joint_kernel<TT, 16, 1, 256, 4>), g, dim3(256), 0, st, a); \
+        else if (nrow <= 512) hipLaunchKernelGGL((joint_kernel<TT, 16, 1, 512, 4>), g, dim3(512), 0, st, a); \
+        else hipLaunchKernelGGL((joint_kernel<TT, 8, 4, 256, 2>), g, dim3(256), 0, st, a);                   \
+    } while (0)
     if (gp->T == 1) {
-        if (small) hipLaunchKernelGGL((joint_kernel<1, 16, 1, 512, 4>), g, dim3(512), 0, st, a);
-        else hipLaunchKernelGGL((joint_kernel<1, 8, 4, 256, 2>), g, dim3(256), 0, st, a);
+        GPMPC_JOINT_LAUNCH(1);
     } else if (gp->T == 3) {
-        if (small) hipLaunchKernelGGL((joint_kernel<3, 16, 1, 512, 4>), g, dim3(512), 0, st, a);
-        else hipLaunchKernelGGL((joint_kernel<3, 8, 4, 256, 2>), g, dim3(256), 0, st, a);
+        GPMPC_JOINT_LAUNCH(3);
     } else {
         return fail(GPMPC_E_UNSUPPORTED, "joint: only T = 1 and T = 3 (D = 2) are instantiated");
     }
+#undef GPMPC_JOINT_LAUNCH
     GPMPC_HIP_CHECK(hipGetLastError());
     return GPMPC_OK;
 }
