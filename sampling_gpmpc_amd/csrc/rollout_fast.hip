@@ -508,16 +508,17 @@ __global__ __launch_bounds__(256, 1) void rollout_fast_kernel(const RolloutArgs 
                     xh1[d] = new1 ? xi[d] : xh1[d];
                 }
                 if (base < kWave) {                                       // uniform: a new row lives in bank 0 (registers)
-                    const int ac = new0 ? a0 : 0;
+                    // only the three owning lanes execute the loads (exec-masked): no select against the old row, and
+                    // the loads can land directly in the registers that hold the row
+                    if (new0) {
+                        const double* src = kvs + a0 * NRP;
 #pragma unroll
-                    for (int ip = 0; ip < NPAIR; ++ip) {
-                        const double2_t vv = *reinterpret_cast<const double2_t*>(kvs + ac * NRP + 2 * ip);
-                        Lhr0[2 * ip] = new0 ? vv.x : Lhr0[2 * ip];
-                        Lhr0[2 * ip + 1] = new0 ? vv.y : Lhr0[2 * ip + 1];
-                    }
-                    if (NR & 1) {
-                        const double vv = kvs[ac * NRP + NR - 1];
-                        Lhr0[NR - 1] = new0 ? vv : Lhr0[NR - 1];
+                        for (int ip = 0; ip < NPAIR; ++ip) {
+                            const double2_t vv = *reinterpret_cast<const double2_t*>(src + 2 * ip);
+                            Lhr0[2 * ip] = vv.x;
+                            Lhr0[2 * ip + 1] = vv.y;
+                        }
+                        if (NR & 1) Lhr0[NR - 1] = src[NR - 1];
                     }
                 }
                 if (base + T > kWave) {                                   // uniform: a new row lives in bank 1 (LDS)
