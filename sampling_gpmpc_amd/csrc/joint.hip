@@ -1,15 +1,18 @@
 // gpmpc_joint_sample: joint posterior draw at m test points per (sample, output) chain (mode "J", gfx950).
 //
-// One 256-thread workgroup per chain; chains are taken grid-stride so the HBM workspace is bounded by the grid.
-// The factorisation is BLOCKED (NB columns at a time): the pivot-block rows are staged in LDS, each thread keeps NB
-// register accumulators per row it owns and streams its own row from HBM/L2 once per block (NB FMAs per 8 bytes).
+// One workgroup per chain, one label row per thread, the workgroup just wide enough for the rows (128 / 256 / 512
+// threads, 4 waves per SIMD; beyond 512 rows four rows per thread); chains are taken grid-stride so the HBM workspace
+// is bounded by the grid.  The factorisation is BLOCKED (NB columns at a time): the pivot-block rows are staged in
+// LDS, each thread keeps NB register accumulators per row it owns and streams its own row from HBM/L2 once per block
+// (NB FMAs per 8 bytes).  The kernel sits at a register-pressure cliff: at 128 VGPRs any hoisting of the broadcast
+// LDS reads spills, hence the data-dependent compiler fences in block_solve and the kernel-evaluation loops.
 // Everything is ONE left-looking factorisation over a tall matrix M whose ROWS are label slots and whose COLUMNS
 // are the conditioning slots (column-major, leading dimension = rows, so "thread = row" is coalesced):
 //
 //      rows   : [ hallucinated slots (n_ho) | w (1) | test slots (m*T) ]
 //      columns: [ real slots (n_r) | hallucinated slots (n_ho) ]
 //
-//   * real columns:   M[row, :n_r] = L_rr^-1 k_r(row)          (dense product with the plan's inverse; w row = w_r)
+//   * real columns:   M[row, :n_r] = L_rr^-1 k_r(row)          (blocked substitution against the plan's L_rr; w row = w_r)
 //   * column n_r+c:   M[row, n_r+c] = (k(row, c) - sum_k M[row,k] M[c,k]) / L_cc   for every row below pivot c
 //                     -> hallucinated rows become L_hh, the w row becomes w_h = L_hh^-1 (y_h - L_hr w_r),
 //                        test rows become V^T = (L^-1 K_o*)^T             
