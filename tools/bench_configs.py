@@ -1,4 +1,6 @@
-"""Time the other BASELINE configs (not the bench.py line): cfg3 car mode R, cfg4 car mode I (as shipped)."""
+"""Time the other BASELINE configs (not the bench.py line): cfg3 car mode R, cfg4 car mode I (as shipped);
+`--sweep` adds a sample-count sweep of the configs[1] workload (how the one-sample-per-SIMD latency bound of Ns=1024
+turns into throughput once several waves share a SIMD / several rounds of workgroups run)."""
 import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, numpy as np
@@ -27,6 +29,12 @@ def run(pname, Ns, H, nograd, reps=10):
     print(f"{pname:28s} Ns={Ns:7d} H={H} mode={'I' if nograd else 'R'}: {ms:9.3f} ms/rollout  {Ns*H/ms*1e3/1e6:10.1f} M traj-steps/s  finite={ok} info=0x{bits:x}", flush=True)
 
 if __name__ == "__main__":
+    if "--sweep" in sys.argv:
+        for ns in (256, 1024, 2048, 4096, 16384, 65536):
+            run("params_pendulum1D_samples", ns, 30, False, 10)
+        for h in (10, 15, 20, 43):
+            run("params_pendulum1D_samples", 4096, h, False, 10)
+        sys.exit(0)
     run("params_pendulum1D_samples", 1024, 30, False, 20)
     run("params_car_residual_fs", 4096, 40, False, 5)
     run("params_car_residual_fs", 32768, 40, True, 5)
