@@ -610,16 +610,15 @@ static void fast_plan(const gpmpc_gp_desc_t* gp, int nx, int H, bool force_globa
     const size_t budget = 160 * 1024 - 64;
     const int max_spw = (G == 1) ? 4 : 1;
     auto shared_doubles = [&](int spw) { return (G * NR * NRS + ((G > 1) ? spw * 2 * G : 0) + 1) & ~1; };
+    // L_hh stays in LDS only if that still leaves one wave on every SIMD (max_spw samples per workgroup): with fewer
+    // resident samples the HBM/L2-workspace variant at full occupancy is faster (tools/horizon_sweep.py, Ns=4096:
+    // H=31 1.07 vs 1.25 ms, H=43 1.9 vs 5.3 ms; at H<=30, where 4 samples fit, LDS wins 0.82 vs 0.95 ms)
     fp->lhh_lds = false;
     fp->spw = max_spw;
-    for (int spw = max_spw; spw >= 1 && !force_global; --spw) {
+    if (!force_global) {
         const long per = vec + fp->chain_doubles;
-        const size_t bytes = ((size_t)shared_doubles(spw) + (size_t)spw * G * ((per + 1) & ~1L)) * sizeof(double);
-        if (bytes <= budget) {
-            fp->lhh_lds = true;
-            fp->spw = spw;
-            break;
-        }
+        const size_t bytes = ((size_t)shared_doubles(max_spw) + (size_t)max_spw * G * ((per + 1) & ~1L)) * sizeof(double);
+        fp->lhh_lds = bytes <= budget;
     }
     fp->waves = fp->spw * G;
     fp->lds_shared = shared_doubles(fp->spw);
