@@ -63,8 +63,14 @@ __device__ __forceinline__ void wave_sync_lds() {
     __builtin_amdgcn_wave_barrier();
 }
 
+// GPMPC_FAST_MAXTHREADS=512 (build.py: GPMPC_EXTRA_DEFS) halves the register budget so that two workgroups share a CU:
+// only for tools/occupancy_experiment.py
+#ifndef GPMPC_FAST_MAXTHREADS
+#define GPMPC_FAST_MAXTHREADS 256
+#endif
+
 template <int T, int NR, int G_NY, int ENV, bool LHH_LDS>
-__global__ __launch_bounds__(256, 1) void rollout_fast_kernel(const RolloutArgs a) {
+__global__ __launch_bounds__(GPMPC_FAST_MAXTHREADS, 1) void rollout_fast_kernel(const RolloutArgs a) {
     constexpr int D = 2;
     constexpr int NS = T * (T + 1) / 2;
     constexpr int NX = (ENV == GPMPC_ENV_PENDULUM1D) ? 2 : 4;
