@@ -217,8 +217,11 @@ def test_joint_draw_against_reference_golden(sg):
         agent.Hallcinated_Y_train = torch.tensor(d[f"y_{it}"]).to(agent.torch_device)
 
 
-@pytest.mark.parametrize("pname,Ns,H,iters", [("params_pendulum1D_samples", 16, 30, 2),
-                                              ("params_car_residual", 8, 12, 3)])
+@pytest.mark.parametrize("pname,Ns,H,iters", [
+    ("params_pendulum1D_samples", 16, 30, 2),     # 91 / 181 label rows: 128- and 256-thread workgroups
+    ("params_car_residual", 8, 12, 3),
+    ("params_pendulum1D_samples", 6, 30, 7),      # up to 631 rows: 512-thread workgroups, then four rows per thread
+])
 def test_joint_draw_against_oracle(sg, pname, Ns, H, iters):
     """sample_gp / dyn_fg_jacobians over several SQP iterations vs the oracle (mean, variance, covariance, samples)."""
     p = load_params(pname)
