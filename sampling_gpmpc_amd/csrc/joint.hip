@@ -72,7 +72,7 @@ __device__ __forceinline__ void block_update(const double* __restrict__ W, int l
     //   * the thread's own row entries: KU columns per batch, the next batch is in flight while this one is consumed;
     //   * the pivot rows of the NEXT KC-column chunk are fetched into registers while this chunk is consumed.
     const int tid = threadIdx.x;
-    constexpr int KU = (RPT >= 4) ? 2 : 8;                       // columns per row batch
+    constexpr int KU = (RPT >= 4) ? 2 : 4;                       // columns per row batch
     constexpr int PV = (NB * KC + NT - 1) / NT;
     constexpr int RD = 2;                                        // row batches in the ring
     static_assert(KC % (RD * KU) == 0, "the batch ring must turn a whole number of times per pivot chunk");
@@ -211,7 +211,7 @@ __device__ __forceinline__ void block_solve(const double (&acc)[NB], double (&x)
 template <int T, int NB, int RPT, int NT, int WPE>
 __global__ __launch_bounds__(NT, WPE) void joint_kernel(const JointArgs a) {
     constexpr int D = 2;
-    constexpr int KC = 64;
+    constexpr int KC = 8;                                        // pivot columns staged per chunk: small chunks (few prefetch registers, early start) measured best
     __shared__ __attribute__((aligned(16))) double piv[KC][NB];
     __shared__ double blk[NB][NB + 1];
     __shared__ double dinv_s[NB];
