@@ -54,6 +54,9 @@ struct JointArgs {
 // HBM/L2 once per block (coalesced: column-major, thread == row): NB FMAs per 8-byte load.
 typedef double double2_j __attribute__((ext_vector_type(2)));
 
+#ifndef GPMPC_JOINT_WPE
+#define GPMPC_JOINT_WPE 4          // waves per SIMD the one-row-per-thread kernels are compiled for (128 VGPRs)
+#endif
 __device__ long long g_joint_phase[16];
 #ifdef GPMPC_PHASE_TIMERS
 #define JPH(idx) do { const long long _n = __builtin_readcyclecounter(); jph[idx] += _n - jt; jt = _n; } while (0)
@@ -694,9 +697,9 @@ int gpmpc_joint_sample(const gpmpc_gp_desc_t* gp, const void* plan, const double
     const dim3 g((unsigned)grid);
 #define GPMPC_JOINT_LAUNCH(TT)                                                                              \
     do {                                                                                                    \
-        if (nrow <= 128) hipLaunchKernelGGL((joint_kernel<TT, 16, 1, 128, 4>), g, dim3(128), 0, st, a);      \
-        else if (nrow <= 256) hipLaunchKernelGGL((joint_kernel<TT, 16, 1, 256, 4>), g, dim3(256), 0, st, a); \
-        else if (nrow <= 512) hipLaunchKernelGGL((joint_kernel<TT, 16, 1, 512, 4>), g, dim3(512), 0, st, a); \
+        if (nrow <= 128) hipLaunchKernelGGL((joint_kernel<TT, 16, 1, 128, GPMPC_JOINT_WPE>), g, dim3(128), 0, st, a);      \
+        else if (nrow <= 256) hipLaunchKernelGGL((joint_kernel<TT, 16, 1, 256, GPMPC_JOINT_WPE>), g, dim3(256), 0, st, a); \
+        else if (nrow <= 512) hipLaunchKernelGGL((joint_kernel<TT, 16, 1, 512, GPMPC_JOINT_WPE>), g, dim3(512), 0, st, a); \
         else hipLaunchKernelGGL((joint_kernel<TT, 8, 4, 256, 2>), g, dim3(256), 0, st, a);                   \
     } while (0)
     if (gp->T == 1) {
