@@ -50,13 +50,20 @@ __host__ __device__ __forceinline__ int lhh_rowofs(int r) {
     const int h = r >> 1;
     return (r & 1) ? 2 * h * (h + 1) : 2 * h * h;
 }
-// + slack for the look-ahead reads of the last row (8 pivots ahead of a pivot index rounded up to 8)
-__host__ __device__ __forceinline__ long lhh_doubles(int nh_max) {
-    const int r = nh_max - 1, cap = r + (r & 1);
-    int slack = ((nh_max + 7) & ~7) + 8 - cap;
+// + slack for the look-ahead reads of the last row (2*rg pivots ahead of a pivot index rounded up to 2*rg; rg = row
+// pairs in the prefetch ring of the substitution)
+__host__ __device__ __forceinline__ long lhh_doubles(int nh_max, int rg) {
+    const int r = nh_max - 1, cap = r + (r & 1), w = 2 * rg;
+    int slack = ((nh_max + w - 1) / w) * w + w - cap;
     slack = (slack < 0) ? 0 : ((slack + 1) & ~1);
     return lhh_rowofs(nh_max) + slack;
 }
+// ring depth: 8 pivots of look-ahead cover the LDS latency; the HBM/L2 workspace variant needs more bytes in flight
+constexpr int kRingLds = 4;
+#ifndef GPMPC_FAST_RING_GLOBAL
+#define GPMPC_FAST_RING_GLOBAL 8
+#endif
+constexpr int kRingGlobal = GPMPC_FAST_RING_GLOBAL;
 
 __device__ __forceinline__ void wave_sync_lds() {
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -78,6 +85,8 @@ __global__ __launch_bounds__(GPMPC_FAST_MAXTHREADS, 1) void rollout_fast_kernel(
     constexpr int NRP = (NR + 1) & ~1;                            // broadcast-buffer row length (even -> b128 aligned)
     constexpr int NRS = ((NRP / 2) & 1) ? NRP : NRP + 2;          // row stride of lane==row tables: 16-byte slots, odd count
     constexpr int NPAIR = NR / 2;
+    constexpr int RG = LHH_LDS ? kRingLds : kRingGlobal;            // row pairs in the prefetch ring of the substitution
+    static_assert(kWave % (2 * RG) == 0, "the ring must turn a whole number of times per 64-row bank");
     extern __shared__ __attribute__((aligned(16))) double smem[];
     __shared__ int s_info[4];
 
@@ -316,15 +325,15 @@ __global__ __launch_bounds__(GPMPC_FAST_MAXTHREADS, 1) void rollout_fast_kernel(
             // slack or in later rows and are masked (finished rows) or multiplied by a zero pivot value.  All T pivot
             // values are broadcast (v_readlane) before the FMAs that consume them, so the SGPR write latency overlaps.
             if (!two) {
-                double2_t ra[4];
+                double2_t ra[RG];
 #pragma unroll
-                for (int k = 0; k < 4; ++k) ra[k] = row0[k];
+                for (int k = 0; k < RG; ++k) ra[k] = row0[k];
 #pragma unroll 1
-                for (int p0 = 0; p0 < n_h; p0 += 8) {
+                for (int p0 = 0; p0 < n_h; p0 += 2 * RG) {
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) {
+                    for (int k = 0; k < RG; ++k) {
                         const double2_t la2 = ra[k];
-                        ra[k] = row0[(p0 >> 1) + 4 + k];
+                        ra[k] = row0[(p0 >> 1) + RG + k];
 #pragma unroll
                         for (int h = 0; h < 2; ++h) {
                             const int p = p0 + 2 * k + h;
@@ -338,19 +347,19 @@ __global__ __launch_bounds__(GPMPC_FAST_MAXTHREADS, 1) void rollout_fast_kernel(
                     }
                 }
             } else {
-                double2_t ra[4], rb[4];
+                double2_t ra[RG], rb[RG];
 #pragma unroll
-                for (int k = 0; k < 4; ++k) {
+                for (int k = 0; k < RG; ++k) {
                     ra[k] = row0[k];
                     rb[k] = row1[k];
                 }
 #pragma unroll 1
-                for (int p0 = 0; p0 < kWave; p0 += 8) {                  // pivots owned by bank 0
+                for (int p0 = 0; p0 < kWave; p0 += 2 * RG) {             // pivots owned by bank 0
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) {
+                    for (int k = 0; k < RG; ++k) {
                         const double2_t la2 = ra[k], lb2 = rb[k];
-                        ra[k] = row0[(p0 >> 1) + 4 + k];
-                        rb[k] = row1[(p0 >> 1) + 4 + k];
+                        ra[k] = row0[(p0 >> 1) + RG + k];
+                        rb[k] = row1[(p0 >> 1) + RG + k];
 #pragma unroll
                         for (int h = 0; h < 2; ++h) {
                             const int p = p0 + 2 * k + h;
@@ -368,11 +377,11 @@ __global__ __launch_bounds__(GPMPC_FAST_MAXTHREADS, 1) void rollout_fast_kernel(
                     }
                 }
 #pragma unroll 1
-                for (int p0 = kWave; p0 < n_h; p0 += 8) {                 // pivots owned by bank 1
+                for (int p0 = kWave; p0 < n_h; p0 += 2 * RG) {            // pivots owned by bank 1
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) {
+                    for (int k = 0; k < RG; ++k) {
                         const double2_t lb2 = rb[k];
-                        rb[k] = row1[(p0 >> 1) + 4 + k];
+                        rb[k] = row1[(p0 >> 1) + RG + k];
 #pragma unroll
                         for (int h = 0; h < 2; ++h) {
                             const int p = p0 + 2 * k + h;
@@ -611,7 +620,7 @@ static void fast_plan(const gpmpc_gp_desc_t* gp, int nx, int H, bool force_globa
     const int NRS = ((NRP / 2) & 1) ? NRP : NRP + 2;
     const int nh_max = 3 * (H - 1);
     const int nb1 = nh_max > 64 ? nh_max - 64 : 0;
-    fp->chain_doubles = lhh_doubles(nh_max);
+    fp->chain_doubles = lhh_doubles(nh_max, kRingLds);
     const long vec = (long)T * NRP + (long)nb1 * NRS;
     const size_t budget = 160 * 1024 - 64;
     const int max_spw = (G == 1) ? 4 : 1;
@@ -626,6 +635,7 @@ static void fast_plan(const gpmpc_gp_desc_t* gp, int nx, int H, bool force_globa
         const size_t bytes = ((size_t)shared_doubles(max_spw) + (size_t)max_spw * G * ((per + 1) & ~1L)) * sizeof(double);
         fp->lhh_lds = bytes <= budget;
     }
+    if (!fp->lhh_lds) fp->chain_doubles = lhh_doubles(nh_max, kRingGlobal);
     fp->waves = fp->spw * G;
     fp->lds_shared = shared_doubles(fp->spw);
     const long per = vec + (fp->lhh_lds ? fp->chain_doubles : 0);
@@ -634,7 +644,7 @@ static void fast_plan(const gpmpc_gp_desc_t* gp, int nx, int H, bool force_globa
 }
 
 size_t rollout_fast_workspace_bytes(const gpmpc_gp_desc_t* gp, int64_t Ns, int H) {
-    return (size_t)Ns * gp->g_ny * (size_t)lhh_doubles(3 * (H - 1)) * sizeof(double);
+    return (size_t)Ns * gp->g_ny * (size_t)lhh_doubles(3 * (H - 1), kRingGlobal) * sizeof(double);
 }
 
 template <int NR, int G_NY, int ENV>
