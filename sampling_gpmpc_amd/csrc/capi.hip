@@ -116,6 +116,15 @@ __global__ void selftest_kernel(int* out) {
     const double s1 = wave_sum(v), s2 = wave_sum_shfl(v);
     if (fabs(s1 - ref) > 1e-9 * fabs(ref)) bad |= 1;
     if (fabs(s2 - ref) > 1e-9 * fabs(ref)) bad |= 2;
+    {   // four sums through the lane-swap tree: quantities with different lane patterns
+        const double q0 = v, q1 = 2.0 - 0.125 * lane, q2 = (lane & 1) ? 3.0 : -1.5, q3 = 1e-3 * lane * lane;
+        double r0, r1, r2, r3;
+        wave_sum4(q0, q1, q2, q3, r0, r1, r2, r3);
+        const double e1 = wave_sum_shfl(q1), e2 = wave_sum_shfl(q2), e3 = wave_sum_shfl(q3);
+        if (fabs(r0 - ref) > 1e-9 * fabs(ref) || fabs(r1 - e1) > 1e-9 * fabs(e1) || fabs(r2 - e2) > 1e-9 * fabs(e2) ||
+            fabs(r3 - e3) > 1e-9 * fabs(e3))
+            bad |= 64;
+    }
     for (int l = 0; l < 64; l += 7) {
         const double r = readlane_f64(v, l);
         if (r != 1.0 + 0.25 * l + 1e-9 * l * l) bad |= 4;

@@ -75,6 +75,42 @@ __device__ __forceinline__ double wave_sum(double v) {
     return readlane_f64(t, 63);
 }
 
+// Four wave sums at once.  A wave is four DPP rows of 16 lanes; the gfx950 lane swaps fold the rows of two registers
+// into one (v_permlane32_swap a, b: a's rows 2,3 <-> b's rows 0,1; v_permlane16_swap a, b: a's odd rows <-> b's even
+// rows), so after two levels ONE register carries the 16-lane partial sums of all four quantities, one per DPP row,
+// and a single row_shr ladder finishes them: 6 swaps + 3 adds + 5 DPP steps + 8 v_readlane instead of 4 x (7 DPP steps
+// + 2 v_readlane).
+__device__ __forceinline__ void lane_swap32_f64(double& a, double& b) {
+    const auto lo = __builtin_amdgcn_permlane32_swap(__double2loint(a), __double2loint(b), false, false);
+    const auto hi = __builtin_amdgcn_permlane32_swap(__double2hiint(a), __double2hiint(b), false, false);
+    a = __hiloint2double(hi[0], lo[0]);
+    b = __hiloint2double(hi[1], lo[1]);
+}
+__device__ __forceinline__ void lane_swap16_f64(double& a, double& b) {
+    const auto lo = __builtin_amdgcn_permlane16_swap(__double2loint(a), __double2loint(b), false, false);
+    const auto hi = __builtin_amdgcn_permlane16_swap(__double2hiint(a), __double2hiint(b), false, false);
+    a = __hiloint2double(hi[0], lo[0]);
+    b = __hiloint2double(hi[1], lo[1]);
+}
+__device__ __forceinline__ void wave_sum4(double a, double b, double c, double d, double& sa, double& sb, double& sc,
+                                          double& sd) {
+    lane_swap32_f64(a, b);                 // a = [a.r0 a.r1 b.r0 b.r1], b = [a.r2 a.r3 b.r2 b.r3]
+    lane_swap32_f64(c, d);
+    double ab = a + b;                     // rows 0,1: partial sums of a; rows 2,3: of b
+    double cd = c + d;
+    lane_swap16_f64(ab, cd);               // ab = [ab.r0 cd.r0 ab.r2 cd.r2], cd = [ab.r1 cd.r1 ab.r3 cd.r3]
+    const double v = ab + cd;              // row 0: a, row 1: c, row 2: b, row 3: d  (16-lane partial sums)
+    double t = v + dpp_f64<0x111, 0xf, 0xf>(v);          // row_shr:1
+    t += dpp_f64<0x112, 0xf, 0xf>(v);                    // row_shr:2
+    t += dpp_f64<0x113, 0xf, 0xf>(v);                    // row_shr:3
+    t += dpp_f64<0x114, 0xf, 0xe>(t);                    // row_shr:4  bank_mask 0xe
+    t += dpp_f64<0x118, 0xf, 0xc>(t);                    // row_shr:8  bank_mask 0xc  -> lane 15 of each row
+    sa = readlane_f64(t, 15);
+    sc = readlane_f64(t, 31);
+    sb = readlane_f64(t, 47);
+    sd = readlane_f64(t, 63);
+}
+
 // portable butterfly (ds_bpermute based) - used by the self test to cross-check the DPP ladder
 __device__ __forceinline__ double wave_sum_shfl(double v) {
 #pragma unroll

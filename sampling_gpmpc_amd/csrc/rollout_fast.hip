@@ -416,14 +416,19 @@ __global__ __launch_bounds__(GPMPC_FAST_MAXTHREADS, 1) void rollout_fast_kernel(
         // ---- posterior mean / covariance at the test point ------------------------------------------------------
         double mu[T], S[T][T];
         {
+            // nine wave sums: two lane-swap trees of four (wave_sum4) and one DPP ladder
+            static_assert(T == 3, "the reduction grouping below is written for T = 3");
+            double r[NS];
+            wave_sum4(pm[0], pm[1], pm[2], pss[0], mu[0], mu[1], mu[2], r[0]);
+            wave_sum4(pss[1], pss[2], pss[3], pss[4], r[1], r[2], r[3], r[4]);
+            r[5] = wave_sum(pss[5]);
             int e = 0;
 #pragma unroll
             for (int b = 0; b < T; ++b) {
-                mu[b] = wave_sum(pm[b]);
 #pragma unroll
                 for (int c = 0; c <= b; ++c) {
                     const double kss = (b == c) ? ((b == 0) ? os : os * il2[b - 1]) : 0.0;
-                    const double val = kss - wave_sum(pss[e++]);
+                    const double val = kss - r[e++];
                     S[b][c] = val;
                     S[c][b] = val;
                 }
