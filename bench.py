@@ -161,7 +161,7 @@ def main():
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / FP64_PEAK_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_hbm_bytes_per_launch": MIN_HBM_BYTES_PER_TRAJ_STEP["pendulum1D_R_H30"] * Ns * H,
-                         "kernel": "rollout_kernel<T=3>", "kernel_ms": kern_ms,
+                         "kernel": "rollout_fast_kernel<3,36,1,pendulum1D,L_hh in LDS>", "kernel_ms": kern_ms,
                          "flop_per_launch": flop,
                          "note": "FP64 (vector FMA; FP64 MFMA peak is the same 78.6 TFLOP/s on MI355X); algorithmic "
                                  "FLOP = 2.55e4 per trajectory-step (SURVEY 8d) x Ns x H; min HBM traffic 80 B per "
