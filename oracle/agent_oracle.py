@@ -267,6 +267,55 @@ class OracleAgent:
             self.Hallcinated_X_train = torch.empty(self.ns, self.g_ny, 0, self.in_dim_x, dtype=F64)
             self.Hallcinated_Y_train = torch.empty(self.ns, self.g_ny, 0, self.in_dim_y, dtype=F64)
 
+    def train_forward_sampling_dynGP(self):           # :283-329  real ++ forward-sampling ++ hallucinated data
+        data_X = torch.concat([self.Dyn_gp_X_train_batch, self.FS_X_train_batch, self.Hallcinated_X_train], dim=2)
+        data_Y = torch.concat([self.Dyn_gp_Y_train_batch, self.FS_Y_train_batch, self.Hallcinated_Y_train], dim=2)
+        self.model_i = OracleGP(data_X, data_Y, GPHyper.from_params(self.params, use_grad=True))
+
+    def prepare_dynamics_set(self, X_soln, U_soln, X_kp1, base_samples=None, rng=None):   # :331-443
+        """Forward sampling with rejection.  ``base_samples``: list of (Ns, g_ny, 1, T) tensors, one per propagation
+        step (the reference draws them internally with ``.sample()``); ``rng``: numpy RandomState for the survivor
+        choice (the reference uses the global ``np.random``).  g_ny == 1 only, like the reference (its ``squeeze`` /
+        ``.t()`` arithmetic does not type-check for more outputs)."""
+        n_sample = self.ns
+        tight = self.params["agent"]["tight"]
+        B_d_norm = np.sqrt(self.params["optimizer"]["terminal_tightening"]["P"][1][1])
+        var_eps = (tight["dyn_eps"] + tight["w_bound"]) * B_d_norm
+        rng = np.random if rng is None else rng
+        self.FS_X_train_batch = torch.empty(n_sample, self.g_ny, 0, self.in_dim_x, dtype=F64)
+        self.FS_Y_train_batch = torch.empty(n_sample, self.g_ny, 0, self.in_dim_y, dtype=F64)
+        X_soln = torch.as_tensor(X_soln, dtype=F64).reshape(X_soln.shape[0], n_sample, self.nx)
+        X_kp1 = torch.as_tensor(X_kp1, dtype=F64).transpose(0, 1)
+        U_soln = torch.as_tensor(U_soln, dtype=F64)
+        samples_left = torch.prod(torch.abs(X_soln[1, :, :] - X_kp1) - var_eps < 0, dim=1)
+        xu_hat = torch.tile(torch.cat([X_kp1, U_soln[[1]]], dim=-1), dims=(n_sample, self.nx, 1, 1))
+        self.rejection_trace = [samples_left.clone()]
+        for i in range(1, X_soln.shape[0] - 1):
+            g_xu_hat = self.env_model.get_g_xu_hat(xu_hat)
+            z = None if base_samples is None else base_samples[i - 1]
+            Y_sample = self.model_i(g_xu_hat).sample(z)
+            g_val = Y_sample[:, :, :].squeeze()[:, : self.g_ny]
+            f_val = self.env_model.known_dyn(xu_hat).squeeze()
+            x_next = f_val + torch.matmul(self.env_model.B_d, g_val.t()).t()
+            samples_left = samples_left * torch.prod(torch.abs(X_soln[i + 1, :, :] - x_next) - self.ci_list[i] < 0, dim=1)
+            self.rejection_trace.append(samples_left.clone())
+            if i == X_soln.shape[0] - 2:
+                break
+            self.FS_X_train_batch = torch.cat([self.FS_X_train_batch, g_xu_hat], dim=2)
+            Y_sample = Y_sample.clone()
+            Y_sample[:, :, :, 1:] = float("nan")
+            self.FS_Y_train_batch = torch.cat([self.FS_Y_train_batch, Y_sample], dim=2)
+            self.train_forward_sampling_dynGP()
+            xu_hat = torch.cat([torch.stack([x_next] * self.nx, dim=1)[:, :, None, :],
+                                torch.tile(U_soln[[i + 1]], dims=(n_sample, self.nx, 1, 1))], dim=-1)
+        if torch.sum(samples_left) > 0:
+            n_rep = int(torch.sum(samples_left == 0).item())
+            remaining = torch.arange(n_sample)[samples_left > 0].numpy()
+            dead = samples_left == 0
+            self.Hallcinated_X_train[dead] = self.Hallcinated_X_train[rng.choice(remaining, n_rep).tolist()]
+            self.Hallcinated_Y_train[dead] = self.Hallcinated_Y_train[rng.choice(remaining, n_rep).tolist()]
+        self.train_hallucinated_dynGP(sqp_iter=self.params["optimizer"]["SEMPC"]["max_sqp_iter"])
+
     def update_hallucinated_Dyn_dataset(self, newX, newY):   # :164-202
         min_distance = self.params["agent"]["Dyn_gp_min_data_dist"]
         X_cond, _ = self.concatenate_real_hallucinated_data()

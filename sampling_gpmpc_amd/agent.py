@@ -327,9 +327,14 @@ class Agent(object):
     # ---------------------------------------------------------------------------------------------------------
     # forward sampling with rejection (reference src/agent.py:331-443)
     # ---------------------------------------------------------------------------------------------------------
-    def prepare_dynamics_set(self, X_soln, U_soln, X_kp1):
+    def prepare_dynamics_set(self, X_soln, U_soln, X_kp1, *, base_samples=None, rng=None):
         """Propagate every sampled dynamics along the shifted solution, reject the samples that leave the
-        ``ci_list`` tube, replace their hallucinated data by randomly chosen survivors'."""
+        ``ci_list`` tube, replace their hallucinated data by randomly chosen survivors'.
+
+        Keyword-only reproducibility hooks (the reference has neither): ``base_samples`` - one ``(Ns, g_ny, 1, T)``
+        tensor per propagation step instead of the internal ``randn`` draw; ``rng`` - a ``numpy.random.RandomState``
+        for the survivor choice instead of the global ``np.random``.  ``self.rejection_trace`` keeps the survivor mask
+        after every step."""
         n_sample = self.ns
         tight = self.params["agent"]["tight"]
         B_d_norm = np.sqrt(self.params["optimizer"]["terminal_tightening"]["P"][1][1])
@@ -344,14 +349,18 @@ class Agent(object):
         samples_left = torch.prod(torch.abs(diff) - var_eps < 0, dim=1)
         xu_init = torch.cat([X_kp1, U_soln[[1]]], dim=-1)
         xu_hat = torch.tile(xu_init, dims=(n_sample, self.nx, 1, 1))
+        rng = np.random if rng is None else rng
+        self.rejection_trace = [samples_left.clone()]
         for i in range(1, X_soln.shape[0] - 1):
             g_xu_hat = self.env_model.get_g_xu_hat(xu_hat).contiguous()
-            Y_sample = self.model_i(g_xu_hat).sample()
+            z = None if base_samples is None else base_samples[i - 1].to(dev)
+            Y_sample = self.model_i(g_xu_hat).sample(z)
             g_val = Y_sample[:, :, :].squeeze()[:, : self.g_ny]
             f_val = self.env_model.known_dyn(xu_hat).squeeze()
             x_next = f_val + torch.matmul(self.env_model.B_d, g_val.t()).t()
             diff = X_soln[i + 1, :, :] - x_next
             samples_left = samples_left * torch.prod(torch.abs(diff) - self.ci_list[i] < 0, dim=1)
+            self.rejection_trace.append(samples_left.clone())
             if i == X_soln.shape[0] - 2:
                 break
             self.FS_X_train_batch = torch.cat([self.FS_X_train_batch, g_xu_hat], dim=2)
@@ -365,7 +374,7 @@ class Agent(object):
             n_rep = int(torch.sum(samples_left == 0).item())
             remaining = torch.arange(n_sample)[(samples_left > 0).cpu()].numpy()
             dead = samples_left == 0
-            self.Hallcinated_X_train[dead] = self.Hallcinated_X_train[np.random.choice(remaining, n_rep).tolist()]
-            self.Hallcinated_Y_train[dead] = self.Hallcinated_Y_train[np.random.choice(remaining, n_rep).tolist()]
+            self.Hallcinated_X_train[dead] = self.Hallcinated_X_train[rng.choice(remaining, n_rep).tolist()]
+            self.Hallcinated_Y_train[dead] = self.Hallcinated_Y_train[rng.choice(remaining, n_rep).tolist()]
         self.train_hallucinated_dynGP(sqp_iter=self.params["optimizer"]["SEMPC"]["max_sqp_iter"])
         return

@@ -585,3 +585,64 @@ def test_forward_sampling_with_min_data_dist(sg, pname, min_dist):
     np.testing.assert_allclose(X, Xo, rtol=RTOL_TRAJ, atol=1e-9)
     np.testing.assert_allclose(Y, Yo, rtol=1e-5, atol=1e-9)
     np.testing.assert_allclose(hy[~nan], hyo[~nano], rtol=1e-5, atol=1e-9)
+
+
+def test_prepare_dynamics_set_against_oracle(sg):
+    """Forward sampling with rejection (reference src/agent.py:331-443): the GP is re-trained on real + forward-sampled
+    (value-only labels) + hallucinated data at every step, samples leaving the tube are rejected and their
+    hallucinated data replaced by survivors'.  Same base samples and the same RandomState on both sides."""
+    Ns, H = 10, 6
+    p = load_params("params_pendulum1D_samples")
+    p["agent"]["num_dyn_samples"], p["optimizer"]["H"] = Ns, H
+    p["common"]["num_MPC_itrs"], p["optimizer"]["SEMPC"]["max_sqp_iter"] = 1, 2
+    agent, oagent = make_agents(sg, p)
+    nx, nu = agent.nx, agent.nu
+    g = torch.Generator().manual_seed(21)
+    x0 = np.array(p["env"]["start"], dtype=np.float64)
+    # one SQP iteration of joint draws so that both agents carry hallucinated data (copied from the oracle)
+    x_h = np.tile(x0, (H, Ns)) + 0.05 * torch.randn(H, Ns * nx, generator=g, dtype=F64).numpy()
+    u_h = 0.3 * torch.randn(H, Ns, nu, generator=g, dtype=F64).numpy()
+    for ag in (agent, oagent):
+        ag.train_hallucinated_dynGP(0)
+    oagent.dyn_fg_jacobians(oagent.get_batch_x_hat_u_diff(x_h, u_h), 0)
+    agent.Hallcinated_X_train = oagent.Hallcinated_X_train.clone().to(agent.torch_device)
+    agent.Hallcinated_Y_train = oagent.Hallcinated_Y_train.clone().to(agent.torch_device)
+    for ag in (agent, oagent):
+        ag.train_hallucinated_dynGP(1)
+    U_soln = 0.5 * torch.randn(H + 1, nu, generator=g, dtype=F64)
+    X_kp1 = torch.tensor(x0[:nx]).reshape(nx, 1)
+    z = [torch.randn(Ns, 1, 1, 3, generator=g, dtype=F64).clamp(-2, 2) for _ in range(H)]
+    X_soln = torch.zeros(H + 1, Ns * nx, dtype=F64)
+    X_soln[1] = torch.tensor(x0[:nx]).repeat(Ns)
+    for ag in (agent, oagent):
+        ag.ci_list = [1e9] * (H + 1)
+    # step 1: everything survives (huge tube); now tighten the tube of step 2 around the median sampled state
+    agent.prepare_dynamics_set(X_soln.clone(), U_soln, X_kp1, base_samples=z, rng=np.random.RandomState(5))
+    oagent.prepare_dynamics_set(X_soln.clone(), U_soln, X_kp1, base_samples=z, rng=np.random.RandomState(5))
+    np.testing.assert_allclose(agent.FS_X_train_batch.cpu().numpy(), oagent.FS_X_train_batch.numpy(), rtol=1e-8, atol=1e-10)
+    fy, fyo = agent.FS_Y_train_batch.cpu().numpy(), oagent.FS_Y_train_batch.numpy()
+    assert fy.shape == fyo.shape == (Ns, 1, H - 2, 3) and (np.isnan(fy) == np.isnan(fyo)).all() and np.isnan(fy[..., 1:]).all()
+    np.testing.assert_allclose(fy[..., 0], fyo[..., 0], rtol=1e-6, atol=1e-9)
+    for a_, b_ in zip(agent.rejection_trace, oagent.rejection_trace):
+        assert (a_.cpu().numpy() == b_.numpy()).all()
+    print(f"prepare_dynamics_set: FS points {fy.shape[2]}, survivors per step {[int(t.sum()) for t in oagent.rejection_trace]}, "
+          f"max |dY| {np.nanmax(np.abs(fy - fyo)):.2e}")
+    # second call with a tube around the sampled states of step 2: part of the samples is rejected and replaced
+    x2 = oagent.FS_X_train_batch[:, 0, 2, 0]                     # theta after two sampled steps (the first differing one)
+    med = float(x2.median())
+    tol = float((x2 - med).abs().median()) + 1e-12
+    X_soln2 = X_soln.clone()
+    X_soln2[3] = torch.stack([torch.full((Ns,), med, dtype=F64), torch.zeros(Ns, dtype=F64)], dim=1).reshape(-1)
+    for ag, dev in ((agent, agent.torch_device), (oagent, "cpu")):
+        ag.ci_list = [1e9] * (H + 1)
+        ag.ci_list[2] = torch.tensor([tol, 1e9], dtype=F64, device=dev)      # tube on theta only at that step
+        ag.train_hallucinated_dynGP(1)
+    hx_before = oagent.Hallcinated_X_train.clone()
+    agent.prepare_dynamics_set(X_soln2.clone(), U_soln, X_kp1, base_samples=z, rng=np.random.RandomState(7))
+    oagent.prepare_dynamics_set(X_soln2.clone(), U_soln, X_kp1, base_samples=z, rng=np.random.RandomState(7))
+    left = oagent.rejection_trace[-1].numpy()
+    assert 0 < left.sum() < Ns, f"the tube should split the samples, survivors: {left}"
+    assert (agent.rejection_trace[-1].cpu().numpy() == left).all()
+    np.testing.assert_allclose(agent.Hallcinated_X_train.cpu().numpy(), oagent.Hallcinated_X_train.numpy(), rtol=1e-9, atol=1e-12)
+    np.testing.assert_allclose(agent.Hallcinated_Y_train.cpu().numpy(), oagent.Hallcinated_Y_train.numpy(), rtol=1e-9, atol=1e-12)
+    assert not np.array_equal(oagent.Hallcinated_X_train.numpy(), hx_before.numpy()), "rejected samples keep their data"
