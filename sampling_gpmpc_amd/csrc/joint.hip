@@ -663,7 +663,7 @@ int gpmpc_joint_sample(const gpmpc_gp_desc_t* gp, const void* plan, const double
     if (gp->D != 2) return fail(GPMPC_E_UNSUPPORTED, "only D = 2 is instantiated");
     const int mT = m * gp->T;
     if (mT > 256) return fail(GPMPC_E_UNSUPPORTED, "joint: m*T > 256");
-    if (n_ho + 1 + mT > 4 * 256) return fail(GPMPC_E_UNSUPPORTED, "joint: more than 1024 label rows per chain");
+    if (n_ho + 1 + mT > 1024) return fail(GPMPC_E_UNSUPPORTED, "joint: more than 1024 label rows per chain");
     JointArgs a;
     a.gp = make_gp_params(gp);
     a.plan = (const double*)plan;
@@ -693,14 +693,15 @@ int gpmpc_joint_sample(const gpmpc_gp_desc_t* gp, const void* plan, const double
     hipStream_t st = (hipStream_t)stream;
     const int nrow = n_ho + 1 + mT;
     // one label row per thread and a workgroup just wide enough for the rows (more chains per CU when they are short:
-    // iteration 0 of config 5 has 121 rows); beyond 512 rows four rows per thread on 8-wide blocks
+    // iteration 0 of config 5 has 121 rows; iteration 0 of every later MPC step conditions on the previous step's
+    // whole hallucinated set - the reference's reset-after-build quirk - i.e. 601 rows at config 5: 1024 threads)
     const dim3 g((unsigned)grid);
 #define GPMPC_JOINT_LAUNCH(TT)                                                                              \
     do {                                                                                                    \
         if (nrow <= 128) hipLaunchKernelGGL((joint_kernel<TT, 16, 1, 128, GPMPC_JOINT_WPE>), g, dim3(128), 0, st, a);      \
         else if (nrow <= 256) hipLaunchKernelGGL((joint_kernel<TT, 16, 1, 256, GPMPC_JOINT_WPE>), g, dim3(256), 0, st, a); \
         else if (nrow <= 512) hipLaunchKernelGGL((joint_kernel<TT, 16, 1, 512, GPMPC_JOINT_WPE>), g, dim3(512), 0, st, a); \
-        else hipLaunchKernelGGL((joint_kernel<TT, 8, 4, 256, 2>), g, dim3(256), 0, st, a);                   \
+        else hipLaunchKernelGGL((joint_kernel<TT, 16, 1, 1024, 4>), g, dim3(1024), 0, st, a);               \
     } while (0)
     if (gp->T == 1) {
         GPMPC_JOINT_LAUNCH(1);
