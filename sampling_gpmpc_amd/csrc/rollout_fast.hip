@@ -20,6 +20,8 @@
 #include "gpmpc_host.hpp"
 #include "rollout_args.hpp"
 
+#include <type_traits>
+
 namespace gpmpc {
 
 __device__ long long g_fast_phase_cycles[16];
@@ -68,6 +70,183 @@ constexpr int kRingGlobal = GPMPC_FAST_RING_GLOBAL;
 __device__ __forceinline__ void wave_sync_lds() {
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Forward substitution on the DPP rows (LHH_LDS variant).  A wave is four DPP rows of 16 lanes and lane == factor row,
+// so a 16-pivot block of the factor coincides with one DPP row:
+//   diagonal block : v_fmac_f64_dpp row_newbcast:i with the running right-hand side ITSELF as the broadcast source and
+//                    row_mask = the block's row - pivot i of the block reaches the 15 other lanes of its row without
+//                    leaving the VALU (the v_readlane -> SGPR -> v_fma chain costs ~100 cycles per pivot, this ~22);
+//   replicate      : the 16 solved values are copied to all four DPP rows with ds_bpermute (6 dwords);
+//   off-diagonal   : v_fmac_f64_dpp row_newbcast:i from the replicated register, row_mask = the later rows (bank 0) or
+//                    all rows (bank 1): three independent accumulation chains, issue bound.
+// Every lane still reads only its own row of L'' (two pivots per ds_read_b128).  Entries at or right of the diagonal are
+// replaced by exact zeros by pointing the read at a zero pair (one v_cmp + v_cndmask per PAIR instead of per pivot and
+// right-hand side), so the arithmetic per row is the same sequence of FMAs as in the v_readlane form: results are
+// bit-identical (tools/ubench/dppsubst.hip).  Hazard: a VGPR written by the VALU may be read through DPP only two wait
+// states later; the compiler cannot see into the asm, hence the s_nop 1 at the head of every block of three.
+// ---------------------------------------------------------------------------------------------------------------
+template <int I, int RM>
+__device__ __forceinline__ void fmac3_dpp_self(double (&v)[3], double la) {
+    asm("s_nop 1\n\t"
+        "v_fmac_f64_dpp %0, %0, -%3 row_newbcast:%4 row_mask:%5 bank_mask:0xf\n\t"
+        "v_fmac_f64_dpp %1, %1, -%3 row_newbcast:%4 row_mask:%5 bank_mask:0xf\n\t"
+        "v_fmac_f64_dpp %2, %2, -%3 row_newbcast:%4 row_mask:%5 bank_mask:0xf"
+        : "+v"(v[0]), "+v"(v[1]), "+v"(v[2])
+        : "v"(la), "n"(I), "n"(RM));
+}
+template <int I, int RM>
+__device__ __forceinline__ void fmac3_dpp_from(double (&v)[3], const double (&R)[3], double la) {
+    asm("s_nop 1\n\t"
+        "v_fmac_f64_dpp %0, %4, -%3 row_newbcast:%7 row_mask:%8 bank_mask:0xf\n\t"
+        "v_fmac_f64_dpp %1, %5, -%3 row_newbcast:%7 row_mask:%8 bank_mask:0xf\n\t"
+        "v_fmac_f64_dpp %2, %6, -%3 row_newbcast:%7 row_mask:%8 bank_mask:0xf"
+        : "+v"(v[0]), "+v"(v[1]), "+v"(v[2])
+        : "v"(la), "v"(R[0]), "v"(R[1]), "v"(R[2]), "n"(I), "n"(RM));
+}
+// acc[b] (+/-)= R[b]@(lane i of the DPP row) * l  for the three right-hand sides; R holds the same 16 values in every DPP
+// row (dpp_replicate), so this is a wave-wide broadcast of pivot i without LDS traffic or SGPR round trip
+template <int I, bool NEG>
+__device__ __forceinline__ void fmac3_dpp_bcast(double (&acc)[3], const double (&R)[3], double l) {
+    if constexpr (NEG) {
+        asm("s_nop 1\n\t"
+            "v_fmac_f64_dpp %0, %4, -%3 row_newbcast:%7 row_mask:0xf bank_mask:0xf\n\t"
+            "v_fmac_f64_dpp %1, %5, -%3 row_newbcast:%7 row_mask:0xf bank_mask:0xf\n\t"
+            "v_fmac_f64_dpp %2, %6, -%3 row_newbcast:%7 row_mask:0xf bank_mask:0xf"
+            : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2])
+            : "v"(l), "v"(R[0]), "v"(R[1]), "v"(R[2]), "n"(I));
+    } else {
+        asm("s_nop 1\n\t"
+            "v_fmac_f64_dpp %0, %4, %3 row_newbcast:%7 row_mask:0xf bank_mask:0xf\n\t"
+            "v_fmac_f64_dpp %1, %5, %3 row_newbcast:%7 row_mask:0xf bank_mask:0xf\n\t"
+            "v_fmac_f64_dpp %2, %6, %3 row_newbcast:%7 row_mask:0xf bank_mask:0xf"
+            : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2])
+            : "v"(l), "v"(R[0]), "v"(R[1]), "v"(R[2]), "n"(I));
+    }
+}
+// mat-vec against a vector whose entries live one per lane (lanes 0..N-1): acc[b] (+/-)= sum_p M[lane][p] * x[b][p],
+// p ascending (the same FMA sequence per row as a broadcast-from-LDS loop).  `entry(p)` returns this lane's M[lane][p].
+template <int N, bool NEG, int P = 0, class Entry>
+__device__ __forceinline__ void dpp_matvec(double (&acc)[3], const double (&R)[(N + 15) / 16][3], const Entry& entry) {
+    if constexpr (P < N) {
+        fmac3_dpp_bcast<P % 16, NEG>(acc, R[P / 16], entry(std::integral_constant<int, P>{}));
+        dpp_matvec<N, NEG, P + 1>(acc, R, entry);
+    }
+}
+template <int N>
+__device__ __forceinline__ void dpp_replicate_vec(const double (&x)[3], int bp_addr, double (&R)[(N + 15) / 16][3]) {
+#pragma unroll
+    for (int blk = 0; blk < (N + 15) / 16; ++blk) {
+#pragma unroll
+        for (int b = 0; b < 3; ++b) {
+            const int lo = __builtin_amdgcn_ds_bpermute(bp_addr + 64 * blk, __double2loint(x[b]));
+            const int hi = __builtin_amdgcn_ds_bpermute(bp_addr + 64 * blk, __double2hiint(x[b]));
+            R[blk][b] = __hiloint2double(hi, lo);
+        }
+    }
+}
+// pivots I0 .. I0+3 of a 16-pivot block whose own-row entries are l[0..7] (pairs)
+template <int RM, int I0>
+__device__ __forceinline__ void dpp_diag4(const double2_t (&l)[8], double (&v)[3]) {
+    fmac3_dpp_self<I0 + 0, RM>(v, l[I0 / 2].x);
+    fmac3_dpp_self<I0 + 1, RM>(v, l[I0 / 2].y);
+    fmac3_dpp_self<I0 + 2, RM>(v, l[I0 / 2 + 1].x);
+    fmac3_dpp_self<I0 + 3, RM>(v, l[I0 / 2 + 1].y);
+}
+template <int RM, int I0>
+__device__ __forceinline__ void dpp_off4(const double2_t (&l)[8], const double (&R)[3], double (&v)[3]) {
+    fmac3_dpp_from<I0 + 0, RM>(v, R, l[I0 / 2].x);
+    fmac3_dpp_from<I0 + 1, RM>(v, R, l[I0 / 2].y);
+    fmac3_dpp_from<I0 + 2, RM>(v, R, l[I0 / 2 + 1].x);
+    fmac3_dpp_from<I0 + 3, RM>(v, R, l[I0 / 2 + 1].y);
+}
+// diagonal block in DPP row K; n_rem = pivots that exist from the block's first pivot on (uniform): whole groups of four
+// beyond them are skipped
+template <int K>
+__device__ __forceinline__ void dpp_diag_block(const double2_t (&l)[8], double (&v)[3], int n_rem) {
+    dpp_diag4<(1 << K), 0>(l, v);
+    if (n_rem > 4) {
+        dpp_diag4<(1 << K), 4>(l, v);
+        if (n_rem > 8) {
+            dpp_diag4<(1 << K), 8>(l, v);
+            if (n_rem > 12) dpp_diag4<(1 << K), 12>(l, v);
+        }
+    }
+}
+template <int RM>
+__device__ __forceinline__ void dpp_off_block(const double2_t (&l)[8], const double (&R)[3], double (&v)[3]) {
+    if constexpr (RM != 0) {
+        dpp_off4<RM, 0>(l, R, v);
+        dpp_off4<RM, 4>(l, R, v);
+        dpp_off4<RM, 8>(l, R, v);
+        dpp_off4<RM, 12>(l, R, v);
+    }
+}
+// the lane's own-row pairs 8*QB .. 8*QB+7; pairs at / right of the diagonal of row `r` come from the zero pair
+template <bool SELECT>
+__device__ __forceinline__ void dpp_load_pairs(const double2_t* row, const double2_t* zero2, int r, int qb, double2_t (&l)[8]) {
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const int qq = 8 * qb + q;
+        l[q] = SELECT ? *((2 * qq < r) ? (row + qq) : zero2) : row[qq];
+    }
+}
+// copy DPP row K of v to all four rows
+template <int K>
+__device__ __forceinline__ void dpp_replicate(const double (&v)[3], int bp_addr, double (&R)[3]) {
+#pragma unroll
+    for (int b = 0; b < 3; ++b) {
+        const int lo = __builtin_amdgcn_ds_bpermute(bp_addr + 64 * K, __double2loint(v[b]));
+        const int hi = __builtin_amdgcn_ds_bpermute(bp_addr + 64 * K, __double2hiint(v[b]));
+        R[b] = __hiloint2double(hi, lo);
+    }
+}
+
+// pivots 16K .. 16K+15 of bank 0 (rows 0..63 in v0, rows 64.. in v1 when TWO)
+template <int K, bool TWO>
+__device__ __forceinline__ void dpp_bank0_block(const double2_t* row0, const double2_t* row1, const double2_t* zero2, int r0,
+                                                int n_h, int bp_addr, double2_t (&la)[8], double (&v0)[3], double (&v1)[3]) {
+    if constexpr (K < 4) {
+        if (!TWO && 16 * K >= n_h) return;
+        double2_t lb[8];
+        if constexpr (TWO) dpp_load_pairs<false>(row1, zero2, 0, K, lb);
+        dpp_diag_block<K>(la, v0, TWO ? 16 : n_h - 16 * K);
+        if (TWO || 16 * (K + 1) < n_h) {
+            double R[3];
+            dpp_replicate<K>(v0, bp_addr, R);
+            double2_t la_next[8];
+            if constexpr (K < 3) dpp_load_pairs<true>(row0, zero2, r0, K + 1, la_next);
+            dpp_off_block<((0xf << (K + 1)) & 0xf)>(la, R, v0);
+            if constexpr (TWO) dpp_off_block<0xf>(lb, R, v1);
+            if constexpr (K < 3) {
+#pragma unroll
+                for (int q = 0; q < 8; ++q) la[q] = la_next[q];
+            }
+            dpp_bank0_block<K + 1, TWO>(row0, row1, zero2, r0, n_h, bp_addr, la, v0, v1);
+        }
+    }
+}
+// pivots 64+16K .. of bank 1
+template <int K>
+__device__ __forceinline__ void dpp_bank1_block(const double2_t* row1, const double2_t* zero2, int r1, int n_h, int bp_addr,
+                                                double2_t (&lb)[8], double (&v1)[3]) {
+    if constexpr (K < 4) {
+        if (kWave + 16 * K >= n_h) return;
+        dpp_diag_block<K>(lb, v1, n_h - kWave - 16 * K);
+        if (kWave + 16 * (K + 1) < n_h) {
+            double R[3];
+            dpp_replicate<K>(v1, bp_addr, R);
+            double2_t lb_next[8];
+            if constexpr (K < 3) dpp_load_pairs<true>(row1, zero2, r1, 4 + K + 1, lb_next);
+            dpp_off_block<((0xf << (K + 1)) & 0xf)>(lb, R, v1);
+            if constexpr (K < 3) {
+#pragma unroll
+                for (int q = 0; q < 8; ++q) lb[q] = lb_next[q];
+            }
+            dpp_bank1_block<K + 1>(row1, zero2, r1, n_h, bp_addr, lb, v1);
+        }
+    }
 }
 
 // GPMPC_FAST_MAXTHREADS=512 (build.py: GPMPC_EXTRA_DEFS) halves the register budget so that two workgroups share a CU:
@@ -153,6 +332,7 @@ __global__ __launch_bounds__(GPMPC_FAST_MAXTHREADS, 1) void rollout_fast_kernel(
     const double2_t* row0 = reinterpret_cast<const double2_t*>(Lhh + lhh_rowofs(min(lane, nh_max - 1)));
     const double2_t* row1 = reinterpret_cast<const double2_t*>(Lhh + lhh_rowofs(min(lane + kWave, nh_max - 1)));
     const double2_t* lhr1row = reinterpret_cast<const double2_t*>(Lhr1 + (long)min(lane, max(nb1 - 1, 0)) * NRS);
+    const double2_t* zero2 = reinterpret_cast<const double2_t*>(Lhh + lhh_rowofs(nh_max));    // first slack pair: never written
     const int a0t = lane - (lane / T) * T, a1t = (lane + kWave) - ((lane + kWave) / T) * T;   // task of this lane's rows
     FPHASE_DECL;
 
@@ -186,60 +366,43 @@ __global__ __launch_bounds__(GPMPC_FAST_MAXTHREADS, 1) void rollout_fast_kernel(
         }
 
         // ---- kernel row against the real data (lane = real point) ---------------------------------------------
+        const int bp_addr = (lane & 15) << 2;                     // ds_bpermute address of "my lane of DPP row 0"
+        double kr[T];
         {
             double q[D];
             const double k = kern_scalar<D>(xr, xi, il2, os, q);
-            if (lane < NR) {
 #pragma unroll
-                for (int b = 0; b < T; ++b) kvs[b * NRP + lane] = kern_entry<D>(q, k, il2, 0, b);
-            }
+            for (int b = 0; b < T; ++b) kr[b] = kern_entry<D>(q, k, il2, 0, b);      // lanes >= NR: never used as pivots
         }
-        wave_sync_lds();
         FPHASE(0);
 
         // ---- v_r = L_rr^-1 k_r (lane = row; own row and the broadcast k_r both two entries per ds_read_b128) ----
         double vr[T];
 #pragma unroll
         for (int b = 0; b < T; ++b) vr[b] = 0.0;
+#ifdef GPMPC_ABLATE_VR
+        vr[0] = kr[0];
+#else
         {
-            // explicit load batches (JB pairs = 4*JB ds_read_b128 in flight), fenced so the scheduler neither serialises
-            // them one by one (what it does under register pressure) nor hoists the whole loop's loads at once
-            constexpr int JB = 3;
+            // k_r replicated to all four DPP rows (16 real points per register), then one v_fmac_f64_dpp per pivot and
+            // right-hand side against the lane's own row of L_rr^-1 (two entries per ds_read_b128): no LDS broadcasts
+            static_assert(T == 3, "dpp_matvec is written for three right-hand sides");
+            double Rk[(NR + 15) / 16][3];
+            dpp_replicate_vec<NR>(kr, bp_addr, Rk);
+            double2_t lrow[(NR + 1) / 2];
 #pragma unroll
-            for (int jp0 = 0; jp0 < NPAIR; jp0 += JB) {
-                double2_t l[JB], kk[JB][T];
-#pragma unroll
-                for (int q = 0; q < JB; ++q) {
-                    if (jp0 + q < NPAIR) {
-                        l[q] = linvrow[jp0 + q];
-#pragma unroll
-                        for (int b = 0; b < T; ++b) kk[q][b] = *reinterpret_cast<const double2_t*>(kvs + b * NRP + 2 * (jp0 + q));
-                    }
-                }
-#pragma unroll
-                for (int q = 0; q < JB; ++q) {
-                    if (jp0 + q < NPAIR) {
-#pragma unroll
-                        for (int b = 0; b < T; ++b) {
-                            vr[b] = fma(l[q].x, kk[q][b].x, vr[b]);
-                            vr[b] = fma(l[q].y, kk[q][b].y, vr[b]);
-                        }
-                    }
-                }
-                asm volatile("" ::: "memory");
-            }
+            for (int jp = 0; jp < (NR + 1) / 2; ++jp) lrow[jp] = linvrow[jp];     // NRS >= NR + 1: the odd tail reads a zero pad
+            dpp_matvec<NR, false>(vr, Rk, [&](auto pc) {
+                constexpr int p = decltype(pc)::value;
+                return (p & 1) ? lrow[p / 2].y : lrow[p / 2].x;
+            });
         }
-        if (NR & 1) {
-            const double l = reinterpret_cast<const double*>(linvrow)[NR - 1];
-#pragma unroll
-            for (int b = 0; b < T; ++b) vr[b] = fma(l, kvs[b * NRP + NR - 1], vr[b]);
-        }
+#endif
         if (lane >= NR) {
 #pragma unroll
             for (int b = 0; b < T; ++b) vr[b] = 0.0;
         }
         double pm[T], pss[NS];
-        wave_sync_lds();                                          // every lane has consumed k_r: the buffer becomes v_r
         {
             int e = 0;
 #pragma unroll
@@ -263,67 +426,69 @@ __global__ __launch_bounds__(GPMPC_FAST_MAXTHREADS, 1) void rollout_fast_kernel(
             const bool two = n_h > kWave;
             const bool ex0 = lane < n_h, ex1 = lane + kWave < n_h;
             // ---- rhs = k_h - L_hr v_r -----------------------------------------------------------------------------
+#ifdef GPMPC_ABLATE_KH
+            for (int b = 0; b < T; ++b) v0[b] = xh0[0] * xi[b & 1], v1[b] = xh1[0] * xi[b & 1];
+            if (n_h < 0)
+#endif
             {
                 double q[D];
                 const double k = kern_scalar<D>(xh0, xi, il2, os, q);
 #pragma unroll
                 for (int b = 0; b < T; ++b) v0[b] = ex0 ? kern_entry<D>(q, k, il2, a0t, b) : 0.0;
             }
+#ifdef GPMPC_ABLATE_KH
+            if (n_h < 0)
+#endif
             if (two) {
                 double q[D];
                 const double k = kern_scalar<D>(xh1, xi, il2, os, q);
 #pragma unroll
                 for (int b = 0; b < T; ++b) v1[b] = ex1 ? kern_entry<D>(q, k, il2, a1t, b) : 0.0;
             }
+#ifndef GPMPC_ABLATE_RHS
             {
-                constexpr int IB = 3;                              // i-pairs per fenced batch
+                // v_r replicated to the DPP rows; bank-0 rows of L_hr come from registers, bank-1 rows from LDS
+                double Rv[(NR + 15) / 16][3];
+                dpp_replicate_vec<NR>(vr, bp_addr, Rv);
+                dpp_matvec<NR, true>(v0, Rv, [&](auto pc) { return Lhr0[decltype(pc)::value]; });
+                if (two) {
+                    double2_t l1[(NR + 1) / 2];
 #pragma unroll
-                for (int ip0 = 0; ip0 < NPAIR; ip0 += IB) {
-                    double2_t vv[IB][T], l1[IB];
-#pragma unroll
-                    for (int q = 0; q < IB; ++q) {
-                        if (ip0 + q < NPAIR) {
-#pragma unroll
-                            for (int b = 0; b < T; ++b)
-                                vv[q][b] = *reinterpret_cast<const double2_t*>(kvs + b * NRP + 2 * (ip0 + q));
-                            if (two) l1[q] = lhr1row[ip0 + q];
-                        }
-                    }
-#pragma unroll
-                    for (int q = 0; q < IB; ++q) {
-                        if (ip0 + q < NPAIR) {
-#pragma unroll
-                            for (int b = 0; b < T; ++b) {
-                                v0[b] = fma(-Lhr0[2 * (ip0 + q)], vv[q][b].x, v0[b]);
-                                v0[b] = fma(-Lhr0[2 * (ip0 + q) + 1], vv[q][b].y, v0[b]);
-                            }
-                            if (two) {
-#pragma unroll
-                                for (int b = 0; b < T; ++b) {
-                                    v1[b] = fma(-l1[q].x, vv[q][b].x, v1[b]);
-                                    v1[b] = fma(-l1[q].y, vv[q][b].y, v1[b]);
-                                }
-                            }
-                        }
-                    }
-                    asm volatile("" ::: "memory");
-                }
-                if (NR & 1) {
-                    const double l1 = two ? reinterpret_cast<const double*>(lhr1row)[NR - 1] : 0.0;
-#pragma unroll
-                    for (int b = 0; b < T; ++b) {
-                        const double vv = kvs[b * NRP + NR - 1];
-                        v0[b] = fma(-Lhr0[NR - 1], vv, v0[b]);
-                        v1[b] = fma(-l1, vv, v1[b]);
-                    }
+                    for (int ip = 0; ip < (NR + 1) / 2; ++ip) l1[ip] = lhr1row[ip];
+                    dpp_matvec<NR, true>(v1, Rv, [&](auto pc) {
+                        constexpr int p = decltype(pc)::value;
+                        return (p & 1) ? l1[p / 2].y : l1[p / 2].x;
+                    });
                 }
             }
+#endif
             FPHASE(2);
 
             // ---- forward substitution (see the header comment) -----------------------------------------------------
             // ring of 4 row pairs per bank = 8 pivots of look-ahead; reads past a row / the allocation land in the
             // slack or in later rows and are masked (finished rows) or multiplied by a zero pivot value.  All T pivot
             // values are broadcast (v_readlane) before the FMAs that consume them, so the SGPR write latency overlaps.
+#ifdef GPMPC_ABLATE_SUBST
+            if (n_h >= 0) {
+            } else
+#endif
+            if constexpr (LHH_LDS) {
+                static_assert(T == 3, "the DPP substitution is written for three right-hand sides");
+                int lane_t = lane;                                       // laundered per step: keeps the address selects
+                asm volatile("" : "+v"(lane_t));                         // of the pair loads out of the loop-invariant set
+                const int bp_addr = (lane_t & 15) << 2;
+                const int r0 = min(lane_t, nh_max - 1), r1 = min(lane_t + kWave, nh_max - 1);   // the rows row0 / row1 point at
+                double2_t la[8];
+                dpp_load_pairs<true>(row0, zero2, r0, 0, la);
+                if (!two) {
+                    dpp_bank0_block<0, false>(row0, row1, zero2, r0, n_h, bp_addr, la, v0, v1);
+                } else {
+                    dpp_bank0_block<0, true>(row0, row1, zero2, r0, n_h, bp_addr, la, v0, v1);
+                    double2_t lb[8];
+                    dpp_load_pairs<true>(row1, zero2, r1, 4, lb);
+                    dpp_bank1_block<0>(row1, zero2, r1, n_h, bp_addr, lb, v1);
+                }
+            } else
             if (!two) {
                 double2_t ra[RG];
 #pragma unroll
