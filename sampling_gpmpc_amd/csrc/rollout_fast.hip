@@ -334,6 +334,27 @@ __global__ __launch_bounds__(GPMPC_FAST_MAXTHREADS, 1) void rollout_fast_kernel(
     const double2_t* lhr1row = reinterpret_cast<const double2_t*>(Lhr1 + (long)min(lane, max(nb1 - 1, 0)) * NRS);
     const double2_t* zero2 = reinterpret_cast<const double2_t*>(Lhh + lhh_rowofs(nh_max));    // first slack pair: never written
     const int a0t = lane - (lane / T) * T, a1t = (lane + kWave) - ((lane + kWave) / T) * T;   // task of this lane's rows
+    // The chain's base samples (H*T <= 129 doubles) and the input sequence (H*NU <= 86) are fetched ONCE, one entry per
+    // lane, and handed out with v_readlane inside the loop: a global load inside the step loop of a single wave costs
+    // its full latency (the three z loads were serialised behind s_waitcnt vmcnt(0), which also waits for the
+    // trajectory stores of the step).  With L_hh in LDS the loop then contains no vector-memory load at all.
+    constexpr int ZREGS = 3, UREGS = 2;
+    double zq[ZREGS], uq[UREGS];
+#pragma unroll
+    for (int r = 0; r < ZREGS; ++r) {
+        const int j = r * kWave + lane, tt = j / T, c = j - tt * T;
+        zq[r] = (j < H * T) ? a.z[(long)tt * a.z_step_stride + (s * G_NY + o) * T + c] : 0.0;
+    }
+#pragma unroll
+    for (int r = 0; r < UREGS; ++r) {
+        const int j = r * kWave + lane;
+        uq[r] = (j < H * NU) ? a.u_ff[j] : 0.0;
+    }
+    auto lane_pick = [&](const double* regs, int nregs, int j) -> double {       // j uniform: entry j of a lane-indexed table
+        double v = regs[0];
+        for (int r = 1; r < nregs; ++r) v = ((j >> 6) == r) ? regs[r] : v;
+        return readlane_f64(v, j & 63);
+    };
     FPHASE_DECL;
 
 #pragma unroll 1
@@ -341,7 +362,9 @@ __global__ __launch_bounds__(GPMPC_FAST_MAXTHREADS, 1) void rollout_fast_kernel(
         // ---- input, GP input -----------------------------------------------------------------------------------
         double u[NU], xi[D];
         {
-            const double* uf = a.u_ff + (long)t * NU;
+            double uf[NU];
+#pragma unroll
+            for (int i = 0; i < NU; ++i) uf[i] = lane_pick(uq, UREGS, t * NU + i);
 #pragma unroll
             for (int i = 0; i < NU; ++i) {
                 if (a.env.use_feedback) {
@@ -365,14 +388,32 @@ __global__ __launch_bounds__(GPMPC_FAST_MAXTHREADS, 1) void rollout_fast_kernel(
             }
         }
 
-        // ---- kernel row against the real data (lane = real point) ---------------------------------------------
+        // ---- kernel entries: the row against the real data (lane = real point) and this lane's rows of k_h ----------
+        // one basic block: the exponentials are independent dependency chains and interleave.  The lane's row of
+        // L_rr^-1 is requested first so that its LDS latency hides behind them.
         const int bp_addr = (lane & 15) << 2;                     // ds_bpermute address of "my lane of DPP row 0"
-        double kr[T];
-        {
-            double q[D];
-            const double k = kern_scalar<D>(xr, xi, il2, os, q);
+        double2_t lrow[(NR + 1) / 2];
 #pragma unroll
-            for (int b = 0; b < T; ++b) kr[b] = kern_entry<D>(q, k, il2, 0, b);      // lanes >= NR: never used as pivots
+        for (int jp = 0; jp < (NR + 1) / 2; ++jp) lrow[jp] = linvrow[jp];         // NRS >= NR + 1: the odd tail reads a zero pad
+        const bool two = n_h > kWave;
+        const bool ex0 = lane < n_h, ex1 = lane + kWave < n_h;
+        double kr[T], v0[T], v1[T];                               // v0 / v1: rows lane / lane+64 of k_h, then rhs, then v_h
+        {
+            double q[D], q0[D];
+            const double k = kern_scalar<D>(xr, xi, il2, os, q);
+            const double k0 = kern_scalar<D>(xh0, xi, il2, os, q0);
+#pragma unroll
+            for (int b = 0; b < T; ++b) {
+                kr[b] = kern_entry<D>(q, k, il2, 0, b);           // lanes >= NR: never used as pivots
+                v0[b] = ex0 ? kern_entry<D>(q0, k0, il2, a0t, b) : 0.0;
+                v1[b] = 0.0;
+            }
+        }
+        if (two) {
+            double q1[D];
+            const double k1 = kern_scalar<D>(xh1, xi, il2, os, q1);
+#pragma unroll
+            for (int b = 0; b < T; ++b) v1[b] = ex1 ? kern_entry<D>(q1, k1, il2, a1t, b) : 0.0;
         }
         FPHASE(0);
 
@@ -389,9 +430,6 @@ __global__ __launch_bounds__(GPMPC_FAST_MAXTHREADS, 1) void rollout_fast_kernel(
             static_assert(T == 3, "dpp_matvec is written for three right-hand sides");
             double Rk[(NR + 15) / 16][3];
             dpp_replicate_vec<NR>(kr, bp_addr, Rk);
-            double2_t lrow[(NR + 1) / 2];
-#pragma unroll
-            for (int jp = 0; jp < (NR + 1) / 2; ++jp) lrow[jp] = linvrow[jp];     // NRS >= NR + 1: the odd tail reads a zero pad
             dpp_matvec<NR, false>(vr, Rk, [&](auto pc) {
                 constexpr int p = decltype(pc)::value;
                 return (p & 1) ? lrow[p / 2].y : lrow[p / 2].x;
@@ -416,35 +454,8 @@ __global__ __launch_bounds__(GPMPC_FAST_MAXTHREADS, 1) void rollout_fast_kernel(
         wave_sync_lds();
         FPHASE(1);
 
-        double v0[T], v1[T];                             // rows lane / lane+64 of v_h
-#pragma unroll
-        for (int b = 0; b < T; ++b) {
-            v0[b] = 0.0;
-            v1[b] = 0.0;
-        }
         if (n_h > 0) {
-            const bool two = n_h > kWave;
-            const bool ex0 = lane < n_h, ex1 = lane + kWave < n_h;
             // ---- rhs = k_h - L_hr v_r -----------------------------------------------------------------------------
-#ifdef GPMPC_ABLATE_KH
-            for (int b = 0; b < T; ++b) v0[b] = xh0[0] * xi[b & 1], v1[b] = xh1[0] * xi[b & 1];
-            if (n_h < 0)
-#endif
-            {
-                double q[D];
-                const double k = kern_scalar<D>(xh0, xi, il2, os, q);
-#pragma unroll
-                for (int b = 0; b < T; ++b) v0[b] = ex0 ? kern_entry<D>(q, k, il2, a0t, b) : 0.0;
-            }
-#ifdef GPMPC_ABLATE_KH
-            if (n_h < 0)
-#endif
-            if (two) {
-                double q[D];
-                const double k = kern_scalar<D>(xh1, xi, il2, os, q);
-#pragma unroll
-                for (int b = 0; b < T; ++b) v1[b] = ex1 ? kern_entry<D>(q, k, il2, a1t, b) : 0.0;
-            }
 #ifndef GPMPC_ABLATE_RHS
             {
                 // v_r replicated to the DPP rows; bank-0 rows of L_hr come from registers, bank-1 rows from LDS
@@ -584,9 +595,14 @@ __global__ __launch_bounds__(GPMPC_FAST_MAXTHREADS, 1) void rollout_fast_kernel(
             // nine wave sums: two lane-swap trees of four (wave_sum4) and one DPP ladder
             static_assert(T == 3, "the reduction grouping below is written for T = 3");
             double r[NS];
+#ifdef GPMPC_ABLATE_REDUCE
+            mu[0] = readlane_f64(pm[0], 0), mu[1] = readlane_f64(pm[1], 0), mu[2] = readlane_f64(pm[2], 0);
+            for (int e2 = 0; e2 < NS; ++e2) r[e2] = readlane_f64(pss[e2], 0) * 1e-3;
+#else
             wave_sum4(pm[0], pm[1], pm[2], pss[0], mu[0], mu[1], mu[2], r[0]);
             wave_sum4(pss[1], pss[2], pss[3], pss[4], r[1], r[2], r[3], r[4]);
             r[5] = wave_sum(pss[5]);
+#endif
             int e = 0;
 #pragma unroll
             for (int b = 0; b < T; ++b) {
@@ -620,10 +636,24 @@ __global__ __launch_bounds__(GPMPC_FAST_MAXTHREADS, 1) void rollout_fast_kernel(
             for (int b = 0; b < T; ++b)
 #pragma unroll
                 for (int c = 0; c < T; ++c) Sn[b][c] = S[b][c] + ((b == c) ? gp.noise[b] : 0.0);
+#ifdef GPMPC_ABLATE_SAMPLE
+            c_ok = true;
+#pragma unroll
+            for (int b = 0; b < T; ++b) {
+                cinv[b] = Sn[b][b];
+#pragma unroll
+                for (int c = 0; c < T; ++c) C[b][c] = Sn[b][c], R[b][c] = S[b][c];
+            }
+#else
             c_ok = chol_small_fast<T>(Sn, C, cinv);        // independent of the root below: the two chains interleave
+#endif
         }
+#ifndef GPMPC_ABLATE_SAMPLE
         info_acc |= root_small_fast<T>(S, gp.jitter, R);
-        const double* zt = a.z + (long)t * a.z_step_stride + (s * G_NY + o) * T;
+#endif
+        double zt[T];
+#pragma unroll
+        for (int c = 0; c < T; ++c) zt[c] = lane_pick(zq, ZREGS, t * T + c);
         double y[T];
 #pragma unroll
         for (int b = 0; b < T; ++b) {
@@ -647,7 +677,12 @@ __global__ __launch_bounds__(GPMPC_FAST_MAXTHREADS, 1) void rollout_fast_kernel(
         FPHASE(5);
 
         // ---- append [v^T, chol(S + noise)] and w to the chain's factor (A.9) -------------------------------------
+#ifdef GPMPC_ABLATE_APPEND
+        if (t + 1 < H) n_h += T;
+        if (t < 0) {
+#else
         if (t + 1 < H) {
+#endif
             double wn[T];
             if (!c_ok) info_acc |= GPMPC_INFO_TRAIN_CHOL_FAIL;
 #pragma unroll
