@@ -146,13 +146,16 @@ __device__ __forceinline__ void dpp_replicate_vec(const double (&x)[3], int bp_a
         }
     }
 }
-// pivots I0 .. I0+3 of a 16-pivot block whose own-row entries are l[0..7] (pairs)
+// The entries of a lane's rows INSIDE their own 16x16 diagonal block live in registers (dg[i] = L''[row][16*(row/16)+i],
+// zero at and right of the diagonal; written once, by the owning lane, when the row is appended): the latency-bound
+// diagonal phase needs no LDS read and no masking, and the off-diagonal phase reads entries left of the diagonal block
+// only, which exist for every row the row_mask lets through - plain ds_read_b128 with immediate offsets.
 template <int RM, int I0>
-__device__ __forceinline__ void dpp_diag4(const double2_t (&l)[8], double (&v)[3]) {
-    fmac3_dpp_self<I0 + 0, RM>(v, l[I0 / 2].x);
-    fmac3_dpp_self<I0 + 1, RM>(v, l[I0 / 2].y);
-    fmac3_dpp_self<I0 + 2, RM>(v, l[I0 / 2 + 1].x);
-    fmac3_dpp_self<I0 + 3, RM>(v, l[I0 / 2 + 1].y);
+__device__ __forceinline__ void dpp_diag4(const double (&dg)[16], double (&v)[3]) {
+    fmac3_dpp_self<I0 + 0, RM>(v, dg[I0 + 0]);
+    fmac3_dpp_self<I0 + 1, RM>(v, dg[I0 + 1]);
+    fmac3_dpp_self<I0 + 2, RM>(v, dg[I0 + 2]);
+    fmac3_dpp_self<I0 + 3, RM>(v, dg[I0 + 3]);
 }
 template <int RM, int I0>
 __device__ __forceinline__ void dpp_off4(const double2_t (&l)[8], const double (&R)[3], double (&v)[3]) {
@@ -164,13 +167,13 @@ __device__ __forceinline__ void dpp_off4(const double2_t (&l)[8], const double (
 // diagonal block in DPP row K; n_rem = pivots that exist from the block's first pivot on (uniform): whole groups of four
 // beyond them are skipped
 template <int K>
-__device__ __forceinline__ void dpp_diag_block(const double2_t (&l)[8], double (&v)[3], int n_rem) {
-    dpp_diag4<(1 << K), 0>(l, v);
+__device__ __forceinline__ void dpp_diag_block(const double (&dg)[16], double (&v)[3], int n_rem) {
+    dpp_diag4<(1 << K), 0>(dg, v);
     if (n_rem > 4) {
-        dpp_diag4<(1 << K), 4>(l, v);
+        dpp_diag4<(1 << K), 4>(dg, v);
         if (n_rem > 8) {
-            dpp_diag4<(1 << K), 8>(l, v);
-            if (n_rem > 12) dpp_diag4<(1 << K), 12>(l, v);
+            dpp_diag4<(1 << K), 8>(dg, v);
+            if (n_rem > 12) dpp_diag4<(1 << K), 12>(dg, v);
         }
     }
 }
@@ -183,14 +186,10 @@ __device__ __forceinline__ void dpp_off_block(const double2_t (&l)[8], const dou
         dpp_off4<RM, 12>(l, R, v);
     }
 }
-// the lane's own-row pairs 8*QB .. 8*QB+7; pairs at / right of the diagonal of row `r` come from the zero pair
-template <bool SELECT>
-__device__ __forceinline__ void dpp_load_pairs(const double2_t* row, const double2_t* zero2, int r, int qb, double2_t (&l)[8]) {
+// the lane's own-row pairs 8*qb .. 8*qb+7
+__device__ __forceinline__ void dpp_load_pairs(const double2_t* row, int qb, double2_t (&l)[8]) {
 #pragma unroll
-    for (int q = 0; q < 8; ++q) {
-        const int qq = 8 * qb + q;
-        l[q] = SELECT ? *((2 * qq < r) ? (row + qq) : zero2) : row[qq];
-    }
+    for (int q = 0; q < 8; ++q) l[q] = row[8 * qb + q];
 }
 // copy DPP row K of v to all four rows
 template <int K>
@@ -205,46 +204,45 @@ __device__ __forceinline__ void dpp_replicate(const double (&v)[3], int bp_addr,
 
 // pivots 16K .. 16K+15 of bank 0 (rows 0..63 in v0, rows 64.. in v1 when TWO)
 template <int K, bool TWO>
-__device__ __forceinline__ void dpp_bank0_block(const double2_t* row0, const double2_t* row1, const double2_t* zero2, int r0,
-                                                int n_h, int bp_addr, double2_t (&la)[8], double (&v0)[3], double (&v1)[3]) {
+__device__ __forceinline__ void dpp_bank0_block(const double2_t* row0, const double2_t* row1, int n_h, int bp_addr,
+                                                const double (&dg0)[16], double (&v0)[3], double (&v1)[3]) {
     if constexpr (K < 4) {
         if (!TWO && 16 * K >= n_h) return;
-        double2_t lb[8];
-        if constexpr (TWO) dpp_load_pairs<false>(row1, zero2, 0, K, lb);
-        dpp_diag_block<K>(la, v0, TWO ? 16 : n_h - 16 * K);
-        if (TWO || 16 * (K + 1) < n_h) {
+        const bool more = TWO || 16 * (K + 1) < n_h;              // rows below this block exist
+        double2_t la[8], lb[8];
+        if (more) {                                               // requested now, needed after the diagonal phase
+            if constexpr (K < 3) dpp_load_pairs(row0, K, la);
+            if constexpr (TWO) dpp_load_pairs(row1, K, lb);
+        }
+        dpp_diag_block<K>(dg0, v0, TWO ? 16 : n_h - 16 * K);
+        if (more) {
             double R[3];
             dpp_replicate<K>(v0, bp_addr, R);
-            double2_t la_next[8];
-            if constexpr (K < 3) dpp_load_pairs<true>(row0, zero2, r0, K + 1, la_next);
-            dpp_off_block<((0xf << (K + 1)) & 0xf)>(la, R, v0);
+            if constexpr (K < 3) dpp_off_block<((0xf << (K + 1)) & 0xf)>(la, R, v0);
             if constexpr (TWO) dpp_off_block<0xf>(lb, R, v1);
-            if constexpr (K < 3) {
-#pragma unroll
-                for (int q = 0; q < 8; ++q) la[q] = la_next[q];
-            }
-            dpp_bank0_block<K + 1, TWO>(row0, row1, zero2, r0, n_h, bp_addr, la, v0, v1);
+            dpp_bank0_block<K + 1, TWO>(row0, row1, n_h, bp_addr, dg0, v0, v1);
         }
     }
 }
 // pivots 64+16K .. of bank 1
 template <int K>
-__device__ __forceinline__ void dpp_bank1_block(const double2_t* row1, const double2_t* zero2, int r1, int n_h, int bp_addr,
-                                                double2_t (&lb)[8], double (&v1)[3]) {
+__device__ __forceinline__ void dpp_bank1_block(const double2_t* row1, int n_h, int bp_addr, const double (&dg1)[16],
+                                                double (&v1)[3]) {
     if constexpr (K < 4) {
         if (kWave + 16 * K >= n_h) return;
-        dpp_diag_block<K>(lb, v1, n_h - kWave - 16 * K);
-        if (kWave + 16 * (K + 1) < n_h) {
-            double R[3];
-            dpp_replicate<K>(v1, bp_addr, R);
-            double2_t lb_next[8];
-            if constexpr (K < 3) dpp_load_pairs<true>(row1, zero2, r1, 4 + K + 1, lb_next);
-            dpp_off_block<((0xf << (K + 1)) & 0xf)>(lb, R, v1);
-            if constexpr (K < 3) {
-#pragma unroll
-                for (int q = 0; q < 8; ++q) lb[q] = lb_next[q];
+        const bool more = kWave + 16 * (K + 1) < n_h;
+        double2_t lb[8];
+        if constexpr (K < 3) {
+            if (more) dpp_load_pairs(row1, 4 + K, lb);
+        }
+        dpp_diag_block<K>(dg1, v1, n_h - kWave - 16 * K);
+        if constexpr (K < 3) {
+            if (more) {
+                double R[3];
+                dpp_replicate<K>(v1, bp_addr, R);
+                dpp_off_block<((0xf << (K + 1)) & 0xf)>(lb, R, v1);
+                dpp_bank1_block<K + 1>(row1, n_h, bp_addr, dg1, v1);
             }
-            dpp_bank1_block<K + 1>(row1, zero2, r1, n_h, bp_addr, lb, v1);
         }
     }
 }
@@ -326,6 +324,9 @@ __global__ __launch_bounds__(GPMPC_FAST_MAXTHREADS, 1) void rollout_fast_kernel(
         xh1[d] = 0.0;
     }
     double dinv0 = 0.0, dinv1 = 0.0, wown0 = 0.0, wown1 = 0.0;
+    double dg0[16], dg1[16];                                      // diagonal-block segments of this lane's rows (see dpp_diag4)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) dg0[i] = 0.0, dg1[i] = 0.0;
     int info_acc = 0;
     int n_h = 0;
     // this lane's L_hh rows (clamped into the allocation; non-existent rows are discarded by ex0 / ex1 below)
@@ -334,6 +335,8 @@ __global__ __launch_bounds__(GPMPC_FAST_MAXTHREADS, 1) void rollout_fast_kernel(
     const double2_t* lhr1row = reinterpret_cast<const double2_t*>(Lhr1 + (long)min(lane, max(nb1 - 1, 0)) * NRS);
     const double2_t* zero2 = reinterpret_cast<const double2_t*>(Lhh + lhh_rowofs(nh_max));    // first slack pair: never written
     const int a0t = lane - (lane / T) * T, a1t = (lane + kWave) - ((lane + kWave) / T) * T;   // task of this lane's rows
+    const double cA0[2] = {(a0t == 1) ? il2[0] : 0.0, (a0t == 2) ? il2[1] : 0.0};              // [a == b > 0] / l_a^2
+    const double cA1[2] = {(a1t == 1) ? il2[0] : 0.0, (a1t == 2) ? il2[1] : 0.0};
     // The chain's base samples (H*T <= 129 doubles) and the input sequence (H*NU <= 86) are fetched ONCE, one entry per
     // lane, and handed out with v_readlane inside the loop: a global load inside the step loop of a single wave costs
     // its full latency (the three z loads were serialised behind s_waitcnt vmcnt(0), which also waits for the
@@ -398,22 +401,33 @@ __global__ __launch_bounds__(GPMPC_FAST_MAXTHREADS, 1) void rollout_fast_kernel(
         const bool two = n_h > kWave;
         const bool ex0 = lane < n_h, ex1 = lane + kWave < n_h;
         double kr[T], v0[T], v1[T];                               // v0 / v1: rows lane / lane+64 of k_h, then rhs, then v_h
+        // cov(task_a(row point), task_b(test point)) = k * (A_a * B_b + [a == b > 0] / l_a^2) with A_0 = B_0 = 1,
+        // A_a = -q_a, B_b = +q_b (kern_entry): the row's task enters through a per-lane select of A and a
+        // per-lane constant, so the evaluation is branch-free (the task-dependent branches of kern_entry cost ~17
+        // exec-mask regions per step here)
         {
+            static_assert(D == 2 && T == 3, "branch-free kernel entries are written for D = 2, T = 3");
             double q[D], q0[D];
             const double k = kern_scalar<D>(xr, xi, il2, os, q);
-            const double k0 = kern_scalar<D>(xh0, xi, il2, os, q0);
+            double k0 = kern_scalar<D>(xh0, xi, il2, os, q0);
+            asm volatile("" ::"v"(k), "v"(k0));                   // both exponentials are due here: their chains interleave
+            k0 = ex0 ? k0 : 0.0;
+            kr[0] = k, kr[1] = k * q[0], kr[2] = k * q[1];        // lanes >= NR: never used as pivots
+            const double A0 = (a0t == 0) ? 1.0 : ((a0t == 1) ? -q0[0] : -q0[1]);
+            v0[0] = k0 * A0;
+            v0[1] = k0 * fma(A0, q0[0], cA0[0]);
+            v0[2] = k0 * fma(A0, q0[1], cA0[1]);
 #pragma unroll
-            for (int b = 0; b < T; ++b) {
-                kr[b] = kern_entry<D>(q, k, il2, 0, b);           // lanes >= NR: never used as pivots
-                v0[b] = ex0 ? kern_entry<D>(q0, k0, il2, a0t, b) : 0.0;
-                v1[b] = 0.0;
-            }
+            for (int b = 0; b < T; ++b) v1[b] = 0.0;
         }
         if (two) {
             double q1[D];
-            const double k1 = kern_scalar<D>(xh1, xi, il2, os, q1);
-#pragma unroll
-            for (int b = 0; b < T; ++b) v1[b] = ex1 ? kern_entry<D>(q1, k1, il2, a1t, b) : 0.0;
+            double k1 = kern_scalar<D>(xh1, xi, il2, os, q1);
+            k1 = ex1 ? k1 : 0.0;
+            const double A1 = (a1t == 0) ? 1.0 : ((a1t == 1) ? -q1[0] : -q1[1]);
+            v1[0] = k1 * A1;
+            v1[1] = k1 * fma(A1, q1[0], cA1[0]);
+            v1[2] = k1 * fma(A1, q1[1], cA1[1]);
         }
         FPHASE(0);
 
@@ -485,19 +499,11 @@ __global__ __launch_bounds__(GPMPC_FAST_MAXTHREADS, 1) void rollout_fast_kernel(
 #endif
             if constexpr (LHH_LDS) {
                 static_assert(T == 3, "the DPP substitution is written for three right-hand sides");
-                int lane_t = lane;                                       // laundered per step: keeps the address selects
-                asm volatile("" : "+v"(lane_t));                         // of the pair loads out of the loop-invariant set
-                const int bp_addr = (lane_t & 15) << 2;
-                const int r0 = min(lane_t, nh_max - 1), r1 = min(lane_t + kWave, nh_max - 1);   // the rows row0 / row1 point at
-                double2_t la[8];
-                dpp_load_pairs<true>(row0, zero2, r0, 0, la);
                 if (!two) {
-                    dpp_bank0_block<0, false>(row0, row1, zero2, r0, n_h, bp_addr, la, v0, v1);
+                    dpp_bank0_block<0, false>(row0, row1, n_h, bp_addr, dg0, v0, v1);
                 } else {
-                    dpp_bank0_block<0, true>(row0, row1, zero2, r0, n_h, bp_addr, la, v0, v1);
-                    double2_t lb[8];
-                    dpp_load_pairs<true>(row1, zero2, r1, 4, lb);
-                    dpp_bank1_block<0>(row1, zero2, r1, n_h, bp_addr, lb, v1);
+                    dpp_bank0_block<0, true>(row0, row1, n_h, bp_addr, dg0, v0, v1);
+                    dpp_bank1_block<0>(row1, n_h, bp_addr, dg1, v1);
                 }
             } else
             if (!two) {
@@ -693,23 +699,27 @@ __global__ __launch_bounds__(GPMPC_FAST_MAXTHREADS, 1) void rollout_fast_kernel(
                 wn[b] = acc * cinv[b];
             }
             const int base = n_h;
-            // (1) new rows base+c of L'': lane p owns the entry in column p:  L''[base+c][p] = v_p[c] / L_pp
+            const int a0 = lane - base, a1 = lane + kWave - base;
+            // (1)+(2) new rows base+c of L'': lane p owns the entry in column p:  L''[base+c][p] = v_p[c] / L_pp for
+            // p < base, the column-scaled new diagonal block for base <= p < base+c.  Branch-free: every lane stores, lanes
+            // at or right of the diagonal store 0.0 into slots of rows that do not exist yet (rows base+c+1.. are written
+            // after row base+c) or, clamped, into the last slack slot of the chain; v_p[c] is exactly zero for p >= base.
+            {
+                const double d10 = C[1][0] * cinv[0], d20 = C[2][0] * cinv[0], d21 = C[2][1] * cinv[1];
+                const int last = (int)a.ws_chain_stride - 1;
+                double dd0[T], dd1[T];
+                dd0[0] = 0.0, dd1[0] = 0.0;
+                dd0[1] = (a0 == 0) ? d10 : 0.0, dd1[1] = (a1 == 0) ? d10 : 0.0;
+                dd0[2] = (a0 == 0) ? d20 : ((a0 == 1) ? d21 : 0.0), dd1[2] = (a1 == 0) ? d20 : ((a1 == 1) ? d21 : 0.0);
 #pragma unroll
-            for (int c = 0; c < T; ++c) {
-                double* rowc = Lhh + lhh_rowofs(base + c);
-                if (lane < base) rowc[lane] = v0[c] * dinv0;
-                if (lane + kWave < base) rowc[lane + kWave] = v1[c] * dinv1;
-                // (2) the new diagonal block, column-scaled
-                if (lane == 0) {
-#pragma unroll
-                    for (int e = 0; e < T; ++e)
-                        if (e < c) rowc[base + e] = C[c][e] * cinv[e];
+                for (int c = 0; c < T; ++c) {
+                    const int ro = lhh_rowofs(base + c);
+                    Lhh[min(ro + lane, last)] = fma(v0[c], dinv0, dd0[c]);
+                    if (base + c > kWave) Lhh[min(ro + lane + kWave, last)] = fma(v1[c], dinv1, dd1[c]);      // uniform
                 }
             }
             // (3) owners of the new rows: 1/L_pp, w_p, the point's GP input, and the L_hr row (= v_r^T)
             {
-                const int a0 = lane - base;
-                const int a1 = lane + kWave - base;
                 const bool new0 = (a0 >= 0 && a0 < T), new1 = (a1 >= 0 && a1 < T);
 #pragma unroll
                 for (int c = 0; c < T; ++c) {
@@ -745,6 +755,30 @@ __global__ __launch_bounds__(GPMPC_FAST_MAXTHREADS, 1) void rollout_fast_kernel(
 #pragma unroll
                     for (int c = 0; c < T; ++c) {
                         if (base + c >= kWave && lane < NR) Lhr1[(long)(base + c - kWave) * NRS + lane] = vr[c];
+                    }
+                }
+                if constexpr (LHH_LDS) {
+                    // the owners read the diagonal-block segment of their new row back (entries at / right of the
+                    // diagonal: the zero pair); same wave, LDS operations complete in order
+                    if (new0) {
+                        const int r = lane, qb = 8 * (r >> 4);
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) {
+                            const double2_t pr = *((2 * (qb + q) < r) ? (row0 + qb + q) : zero2);
+                            dg0[2 * q] = pr.x;
+                            dg0[2 * q + 1] = pr.y;
+                        }
+                    }
+                    if (base + T > kWave) {
+                        if (new1) {
+                            const int r = lane + kWave, qb = 8 * (r >> 4);
+#pragma unroll
+                            for (int q = 0; q < 8; ++q) {
+                                const double2_t pr = *((2 * (qb + q) < r) ? (row1 + qb + q) : zero2);
+                                dg1[2 * q] = pr.x;
+                                dg1[2 * q + 1] = pr.y;
+                            }
+                        }
                     }
                 }
             }
