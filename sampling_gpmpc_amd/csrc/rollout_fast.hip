@@ -125,11 +125,48 @@ __device__ __forceinline__ void fmac3_dpp_bcast(double (&acc)[3], const double (
             : "v"(l), "v"(R[0]), "v"(R[1]), "v"(R[2]), "n"(I));
     }
 }
+// four pivots (I0..I0+3) x three right-hand sides in ONE asm block: the DPP read-after-VALU-write hazard can only
+// arise at the head of a block (nothing is scheduled inside it), so one s_nop 1 covers twelve fmacs
+#define GPMPC_FMAC12(SRC0, SRC1, SRC2, SIGN, CTRL)                                                     \
+    "s_nop 1\n\t"                                                                                      \
+    "v_fmac_f64_dpp %0, " SRC0 ", " SIGN "%3 row_newbcast:%7 " CTRL "\n\t"                              \
+    "v_fmac_f64_dpp %1, " SRC1 ", " SIGN "%3 row_newbcast:%7 " CTRL "\n\t"                              \
+    "v_fmac_f64_dpp %2, " SRC2 ", " SIGN "%3 row_newbcast:%7 " CTRL "\n\t"                              \
+    "v_fmac_f64_dpp %0, " SRC0 ", " SIGN "%4 row_newbcast:%8 " CTRL "\n\t"                              \
+    "v_fmac_f64_dpp %1, " SRC1 ", " SIGN "%4 row_newbcast:%8 " CTRL "\n\t"                              \
+    "v_fmac_f64_dpp %2, " SRC2 ", " SIGN "%4 row_newbcast:%8 " CTRL "\n\t"                              \
+    "v_fmac_f64_dpp %0, " SRC0 ", " SIGN "%5 row_newbcast:%9 " CTRL "\n\t"                              \
+    "v_fmac_f64_dpp %1, " SRC1 ", " SIGN "%5 row_newbcast:%9 " CTRL "\n\t"                              \
+    "v_fmac_f64_dpp %2, " SRC2 ", " SIGN "%5 row_newbcast:%9 " CTRL "\n\t"                              \
+    "v_fmac_f64_dpp %0, " SRC0 ", " SIGN "%6 row_newbcast:%10 " CTRL "\n\t"                             \
+    "v_fmac_f64_dpp %1, " SRC1 ", " SIGN "%6 row_newbcast:%10 " CTRL "\n\t"                             \
+    "v_fmac_f64_dpp %2, " SRC2 ", " SIGN "%6 row_newbcast:%10 " CTRL
+// acc[b] (+/-)= R[b]@(lane I0+j of the DPP row) * l_j, j = 0..3, rows in RM
+template <int I0, int RM, bool NEG>
+__device__ __forceinline__ void fmac12_dpp_from(double (&acc)[3], const double (&R)[3], double l0, double l1, double l2,
+                                                double l3) {
+    if constexpr (NEG) {
+        asm(GPMPC_FMAC12("%11", "%12", "%13", "-", "row_mask:%14 bank_mask:0xf")
+            : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2])
+            : "v"(l0), "v"(l1), "v"(l2), "v"(l3), "n"(I0), "n"(I0 + 1), "n"(I0 + 2), "n"(I0 + 3), "v"(R[0]), "v"(R[1]),
+              "v"(R[2]), "n"(RM));
+    } else {
+        asm(GPMPC_FMAC12("%11", "%12", "%13", "", "row_mask:%14 bank_mask:0xf")
+            : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2])
+            : "v"(l0), "v"(l1), "v"(l2), "v"(l3), "n"(I0), "n"(I0 + 1), "n"(I0 + 2), "n"(I0 + 3), "v"(R[0]), "v"(R[1]),
+              "v"(R[2]), "n"(RM));
+    }
+}
 // mat-vec against a vector whose entries live one per lane (lanes 0..N-1): acc[b] (+/-)= sum_p M[lane][p] * x[b][p],
 // p ascending (the same FMA sequence per row as a broadcast-from-LDS loop).  `entry(p)` returns this lane's M[lane][p].
 template <int N, bool NEG, int P = 0, class Entry>
 __device__ __forceinline__ void dpp_matvec(double (&acc)[3], const double (&R)[(N + 15) / 16][3], const Entry& entry) {
-    if constexpr (P < N) {
+    if constexpr (P + 4 <= N) {                                   // P % 4 == 0: the four pivots share a 16-block
+        fmac12_dpp_from<P % 16, 0xf, NEG>(acc, R[P / 16], entry(std::integral_constant<int, P>{}),
+                                          entry(std::integral_constant<int, P + 1>{}), entry(std::integral_constant<int, P + 2>{}),
+                                          entry(std::integral_constant<int, P + 3>{}));
+        dpp_matvec<N, NEG, P + 4>(acc, R, entry);
+    } else if constexpr (P < N) {
         fmac3_dpp_bcast<P % 16, NEG>(acc, R[P / 16], entry(std::integral_constant<int, P>{}));
         dpp_matvec<N, NEG, P + 1>(acc, R, entry);
     }
@@ -159,10 +196,7 @@ __device__ __forceinline__ void dpp_diag4(const double (&dg)[16], double (&v)[3]
 }
 template <int RM, int I0>
 __device__ __forceinline__ void dpp_off4(const double2_t (&l)[8], const double (&R)[3], double (&v)[3]) {
-    fmac3_dpp_from<I0 + 0, RM>(v, R, l[I0 / 2].x);
-    fmac3_dpp_from<I0 + 1, RM>(v, R, l[I0 / 2].y);
-    fmac3_dpp_from<I0 + 2, RM>(v, R, l[I0 / 2 + 1].x);
-    fmac3_dpp_from<I0 + 3, RM>(v, R, l[I0 / 2 + 1].y);
+    fmac12_dpp_from<I0, RM, true>(v, R, l[I0 / 2].x, l[I0 / 2].y, l[I0 / 2 + 1].x, l[I0 / 2 + 1].y);
 }
 // diagonal block in DPP row K; n_rem = pivots that exist from the block's first pivot on (uniform): whole groups of four
 // beyond them are skipped
