@@ -142,6 +142,18 @@ __global__ void selftest_kernel(int* out) {
     double Sn[3][3] = {{1.0, 2.0, 0.0}, {2.0, 1.0, 0.0}, {0.0, 0.0, 1.0}}, R[3][3];
     const int inf = root_small<3>(Sn, 1e-6, R);
     if (!(inf & GPMPC_INFO_ROOT_FAIL)) bad |= 32;
+    {   // lockstep exponentials against the library's exp over the argument range of the kernels
+        const double xs[3] = {-1e-3 * lane * lane, -0.37 * lane - 1e-7, -11.0 * lane - 0.123};
+        double es[3];
+        exp3_neg(xs, es);
+        for (int i = 0; i < 3; ++i) {
+            const double ref_e = exp(xs[i]);
+            if (!(fabs(es[i] - ref_e) <= 4e-16 * ref_e)) bad |= 128;
+        }
+        const double xz[3] = {-800.0, -1e6, 0.0};
+        exp3_neg(xz, es);
+        if (es[0] != 0.0 || es[1] != 0.0 || es[2] != 1.0) bad |= 256;
+    }
     const unsigned long long any = __ballot(bad != 0);
     if (lane == 0) out[0] = (any != 0ull) ? (bad | 0x1000) : 0;
     if (bad) atomicOr(out + 1, bad);

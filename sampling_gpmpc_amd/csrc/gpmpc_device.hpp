@@ -132,6 +132,19 @@ __device__ __forceinline__ double kern_entry(const double (&q)[D], double k, con
     return k * v;
 }
 
+// q[d] = r_d / l_d^2 and the scaled squared distance sum_d r_d q_d (kern_scalar without the exponential)
+template <int D>
+__device__ __forceinline__ double kern_sqdist(const double* x, const double* xp, const double* inv_l2, double (&q)[D]) {
+    double s = 0.0;
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+        const double r = x[d] - xp[d];
+        q[d] = r * inv_l2[d];
+        s += r * q[d];
+    }
+    return s;
+}
+
 template <int D>
 __device__ __forceinline__ double kern_scalar(const double* x, const double* xp, const double* inv_l2, double os,
                                               double (&q)[D]) {
@@ -144,6 +157,53 @@ __device__ __forceinline__ double kern_scalar(const double* x, const double* xp,
     }
     return os * exp(-0.5 * s);
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// Two or three exponentials of non-positive arguments in lockstep.  A single wave issues in order, so three separate exp()
+// calls cost three full dependency chains (~25 dependent FP64 operations each, the scheduler does not interleave
+// them); here the chains advance row by row (one operation of each per row, rows pinned with sched_barrier), the
+// degree-11 polynomial is evaluated in Estrin form (depth 4 instead of 11) and the coefficient constants are
+// materialised once for all three.  Cody-Waite reduction x = n ln2 + r, |r| <= ln2/2; coefficients = the minimax set of
+// the ROCm device library's exp; result 2^n p(r) through v_ldexp_f64 (underflows to 0 for x < -745 by itself).
+// Max. relative deviation from exp() over [-700, 0]: < 4e-16 (checked by gpmpc_selftest).
+// ---------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ double bits_f64(unsigned long long u) { return __builtin_bit_cast(double, u); }
+#define GPMPC_ROW3(stmt)               \
+    _Pragma("unroll") for (int i_ = 0; i_ < N; ++i_) { stmt; } \
+    __builtin_amdgcn_sched_barrier(0)
+template <int N>
+__device__ __forceinline__ void expn_neg(const double (&x)[N], double (&e)[N]) {
+    static_assert(N == 2 || N == 3, "two or three chains");
+    const double log2e = bits_f64(0x3FF71547652B82FEull), nln2h = bits_f64(0xBFE62E42FEFA39EFull),
+                 nln2l = bits_f64(0xBC7ABC9E3B39803Full);
+    const double c2 = bits_f64(0x3FE000000000000Bull), c3 = bits_f64(0x3FC5555555555511ull), c4 = bits_f64(0x3FA55555555502A1ull),
+                 c5 = bits_f64(0x3F81111111122322ull), c6 = bits_f64(0x3F56C16C1852B7B0ull), c7 = bits_f64(0x3F2A01A014761F6Eull),
+                 c8 = bits_f64(0x3EFA01997C89E6B0ull), c9 = bits_f64(0x3EC71DEE623FDE64ull), c10 = bits_f64(0x3E928AF3FCA7AB0Cull),
+                 c11 = bits_f64(0x3E5ADE156A5DCB37ull);
+    double n[N], r[N], r2[N], r4[N], a0[N], a1[N], a2[N], a3[N], a4[N], a5[N];
+    __builtin_amdgcn_sched_barrier(0);
+    GPMPC_ROW3(n[i_] = rint(x[i_] * log2e));
+    GPMPC_ROW3(r[i_] = fma(n[i_], nln2h, x[i_]));
+    GPMPC_ROW3(r[i_] = fma(n[i_], nln2l, r[i_]));
+    GPMPC_ROW3(r2[i_] = r[i_] * r[i_]);
+    GPMPC_ROW3(a0[i_] = 1.0 + r[i_]);
+    GPMPC_ROW3(a1[i_] = fma(c3, r[i_], c2));
+    GPMPC_ROW3(a2[i_] = fma(c5, r[i_], c4));
+    GPMPC_ROW3(a3[i_] = fma(c7, r[i_], c6));
+    GPMPC_ROW3(a4[i_] = fma(c9, r[i_], c8));
+    GPMPC_ROW3(a5[i_] = fma(c11, r[i_], c10));
+    GPMPC_ROW3(r4[i_] = r2[i_] * r2[i_]);
+    GPMPC_ROW3(a0[i_] = fma(a1[i_], r2[i_], a0[i_]));       // b0 = (1 + r) + (c2 + c3 r) r^2
+    GPMPC_ROW3(a2[i_] = fma(a3[i_], r2[i_], a2[i_]));       // b1
+    GPMPC_ROW3(a4[i_] = fma(a5[i_], r2[i_], a4[i_]));       // b2
+    GPMPC_ROW3(a2[i_] = fma(a4[i_], r4[i_], a2[i_]));       // b1 + b2 r^4
+    GPMPC_ROW3(a0[i_] = fma(a2[i_], r4[i_], a0[i_]));       // p
+    GPMPC_ROW3(e[i_] = ldexp(a0[i_], (int)n[i_]));
+    // all results are due HERE: keeps the optimiser from sinking a chain to its (later) first use, out of the lockstep rows
+    if constexpr (N == 3) asm volatile("" ::"v"(e[0]), "v"(e[1]), "v"(e[2]));
+    else asm volatile("" ::"v"(e[0]), "v"(e[1]));
+}
+__device__ __forceinline__ void exp3_neg(const double (&x)[3], double (&e)[3]) { expn_neg<3>(x, e); }
 
 // ---------------------------------------------------------------------------------------------------------------
 // small dense Cholesky (LAPACK dpotrf lower semantics: fail on pivot <= 0 or NaN), T x T, in registers

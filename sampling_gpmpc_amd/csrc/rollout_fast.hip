@@ -441,23 +441,28 @@ __global__ __launch_bounds__(GPMPC_FAST_MAXTHREADS, 1) void rollout_fast_kernel(
         // exec-mask regions per step here)
         {
             static_assert(D == 2 && T == 3, "branch-free kernel entries are written for D = 2, T = 3");
-            double q[D], q0[D];
-            const double k = kern_scalar<D>(xr, xi, il2, os, q);
-            double k0 = kern_scalar<D>(xh0, xi, il2, os, q0);
-            asm volatile("" ::"v"(k), "v"(k0));                   // both exponentials are due here: their chains interleave
-            k0 = ex0 ? k0 : 0.0;
+            // squared distances to the real point, the bank-0 row's point and the bank-1 row's point (the latter only
+            // needed once n_h > 64)
+            double q[D], q0[D], q1[D], arg[3], ee[3];
+            arg[0] = -0.5 * kern_sqdist<D>(xr, xi, il2, q);
+            arg[1] = -0.5 * kern_sqdist<D>(xh0, xi, il2, q0);
+            arg[2] = -0.5 * kern_sqdist<D>(xh1, xi, il2, q1);
+            if (two) {                                            // uniform
+                exp3_neg(arg, ee);
+            } else {
+                const double arg2[2] = {arg[0], arg[1]};
+                double ee2[2];
+                expn_neg<2>(arg2, ee2);
+                ee[0] = ee2[0], ee[1] = ee2[1], ee[2] = 0.0;
+            }
+            const double k = os * ee[0];
+            const double k0 = ex0 ? os * ee[1] : 0.0;
+            const double k1 = ex1 ? os * ee[2] : 0.0;
             kr[0] = k, kr[1] = k * q[0], kr[2] = k * q[1];        // lanes >= NR: never used as pivots
             const double A0 = (a0t == 0) ? 1.0 : ((a0t == 1) ? -q0[0] : -q0[1]);
             v0[0] = k0 * A0;
             v0[1] = k0 * fma(A0, q0[0], cA0[0]);
             v0[2] = k0 * fma(A0, q0[1], cA0[1]);
-#pragma unroll
-            for (int b = 0; b < T; ++b) v1[b] = 0.0;
-        }
-        if (two) {
-            double q1[D];
-            double k1 = kern_scalar<D>(xh1, xi, il2, os, q1);
-            k1 = ex1 ? k1 : 0.0;
             const double A1 = (a1t == 0) ? 1.0 : ((a1t == 1) ? -q1[0] : -q1[1]);
             v1[0] = k1 * A1;
             v1[1] = k1 * fma(A1, q1[0], cA1[0]);
