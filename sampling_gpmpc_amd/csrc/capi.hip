@@ -142,6 +142,18 @@ __global__ void selftest_kernel(int* out) {
     double Sn[3][3] = {{1.0, 2.0, 0.0}, {2.0, 1.0, 0.0}, {0.0, 0.0, 1.0}}, R[3][3];
     const int inf = root_small<3>(Sn, 1e-6, R);
     if (!(inf & GPMPC_INFO_ROOT_FAIL)) bad |= 32;
+    {   // nine sums in lockstep against the single-quantity reductions
+        const double qa[4] = {v, 2.0 - 0.125 * lane, (lane & 1) ? 3.0 : -1.5, 1e-3 * lane * lane};
+        const double qb[4] = {0.5 * lane, 1.0 / (1 + lane), -v, (lane & 3) * 0.25};
+        const double qc = 7.0 - 0.01 * lane;
+        double ra[4], rb[4], rc;
+        wave_sum9(qa, qb, qc, ra, rb, rc);
+        for (int i = 0; i < 4; ++i) {
+            if (ra[i] != wave_sum(qa[i]) && fabs(ra[i] - wave_sum_shfl(qa[i])) > 1e-12 * fabs(ra[i])) bad |= 512;
+            if (fabs(rb[i] - wave_sum_shfl(qb[i])) > 1e-12 * (1.0 + fabs(rb[i]))) bad |= 512;
+        }
+        if (rc != wave_sum(qc)) bad |= 512;
+    }
     {   // lockstep exponentials against the library's exp over the argument range of the kernels
         const double xs[3] = {-1e-3 * lane * lane, -0.37 * lane - 1e-7, -11.0 * lane - 0.123};
         double es[3];

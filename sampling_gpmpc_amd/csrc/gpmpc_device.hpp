@@ -111,6 +111,58 @@ __device__ __forceinline__ void wave_sum4(double a, double b, double c, double d
     sd = readlane_f64(t, 63);
 }
 
+// Nine wave sums (the per-step reductions of the tuned rollout: three means, six covariance terms) as two lane-swap
+// trees of four and one DPP ladder advancing in LOCKSTEP (rows pinned with sched_barrier): each tree is a chain of ~13
+// dependent steps, and a single in-order wave does not overlap them by itself.  Per quantity the operations and their
+// order are those of wave_sum4 / wave_sum => bit-identical sums.
+__device__ __forceinline__ void wave_sum9(const double (&a)[4], const double (&b)[4], double c, double (&sa)[4], double (&sb)[4],
+                                          double& sc) {
+    double a0 = a[0], a1 = a[1], a2 = a[2], a3 = a[3], b0 = b[0], b1 = b[1], b2 = b[2], b3 = b[3];
+    __builtin_amdgcn_sched_barrier(0);
+    lane_swap32_f64(a0, a1);
+    lane_swap32_f64(a2, a3);
+    lane_swap32_f64(b0, b1);
+    lane_swap32_f64(b2, b3);
+    const double c1 = dpp_f64<0x111, 0xf, 0xf>(c), c2 = dpp_f64<0x112, 0xf, 0xf>(c), c3 = dpp_f64<0x113, 0xf, 0xf>(c);
+    __builtin_amdgcn_sched_barrier(0);
+    double aab = a0 + a1, acd = a2 + a3, bab = b0 + b1, bcd = b2 + b3;
+    double tc = c + c1;
+    __builtin_amdgcn_sched_barrier(0);
+    lane_swap16_f64(aab, acd);
+    lane_swap16_f64(bab, bcd);
+    tc += c2;
+    __builtin_amdgcn_sched_barrier(0);
+    const double va = aab + acd, vb = bab + bcd;          // DPP row 0: first, row 1: third, row 2: second, row 3: fourth
+    tc += c3;
+    __builtin_amdgcn_sched_barrier(0);
+    const double va1 = dpp_f64<0x111, 0xf, 0xf>(va), va2 = dpp_f64<0x112, 0xf, 0xf>(va), va3 = dpp_f64<0x113, 0xf, 0xf>(va);
+    const double vb1 = dpp_f64<0x111, 0xf, 0xf>(vb), vb2 = dpp_f64<0x112, 0xf, 0xf>(vb), vb3 = dpp_f64<0x113, 0xf, 0xf>(vb);
+    double yc = dpp_f64<0x114, 0xf, 0xe>(tc);
+    __builtin_amdgcn_sched_barrier(0);
+    double ta = va + va1, tb = vb + vb1;
+    tc += yc;
+    __builtin_amdgcn_sched_barrier(0);
+    ta += va2, tb += vb2;
+    yc = dpp_f64<0x118, 0xf, 0xc>(tc);
+    __builtin_amdgcn_sched_barrier(0);
+    ta += va3, tb += vb3;
+    tc += yc;
+    __builtin_amdgcn_sched_barrier(0);
+    double ya = dpp_f64<0x114, 0xf, 0xe>(ta), yb = dpp_f64<0x114, 0xf, 0xe>(tb);
+    yc = dpp_f64<0x142, 0xa, 0xf>(tc);                    // row_bcast:15
+    __builtin_amdgcn_sched_barrier(0);
+    ta += ya, tb += yb, tc += yc;
+    __builtin_amdgcn_sched_barrier(0);
+    ya = dpp_f64<0x118, 0xf, 0xc>(ta), yb = dpp_f64<0x118, 0xf, 0xc>(tb);
+    yc = dpp_f64<0x143, 0xc, 0xf>(tc);                    // row_bcast:31
+    __builtin_amdgcn_sched_barrier(0);
+    ta += ya, tb += yb, tc += yc;
+    __builtin_amdgcn_sched_barrier(0);
+    sa[0] = readlane_f64(ta, 15), sa[2] = readlane_f64(ta, 31), sa[1] = readlane_f64(ta, 47), sa[3] = readlane_f64(ta, 63);
+    sb[0] = readlane_f64(tb, 15), sb[2] = readlane_f64(tb, 31), sb[1] = readlane_f64(tb, 47), sb[3] = readlane_f64(tb, 63);
+    sc = readlane_f64(tc, 63);
+}
+
 // portable butterfly (ds_bpermute based) - used by the self test to cross-check the DPP ladder
 __device__ __forceinline__ double wave_sum_shfl(double v) {
 #pragma unroll
@@ -309,6 +361,77 @@ __device__ __forceinline__ bool chol_small_fast(const double (&S)[T][T], double 
         for (int i = 0; i < j; ++i) L[i][j] = 0.0;
     }
     return true;
+}
+
+// Two 3 x 3 Choleskys (rsqrt pivots, as chol_small_fast) advancing in lockstep: the chain of one factorisation is ~28
+// dependent FP64 operations, and a single in-order wave does not overlap two of them by itself.  Same operations in the
+// same order per matrix as chol_small_fast => bit-identical factors; no early exit: ok[m] reports whether every pivot
+// of matrix m was positive (the factor of a failed matrix is garbage, as it is unspecified there).
+#define GPMPC_ROW2(stmt)                                        \
+    _Pragma("unroll") for (int m_ = 0; m_ < 2; ++m_) { stmt; }  \
+    __builtin_amdgcn_sched_barrier(0)
+__device__ __forceinline__ void chol3_pair_fast(const double (&A)[3][3], const double (&B)[3][3], double (&LA)[3][3],
+                                                double (&LB)[3][3], double (&invA)[3], double (&invB)[3], bool& okA,
+                                                bool& okB) {
+    double s10[2] = {A[1][0], B[1][0]}, s20[2] = {A[2][0], B[2][0]}, s21[2] = {A[2][1], B[2][1]};
+    double s11[2] = {A[1][1], B[1][1]}, s22[2] = {A[2][2], B[2][2]};
+    double d0[2] = {A[0][0], B[0][0]}, d1[2], d2[2], y0[2], y1[2], y2[2], h[2], t[2], e[2];
+    double l10[2], l20[2], l21[2], n21[2], p2[2], r0[2], r1[2], r2[2], dd[2], hy[2];
+    __builtin_amdgcn_sched_barrier(0);
+#define GPMPC_NEWTON(y)                                         \
+    GPMPC_ROW2(t[m_] = h[m_] * y[m_]);                          \
+    GPMPC_ROW2(e[m_] = fma(-t[m_], y[m_], 0.5));                \
+    GPMPC_ROW2(y[m_] = fma(y[m_], e[m_], y[m_]));               \
+    GPMPC_ROW2(t[m_] = h[m_] * y[m_]);                          \
+    GPMPC_ROW2(e[m_] = fma(-t[m_], y[m_], 0.5));                \
+    GPMPC_ROW2(y[m_] = fma(y[m_], e[m_], y[m_]))
+    GPMPC_ROW2(y0[m_] = __builtin_amdgcn_rsq(d0[m_]); h[m_] = 0.5 * d0[m_]);
+    GPMPC_NEWTON(y0);
+    GPMPC_ROW2(l10[m_] = s10[m_] * y0[m_]; l20[m_] = s20[m_] * y0[m_]; r0[m_] = d0[m_] * y0[m_]);
+    GPMPC_ROW2(d1[m_] = fma(-l10[m_], l10[m_], s11[m_]); n21[m_] = fma(-l20[m_], l10[m_], s21[m_]);
+               dd[m_] = fma(-r0[m_], r0[m_], d0[m_]); hy[m_] = 0.5 * y0[m_]);
+    GPMPC_ROW2(y1[m_] = __builtin_amdgcn_rsq(d1[m_]); h[m_] = 0.5 * d1[m_]; r0[m_] = fma(dd[m_], hy[m_], r0[m_]);
+               p2[m_] = fma(-l20[m_], l20[m_], s22[m_]));
+    GPMPC_NEWTON(y1);
+    GPMPC_ROW2(l21[m_] = n21[m_] * y1[m_]; r1[m_] = d1[m_] * y1[m_]);
+    GPMPC_ROW2(d2[m_] = fma(-l21[m_], l21[m_], p2[m_]); dd[m_] = fma(-r1[m_], r1[m_], d1[m_]); hy[m_] = 0.5 * y1[m_]);
+    GPMPC_ROW2(y2[m_] = __builtin_amdgcn_rsq(d2[m_]); h[m_] = 0.5 * d2[m_]; r1[m_] = fma(dd[m_], hy[m_], r1[m_]));
+    GPMPC_NEWTON(y2);
+    GPMPC_ROW2(r2[m_] = d2[m_] * y2[m_]);
+    GPMPC_ROW2(dd[m_] = fma(-r2[m_], r2[m_], d2[m_]); hy[m_] = 0.5 * y2[m_]);
+    GPMPC_ROW2(r2[m_] = fma(dd[m_], hy[m_], r2[m_]));
+#undef GPMPC_NEWTON
+    // both chains are due here (otherwise the optimiser sinks the one whose results are used later out of the rows)
+    asm volatile("" ::"v"(r0[0]), "v"(r1[0]), "v"(r2[0]), "v"(r0[1]), "v"(r1[1]), "v"(r2[1]));
+    okA = (d0[0] > 0.0) && (d1[0] > 0.0) && (d2[0] > 0.0);
+    okB = (d0[1] > 0.0) && (d1[1] > 0.0) && (d2[1] > 0.0);
+    LA[0][0] = r0[0], LA[1][0] = l10[0], LA[2][0] = l20[0], LA[1][1] = r1[0], LA[2][1] = l21[0], LA[2][2] = r2[0];
+    LB[0][0] = r0[1], LB[1][0] = l10[1], LB[2][0] = l20[1], LB[1][1] = r1[1], LB[2][1] = l21[1], LB[2][2] = r2[1];
+    LA[0][1] = LA[0][2] = LA[1][2] = 0.0;
+    LB[0][1] = LB[0][2] = LB[1][2] = 0.0;
+    invA[0] = y0[0], invA[1] = y1[0], invA[2] = y2[0];
+    invB[0] = y0[1], invB[1] = y1[1], invB[2] = y2[1];
+}
+
+// the jitter-on-failure retries of root_small_fast (after a failed un-jittered attempt)
+template <int T>
+__device__ __forceinline__ int root_small_fast_retry(const double (&S)[T][T], double jitter, double (&R)[T][T]) {
+    double linv[T], A[T][T];
+#pragma unroll
+    for (int i = 0; i < T; ++i)
+#pragma unroll
+        for (int j = 0; j < T; ++j) A[i][j] = S[i][j];
+    double prev = 0.0, jn = jitter;
+#pragma unroll 1
+    for (int t = 0; t < 3; ++t) {
+        const double add = jn - prev;
+#pragma unroll
+        for (int i = 0; i < T; ++i) A[i][i] += add;
+        prev = jn;
+        if (chol_small_fast<T>(A, R, linv)) return (t + 1) << 1;
+        jn *= 10.0;
+    }
+    return (3 << 1) | GPMPC_INFO_ROOT_FAIL;
 }
 
 template <int T>

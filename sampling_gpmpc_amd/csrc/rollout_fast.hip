@@ -637,16 +637,20 @@ __global__ __launch_bounds__(GPMPC_FAST_MAXTHREADS, 1) void rollout_fast_kernel(
         // ---- posterior mean / covariance at the test point ------------------------------------------------------
         double mu[T], S[T][T];
         {
-            // nine wave sums: two lane-swap trees of four (wave_sum4) and one DPP ladder
+            // nine wave sums: two lane-swap trees of four and one DPP ladder, in lockstep (wave_sum9)
             static_assert(T == 3, "the reduction grouping below is written for T = 3");
             double r[NS];
 #ifdef GPMPC_ABLATE_REDUCE
             mu[0] = readlane_f64(pm[0], 0), mu[1] = readlane_f64(pm[1], 0), mu[2] = readlane_f64(pm[2], 0);
             for (int e2 = 0; e2 < NS; ++e2) r[e2] = readlane_f64(pss[e2], 0) * 1e-3;
 #else
-            wave_sum4(pm[0], pm[1], pm[2], pss[0], mu[0], mu[1], mu[2], r[0]);
-            wave_sum4(pss[1], pss[2], pss[3], pss[4], r[1], r[2], r[3], r[4]);
-            r[5] = wave_sum(pss[5]);
+            {
+                const double qa[4] = {pm[0], pm[1], pm[2], pss[0]}, qb[4] = {pss[1], pss[2], pss[3], pss[4]};
+                double ra[4], rb[4];
+                wave_sum9(qa, qb, pss[5], ra, rb, r[5]);
+                mu[0] = ra[0], mu[1] = ra[1], mu[2] = ra[2], r[0] = ra[3];
+                r[1] = rb[0], r[2] = rb[1], r[3] = rb[2], r[4] = rb[3];
+            }
 #endif
             int e = 0;
 #pragma unroll
@@ -690,12 +694,13 @@ __global__ __launch_bounds__(GPMPC_FAST_MAXTHREADS, 1) void rollout_fast_kernel(
                 for (int c = 0; c < T; ++c) C[b][c] = Sn[b][c], R[b][c] = S[b][c];
             }
 #else
-            c_ok = chol_small_fast<T>(Sn, C, cinv);        // independent of the root below: the two chains interleave
+            // chol(S + noise) and the root of S are independent: both factorisations advance in lockstep
+            double rinv[T];
+            bool r_ok;
+            chol3_pair_fast(Sn, S, C, R, cinv, rinv, c_ok, r_ok);
+            if (!r_ok) info_acc |= root_small_fast_retry<T>(S, gp.jitter, R);
 #endif
         }
-#ifndef GPMPC_ABLATE_SAMPLE
-        info_acc |= root_small_fast<T>(S, gp.jitter, R);
-#endif
         double zt[T];
 #pragma unroll
         for (int c = 0; c < T; ++c) zt[c] = lane_pick(zq, ZREGS, t * T + c);
