@@ -281,6 +281,59 @@ __device__ __forceinline__ void dpp_bank1_block(const double2_t* row1, int n_h, 
     }
 }
 
+// The same substitution with L'' in the HBM/L2 workspace (the chain's factor does not fit LDS): identical arithmetic, but the
+// own-row pairs of the off-diagonal phase are global loads, requested one whole block (a diagonal phase + a replicate +
+// an off-diagonal phase, ~800 cycles) before they are needed.
+template <int K, bool TWO>
+__device__ __forceinline__ void dppg_bank0_block(const double2_t* row0, const double2_t* row1, int n_h, int bp_addr,
+                                                 const double (&dg0)[16], const double2_t (&la)[8], const double2_t (&lb)[8],
+                                                 double (&v0)[3], double (&v1)[3]) {
+    if constexpr (K < 4) {
+        if (!TWO && 16 * K >= n_h) return;
+        const bool more = TWO || 16 * (K + 1) < n_h;
+        double2_t la_n[8], lb_n[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) la_n[q] = la[q], lb_n[q] = lb[q];
+        if (more) {                                               // the next block's pairs
+            if constexpr (K < 2) {
+                if (TWO || 16 * (K + 2) < n_h) dpp_load_pairs(row0, K + 1, la_n);
+            }
+            if constexpr (TWO && K < 3) dpp_load_pairs(row1, K + 1, lb_n);
+        }
+        dpp_diag_block<K>(dg0, v0, TWO ? 16 : n_h - 16 * K);
+        if (more) {
+            double R[3];
+            dpp_replicate<K>(v0, bp_addr, R);
+            if constexpr (K < 3) dpp_off_block<((0xf << (K + 1)) & 0xf)>(la, R, v0);
+            if constexpr (TWO) dpp_off_block<0xf>(lb, R, v1);
+            dppg_bank0_block<K + 1, TWO>(row0, row1, n_h, bp_addr, dg0, la_n, lb_n, v0, v1);
+        }
+    }
+}
+template <int K>
+__device__ __forceinline__ void dppg_bank1_block(const double2_t* row1, int n_h, int bp_addr, const double (&dg1)[16],
+                                                 const double2_t (&lb)[8], double (&v1)[3]) {
+    if constexpr (K < 4) {
+        if (kWave + 16 * K >= n_h) return;
+        const bool more = kWave + 16 * (K + 1) < n_h;
+        double2_t lb_n[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) lb_n[q] = lb[q];
+        if constexpr (K < 2) {
+            if (kWave + 16 * (K + 2) < n_h) dpp_load_pairs(row1, 4 + K + 1, lb_n);
+        }
+        dpp_diag_block<K>(dg1, v1, n_h - kWave - 16 * K);
+        if constexpr (K < 3) {
+            if (more) {
+                double R[3];
+                dpp_replicate<K>(v1, bp_addr, R);
+                dpp_off_block<((0xf << (K + 1)) & 0xf)>(lb, R, v1);
+                dppg_bank1_block<K + 1>(row1, n_h, bp_addr, dg1, lb_n, v1);
+            }
+        }
+    }
+}
+
 // GPMPC_FAST_MAXTHREADS=512 (build.py: GPMPC_EXTRA_DEFS) halves the register budget so that two workgroups share a CU:
 // only for tools/occupancy_experiment.py
 #ifndef GPMPC_FAST_MAXTHREADS
@@ -318,6 +371,7 @@ __global__ __launch_bounds__(GPMPC_FAST_MAXTHREADS, 1) void rollout_fast_kernel(
     double* Lhr1 = kvs + T * NRP;                                 // [nb1][NRS]
     double* Lhh = LHH_LDS ? (Lhr1 + nb1 * NRS) : (a.ws + (s * G_NY + o) * a.ws_chain_stride);
     double* ybuf = ybuf_all + sw * 2 * G_NY;
+    double* dgs = Lhr1 + nb1 * NRS;                               // [3][16] diagonal-segment scratch (global-factor variant only)
 
     for (int e = threadIdx.x; e < G_NY * NR * NRS; e += blockDim.x) {
         const int oo = e / (NR * NRS), rem = e - oo * NR * NRS;
@@ -508,6 +562,13 @@ __global__ __launch_bounds__(GPMPC_FAST_MAXTHREADS, 1) void rollout_fast_kernel(
         FPHASE(1);
 
         if (n_h > 0) {
+            double2_t lg0[8], lg1[8];                             // global-factor variant: own-row pairs of pivot block 0
+            if constexpr (!LHH_LDS) {
+#pragma unroll
+                for (int q = 0; q < 8; ++q) lg0[q] = double2_t{0.0, 0.0}, lg1[q] = double2_t{0.0, 0.0};
+                if (n_h > 16) dpp_load_pairs(row0, 0, lg0);
+                if (two) dpp_load_pairs(row1, 0, lg1);
+            }
             // ---- rhs = k_h - L_hr v_r -----------------------------------------------------------------------------
 #ifndef GPMPC_ABLATE_RHS
             {
@@ -544,76 +605,19 @@ __global__ __launch_bounds__(GPMPC_FAST_MAXTHREADS, 1) void rollout_fast_kernel(
                     dpp_bank0_block<0, true>(row0, row1, n_h, bp_addr, dg0, v0, v1);
                     dpp_bank1_block<0>(row1, n_h, bp_addr, dg1, v1);
                 }
-            } else
-            if (!two) {
-                double2_t ra[RG];
-#pragma unroll
-                for (int k = 0; k < RG; ++k) ra[k] = row0[k];
-#pragma unroll 1
-                for (int p0 = 0; p0 < n_h; p0 += 2 * RG) {
-#pragma unroll
-                    for (int k = 0; k < RG; ++k) {
-                        const double2_t la2 = ra[k];
-                        ra[k] = row0[(p0 >> 1) + RG + k];
-#pragma unroll
-                        for (int h = 0; h < 2; ++h) {
-                            const int p = p0 + 2 * k + h;
-                            double sp[T];
-#pragma unroll
-                            for (int b = 0; b < T; ++b) sp[b] = readlane_f64(v0[b], p);
-                            const double la = (lane > p) ? (h ? la2.y : la2.x) : 0.0;
-#pragma unroll
-                            for (int b = 0; b < T; ++b) v0[b] = fma(-la, sp[b], v0[b]);
-                        }
-                    }
-                }
             } else {
-                double2_t ra[RG], rb[RG];
+                double2_t la[8], lb[8];
 #pragma unroll
-                for (int k = 0; k < RG; ++k) {
-                    ra[k] = row0[k];
-                    rb[k] = row1[k];
-                }
-#pragma unroll 1
-                for (int p0 = 0; p0 < kWave; p0 += 2 * RG) {             // pivots owned by bank 0
+                for (int q = 0; q < 8; ++q) la[q] = lg0[q], lb[q] = lg1[q];     // requested before the L_hr product
+                if (!two) {
+                    dppg_bank0_block<0, false>(row0, row1, n_h, bp_addr, dg0, la, lb, v0, v1);
+                } else {
+                    dppg_bank0_block<0, true>(row0, row1, n_h, bp_addr, dg0, la, lb, v0, v1);
+                    double2_t lc[8];
 #pragma unroll
-                    for (int k = 0; k < RG; ++k) {
-                        const double2_t la2 = ra[k], lb2 = rb[k];
-                        ra[k] = row0[(p0 >> 1) + RG + k];
-                        rb[k] = row1[(p0 >> 1) + RG + k];
-#pragma unroll
-                        for (int h = 0; h < 2; ++h) {
-                            const int p = p0 + 2 * k + h;
-                            double sp[T];
-#pragma unroll
-                            for (int b = 0; b < T; ++b) sp[b] = readlane_f64(v0[b], p);
-                            const double la = (lane > p) ? (h ? la2.y : la2.x) : 0.0;
-                            const double lb = h ? lb2.y : lb2.x;
-#pragma unroll
-                            for (int b = 0; b < T; ++b) {
-                                v0[b] = fma(-la, sp[b], v0[b]);
-                                v1[b] = fma(-lb, sp[b], v1[b]);
-                            }
-                        }
-                    }
-                }
-#pragma unroll 1
-                for (int p0 = kWave; p0 < n_h; p0 += 2 * RG) {            // pivots owned by bank 1
-#pragma unroll
-                    for (int k = 0; k < RG; ++k) {
-                        const double2_t lb2 = rb[k];
-                        rb[k] = row1[(p0 >> 1) + RG + k];
-#pragma unroll
-                        for (int h = 0; h < 2; ++h) {
-                            const int p = p0 + 2 * k + h;
-                            double sp[T];
-#pragma unroll
-                            for (int b = 0; b < T; ++b) sp[b] = readlane_f64(v1[b], p - kWave);
-                            const double lb = (lane + kWave > p) ? (h ? lb2.y : lb2.x) : 0.0;
-#pragma unroll
-                            for (int b = 0; b < T; ++b) v1[b] = fma(-lb, sp[b], v1[b]);
-                        }
-                    }
+                    for (int q = 0; q < 8; ++q) lc[q] = la[q];
+                    if (kWave + 16 < n_h) dpp_load_pairs(row1, 4, lc);
+                    dppg_bank1_block<0>(row1, n_h, bp_addr, dg1, lc, v1);
                 }
             }
             // v = rhs / L_pp (own rows; rows that do not exist yet are dropped); partial sums
@@ -744,6 +748,7 @@ __global__ __launch_bounds__(GPMPC_FAST_MAXTHREADS, 1) void rollout_fast_kernel(
             }
             const int base = n_h;
             const int a0 = lane - base, a1 = lane + kWave - base;
+            double dd0s[T] = {0.0, 0.0, 0.0}, dd1s[T] = {0.0, 0.0, 0.0};
             // (1)+(2) new rows base+c of L'': lane p owns the entry in column p:  L''[base+c][p] = v_p[c] / L_pp for
             // p < base, the column-scaled new diagonal block for base <= p < base+c.  Branch-free: every lane stores, lanes
             // at or right of the diagonal store 0.0 into slots of rows that do not exist yet (rows base+c+1.. are written
@@ -760,6 +765,7 @@ __global__ __launch_bounds__(GPMPC_FAST_MAXTHREADS, 1) void rollout_fast_kernel(
                     const int ro = lhh_rowofs(base + c);
                     Lhh[min(ro + lane, last)] = fma(v0[c], dinv0, dd0[c]);
                     if (base + c > kWave) Lhh[min(ro + lane + kWave, last)] = fma(v1[c], dinv1, dd1[c]);      // uniform
+                    dd0s[c] = dd0[c], dd1s[c] = dd1[c];
                 }
             }
             // (3) owners of the new rows: 1/L_pp, w_p, the point's GP input, and the L_hr row (= v_r^T)
@@ -819,6 +825,38 @@ __global__ __launch_bounds__(GPMPC_FAST_MAXTHREADS, 1) void rollout_fast_kernel(
 #pragma unroll
                             for (int q = 0; q < 8; ++q) {
                                 const double2_t pr = *((2 * (qb + q) < r) ? (row1 + qb + q) : zero2);
+                                dg1[2 * q] = pr.x;
+                                dg1[2 * q + 1] = pr.y;
+                            }
+                        }
+                    }
+                } else {
+                    // factor in the HBM/L2 workspace: the new rows' diagonal-block segments travel through a 3 x 16
+                    // LDS scratch (lane p of the row's own 16-block deposits column p; zero at / right of the diagonal
+                    // by construction of the stored values), no global read-back
+#pragma unroll
+                    for (int c = 0; c < T; ++c) {
+                        const int blk = (base + c) >> 4;
+                        if (blk < 4) {
+                            if ((lane >> 4) == blk) dgs[c * 16 + (lane & 15)] = fma(v0[c], dinv0, (c == 0) ? 0.0 : ((c == 1) ? dd0s[1] : dd0s[2]));
+                        } else {
+                            if ((lane >> 4) == blk - 4) dgs[c * 16 + (lane & 15)] = fma(v1[c], dinv1, (c == 0) ? 0.0 : ((c == 1) ? dd1s[1] : dd1s[2]));
+                        }
+                    }
+                    wave_sync_lds();
+                    if (new0) {
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) {
+                            const double2_t pr = *reinterpret_cast<const double2_t*>(dgs + a0 * 16 + 2 * q);
+                            dg0[2 * q] = pr.x;
+                            dg0[2 * q + 1] = pr.y;
+                        }
+                    }
+                    if (base + T > kWave) {
+                        if (new1) {
+#pragma unroll
+                            for (int q = 0; q < 8; ++q) {
+                                const double2_t pr = *reinterpret_cast<const double2_t*>(dgs + a1 * 16 + 2 * q);
                                 dg1[2 * q] = pr.x;
                                 dg1[2 * q + 1] = pr.y;
                             }
@@ -921,7 +959,7 @@ static void fast_plan(const gpmpc_gp_desc_t* gp, int nx, int H, bool force_globa
     if (!fp->lhh_lds) fp->chain_doubles = lhh_doubles(nh_max, kRingGlobal);
     fp->waves = fp->spw * G;
     fp->lds_shared = shared_doubles(fp->spw);
-    const long per = vec + (fp->lhh_lds ? fp->chain_doubles : 0);
+    const long per = vec + (fp->lhh_lds ? fp->chain_doubles : 48);          // 48: diagonal-segment scratch (dgs)
     fp->lds_per_wave = (int)((per + 1) & ~1L);
     fp->lds_bytes = ((size_t)fp->lds_shared + (size_t)fp->waves * fp->lds_per_wave) * sizeof(double);
 }
