@@ -2,21 +2,29 @@
 // appended slots, value-only real labels on an N_r = 36 / 45 grid).  gfx950, wave64.
 //
 // One wave per (sample, output) chain; a workgroup holds WAVES = G_NY * SPW chains (pendulum1D: 4 independent samples,
-// car: the 3 outputs of one sample, which meet at one barrier per step).  With one wave per SIMD every instruction of
-// the chain costs ~4-7 cycles, so the kernel is organised around INSTRUCTION COUNT:
+// car: the 3 outputs of one sample, which meet at one barrier per step).  At BASELINE configs[1] there is exactly ONE
+// wave per SIMD, which issues in order: nothing overlaps unless it is adjacent in the instruction stream.  The kernel
+// is therefore organised around (a) instruction count, (b) keeping every wave-wide broadcast on the VALU, and (c)
+// running independent dependency chains in lockstep:
 //
-//   registers : this lane's row of L_rr^-1 (NR doubles, loaded once), this lane's bank-0 row of L_hr (rows 0..63 of the
-//               chain's appended slots), the running right-hand sides, 1/L_pp and w_p of the lane's own rows
-//   LDS       : k_r / v_r broadcast buffers laid out for ds_read_b128 (two doubles per instruction), the bank-1 rows
-//               of L_hr (rows 64..), and - when it fits (LHH_LDS) - the chain's L_hh; otherwise L_hh streams from an
-//               HBM/L2 workspace
+//   * lane == row of every triangular / rectangular factor block.  A pivot value is broadcast with
+//     v_fmac_f64_dpp row_newbcast (a wave is four DPP rows of 16 lanes): the forward substitution works on 16-pivot
+//     blocks = DPP rows (dpp_bank0_block), the two mat-vecs against k_r / v_r read their vector from registers that
+//     ds_bpermute replicated to all four DPP rows (dpp_matvec).  No v_readlane -> SGPR -> v_fma round trip (~100 cycles
+//     per pivot), no LDS broadcast reads (the LDS pipe is shared by the CU's four waves);
+//   * registers: the lane's bank-0 row of L_hr (rows 0..63 of the chain's appended slots), the diagonal-block segments
+//     of the lane's rows of L'' (dg0 / dg1), 1/L_pp and w_p of the lane's rows, the chain's base samples and the input
+//     sequence (lane-indexed, v_readlane per step: no vector-memory load inside the step loop);
+//   * LDS: L_rr^-1 rows (shared by the workgroup), the bank-1 rows of L_hr, a v_r buffer for the appending lanes and -
+//     when it fits (LHH_LDS) - the chain's L_hh; otherwise L_hh lives in an HBM/L2 workspace;
+//   * exponentials, the two 3x3 Choleskys and the nine wave reductions of a step advance in lockstep
+//     (gpmpc_device.hpp: expn_neg, chol3_pair_fast, wave_sum9).
 //
 // L_hh is stored ROW-major (row r = its r entries, 16-byte aligned) and COLUMN-SCALED (L''[r][p] = L[r][p] / L[p][p]):
-//   * lane == row reads its own row two pivots per ds_read_b128 with immediate offsets (no per-pivot address math);
-//   * the forward substitution  rhs_r -= L''[r][p] * rhs_p  has a dependency chain of v_readlane -> v_fma_f64 per
-//     pivot (no divide, no LDS access on the chain); v_p = rhs_p / L_pp is formed once after the loop;
-//   * appending a row is one coalesced ds_write_b64 per lane (lane p owns the new row's entry in column p);
-//   * the storage is zero-initialised, so not-yet-appended rows read as zero; finished rows (r <= p) are masked.
+//   * lane == row reads its own row two pivots per 16-byte load with immediate offsets;
+//   * the substitution rhs_r -= L''[r][p] * rhs_p needs no divide; v_p = rhs_p / L_pp is formed once after the loop;
+//   * appending a row is one coalesced 8-byte store per lane (lane p owns the new row's entry in column p);
+//   * the storage is zero-initialised, so not-yet-appended rows read as zero.
 #include "gpmpc_host.hpp"
 #include "rollout_args.hpp"
 
@@ -52,15 +60,14 @@ __host__ __device__ __forceinline__ int lhh_rowofs(int r) {
     const int h = r >> 1;
     return (r & 1) ? 2 * h * (h + 1) : 2 * h * h;
 }
-// + slack for the look-ahead reads of the last row (2*rg pivots ahead of a pivot index rounded up to 2*rg; rg = row
-// pairs in the prefetch ring of the substitution)
+// + slack after the last row: its first pair is the chain's zero pair / the sink of the branch-free append stores (the
+// size formula is the one the workspace query has always used: rg = 4 in LDS, GPMPC_FAST_RING_GLOBAL in the workspace)
 __host__ __device__ __forceinline__ long lhh_doubles(int nh_max, int rg) {
     const int r = nh_max - 1, cap = r + (r & 1), w = 2 * rg;
     int slack = ((nh_max + w - 1) / w) * w + w - cap;
     slack = (slack < 0) ? 0 : ((slack + 1) & ~1);
     return lhh_rowofs(nh_max) + slack;
 }
-// ring depth: 8 pivots of look-ahead cover the LDS latency; the HBM/L2 workspace variant needs more bytes in flight
 constexpr int kRingLds = 4;
 #ifndef GPMPC_FAST_RING_GLOBAL
 #define GPMPC_FAST_RING_GLOBAL 8
@@ -95,15 +102,6 @@ __device__ __forceinline__ void fmac3_dpp_self(double (&v)[3], double la) {
         "v_fmac_f64_dpp %2, %2, -%3 row_newbcast:%4 row_mask:%5 bank_mask:0xf"
         : "+v"(v[0]), "+v"(v[1]), "+v"(v[2])
         : "v"(la), "n"(I), "n"(RM));
-}
-template <int I, int RM>
-__device__ __forceinline__ void fmac3_dpp_from(double (&v)[3], const double (&R)[3], double la) {
-    asm("s_nop 1\n\t"
-        "v_fmac_f64_dpp %0, %4, -%3 row_newbcast:%7 row_mask:%8 bank_mask:0xf\n\t"
-        "v_fmac_f64_dpp %1, %5, -%3 row_newbcast:%7 row_mask:%8 bank_mask:0xf\n\t"
-        "v_fmac_f64_dpp %2, %6, -%3 row_newbcast:%7 row_mask:%8 bank_mask:0xf"
-        : "+v"(v[0]), "+v"(v[1]), "+v"(v[2])
-        : "v"(la), "v"(R[0]), "v"(R[1]), "v"(R[2]), "n"(I), "n"(RM));
 }
 // acc[b] (+/-)= R[b]@(lane i of the DPP row) * l  for the three right-hand sides; R holds the same 16 values in every DPP
 // row (dpp_replicate), so this is a wave-wide broadcast of pivot i without LDS traffic or SGPR round trip
@@ -349,8 +347,6 @@ __global__ __launch_bounds__(GPMPC_FAST_MAXTHREADS, 1) void rollout_fast_kernel(
     constexpr int NRP = (NR + 1) & ~1;                            // broadcast-buffer row length (even -> b128 aligned)
     constexpr int NRS = ((NRP / 2) & 1) ? NRP : NRP + 2;          // row stride of lane==row tables: 16-byte slots, odd count
     constexpr int NPAIR = NR / 2;
-    constexpr int RG = LHH_LDS ? kRingLds : kRingGlobal;            // row pairs in the prefetch ring of the substitution
-    static_assert(kWave % (2 * RG) == 0, "the ring must turn a whole number of times per 64-row bank");
     extern __shared__ __attribute__((aligned(16))) double smem[];
     __shared__ int s_info[4];
 
