@@ -12,6 +12,44 @@ std::string& last_error() {
 // plan: factorise K_rr + Sigma_r once per output (shared by all samples).  One workgroup per output; the matrix
 // lives in LDS (n_r <= 143 -> <= 160 KiB).  Right-looking Cholesky; then L^-1 column by column (thread per column).
 // ---------------------------------------------------------------------------------------------------------------
+// cyclic Jacobi eigen-decomposition of a symmetric n x n matrix (n <= 16, row stride 16), one thread: A -> diagonal
+// (eigenvalues), V -> eigenvectors in columns.  High relative accuracy for the SPD kernel matrices it is used on.
+__device__ void jacobi_eig16(double* A, int n, double* V) {
+    for (int i = 0; i < n; ++i)
+        for (int j = 0; j < n; ++j) V[i * 16 + j] = (i == j) ? 1.0 : 0.0;
+    for (int sweep = 0; sweep < 30; ++sweep) {
+        double off = 0.0, dia = 0.0;
+        for (int i = 0; i < n; ++i) {
+            dia += A[i * 16 + i] * A[i * 16 + i];
+            for (int j = 0; j < i; ++j) off += A[i * 16 + j] * A[i * 16 + j];
+        }
+        if (off <= 1e-60 * dia || off == 0.0) break;
+        for (int p = 0; p < n - 1; ++p)
+            for (int q = p + 1; q < n; ++q) {
+                const double apq = A[p * 16 + q];
+                if (apq == 0.0) continue;
+                const double theta = (A[q * 16 + q] - A[p * 16 + p]) / (2.0 * apq);
+                const double t = ((theta >= 0.0) ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+                const double c = 1.0 / sqrt(t * t + 1.0), sn = t * c;
+                for (int k = 0; k < n; ++k) {                // columns p, q
+                    const double akp = A[k * 16 + p], akq = A[k * 16 + q];
+                    A[k * 16 + p] = c * akp - sn * akq;
+                    A[k * 16 + q] = sn * akp + c * akq;
+                }
+                for (int k = 0; k < n; ++k) {                // rows p, q
+                    const double apk = A[p * 16 + k], aqk = A[q * 16 + k];
+                    A[p * 16 + k] = c * apk - sn * aqk;
+                    A[q * 16 + k] = sn * apk + c * aqk;
+                }
+                for (int k = 0; k < n; ++k) {
+                    const double vkp = V[k * 16 + p], vkq = V[k * 16 + q];
+                    V[k * 16 + p] = c * vkp - sn * vkq;
+                    V[k * 16 + q] = sn * vkp + c * vkq;
+                }
+            }
+    }
+}
+
 template <int D>
 __global__ __launch_bounds__(256) void plan_kernel(GpParams gp, const double* __restrict__ X_r,
                                                    const double* __restrict__ Y_r, double* __restrict__ plan,
@@ -101,6 +139,44 @@ __global__ __launch_bounds__(256) void plan_kernel(GpParams gp, const double* __
         double s = 0.0;
         for (int i = j; i < n; ++i) s += LinvT[(long)j * n + i] * w[i];
         alpha[j] = s;
+    }
+    // ---- grid root (see plan_doubles_per_output): eigen-decomposition of the two axis kernel matrices ------------------
+    if (plan_has_grid_root(gp.grid_n0, gp.grid_n1, gp.real_has_grad)) {
+        __shared__ double Ka[16 * 16], Kb[16 * 16], Va[16 * 16], Vb[16 * 16];
+        const int n0 = gp.grid_n0, n1 = gp.grid_n1;
+        double* Qa = alpha + n;
+        double* Qb = Qa + n0 * n0;
+        double* dsc = Qb + n1 * n1;
+        double* wE = dsc + n0 * n1;
+        for (int e = tid; e < n0 * n0; e += nt) {
+            const int i = e / n0, j = e - i * n0;
+            const double r = X_r[(long)(i * n1) * D + 0] - X_r[(long)(j * n1) * D + 0];
+            Ka[i * 16 + j] = exp(-0.5 * r * r * inv_l2[0]);
+        }
+        for (int e = tid; e < n1 * n1; e += nt) {
+            const int i = e / n1, j = e - i * n1;
+            const double r = X_r[(long)i * D + 1] - X_r[(long)j * D + 1];
+            Kb[i * 16 + j] = exp(-0.5 * r * r * inv_l2[1]);
+        }
+        __syncthreads();
+        if (tid == 0) jacobi_eig16(Ka, n0, Va);             // eigenvalues end up on the diagonal of Ka / Kb,
+        if (tid == 64) jacobi_eig16(Kb, n1, Vb);            // eigenvectors in the columns of Va / Vb
+        __syncthreads();
+        for (int e = tid; e < n0 * n0; e += nt) Qa[e] = Va[(e / n0) * 16 + (e % n0)];
+        for (int e = tid; e < n1 * n1; e += nt) Qb[e] = Vb[(e / n1) * 16 + (e % n1)];
+        for (int r = tid; r < n0 * n1; r += nt) {
+            const int a = r / n1, c = r - a * n1;
+            const double la = fmax(Ka[a * 16 + a], 0.0), lb = fmax(Kb[c * 16 + c], 0.0);
+            const double dinv = 1.0 / sqrt(gp.os[o] * la * lb + gp.noise[0]);
+            double acc = 0.0;                                // ((Qa (x) Qb)^T y)_r
+            for (int a2 = 0; a2 < n0; ++a2) {
+                double inner = 0.0;
+                for (int c2 = 0; c2 < n1; ++c2) inner += Vb[c2 * 16 + c] * Y_r[((long)o * gp.N_r + a2 * n1 + c2) * gp.T];
+                acc += Va[a2 * 16 + a] * inner;
+            }
+            dsc[r] = gp.os[o] * dinv;
+            wE[r] = dinv * acc;
+        }
     }
 }
 
@@ -213,7 +289,7 @@ int gpmpc_selftest(void* stream) {
 size_t gpmpc_plan_bytes(const gpmpc_gp_desc_t* gp) {
     if (check_gp(gp) != GPMPC_OK) return 0;
     const int n_r = observed_real_slots(gp);
-    return align_up((size_t)gp->g_ny * plan_doubles_per_output(n_r) * sizeof(double), 256);
+    return align_up((size_t)gp->g_ny * plan_doubles_per_output(n_r, gp->grid_n0, gp->grid_n1) * sizeof(double), 256);
 }
 
 int gpmpc_plan_build(const gpmpc_gp_desc_t* gp, const double* X_r, const double* Y_r, void* plan, int32_t* info,

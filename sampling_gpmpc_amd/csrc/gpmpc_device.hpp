@@ -32,7 +32,17 @@ struct EnvParams {
 
 // plan buffer layout per output o (doubles): [ L (n_r*n_r, row-major) | LinvT (n_r*n_r, LinvT[j*n_r+i]=Linv[i][j])
 //                                            | w (n_r) = L^-1 y | alpha (n_r) = L^-T w ]
-__host__ __device__ inline long plan_doubles_per_output(int n_r) { return 2L * n_r * n_r + 2L * n_r; }
+//                                            | grid root (value-only real labels on a tensor grid n0 x n1, else absent):
+//                                              Qa (n0*n0, row-major, column a = eigenvector a of the axis-0 kernel matrix)
+//                                              | Qb (n1*n1) | dsc (N_r) | wE (N_r) ]
+// The grid root: K_rr + s2 I = os Ka (x) Kb + s2 I = (Qa (x) Qb) D (Qa (x) Qb)^T, D = os la_a lb_c + s2, so
+// W = D^-1/2 (Qa (x) Qb)^T satisfies W^T W = (K_rr + s2 I)^-1 and can stand in for L_rr^-1 everywhere (the Schur
+// complement, the posterior mean and covariance only see W^T W).  W k_r for a separable kernel row costs n0 + n1 pivots
+// instead of N_r.  dsc[r] = os / sqrt(D_r) (the outputscale of k_r folded in), wE = W y_r.
+__host__ __device__ inline long plan_doubles_per_output(int n_r, int n0 = 0, int n1 = 0) {
+    const long grid = (n0 > 0 && n1 > 0) ? ((long)n0 * n0 + (long)n1 * n1 + 2L * n0 * n1 + 1) & ~1L : 0;
+    return 2L * n_r * n_r + 2L * n_r + grid;
+}
 __device__ inline const double* plan_L(const double* plan, const GpParams& gp, int o) { return plan + o * gp.plan_stride; }
 __device__ inline const double* plan_LinvT(const double* plan, const GpParams& gp, int o) {
     return plan + o * gp.plan_stride + (long)gp.n_r * gp.n_r;
@@ -42,6 +52,21 @@ __device__ inline const double* plan_w(const double* plan, const GpParams& gp, i
 }
 __device__ inline const double* plan_alpha(const double* plan, const GpParams& gp, int o) {
     return plan + o * gp.plan_stride + 2L * gp.n_r * gp.n_r + gp.n_r;
+}
+__device__ inline const double* plan_grid_Qa(const double* plan, const GpParams& gp, int o) {
+    return plan + o * gp.plan_stride + 2L * gp.n_r * gp.n_r + 2L * gp.n_r;
+}
+__device__ inline const double* plan_grid_Qb(const double* plan, const GpParams& gp, int o) {
+    return plan_grid_Qa(plan, gp, o) + (long)gp.grid_n0 * gp.grid_n0;
+}
+__device__ inline const double* plan_grid_dsc(const double* plan, const GpParams& gp, int o) {
+    return plan_grid_Qb(plan, gp, o) + (long)gp.grid_n1 * gp.grid_n1;
+}
+__device__ inline const double* plan_grid_w(const double* plan, const GpParams& gp, int o) {
+    return plan_grid_dsc(plan, gp, o) + (long)gp.grid_n0 * gp.grid_n1;
+}
+__host__ __device__ inline bool plan_has_grid_root(int grid_n0, int grid_n1, int real_has_grad) {
+    return grid_n0 > 0 && grid_n1 > 0 && grid_n0 <= 16 && grid_n1 <= 16 && !real_has_grad;
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -211,7 +236,7 @@ __device__ __forceinline__ double kern_scalar(const double* x, const double* xp,
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// Two or three exponentials of non-positive arguments in lockstep.  A single wave issues in order, so three separate exp()
+// Two to four exponentials of non-positive arguments in lockstep.  A single wave issues in order, so three separate exp()
 // calls cost three full dependency chains (~25 dependent FP64 operations each, the scheduler does not interleave
 // them); here the chains advance row by row (one operation of each per row, rows pinned with sched_barrier), the
 // degree-11 polynomial is evaluated in Estrin form (depth 4 instead of 11) and the coefficient constants are
@@ -225,7 +250,7 @@ __device__ __forceinline__ double bits_f64(unsigned long long u) { return __buil
     __builtin_amdgcn_sched_barrier(0)
 template <int N>
 __device__ __forceinline__ void expn_neg(const double (&x)[N], double (&e)[N]) {
-    static_assert(N == 2 || N == 3, "two or three chains");
+    static_assert(N >= 2 && N <= 4, "two to four chains");
     const double log2e = bits_f64(0x3FF71547652B82FEull), nln2h = bits_f64(0xBFE62E42FEFA39EFull),
                  nln2l = bits_f64(0xBC7ABC9E3B39803Full);
     const double c2 = bits_f64(0x3FE000000000000Bull), c3 = bits_f64(0x3FC5555555555511ull), c4 = bits_f64(0x3FA55555555502A1ull),
@@ -252,7 +277,8 @@ __device__ __forceinline__ void expn_neg(const double (&x)[N], double (&e)[N]) {
     GPMPC_ROW3(a0[i_] = fma(a2[i_], r4[i_], a0[i_]));       // p
     GPMPC_ROW3(e[i_] = ldexp(a0[i_], (int)n[i_]));
     // all results are due HERE: keeps the optimiser from sinking a chain to its (later) first use, out of the lockstep rows
-    if constexpr (N == 3) asm volatile("" ::"v"(e[0]), "v"(e[1]), "v"(e[2]));
+    if constexpr (N == 4) asm volatile("" ::"v"(e[0]), "v"(e[1]), "v"(e[2]), "v"(e[3]));
+    else if constexpr (N == 3) asm volatile("" ::"v"(e[0]), "v"(e[1]), "v"(e[2]));
     else asm volatile("" ::"v"(e[0]), "v"(e[1]));
 }
 __device__ __forceinline__ void exp3_neg(const double (&x)[3], double (&e)[3]) { expn_neg<3>(x, e); }

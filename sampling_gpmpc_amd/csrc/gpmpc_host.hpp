@@ -57,7 +57,7 @@ inline GpParams make_gp_params(const gpmpc_gp_desc_t* gp) {
     for (int t = 0; t < gp->T; ++t) p.noise[t] = gp->noise[t];
     p.jitter = gp->jitter;
     p.var_floor = gp->var_floor;
-    p.plan_stride = plan_doubles_per_output(p.n_r);
+    p.plan_stride = plan_doubles_per_output(p.n_r, p.grid_n0, p.grid_n1);
     return p;
 }
 

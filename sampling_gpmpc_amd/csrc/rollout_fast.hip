@@ -155,6 +155,30 @@ __device__ __forceinline__ void fmac12_dpp_from(double (&acc)[3], const double (
               "v"(R[2]), "n"(RM));
     }
 }
+__device__ __forceinline__ double bpermute_f64(double v, int addr) {
+    const int lo = __builtin_amdgcn_ds_bpermute(addr, __double2loint(v));
+    const int hi = __builtin_amdgcn_ds_bpermute(addr, __double2hiint(v));
+    return __hiloint2double(hi, lo);
+}
+// acc0 += R0@(lane I of the DPP row) * l ; acc1 += R1@(lane I) * l   (the grid-root products, two vectors per axis)
+template <int I>
+__device__ __forceinline__ void fmac2_dpp_bcast(double& acc0, double& acc1, double R0, double R1, double l) {
+    asm("s_nop 1\n\t"
+        "v_fmac_f64_dpp %0, %3, %2 row_newbcast:%5 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f64_dpp %1, %4, %2 row_newbcast:%5 row_mask:0xf bank_mask:0xf"
+        : "+v"(acc0), "+v"(acc1)
+        : "v"(l), "v"(R0), "v"(R1), "n"(I));
+}
+// P0[lane] = sum_j e0[lane STRIDE*j] * coef[j], P1 likewise with e1; the sources were replicated block-wise (Rb[blk][0/1])
+template <int N, int STRIDE, int J = 0>
+__device__ __forceinline__ void grid_axis_product(double& P0, double& P1, const double (&Rb)[3][2], const double (&coef)[N]) {
+    if constexpr (J < N) {
+        constexpr int src = STRIDE * J;
+        fmac2_dpp_bcast<src % 16>(P0, P1, Rb[src / 16][0], Rb[src / 16][1], coef[J]);
+        grid_axis_product<N, STRIDE, J + 1>(P0, P1, Rb, coef);
+    }
+}
+
 // mat-vec against a vector whose entries live one per lane (lanes 0..N-1): acc[b] (+/-)= sum_p M[lane][p] * x[b][p],
 // p ascending (the same FMA sequence per row as a broadcast-from-LDS loop).  `entry(p)` returns this lane's M[lane][p].
 template <int N, bool NEG, int P = 0, class Entry>
@@ -338,9 +362,11 @@ __device__ __forceinline__ void dppg_bank1_block(const double2_t* row1, int n_h,
 #define GPMPC_FAST_MAXTHREADS 256
 #endif
 
-template <int T, int NR, int G_NY, int ENV, bool LHH_LDS>
+template <int T, int NR, int G_NY, int ENV, bool LHH_LDS, bool GRID>
 __global__ __launch_bounds__(GPMPC_FAST_MAXTHREADS, 1) void rollout_fast_kernel(const RolloutArgs a) {
     constexpr int D = 2;
+    constexpr int N1 = 9, N0 = NR / N1;                           // GRID: the real inputs are meshgrid(axis0[N0], axis1[N1], "ij")
+    static_assert(N0 * N1 == NR, "the BASELINE real-data grids have 9 points on axis 1");
     constexpr int NS = T * (T + 1) / 2;
     constexpr int NX = (ENV == GPMPC_ENV_PENDULUM1D) ? 2 : 4;
     constexpr int NU = (ENV == GPMPC_ENV_PENDULUM1D) ? 1 : 2;
@@ -372,7 +398,7 @@ __global__ __launch_bounds__(GPMPC_FAST_MAXTHREADS, 1) void rollout_fast_kernel(
     for (int e = threadIdx.x; e < G_NY * NR * NRS; e += blockDim.x) {
         const int oo = e / (NR * NRS), rem = e - oo * NR * NRS;
         const int i = rem / NRS, j = rem - i * NRS;
-        Linv_all[e] = (j < NR) ? plan_LinvT(a.plan, gp, oo)[j * NR + i] : 0.0;
+        Linv_all[e] = (!GRID && j < NR) ? plan_LinvT(a.plan, gp, oo)[j * NR + i] : 0.0;
     }
     if constexpr (G_NY > 1) {
         if (threadIdx.x < 4) s_info[threadIdx.x] = 0;
@@ -390,7 +416,17 @@ __global__ __launch_bounds__(GPMPC_FAST_MAXTHREADS, 1) void rollout_fast_kernel(
     double xr[D];
 #pragma unroll
     for (int d = 0; d < D; ++d) xr[d] = (lane < NR) ? a.X_r[lane * D + d] : 0.0;
-    const double w_lane = (lane < NR) ? plan_w(a.plan, gp, o)[lane] : 0.0;
+    const double w_lane = (lane < NR) ? (GRID ? plan_grid_w(a.plan, gp, o) : plan_w(a.plan, gp, o))[lane] : 0.0;
+    // GRID: this lane's real point is (ga, gc) on the grid; columns ga of Qa and gc of Qb, and os / sqrt(D) of the point
+    const int lr = (lane < NR) ? lane : 0, ga = lr / N1, gc = lr - ga * N1;
+    double qa[N0], qb[N1], dsc = 0.0;
+    if constexpr (GRID) {
+#pragma unroll
+        for (int j = 0; j < N0; ++j) qa[j] = plan_grid_Qa(a.plan, gp, o)[j * N0 + ga];
+#pragma unroll
+        for (int j = 0; j < N1; ++j) qb[j] = plan_grid_Qb(a.plan, gp, o)[j * N1 + gc];
+        dsc = plan_grid_dsc(a.plan, gp, o)[lr];
+    }
     // lane == row of L_rr^-1 (lanes >= NR read row 0 and discard the result)
     const double2_t* linvrow = reinterpret_cast<const double2_t*>(Linv_all + ((long)o * NR + ((lane < NR) ? lane : 0)) * NRS);
 
@@ -480,11 +516,14 @@ __global__ __launch_bounds__(GPMPC_FAST_MAXTHREADS, 1) void rollout_fast_kernel(
         // L_rr^-1 is requested first so that its LDS latency hides behind them.
         const int bp_addr = (lane & 15) << 2;                     // ds_bpermute address of "my lane of DPP row 0"
         double2_t lrow[(NR + 1) / 2];
+        if constexpr (!GRID) {
 #pragma unroll
-        for (int jp = 0; jp < (NR + 1) / 2; ++jp) lrow[jp] = linvrow[jp];         // NRS >= NR + 1: the odd tail reads a zero pad
+            for (int jp = 0; jp < (NR + 1) / 2; ++jp) lrow[jp] = linvrow[jp];     // NRS >= NR + 1: the odd tail reads a zero pad
+        }
         const bool two = n_h > kWave;
         const bool ex0 = lane < n_h, ex1 = lane + kWave < n_h;
         double kr[T], v0[T], v1[T];                               // v0 / v1: rows lane / lane+64 of k_h, then rhs, then v_h
+        double gq0 = 0.0, gq1 = 0.0;
         // cov(task_a(row point), task_b(test point)) = k * (A_a * B_b + [a == b > 0] / l_a^2) with A_0 = B_0 = 1,
         // A_a = -q_a, B_b = +q_b (kern_entry): the row's task enters through a per-lane select of A and a
         // per-lane constant, so the evaluation is branch-free (the task-dependent branches of kern_entry cost ~17
@@ -494,10 +533,25 @@ __global__ __launch_bounds__(GPMPC_FAST_MAXTHREADS, 1) void rollout_fast_kernel(
             // squared distances to the real point, the bank-0 row's point and the bank-1 row's point (the latter only
             // needed once n_h > 64)
             double q[D], q0[D], q1[D], arg[3], ee[3];
+            double ea = 0.0, eb = 0.0;                            // GRID: the two axis factors of the real point's kernel value
             arg[0] = -0.5 * kern_sqdist<D>(xr, xi, il2, q);
             arg[1] = -0.5 * kern_sqdist<D>(xh0, xi, il2, q0);
             arg[2] = -0.5 * kern_sqdist<D>(xh1, xi, il2, q1);
-            if (two) {                                            // uniform
+            if constexpr (GRID) {
+                // separable row: exp(-(s0 + s1)/2) = ea * eb; the two factors are what the axis products need
+                const double r0 = xr[0] - xi[0], r1 = xr[1] - xi[1];
+                const double a4[4] = {-0.5 * r0 * q[0], -0.5 * r1 * q[1], arg[1], arg[2]};
+                double e4[4];
+                if (two) {                                        // uniform
+                    expn_neg<4>(a4, e4);
+                } else {
+                    const double a3[3] = {a4[0], a4[1], a4[2]};
+                    double e3[3];
+                    expn_neg<3>(a3, e3);
+                    e4[0] = e3[0], e4[1] = e3[1], e4[2] = e3[2], e4[3] = 0.0;
+                }
+                ea = e4[0], eb = e4[1], ee[0] = 0.0, ee[1] = e4[2], ee[2] = e4[3];
+            } else if (two) {                                     // uniform
                 exp3_neg(arg, ee);
             } else {
                 const double arg2[2] = {arg[0], arg[1]};
@@ -508,7 +562,12 @@ __global__ __launch_bounds__(GPMPC_FAST_MAXTHREADS, 1) void rollout_fast_kernel(
             const double k = os * ee[0];
             const double k0 = ex0 ? os * ee[1] : 0.0;
             const double k1 = ex1 ? os * ee[2] : 0.0;
-            kr[0] = k, kr[1] = k * q[0], kr[2] = k * q[1];        // lanes >= NR: never used as pivots
+            if constexpr (GRID) {
+                kr[0] = ea, kr[1] = eb, kr[2] = 0.0;              // the axis factors travel in kr; q[] is needed below
+                gq0 = q[0], gq1 = q[1];
+            } else {
+                kr[0] = k, kr[1] = k * q[0], kr[2] = k * q[1];    // lanes >= NR: never used as pivots
+            }
             const double A0 = (a0t == 0) ? 1.0 : ((a0t == 1) ? -q0[0] : -q0[1]);
             v0[0] = k0 * A0;
             v0[1] = k0 * fma(A0, q0[0], cA0[0]);
@@ -527,7 +586,29 @@ __global__ __launch_bounds__(GPMPC_FAST_MAXTHREADS, 1) void rollout_fast_kernel(
 #ifdef GPMPC_ABLATE_VR
         vr[0] = kr[0];
 #else
-        {
+        if constexpr (GRID) {
+            // v_r = W k_r with the grid root W = D^-1/2 (Qa (x) Qb)^T (plan, gpmpc_device.hpp): the three kernel rows are
+            // os (ea (x) eb), os (ea q0 (x) eb), os (ea (x) eb q1), so W k_r needs Qa^T {ea, ea q0} (N0 pivots) and
+            // Qb^T {eb, eb q1} (N1 pivots) instead of NR pivots x three right-hand sides.  Axis-0 values sit in the lanes
+            // (a', 0) = N1 a', axis-1 values in the lanes (0, c') = c'.
+            static_assert(T == 3, "written for three right-hand sides");
+            const double eaq = kr[0] * gq0, ebq = kr[1] * gq1;
+            double Ra[3][2], Rb[3][2];
+#pragma unroll
+            for (int blk = 0; blk < (N1 * (N0 - 1)) / 16 + 1; ++blk) {
+                Ra[blk][0] = bpermute_f64(kr[0], bp_addr + 64 * blk);
+                Ra[blk][1] = bpermute_f64(eaq, bp_addr + 64 * blk);
+            }
+            Rb[0][0] = bpermute_f64(kr[1], bp_addr);
+            Rb[0][1] = bpermute_f64(ebq, bp_addr);
+            double PA0 = 0.0, PA1 = 0.0, PB0 = 0.0, PB1 = 0.0;
+            grid_axis_product<N0, N1>(PA0, PA1, Ra, qa);
+            grid_axis_product<N1, 1>(PB0, PB1, Rb, qb);
+            const double s0 = dsc * PB0;
+            vr[0] = s0 * PA0;
+            vr[1] = s0 * PA1;
+            vr[2] = dsc * PA0 * PB1;
+        } else {
             // k_r replicated to all four DPP rows (16 real points per register), then one v_fmac_f64_dpp per pivot and
             // right-hand side against the lane's own row of L_rr^-1 (two entries per ds_read_b128): no LDS broadcasts
             static_assert(T == 3, "dpp_matvec is written for three right-hand sides");
@@ -964,16 +1045,16 @@ size_t rollout_fast_workspace_bytes(const gpmpc_gp_desc_t* gp, int64_t Ns, int H
     return (size_t)Ns * gp->g_ny * (size_t)lhh_doubles(3 * (H - 1), kRingGlobal) * sizeof(double);
 }
 
-template <int NR, int G_NY, int ENV>
+template <int NR, int G_NY, int ENV, bool GRID>
 static int launch_fast(RolloutArgs& args, const FastPlan& fp, hipStream_t st) {
     const long nblk = (args.Ns + fp.spw - 1) / fp.spw;
     const dim3 grid((unsigned)nblk), block(64 * fp.waves);
     if (fp.lhh_lds) {
-        auto k = rollout_fast_kernel<3, NR, G_NY, ENV, true>;
+        auto k = rollout_fast_kernel<3, NR, G_NY, ENV, true, GRID>;
         GPMPC_HIP_CHECK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fp.lds_bytes));
         hipLaunchKernelGGL(k, grid, block, fp.lds_bytes, st, args);
     } else {
-        auto k = rollout_fast_kernel<3, NR, G_NY, ENV, false>;
+        auto k = rollout_fast_kernel<3, NR, G_NY, ENV, false, GRID>;
         GPMPC_HIP_CHECK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fp.lds_bytes));
         hipLaunchKernelGGL(k, grid, block, fp.lds_bytes, st, args);
     }
@@ -996,8 +1077,15 @@ int rollout_fast_launch(const gpmpc_gp_desc_t* gp, const gpmpc_env_desc_t* env, 
         if (!ws || ws_bytes < rollout_fast_workspace_bytes(gp, args.Ns, args.H))
             return fail(GPMPC_E_WORKSPACE, "gpmpc_rollout: workspace too small");
     }
-    if (env->env_id == GPMPC_ENV_PENDULUM1D) return launch_fast<36, 1, GPMPC_ENV_PENDULUM1D>(args, fp, st);
-    return launch_fast<45, 3, GPMPC_ENV_CAR_RESIDUAL>(args, fp, st);
+    // the grid root of the plan (separable real-data kernel row) when the real inputs are the reference's tensor grid
+    const char* eg = std::getenv("GPMPC_DISABLE_GRID_ROOT");
+    const bool grid = !(eg && eg[0] == '1') && gp->grid_n1 == 9 && gp->grid_n0 * 9 == gp->N_r &&
+                      plan_has_grid_root(gp->grid_n0, gp->grid_n1, gp->real_has_grad);
+    if (env->env_id == GPMPC_ENV_PENDULUM1D)
+        return grid ? launch_fast<36, 1, GPMPC_ENV_PENDULUM1D, true>(args, fp, st)
+                    : launch_fast<36, 1, GPMPC_ENV_PENDULUM1D, false>(args, fp, st);
+    return grid ? launch_fast<45, 3, GPMPC_ENV_CAR_RESIDUAL, true>(args, fp, st)
+                : launch_fast<45, 3, GPMPC_ENV_CAR_RESIDUAL, false>(args, fp, st);
 }
 
 }  // namespace gpmpc

@@ -423,6 +423,33 @@ def test_generic_kernels_agree_with_tuned_kernels(sg, pname, Ns, H, nograd, monk
     np.testing.assert_allclose(Y_fast, Y_gen, rtol=1e-7, atol=1e-11)
 
 
+@pytest.mark.parametrize("pname,Ns,H", [("params_pendulum1D_samples", 12, 25), ("params_car_residual_fs", 5, 24)])
+def test_tuned_kernel_grid_root_vs_cholesky_root(sg, pname, Ns, H, monkeypatch):
+    """The tuned kernel conditions on the real data through the plan's grid root W = D^-1/2 (Qa (x) Qb)^T (tensor-grid
+    real inputs, separable kernel row) or, with GPMPC_DISABLE_GRID_ROOT=1, through L_rr^-1.  Both satisfy
+    W^T W = (K_rr + s2 I)^-1, so trajectories and samples agree to round-off, and both match the oracle."""
+    from sampling_gpmpc_amd.rollout import forward_sampling_rollout
+    p = fs_params(pname, Ns, H, nograd=False, beta=(3.0 if "car" in pname else None))
+    agent, oagent = make_agents(sg, p)
+    u_ff = synthetic_u_ff(agent.nu, H)
+    lib = sg._lib.load()
+    X_grid, Y_grid = forward_sampling_rollout(agent, u_ff, return_samples=True)
+    assert lib.gpmpc_debug_last_rollout_path() == 1
+    assert agent._plan(use_grad=True).desc.grid_n1 == 9, "the facade did not detect the reference's training grid"
+    monkeypatch.setenv("GPMPC_DISABLE_GRID_ROOT", "1")
+    agent2, _ = make_agents(sg, p, erv=agent.epistimic_random_vector.cpu().numpy())
+    X_chol, Y_chol = forward_sampling_rollout(agent2, u_ff, return_samples=True)
+    assert lib.gpmpc_debug_last_rollout_path() == 1
+    Xo, Yo = ao.forward_sampling_rollout(oagent, u_ff, return_samples=True)
+    print(f"{pname} Ns={Ns} H={H}: grid root vs Cholesky root max abs diff X {np.abs(X_grid - X_chol).max():.2e} "
+          f"Y {np.abs(Y_grid - Y_chol).max():.2e}; vs oracle {relerr(X_grid, Xo):.2e} / {relerr(X_chol, Xo):.2e}")
+    assert np.abs(X_grid - X_chol).max() > 0.0, "the two roots produced bit-identical results: the knob is not wired"
+    assert relerr(X_grid, Xo) < RTOL_TRAJ and relerr(X_chol, Xo) < RTOL_TRAJ
+    np.testing.assert_allclose(X_grid, X_chol, rtol=1e-9, atol=1e-11)
+    np.testing.assert_allclose(Y_grid, Y_chol, rtol=1e-7, atol=1e-11)
+    np.testing.assert_allclose(Y_grid, Yo, rtol=1e-4, atol=1e-8)
+
+
 @pytest.mark.parametrize("pname,Ns,H", [
     ("params_pendulum1D_samples", 1, 2),        # a single sample, the shortest horizon that appends (n_h max 3)
     ("params_pendulum1D_samples", 5, 43),       # longest horizon of the tuned kernel (n_h max 126 of 128)
