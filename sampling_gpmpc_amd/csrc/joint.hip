@@ -64,6 +64,36 @@ __device__ long long g_joint_phase[16];
 #define JPH(idx)
 #endif
 
+#ifndef GPMPC_JOINT_LDS_BCAST
+#define GPMPC_JOINT_LDS_BCAST 0          // 1: the broadcast-ds_read_b128 update (comparison builds, tools/joint_sweep.sh)
+#endif
+// acc[q] -= w * p[q] for the 16 pivot-row entries of one column, p held ONE ENTRY PER LANE (lane i of every DPP row =
+// entry i): v_fmac_f64_dpp row_newbcast:q broadcasts entry q without leaving the VALU.  The broadcast ds_read_b128 form
+// (eight 1 KiB reads per 16 FMAs and wave) is bound by the LDS pipe the CU's waves share; this one needs a single
+// 512-byte ds_read_b64 per column and wave.
+__device__ __forceinline__ void fmac16_dpp(double (&acc)[16], double p, double w) {
+    asm("s_nop 1\n\t"
+        "v_fmac_f64_dpp %0, %16, -%17 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f64_dpp %1, %16, -%17 row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f64_dpp %2, %16, -%17 row_newbcast:2 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f64_dpp %3, %16, -%17 row_newbcast:3 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f64_dpp %4, %16, -%17 row_newbcast:4 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f64_dpp %5, %16, -%17 row_newbcast:5 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f64_dpp %6, %16, -%17 row_newbcast:6 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f64_dpp %7, %16, -%17 row_newbcast:7 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f64_dpp %8, %16, -%17 row_newbcast:8 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f64_dpp %9, %16, -%17 row_newbcast:9 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f64_dpp %10, %16, -%17 row_newbcast:10 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f64_dpp %11, %16, -%17 row_newbcast:11 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f64_dpp %12, %16, -%17 row_newbcast:12 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f64_dpp %13, %16, -%17 row_newbcast:13 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f64_dpp %14, %16, -%17 row_newbcast:14 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f64_dpp %15, %16, -%17 row_newbcast:15 row_mask:0xf bank_mask:0xf"
+        : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]), "+v"(acc[4]), "+v"(acc[5]), "+v"(acc[6]), "+v"(acc[7]),
+          "+v"(acc[8]), "+v"(acc[9]), "+v"(acc[10]), "+v"(acc[11]), "+v"(acc[12]), "+v"(acc[13]), "+v"(acc[14]), "+v"(acc[15])
+        : "v"(p), "v"(w));
+}
+
 template <int NB, int RPT, int KC, int NT>
 __device__ __forceinline__ void block_update(const double* __restrict__ W, int ld, int kdone,
                                              const double* __restrict__ P, long p_rs, long p_cs, int nb,
@@ -136,6 +166,13 @@ __device__ __forceinline__ void block_update(const double* __restrict__ W, int l
                     fetch_rows(k0 + kb + (RD - 1) * KU, ring[(r + RD - 1) % RD]);
 #pragma unroll
                     for (int j = 0; j < KU; ++j) {
+                        if constexpr (NB == 16 && !GPMPC_JOINT_LDS_BCAST) {
+                            if (kb + j < kc) {
+                                const double pk = piv[kb + j][tid & 15];
+#pragma unroll
+                                for (int rs = 0; rs < RPT; ++rs) fmac16_dpp(acc[rs], pk, ring[r][j][rs]);
+                            }
+                        } else
                         if (kb + j < kc) {
 #pragma unroll
                             for (int qq = 0; qq < NB / 2; ++qq) {
