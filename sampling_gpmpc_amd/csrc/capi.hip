@@ -12,42 +12,55 @@ std::string& last_error() {
 // plan: factorise K_rr + Sigma_r once per output (shared by all samples).  One workgroup per output; the matrix
 // lives in LDS (n_r <= 143 -> <= 160 KiB).  Right-looking Cholesky; then L^-1 column by column (thread per column).
 // ---------------------------------------------------------------------------------------------------------------
-// cyclic Jacobi eigen-decomposition of a symmetric n x n matrix (n <= 16, row stride 16), one thread: A -> diagonal
-// (eigenvalues), V -> eigenvectors in columns.  High relative accuracy for the SPD kernel matrices it is used on.
-__device__ void jacobi_eig16(double* A, int n, double* V) {
-    for (int i = 0; i < n; ++i)
-        for (int j = 0; j < n; ++j) V[i * 16 + j] = (i == j) ? 1.0 : 0.0;
+// cyclic Jacobi eigen-decomposition of a symmetric n x n matrix (n <= 16, row stride 16) in LDS, executed by ONE WAVE
+// (lane k owns element k of the rotated rows / columns): A -> diagonal (eigenvalues), V -> eigenvectors in columns.
+// High relative accuracy for the SPD kernel matrices it is used on.
+__device__ void jacobi_eig16_wave(double* A, int n, double* V) {
+    const int lane = threadIdx.x & 63;
+    auto sync = [] {
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    };
+    for (int e = lane; e < n * n; e += 64) V[(e / n) * 16 + (e % n)] = ((e / n) == (e % n)) ? 1.0 : 0.0;
+    sync();
     for (int sweep = 0; sweep < 30; ++sweep) {
         double off = 0.0, dia = 0.0;
-        for (int i = 0; i < n; ++i) {
-            dia += A[i * 16 + i] * A[i * 16 + i];
-            for (int j = 0; j < i; ++j) off += A[i * 16 + j] * A[i * 16 + j];
+        if (lane < n) {
+            dia = A[lane * 16 + lane] * A[lane * 16 + lane];
+            for (int j = 0; j < lane; ++j) off += A[lane * 16 + j] * A[lane * 16 + j];
         }
-        if (off <= 1e-60 * dia || off == 0.0) break;
+        off = wave_sum_shfl(off);
+        dia = wave_sum_shfl(dia);
+        if (off <= 1e-34 * dia) break;                       // uniform
         for (int p = 0; p < n - 1; ++p)
             for (int q = p + 1; q < n; ++q) {
-                const double apq = A[p * 16 + q];
-                if (apq == 0.0) continue;
-                const double theta = (A[q * 16 + q] - A[p * 16 + p]) / (2.0 * apq);
-                const double t = ((theta >= 0.0) ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
-                const double c = 1.0 / sqrt(t * t + 1.0), sn = t * c;
-                for (int k = 0; k < n; ++k) {                // columns p, q
-                    const double akp = A[k * 16 + p], akq = A[k * 16 + q];
-                    A[k * 16 + p] = c * akp - sn * akq;
-                    A[k * 16 + q] = sn * akp + c * akq;
-                }
-                for (int k = 0; k < n; ++k) {                // rows p, q
-                    const double apk = A[p * 16 + k], aqk = A[q * 16 + k];
-                    A[p * 16 + k] = c * apk - sn * aqk;
-                    A[q * 16 + k] = sn * apk + c * aqk;
-                }
-                for (int k = 0; k < n; ++k) {
-                    const double vkp = V[k * 16 + p], vkq = V[k * 16 + q];
-                    V[k * 16 + p] = c * vkp - sn * vkq;
-                    V[k * 16 + q] = sn * vkp + c * vkq;
+                const double apq = A[p * 16 + q];            // uniform (broadcast reads)
+                if (apq != 0.0) {
+                    const double theta = (A[q * 16 + q] - A[p * 16 + p]) / (2.0 * apq);
+                    const double t = ((theta >= 0.0) ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+                    const double c = 1.0 / sqrt(t * t + 1.0), sn = t * c;
+                    sync();
+                    if (lane < n) {                          // columns p, q (element k = lane) and the eigenvectors
+                        const int k = lane;
+                        const double akp = A[k * 16 + p], akq = A[k * 16 + q];
+                        A[k * 16 + p] = c * akp - sn * akq;
+                        A[k * 16 + q] = sn * akp + c * akq;
+                        const double vkp = V[k * 16 + p], vkq = V[k * 16 + q];
+                        V[k * 16 + p] = c * vkp - sn * vkq;
+                        V[k * 16 + q] = sn * vkp + c * vkq;
+                    }
+                    sync();
+                    if (lane < n) {                          // rows p, q
+                        const int k = lane;
+                        const double apk = A[p * 16 + k], aqk = A[q * 16 + k];
+                        A[p * 16 + k] = c * apk - sn * aqk;
+                        A[q * 16 + k] = sn * apk + c * aqk;
+                    }
+                    sync();
                 }
             }
     }
+    sync();
 }
 
 template <int D>
@@ -159,8 +172,8 @@ __global__ __launch_bounds__(256) void plan_kernel(GpParams gp, const double* __
             Kb[i * 16 + j] = exp(-0.5 * r * r * inv_l2[1]);
         }
         __syncthreads();
-        if (tid == 0) jacobi_eig16(Ka, n0, Va);             // eigenvalues end up on the diagonal of Ka / Kb,
-        if (tid == 64) jacobi_eig16(Kb, n1, Vb);            // eigenvectors in the columns of Va / Vb
+        if (tid < 64) jacobi_eig16_wave(Ka, n0, Va);        // eigenvalues end up on the diagonal of Ka / Kb,
+        else if (tid < 128) jacobi_eig16_wave(Kb, n1, Vb);  // eigenvectors in the columns of Va / Vb (one wave each)
         __syncthreads();
         for (int e = tid; e < n0 * n0; e += nt) Qa[e] = Va[(e / n0) * 16 + (e % n0)];
         for (int e = tid; e < n1 * n1; e += nt) Qb[e] = Vb[(e / n1) * 16 + (e % n1)];

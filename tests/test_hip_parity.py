@@ -83,7 +83,10 @@ def test_plan_matches_dense_cholesky(sg, pname, use_grad):
     hy = GPHyper.from_params(p, use_grad)
     n = plan.n_r
     buf = plan.buf.cpu()
-    per = 2 * n * n + 2 * n
+    n0, n1 = int(plan.desc.grid_n0), int(plan.desc.grid_n1)
+    assert (n0, n1) == ((4, 9) if "pendulum" in pname else (5, 9)), "training grid not detected"
+    grid = (n0 * n0 + n1 * n1 + 2 * n0 * n1 + 1) & ~1            # the plan's grid-root block (gpmpc_device.hpp)
+    per = 2 * n * n + 2 * n + grid
     for o in range(hy.ell.shape[0]):
         K = scaled_rbf_kernel(X, X, hy.ell[o], hy.outputscale[o], use_grad)
         T = hy.T
@@ -99,7 +102,20 @@ def test_plan_matches_dense_cholesky(sg, pname, use_grad):
         np.testing.assert_allclose(blk[2 * n * n:2 * n * n + n].numpy(), (Linv @ yo).numpy(), rtol=1e-7,
                                    atol=1e-9 * float((Linv @ yo).abs().max()))
         alpha = torch.cholesky_solve(yo.unsqueeze(-1), L).squeeze(-1)
-        np.testing.assert_allclose(blk[2 * n * n + n:].numpy(), alpha.numpy(), rtol=1e-6, atol=1e-7 * float(alpha.abs().max()))
+        np.testing.assert_allclose(blk[2 * n * n + n:2 * n * n + 2 * n].numpy(), alpha.numpy(), rtol=1e-6,
+                                   atol=1e-7 * float(alpha.abs().max()))
+        # grid root W = D^-1/2 (Qa (x) Qb)^T: W^T W = (K_rr + s2 I)^-1 and wE = W y (value-only real labels: n == N_r)
+        assert n == n0 * n1
+        g = blk[2 * n * n + 2 * n:]
+        Qa, Qb = g[:n0 * n0].reshape(n0, n0), g[n0 * n0:n0 * n0 + n1 * n1].reshape(n1, n1)
+        dsc, wE = g[n0 * n0 + n1 * n1:][:n], g[n0 * n0 + n1 * n1 + n:][:n]
+        np.testing.assert_allclose((Qa.T @ Qa).numpy(), np.eye(n0), atol=1e-13)
+        np.testing.assert_allclose((Qb.T @ Qb).numpy(), np.eye(n1), atol=1e-13)
+        W = torch.diag(dsc / hy.outputscale[o]) @ torch.kron(Qa, Qb).T
+        Kinv = torch.cholesky_inverse(L)
+        assert float((W.T @ W - Kinv).abs().max()) < 1e-8 * float(Kinv.abs().max())
+        assert float((W @ K @ W.T - torch.eye(n, dtype=K.dtype)).abs().max()) < 1e-9
+        np.testing.assert_allclose(wE.numpy(), (W @ yo).numpy(), rtol=1e-7, atol=1e-9 * float((W @ yo).abs().max()))
 
 
 @pytest.mark.parametrize("tag,pname", [("R_pendulum1D", "params_pendulum1D_samples"),
