@@ -457,27 +457,16 @@ __global__ __launch_bounds__(GPMPC_FAST_MAXTHREADS, 1) void rollout_fast_kernel(
     const int a0t = lane - (lane / T) * T, a1t = (lane + kWave) - ((lane + kWave) / T) * T;   // task of this lane's rows
     const double cA0[2] = {(a0t == 1) ? il2[0] : 0.0, (a0t == 2) ? il2[1] : 0.0};              // [a == b > 0] / l_a^2
     const double cA1[2] = {(a1t == 1) ? il2[0] : 0.0, (a1t == 2) ? il2[1] : 0.0};
-    // The chain's base samples (H*T <= 129 doubles) and the input sequence (H*NU <= 86) are fetched ONCE, one entry per
+    // The chain's base samples (H*T doubles) and the input sequence (H*NU) are fetched ONCE, one step per
     // lane, and handed out with v_readlane inside the loop: a global load inside the step loop of a single wave costs
     // its full latency (the three z loads were serialised behind s_waitcnt vmcnt(0), which also waits for the
     // trajectory stores of the step).  With L_hh in LDS the loop then contains no vector-memory load at all.
-    constexpr int ZREGS = 3, UREGS = 2;
-    double zq[ZREGS], uq[UREGS];
+    // layout: register c, lane t = component c of step t (H <= 43 < 64), so a pick is two v_readlane, no register select
+    double zq[T], uq[NU];
 #pragma unroll
-    for (int r = 0; r < ZREGS; ++r) {
-        const int j = r * kWave + lane, tt = j / T, c = j - tt * T;
-        zq[r] = (j < H * T) ? a.z[(long)tt * a.z_step_stride + (s * G_NY + o) * T + c] : 0.0;
-    }
+    for (int c = 0; c < T; ++c) zq[c] = (lane < H) ? a.z[(long)lane * a.z_step_stride + (s * G_NY + o) * T + c] : 0.0;
 #pragma unroll
-    for (int r = 0; r < UREGS; ++r) {
-        const int j = r * kWave + lane;
-        uq[r] = (j < H * NU) ? a.u_ff[j] : 0.0;
-    }
-    auto lane_pick = [&](const double* regs, int nregs, int j) -> double {       // j uniform: entry j of a lane-indexed table
-        double v = regs[0];
-        for (int r = 1; r < nregs; ++r) v = ((j >> 6) == r) ? regs[r] : v;
-        return readlane_f64(v, j & 63);
-    };
+    for (int i = 0; i < NU; ++i) uq[i] = (lane < H) ? a.u_ff[lane * NU + i] : 0.0;
     FPHASE_DECL;
 
 #pragma unroll 1
@@ -487,7 +476,7 @@ __global__ __launch_bounds__(GPMPC_FAST_MAXTHREADS, 1) void rollout_fast_kernel(
         {
             double uf[NU];
 #pragma unroll
-            for (int i = 0; i < NU; ++i) uf[i] = lane_pick(uq, UREGS, t * NU + i);
+            for (int i = 0; i < NU; ++i) uf[i] = readlane_f64(uq[i], t);
 #pragma unroll
             for (int i = 0; i < NU; ++i) {
                 if (a.env.use_feedback) {
@@ -784,7 +773,7 @@ __global__ __launch_bounds__(GPMPC_FAST_MAXTHREADS, 1) void rollout_fast_kernel(
         }
         double zt[T];
 #pragma unroll
-        for (int c = 0; c < T; ++c) zt[c] = lane_pick(zq, ZREGS, t * T + c);
+        for (int c = 0; c < T; ++c) zt[c] = readlane_f64(zq[c], t);
         double y[T];
 #pragma unroll
         for (int b = 0; b < T; ++b) {
@@ -876,6 +865,17 @@ __global__ __launch_bounds__(GPMPC_FAST_MAXTHREADS, 1) void rollout_fast_kernel(
                             Lhr0[2 * ip + 1] = vv.y;
                         }
                         if (NR & 1) Lhr0[NR - 1] = src[NR - 1];
+                        if constexpr (LHH_LDS) {
+                            // ... and read the diagonal-block segment of their new row back (entries at / right of the
+                            // diagonal: the zero pair); same wave, LDS operations complete in order
+                            const int r = lane, qb = 8 * (r >> 4);
+#pragma unroll
+                            for (int q = 0; q < 8; ++q) {
+                                const double2_t pr = *((2 * (qb + q) < r) ? (row0 + qb + q) : zero2);
+                                dg0[2 * q] = pr.x;
+                                dg0[2 * q + 1] = pr.y;
+                            }
+                        }
                     }
                 }
                 if (base + T > kWave) {                                   // uniform: a new row lives in bank 1 (LDS)
@@ -885,17 +885,6 @@ __global__ __launch_bounds__(GPMPC_FAST_MAXTHREADS, 1) void rollout_fast_kernel(
                     }
                 }
                 if constexpr (LHH_LDS) {
-                    // the owners read the diagonal-block segment of their new row back (entries at / right of the
-                    // diagonal: the zero pair); same wave, LDS operations complete in order
-                    if (new0) {
-                        const int r = lane, qb = 8 * (r >> 4);
-#pragma unroll
-                        for (int q = 0; q < 8; ++q) {
-                            const double2_t pr = *((2 * (qb + q) < r) ? (row0 + qb + q) : zero2);
-                            dg0[2 * q] = pr.x;
-                            dg0[2 * q + 1] = pr.y;
-                        }
-                    }
                     if (base + T > kWave) {
                         if (new1) {
                             const int r = lane + kWave, qb = 8 * (r >> 4);
