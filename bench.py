@@ -14,7 +14,8 @@ are synthetic and resident in HBM before the timed region
 
 Prints ONE JSON line on rank 0 (see the keys below).  `roofline` is for the dominant kernel (rollout_kernel):
 algorithmic FP64 FLOP per launch (2.55e4 FLOP per trajectory-step for this config) divided by
-the launch duration measured with HIP events on the launch stream.  `cpu_baseline` times the CPU oracle (the
+the launch duration measured with HIP events on the launch stream (one event pair per launch, in a pass of the same
+launches right after the timed region; the timed region itself carries one event at either end).  `cpu_baseline` times the CPU oracle (the
 reference-faithful from-scratch algorithm, torch CPU FP64) on rank 0 at N = 1 on a bounded sample of the same
 workload.
 """
@@ -112,20 +113,31 @@ def main():
     for _ in range(a.warmup):
         step()
     fence()
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(a.steps)]
+    # timed region: EXACTLY a.steps steps between two fences; one HIP event at either end on the launch stream (per-launch
+    # events inside the loop cost ~6 us per step: every record is a queue packet the next dispatch waits for)
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
+    ev0.record()
     for k in range(a.steps):
-        ev[k][0].record()
         X = runner.launch()
-        ev[k][1].record()
         if world > 1:
             dist.all_gather_into_tensor(tube, X)
+    ev1.record()
     fence()
     wall = time.perf_counter() - t0
     if world > 1:
         t = torch.tensor([wall], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         wall = float(t.item())
+    region_ms = ev0.elapsed_time(ev1) / a.steps             # per step over the timed region (includes the collective)
+    # the rollout kernel's launch duration, one HIP event pair per launch (what rocprofv3 --kernel-trace reports per
+    # dispatch): a second, untimed pass of the same launches, so that the instrumentation stays out of the timed region
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(a.steps)]
+    for k in range(a.steps):
+        ev[k][0].record()
+        runner.launch()
+        ev[k][1].record()
+    torch.cuda.synchronize()
     kern_ms = float(np.mean([s.elapsed_time(e) for s, e in ev]))
     bits = int(runner.info.max().item())
     assert torch.isfinite(runner.X_traj).all() and not (bits & (_lib.INFO_TRAIN_CHOL_FAIL | _lib.INFO_ROOT_FAIL)), bits
@@ -161,7 +173,8 @@ def main():
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / FP64_PEAK_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_hbm_bytes_per_launch": MIN_HBM_BYTES_PER_TRAJ_STEP["pendulum1D_R_H30"] * Ns * H,
-                         "kernel": "rollout_fast_kernel<3,36,1,pendulum1D,L_hh in LDS>", "kernel_ms": kern_ms,
+                         "kernel": "rollout_fast_kernel<3,36,1,pendulum1D,L_hh in LDS,grid root>", "kernel_ms": kern_ms,
+                         "timed_region_ms_per_step_hip_events": region_ms,
                          "flop_per_launch": flop,
                          "note": "FP64 (vector FMA; FP64 MFMA peak is the same 78.6 TFLOP/s on MI355X); algorithmic "
                                  "FLOP = 2.55e4 per trajectory-step (SURVEY 8d) x Ns x H; min HBM traffic 80 B per "
