@@ -169,13 +169,13 @@ __device__ __forceinline__ void fmac2_dpp_bcast(double& acc0, double& acc1, doub
         : "+v"(acc0), "+v"(acc1)
         : "v"(l), "v"(R0), "v"(R1), "n"(I));
 }
-// P0[lane] = sum_j e0[lane STRIDE*j] * coef[j], P1 likewise with e1; the sources were replicated block-wise (Rb[blk][0/1])
-template <int N, int STRIDE, int J = 0>
+// P0[lane] = sum_j e0[lane OFS + STRIDE*j] * coef[j], P1 likewise with e1; the sources were replicated block-wise (Rb[blk][0/1])
+template <int N, int STRIDE, int OFS, int J = 0>
 __device__ __forceinline__ void grid_axis_product(double& P0, double& P1, const double (&Rb)[3][2], const double (&coef)[N]) {
     if constexpr (J < N) {
-        constexpr int src = STRIDE * J;
+        constexpr int src = OFS + STRIDE * J;
         fmac2_dpp_bcast<src % 16>(P0, P1, Rb[src / 16][0], Rb[src / 16][1], coef[J]);
-        grid_axis_product<N, STRIDE, J + 1>(P0, P1, Rb, coef);
+        grid_axis_product<N, STRIDE, OFS, J + 1>(P0, P1, Rb, coef);
     }
 }
 
@@ -366,7 +366,7 @@ template <int T, int NR, int G_NY, int ENV, bool LHH_LDS, bool GRID>
 __global__ __launch_bounds__(GPMPC_FAST_MAXTHREADS, 1) void rollout_fast_kernel(const RolloutArgs a) {
     constexpr int D = 2;
     constexpr int N1 = 9, N0 = NR / N1;                           // GRID: the real inputs are meshgrid(axis0[N0], axis1[N1], "ij")
-    static_assert(N0 * N1 == NR, "the BASELINE real-data grids have 9 points on axis 1");
+    static_assert(N0 * N1 == NR && N0 + N1 <= 16, "the BASELINE real-data grids have 9 points on axis 1");
     constexpr int NS = T * (T + 1) / 2;
     constexpr int NX = (ENV == GPMPC_ENV_PENDULUM1D) ? 2 : 4;
     constexpr int NU = (ENV == GPMPC_ENV_PENDULUM1D) ? 1 : 2;
@@ -427,6 +427,11 @@ __global__ __launch_bounds__(GPMPC_FAST_MAXTHREADS, 1) void rollout_fast_kernel(
         for (int j = 0; j < N1; ++j) qb[j] = plan_grid_Qb(a.plan, gp, o)[j * N1 + gc];
         dsc = plan_grid_dsc(a.plan, gp, o)[lr];
     }
+    // GRID: the N0 + N1 distinct axis factors of the real data's kernel row are evaluated in ONE chain: lane j < N0 holds
+    // axis-0 point j (real point (j, 0) = N1 j), lane N0 + j axis-1 point j (real point (0, j) = j)
+    const bool g_ax0 = lane < N0;
+    const int g_pt = g_ax0 ? lane * N1 : ((lane < N0 + N1) ? lane - N0 : 0);
+    const double g_x = a.X_r[g_pt * D + (g_ax0 ? 0 : 1)], g_il2 = g_ax0 ? il2[0] : il2[1];
     // lane == row of L_rr^-1 (lanes >= NR read row 0 and discard the result)
     const double2_t* linvrow = reinterpret_cast<const double2_t*>(Linv_all + ((long)o * NR + ((lane < NR) ? lane : 0)) * NRS);
 
@@ -512,7 +517,7 @@ __global__ __launch_bounds__(GPMPC_FAST_MAXTHREADS, 1) void rollout_fast_kernel(
         const bool two = n_h > kWave;
         const bool ex0 = lane < n_h, ex1 = lane + kWave < n_h;
         double kr[T], v0[T], v1[T];                               // v0 / v1: rows lane / lane+64 of k_h, then rhs, then v_h
-        double gq0 = 0.0, gq1 = 0.0;
+        double gq = 0.0;
         // cov(task_a(row point), task_b(test point)) = k * (A_a * B_b + [a == b > 0] / l_a^2) with A_0 = B_0 = 1,
         // A_a = -q_a, B_b = +q_b (kern_entry): the row's task enters through a per-lane select of A and a
         // per-lane constant, so the evaluation is branch-free (the task-dependent branches of kern_entry cost ~17
@@ -522,24 +527,25 @@ __global__ __launch_bounds__(GPMPC_FAST_MAXTHREADS, 1) void rollout_fast_kernel(
             // squared distances to the real point, the bank-0 row's point and the bank-1 row's point (the latter only
             // needed once n_h > 64)
             double q[D], q0[D], q1[D], arg[3], ee[3];
-            double ea = 0.0, eb = 0.0;                            // GRID: the two axis factors of the real point's kernel value
+            double ea = 0.0;                                      // GRID: this lane's axis factor (see g_ax0)
             arg[0] = -0.5 * kern_sqdist<D>(xr, xi, il2, q);
             arg[1] = -0.5 * kern_sqdist<D>(xh0, xi, il2, q0);
             arg[2] = -0.5 * kern_sqdist<D>(xh1, xi, il2, q1);
             if constexpr (GRID) {
-                // separable row: exp(-(s0 + s1)/2) = ea * eb; the two factors are what the axis products need
-                const double r0 = xr[0] - xi[0], r1 = xr[1] - xi[1];
-                const double a4[4] = {-0.5 * r0 * q[0], -0.5 * r1 * q[1], arg[1], arg[2]};
-                double e4[4];
+                // separable row: exp(-(s0 + s1)/2) = ea * eb; only the N0 + N1 axis factors are needed (one per lane)
+                const double gr = g_x - (g_ax0 ? xi[0] : xi[1]);
+                gq = gr * g_il2;
+                const double a3[3] = {-0.5 * gr * gq, arg[1], arg[2]};
+                double e3[3];
                 if (two) {                                        // uniform
-                    expn_neg<4>(a4, e4);
-                } else {
-                    const double a3[3] = {a4[0], a4[1], a4[2]};
-                    double e3[3];
                     expn_neg<3>(a3, e3);
-                    e4[0] = e3[0], e4[1] = e3[1], e4[2] = e3[2], e4[3] = 0.0;
+                } else {
+                    const double a2[2] = {a3[0], a3[1]};
+                    double e2[2];
+                    expn_neg<2>(a2, e2);
+                    e3[0] = e2[0], e3[1] = e2[1], e3[2] = 0.0;
                 }
-                ea = e4[0], eb = e4[1], ee[0] = 0.0, ee[1] = e4[2], ee[2] = e4[3];
+                ea = e3[0], ee[0] = 0.0, ee[1] = e3[1], ee[2] = e3[2];
             } else if (two) {                                     // uniform
                 exp3_neg(arg, ee);
             } else {
@@ -552,8 +558,7 @@ __global__ __launch_bounds__(GPMPC_FAST_MAXTHREADS, 1) void rollout_fast_kernel(
             const double k0 = ex0 ? os * ee[1] : 0.0;
             const double k1 = ex1 ? os * ee[2] : 0.0;
             if constexpr (GRID) {
-                kr[0] = ea, kr[1] = eb, kr[2] = 0.0;              // the axis factors travel in kr; q[] is needed below
-                gq0 = q[0], gq1 = q[1];
+                kr[0] = ea, kr[1] = ea * gq, kr[2] = 0.0;         // the axis factor and its derivative factor travel in kr
             } else {
                 kr[0] = k, kr[1] = k * q[0], kr[2] = k * q[1];    // lanes >= NR: never used as pivots
             }
@@ -578,21 +583,15 @@ __global__ __launch_bounds__(GPMPC_FAST_MAXTHREADS, 1) void rollout_fast_kernel(
         if constexpr (GRID) {
             // v_r = W k_r with the grid root W = D^-1/2 (Qa (x) Qb)^T (plan, gpmpc_device.hpp): the three kernel rows are
             // os (ea (x) eb), os (ea q0 (x) eb), os (ea (x) eb q1), so W k_r needs Qa^T {ea, ea q0} (N0 pivots) and
-            // Qb^T {eb, eb q1} (N1 pivots) instead of NR pivots x three right-hand sides.  Axis-0 values sit in the lanes
-            // (a', 0) = N1 a', axis-1 values in the lanes (0, c') = c'.
+            // Qb^T {eb, eb q1} (N1 pivots) instead of NR pivots x three right-hand sides.  Axis-0 factors sit in the lanes
+            // 0..N0-1, axis-1 factors in the lanes N0..N0+N1-1 (g_ax0 above).
             static_assert(T == 3, "written for three right-hand sides");
-            const double eaq = kr[0] * gq0, ebq = kr[1] * gq1;
-            double Ra[3][2], Rb[3][2];
-#pragma unroll
-            for (int blk = 0; blk < (N1 * (N0 - 1)) / 16 + 1; ++blk) {
-                Ra[blk][0] = bpermute_f64(kr[0], bp_addr + 64 * blk);
-                Ra[blk][1] = bpermute_f64(eaq, bp_addr + 64 * blk);
-            }
-            Rb[0][0] = bpermute_f64(kr[1], bp_addr);
-            Rb[0][1] = bpermute_f64(ebq, bp_addr);
+            double Rg[3][2];                                      // DPP block 0 holds all N0 + N1 <= 16 axis factors
+            Rg[0][0] = bpermute_f64(kr[0], bp_addr);
+            Rg[0][1] = bpermute_f64(kr[1], bp_addr);
             double PA0 = 0.0, PA1 = 0.0, PB0 = 0.0, PB1 = 0.0;
-            grid_axis_product<N0, N1>(PA0, PA1, Ra, qa);
-            grid_axis_product<N1, 1>(PB0, PB1, Rb, qb);
+            grid_axis_product<N0, 1, 0>(PA0, PA1, Rg, qa);
+            grid_axis_product<N1, 1, N0>(PB0, PB1, Rg, qb);
             const double s0 = dsc * PB0;
             vr[0] = s0 * PA0;
             vr[1] = s0 * PA1;
