@@ -453,7 +453,7 @@ __global__ __launch_bounds__(GPMPC_FAST_MAXTHREADS, 1) void rollout_fast_kernel(
 #pragma unroll
     for (int i = 0; i < 16; ++i) dg0[i] = 0.0, dg1[i] = 0.0;
     int info_acc = 0;
-    int n_h = 0;
+    int n_h = 0, ro_nh = 0;                                       // appended slots, lhh_rowofs(n_h)
     // this lane's L_hh rows (clamped into the allocation; non-existent rows are discarded by ex0 / ex1 below)
     const double2_t* row0 = reinterpret_cast<const double2_t*>(Lhh + lhh_rowofs(min(lane, nh_max - 1)));
     const double2_t* row1 = reinterpret_cast<const double2_t*>(Lhh + lhh_rowofs(min(lane + kWave, nh_max - 1)));
@@ -496,7 +496,11 @@ __global__ __launch_bounds__(GPMPC_FAST_MAXTHREADS, 1) void rollout_fast_kernel(
             xi[0] = (ENV == GPMPC_ENV_PENDULUM1D) ? x[0] : x[2];
             xi[1] = u[0];
         }
+#ifdef GPMPC_ABLATE_STORES
+        if (lane == 0 && o == 0 && t < 0) {
+#else
         if (lane == 0 && o == 0) {
+#endif
 #pragma unroll
             for (int d = 0; d < NX; ++d) a.X_traj[(s * NX + d) * (H + 1) + t] = x[d];
             if (a.Xi) {
@@ -789,7 +793,11 @@ __global__ __launch_bounds__(GPMPC_FAST_MAXTHREADS, 1) void rollout_fast_kernel(
             }
             y[b] = yb;
         }
+#ifdef GPMPC_ABLATE_STORES
+        if (lane == 0 && a.Y && t < 0) {
+#else
         if (lane == 0 && a.Y) {
+#endif
 #pragma unroll
             for (int b = 0; b < T; ++b) a.Y[((s * G_NY + o) * H + t) * T + b] = y[b];
         }
@@ -825,13 +833,15 @@ __global__ __launch_bounds__(GPMPC_FAST_MAXTHREADS, 1) void rollout_fast_kernel(
                 dd0[0] = 0.0, dd1[0] = 0.0;
                 dd0[1] = (a0 == 0) ? d10 : 0.0, dd1[1] = (a1 == 0) ? d10 : 0.0;
                 dd0[2] = (a0 == 0) ? d20 : ((a0 == 1) ? d21 : 0.0), dd1[2] = (a1 == 0) ? d20 : ((a1 == 1) ? d21 : 0.0);
+                int ro = ro_nh;                                   // = lhh_rowofs(base), carried from step to step
 #pragma unroll
                 for (int c = 0; c < T; ++c) {
-                    const int ro = lhh_rowofs(base + c);
+                    if (c > 0) ro += (base + c - 1) + ((base + c - 1) & 1);       // slot of row r: r rounded up to even
                     Lhh[min(ro + lane, last)] = fma(v0[c], dinv0, dd0[c]);
                     if (base + c > kWave) Lhh[min(ro + lane + kWave, last)] = fma(v1[c], dinv1, dd1[c]);      // uniform
                     dd0s[c] = dd0[c], dd1s[c] = dd1[c];
                 }
+                ro_nh = ro + (base + T - 1) + ((base + T - 1) & 1);
             }
             // (3) owners of the new rows: 1/L_pp, w_p, the point's GP input, and the L_hr row (= v_r^T)
             {
