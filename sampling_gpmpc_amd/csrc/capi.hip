@@ -161,6 +161,8 @@ __global__ __launch_bounds__(256) void plan_kernel(GpParams gp, const double* __
         double* Qb = Qa + n0 * n0;
         double* dsc = Qb + n1 * n1;
         double* wE = dsc + n0 * n1;
+        double* m1 = wE + n0 * n1;
+        double* m2 = m1 + n0 * n1;
         for (int e = tid; e < n0 * n0; e += nt) {
             const int i = e / n0, j = e - i * n0;
             const double r = X_r[(long)(i * n1) * D + 0] - X_r[(long)(j * n1) * D + 0];
@@ -189,6 +191,8 @@ __global__ __launch_bounds__(256) void plan_kernel(GpParams gp, const double* __
             }
             dsc[r] = gp.os[o] * dinv;
             wE[r] = dinv * acc;
+            m1[r] = (gp.os[o] * dinv) * (dinv * acc);
+            m2[r] = (gp.os[o] * dinv) * (gp.os[o] * dinv);
         }
     }
 }

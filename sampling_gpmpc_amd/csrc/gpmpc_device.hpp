@@ -34,13 +34,13 @@ struct EnvParams {
 //                                            | w (n_r) = L^-1 y | alpha (n_r) = L^-T w ]
 //                                            | grid root (value-only real labels on a tensor grid n0 x n1, else absent):
 //                                              Qa (n0*n0, row-major, column a = eigenvector a of the axis-0 kernel matrix)
-//                                              | Qb (n1*n1) | dsc (N_r) | wE (N_r) ]
+//                                              | Qb (n1*n1) | dsc (N_r) | wE (N_r) | m1 (N_r) = dsc wE | m2 (N_r) = dsc^2 ]
 // The grid root: K_rr + s2 I = os Ka (x) Kb + s2 I = (Qa (x) Qb) D (Qa (x) Qb)^T, D = os la_a lb_c + s2, so
 // W = D^-1/2 (Qa (x) Qb)^T satisfies W^T W = (K_rr + s2 I)^-1 and can stand in for L_rr^-1 everywhere (the Schur
 // complement, the posterior mean and covariance only see W^T W).  W k_r for a separable kernel row costs n0 + n1 pivots
 // instead of N_r.  dsc[r] = os / sqrt(D_r) (the outputscale of k_r folded in), wE = W y_r.
 __host__ __device__ inline long plan_doubles_per_output(int n_r, int n0 = 0, int n1 = 0) {
-    const long grid = (n0 > 0 && n1 > 0) ? ((long)n0 * n0 + (long)n1 * n1 + 2L * n0 * n1 + 1) & ~1L : 0;
+    const long grid = (n0 > 0 && n1 > 0) ? ((long)n0 * n0 + (long)n1 * n1 + 4L * n0 * n1 + 1) & ~1L : 0;
     return 2L * n_r * n_r + 2L * n_r + grid;
 }
 __device__ inline const double* plan_L(const double* plan, const GpParams& gp, int o) { return plan + o * gp.plan_stride; }
@@ -64,6 +64,14 @@ __device__ inline const double* plan_grid_dsc(const double* plan, const GpParams
 }
 __device__ inline const double* plan_grid_w(const double* plan, const GpParams& gp, int o) {
     return plan_grid_dsc(plan, gp, o) + (long)gp.grid_n0 * gp.grid_n1;
+}
+// m1 / m2: the mean and variance weights of the mode-I kernel (rollout_indep.hip): mu = sum_r m1_r A_a B_c,
+// k_r^T (K_rr + s2 I)^-1 k_r = sum_r m2_r A_a^2 B_c^2 with A = Qa^T ea, B = Qb^T eb
+__device__ inline const double* plan_grid_m1(const double* plan, const GpParams& gp, int o) {
+    return plan_grid_w(plan, gp, o) + (long)gp.grid_n0 * gp.grid_n1;
+}
+__device__ inline const double* plan_grid_m2(const double* plan, const GpParams& gp, int o) {
+    return plan_grid_m1(plan, gp, o) + (long)gp.grid_n0 * gp.grid_n1;
 }
 __host__ __device__ inline bool plan_has_grid_root(int grid_n0, int grid_n1, int real_has_grad) {
     return grid_n0 > 0 && grid_n1 > 0 && grid_n0 <= 16 && grid_n1 <= 16 && !real_has_grad;

@@ -484,7 +484,7 @@ int gpmpc_rollout(const gpmpc_gp_desc_t* gp, const gpmpc_env_desc_t* env, const 
     }
     if (rollout_indep_eligible(gp, env, mode)) {
         g_last_rollout_path = 2;
-        return rollout_indep_launch(env, args, st);
+        return rollout_indep_launch(gp, env, args, st);
     }
     g_last_rollout_path = 0;
     const int T = gp->T;

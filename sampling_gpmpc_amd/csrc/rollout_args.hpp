@@ -41,6 +41,6 @@ int rollout_fast_launch(const gpmpc_gp_desc_t* gp, const gpmpc_env_desc_t* env, 
 
 // mode-I thread-per-sample path (rollout_indep.hip)
 bool rollout_indep_eligible(const gpmpc_gp_desc_t* gp, const gpmpc_env_desc_t* env, int mode);
-int rollout_indep_launch(const gpmpc_env_desc_t* env, RolloutArgs& args, hipStream_t st);
+int rollout_indep_launch(const gpmpc_gp_desc_t* gp, const gpmpc_env_desc_t* env, RolloutArgs& args, hipStream_t st);
 
 }  // namespace gpmpc

@@ -157,6 +157,227 @@ __global__ __launch_bounds__(256) void rollout_indep_kernel(const RolloutArgs a)
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// rollout_indep_grid_kernel: the same rollout with the GRID ROOT of the real block (plan, gpmpc_device.hpp).
+// The real inputs are the tensor grid meshgrid(axis0[N0], axis1[N1]) with value-only labels, so
+//   (K_rr + s2 I)^-1 = W^T W,  W = D^-1/2 (Qa (x) Qb)^T,  k_r = os (ea (x) eb)   =>   W k_r = dsc . (A (x) B),
+//   A = Qa^T ea (N0 x N0),  B = Qb^T eb (N1 x N1),
+//   mu = sum_a A_a sum_c m1[a][c] B_c,      k_r^T (K_rr + s2 I)^-1 k_r = sum_a A_a^2 sum_c m2[a][c] B_c^2
+// with m1 = dsc . wE and m2 = dsc^2 from the plan: N0^2 + N1^2 + 2 N0 N1 + 2 N0 (+ N0 + N1 squares) = 220 FMA per
+// output and step (car) instead of the 1035 + 90 of the triangular product above - the posterior mean and variance
+// only see W^T W, so the two forms agree to round-off (tests/test_hip_parity.py compares both with the oracle).
+// Mapping: one SAMPLE per lane, one OUTPUT per wave (workgroup = G_NY waves = 64 samples; the outputs of a step meet
+// in a double-buffered LDS exchange, one barrier per step).  Every matrix entry is uniform across the wave and the
+// per-output tables are 1.9 KB, so they are read with scalar loads (constant address space -> s_load, K$-resident)
+// and enter the FMAs as SGPR operands: no LDS or vector-memory traffic for the factor at all.
+// ---------------------------------------------------------------------------------------------------------------
+typedef const double __attribute__((address_space(4))) cdouble_t;
+__device__ __forceinline__ const cdouble_t* as_uniform(const double* p) {
+    return reinterpret_cast<const cdouble_t*>(reinterpret_cast<uintptr_t>(p));
+}
+
+// exp(x) for x <= 0 (the arithmetic of expn_neg, gpmpc_device.hpp, as a single chain: with several waves per SIMD the
+// hardware interleaves the chains of different waves)
+__device__ __forceinline__ double exp_neg1(double x) {
+    const double log2e = bits_f64(0x3FF71547652B82FEull), nln2h = bits_f64(0xBFE62E42FEFA39EFull),
+                 nln2l = bits_f64(0xBC7ABC9E3B39803Full);
+    const double c2 = bits_f64(0x3FE000000000000Bull), c3 = bits_f64(0x3FC5555555555511ull), c4 = bits_f64(0x3FA55555555502A1ull),
+                 c5 = bits_f64(0x3F81111111122322ull), c6 = bits_f64(0x3F56C16C1852B7B0ull), c7 = bits_f64(0x3F2A01A014761F6Eull),
+                 c8 = bits_f64(0x3EFA01997C89E6B0ull), c9 = bits_f64(0x3EC71DEE623FDE64ull), c10 = bits_f64(0x3E928AF3FCA7AB0Cull),
+                 c11 = bits_f64(0x3E5ADE156A5DCB37ull);
+    const double n = rint(x * log2e);
+    double r = fma(n, nln2h, x);
+    r = fma(n, nln2l, r);
+    const double r2 = r * r, r4 = r2 * r2;
+    const double b0 = fma(fma(c3, r, c2), r2, 1.0 + r);
+    const double b1 = fma(fma(c7, r, c6), r2, fma(c5, r, c4));
+    const double b2 = fma(fma(c11, r, c10), r2, fma(c9, r, c8));
+    return ldexp(fma(fma(b2, r4, b1), r4, b0), (int)n);
+}
+
+template <int N>
+__device__ __forceinline__ void load_row(const cdouble_t* p, double (&r)[N]) {
+#pragma unroll
+    for (int k = 0; k < N; ++k) r[k] = p[k];
+}
+// a use of the row in SGPRs: the compiler's s_waitcnt for the row's scalar loads lands here
+template <int N>
+__device__ __forceinline__ void touch_row(double (&r)[N]) {
+#pragma unroll
+    for (int k = 0; k < N; ++k) asm volatile("" : "+s"(r[k]));
+}
+
+template <int ENV, int N0, int N1, int G_NY>
+__global__ __launch_bounds__(64 * G_NY) void rollout_indep_grid_kernel(const RolloutArgs a) {
+    constexpr int NR = N0 * N1;
+    constexpr int NX = (ENV == GPMPC_ENV_PENDULUM1D) ? 2 : 4;
+    constexpr int NU = (ENV == GPMPC_ENV_PENDULUM1D) ? 1 : 2;
+    __shared__ double ybuf[2][G_NY][kWave];
+    __shared__ int s_info[kWave];
+    const GpParams& gp = a.gp;
+    const int lane = threadIdx.x & 63;
+    const int o = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);       // this wave's output
+    const long sraw = (long)blockIdx.x * kWave + lane;
+    const bool active = sraw < a.Ns;
+    const long s = active ? sraw : a.Ns - 1;
+    const int H = a.H;
+    const cdouble_t* Xr = as_uniform(a.X_r);
+    const cdouble_t* Qa = as_uniform(plan_grid_Qa(a.plan, gp, o));
+    const cdouble_t* Qb = as_uniform(plan_grid_Qb(a.plan, gp, o));
+    const cdouble_t* m1 = as_uniform(plan_grid_m1(a.plan, gp, o));
+    const cdouble_t* m2 = as_uniform(plan_grid_m2(a.plan, gp, o));
+    const cdouble_t* uff = as_uniform(a.u_ff);
+    const double il0 = gp.inv_l2[o][0], il1 = gp.inv_l2[o][1], os = gp.os[o];
+    if (threadIdx.x < kWave) s_info[threadIdx.x] = 0;
+
+    double x[NX];
+#pragma unroll
+    for (int d = 0; d < NX; ++d) x[d] = a.x0[(a.x0_per_sample ? s * NX : 0) + d];
+    int info_acc = 0;
+
+#pragma unroll 1
+    for (int t = 0; t < H; ++t) {
+        double u[NU], xi[2];
+#pragma unroll
+        for (int i = 0; i < NU; ++i) {
+            const double uf = uff[t * NU + i];
+            if (a.env.use_feedback) {
+                double acc = 0.0;
+#pragma unroll
+                for (int j = 0; j < NX; ++j) acc += (a.env.x_goal[j] - x[j]) * a.env.K[i][j];
+                u[i] = -acc + uf;
+            } else {
+                u[i] = uf;
+            }
+        }
+        xi[0] = (ENV == GPMPC_ENV_PENDULUM1D) ? x[0] : x[2];
+        xi[1] = u[0];
+        if (active && o == 0) {
+#pragma unroll
+            for (int d = 0; d < NX; ++d) a.X_traj[(s * NX + d) * (H + 1) + t] = x[d];
+            if (a.Xi) {
+                a.Xi[(s * H + t) * 2 + 0] = xi[0];
+                a.Xi[(s * H + t) * 2 + 1] = xi[1];
+            }
+        }
+        const double z = a.z[(long)t * a.z_step_stride + (s * G_NY + o)];
+        // axis factors of the separable kernel row, then their images under the axis eigenvectors
+        double ea[N0], eb[N1];
+#pragma unroll
+        for (int q = 0; q < N0; ++q) {
+            const double r = Xr[(q * N1) * 2 + 0] - xi[0];
+            ea[q] = exp_neg1(-0.5 * r * r * il0);
+        }
+#pragma unroll
+        for (int c = 0; c < N1; ++c) {
+            const double r = Xr[c * 2 + 1] - xi[1];
+            eb[c] = exp_neg1(-0.5 * r * r * il1);
+        }
+        // Row-wise products with the table rows prefetched one row ahead (scalar loads return out of order, so a wait is
+        // always lgkmcnt(0): the row in use is touched - which places the wait - BEFORE the next row's load is issued,
+        // and the scheduling barriers keep at most two rows live in SGPRs).
+        double A[N0], B[N1];
+        {
+            double rc[N0], rn[N0];
+            load_row<N0>(Qa, rc);
+#pragma unroll
+            for (int i = 0; i < N0; ++i) {
+                touch_row<N0>(rc);
+                __builtin_amdgcn_sched_barrier(0);
+                if (i + 1 < N0) load_row<N0>(Qa + (i + 1) * N0, rn);
+#pragma unroll
+                for (int k = 0; k < N0; ++k) A[k] = (i == 0) ? rc[k] * ea[0] : fma(rc[k], ea[i], A[k]);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int k = 0; k < N0; ++k) rc[k] = rn[k];
+            }
+        }
+        double tm[N1], tv[N1];
+        {
+            double rc[N1], rn[N1], pc[N1], pn[N1];
+            load_row<N1>(Qb, rc);
+#pragma unroll
+            for (int j = 0; j < N1; ++j) {
+                touch_row<N1>(rc);
+                __builtin_amdgcn_sched_barrier(0);
+                if (j + 1 < N1) load_row<N1>(Qb + (j + 1) * N1, rn);
+                else load_row<N1>(m1, rn), load_row<N1>(m2, pn);
+#pragma unroll
+                for (int k = 0; k < N1; ++k) B[k] = (j == 0) ? rc[k] * eb[0] : fma(rc[k], eb[j], B[k]);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int k = 0; k < N1; ++k) rc[k] = rn[k];
+            }
+#pragma unroll
+            for (int k = 0; k < N1; ++k) pc[k] = pn[k];
+            // tm[c] = sum_a m1[a][c] A_a, tv[c] = sum_a m2[a][c] A_a^2 (2 N1 independent chains)
+#pragma unroll
+            for (int i = 0; i < N0; ++i) {
+                touch_row<N1>(rc);
+                touch_row<N1>(pc);
+                __builtin_amdgcn_sched_barrier(0);
+                if (i + 1 < N0) load_row<N1>(m1 + (i + 1) * N1, rn), load_row<N1>(m2 + (i + 1) * N1, pn);
+                const double a2 = A[i] * A[i];
+#pragma unroll
+                for (int c = 0; c < N1; ++c) {
+                    tm[c] = (i == 0) ? rc[c] * A[0] : fma(rc[c], A[i], tm[c]);
+                    tv[c] = (i == 0) ? pc[c] * a2 : fma(pc[c], a2, tv[c]);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int c = 0; c < N1; ++c) rc[c] = rn[c], pc[c] = pn[c];
+            }
+        }
+        double mu = 0.0, ss = 0.0;
+#pragma unroll
+        for (int c = 0; c < N1; ++c) {
+            mu = fma(tm[c], B[c], mu);
+            ss = fma(tv[c], B[c] * B[c], ss);
+        }
+        const double S = os - ss;
+        double var = S;
+        if (var < gp.var_floor) {
+            var = gp.var_floor;
+            info_acc |= GPMPC_INFO_VAR_CLAMPED;
+        }
+        if (S < 0.0) info_acc |= GPMPC_INFO_NEG_1x1;
+        double y = fma(sqrt(S), z, mu);
+        if (a.var_zero_thr >= 0.0 && var <= a.var_zero_thr) y = mu;
+        const double sd = a.beta * sqrt(var);
+        y = fmin(fmax(y, mu - sd), mu + sd);
+        if (active && a.Y) a.Y[(s * G_NY + o) * H + t] = y;
+
+        double g[G_NY];
+        if constexpr (G_NY == 1) {
+            g[0] = y;
+        } else {
+            ybuf[t & 1][o][lane] = y;
+            __syncthreads();
+#pragma unroll
+            for (int oo = 0; oo < G_NY; ++oo) g[oo] = ybuf[t & 1][oo][lane];
+        }
+        if (ENV == GPMPC_ENV_PENDULUM1D) {
+            const double x0n = x[0] + x[1] * a.env.dt;
+            x[1] = x[1] + g[0];
+            x[0] = x0n;
+        } else {
+            const double vv = x[3];
+            x[0] = x[0] + vv * g[0];
+            x[1] = x[1] + vv * g[G_NY > 1 ? 1 : 0];
+            x[2] = x[2] + vv * g[G_NY > 2 ? 2 : 0];
+            x[3] = x[3] + u[NU - 1] * a.env.dt;
+        }
+    }
+    if (info_acc) atomicOr(&s_info[lane], info_acc);
+    __syncthreads();
+    if (active && o == 0) {
+#pragma unroll
+        for (int d = 0; d < NX; ++d) a.X_traj[(s * NX + d) * (H + 1) + H] = x[d];
+        a.info[s] = s_info[lane];
+    }
+}
+
+
 bool rollout_indep_eligible(const gpmpc_gp_desc_t* gp, const gpmpc_env_desc_t* env, int mode) {
     const char* e = std::getenv("GPMPC_DISABLE_FAST_ROLLOUT");
     if (e && e[0] == '1') return false;
@@ -166,12 +387,24 @@ bool rollout_indep_eligible(const gpmpc_gp_desc_t* gp, const gpmpc_env_desc_t* e
     return false;
 }
 
-int rollout_indep_launch(const gpmpc_env_desc_t* env, RolloutArgs& args, hipStream_t st) {
-    const dim3 grid((unsigned)((args.Ns + 255) / 256)), block(256);
-    if (env->env_id == GPMPC_ENV_CAR_RESIDUAL)
-        hipLaunchKernelGGL((rollout_indep_kernel<GPMPC_ENV_CAR_RESIDUAL, 5, 9, 3>), grid, block, 0, st, args);
-    else
-        hipLaunchKernelGGL((rollout_indep_kernel<GPMPC_ENV_PENDULUM1D, 4, 9, 1>), grid, block, 0, st, args);
+int rollout_indep_launch(const gpmpc_gp_desc_t* gp, const gpmpc_env_desc_t* env, RolloutArgs& args, hipStream_t st) {
+    // the grid root of the plan unless disabled (GPMPC_DISABLE_GRID_ROOT=1 keeps the triangular L_rr^-1 form, used by
+    // the tests to compare the two)
+    const char* eg = std::getenv("GPMPC_DISABLE_GRID_ROOT");
+    const bool grid_root = !(eg && eg[0] == '1') && plan_has_grid_root(gp->grid_n0, gp->grid_n1, gp->real_has_grad);
+    if (grid_root) {
+        const dim3 grid((unsigned)((args.Ns + 63) / 64));
+        if (env->env_id == GPMPC_ENV_CAR_RESIDUAL)
+            hipLaunchKernelGGL((rollout_indep_grid_kernel<GPMPC_ENV_CAR_RESIDUAL, 5, 9, 3>), grid, dim3(64 * 3), 0, st, args);
+        else
+            hipLaunchKernelGGL((rollout_indep_grid_kernel<GPMPC_ENV_PENDULUM1D, 4, 9, 1>), grid, dim3(64), 0, st, args);
+    } else {
+        const dim3 grid((unsigned)((args.Ns + 255) / 256)), block(256);
+        if (env->env_id == GPMPC_ENV_CAR_RESIDUAL)
+            hipLaunchKernelGGL((rollout_indep_kernel<GPMPC_ENV_CAR_RESIDUAL, 5, 9, 3>), grid, block, 0, st, args);
+        else
+            hipLaunchKernelGGL((rollout_indep_kernel<GPMPC_ENV_PENDULUM1D, 4, 9, 1>), grid, block, 0, st, args);
+    }
     GPMPC_HIP_CHECK(hipGetLastError());
     return GPMPC_OK;
 }

@@ -85,7 +85,7 @@ def test_plan_matches_dense_cholesky(sg, pname, use_grad):
     buf = plan.buf.cpu()
     n0, n1 = int(plan.desc.grid_n0), int(plan.desc.grid_n1)
     assert (n0, n1) == ((4, 9) if "pendulum" in pname else (5, 9)), "training grid not detected"
-    grid = (n0 * n0 + n1 * n1 + 2 * n0 * n1 + 1) & ~1            # the plan's grid-root block (gpmpc_device.hpp)
+    grid = (n0 * n0 + n1 * n1 + 4 * n0 * n1 + 1) & ~1            # the plan's grid-root block (gpmpc_device.hpp)
     per = 2 * n * n + 2 * n + grid
     for o in range(hy.ell.shape[0]):
         K = scaled_rbf_kernel(X, X, hy.ell[o], hy.outputscale[o], use_grad)
@@ -116,6 +116,9 @@ def test_plan_matches_dense_cholesky(sg, pname, use_grad):
         assert float((W.T @ W - Kinv).abs().max()) < 1e-8 * float(Kinv.abs().max())
         assert float((W @ K @ W.T - torch.eye(n, dtype=K.dtype)).abs().max()) < 1e-9
         np.testing.assert_allclose(wE.numpy(), (W @ yo).numpy(), rtol=1e-7, atol=1e-9 * float((W @ yo).abs().max()))
+        m1, m2 = g[n0 * n0 + n1 * n1 + 2 * n:][:n], g[n0 * n0 + n1 * n1 + 3 * n:][:n]
+        np.testing.assert_allclose(m1.numpy(), (dsc * wE).numpy(), rtol=1e-14)
+        np.testing.assert_allclose(m2.numpy(), (dsc * dsc).numpy(), rtol=1e-14)
 
 
 @pytest.mark.parametrize("tag,pname", [("R_pendulum1D", "params_pendulum1D_samples"),
@@ -439,23 +442,28 @@ def test_generic_kernels_agree_with_tuned_kernels(sg, pname, Ns, H, nograd, monk
     np.testing.assert_allclose(Y_fast, Y_gen, rtol=1e-7, atol=1e-11)
 
 
-@pytest.mark.parametrize("pname,Ns,H", [("params_pendulum1D_samples", 12, 25), ("params_car_residual_fs", 5, 24)])
-def test_tuned_kernel_grid_root_vs_cholesky_root(sg, pname, Ns, H, monkeypatch):
+@pytest.mark.parametrize("pname,Ns,H,nograd", [("params_pendulum1D_samples", 12, 25, False),
+                                               ("params_car_residual_fs", 5, 24, False),
+                                               ("params_car_residual_fs", 150, 40, True),       # mode I, ragged workgroup
+                                               ("params_pendulum1D_samples", 70, 20, True)])
+def test_tuned_kernel_grid_root_vs_cholesky_root(sg, pname, Ns, H, nograd, monkeypatch):
     """The tuned kernel conditions on the real data through the plan's grid root W = D^-1/2 (Qa (x) Qb)^T (tensor-grid
     real inputs, separable kernel row) or, with GPMPC_DISABLE_GRID_ROOT=1, through L_rr^-1.  Both satisfy
-    W^T W = (K_rr + s2 I)^-1, so trajectories and samples agree to round-off, and both match the oracle."""
+    W^T W = (K_rr + s2 I)^-1, so trajectories and samples agree to round-off, and both match the oracle.  Mode I
+    (nograd): rollout_indep_grid_kernel against the triangular rollout_indep_kernel."""
     from sampling_gpmpc_amd.rollout import forward_sampling_rollout
-    p = fs_params(pname, Ns, H, nograd=False, beta=(3.0 if "car" in pname else None))
+    path = 2 if nograd else 1
+    p = fs_params(pname, Ns, H, nograd=nograd, beta=(3.0 if (not nograd and "car" in pname) else None))
     agent, oagent = make_agents(sg, p)
     u_ff = synthetic_u_ff(agent.nu, H)
     lib = sg._lib.load()
     X_grid, Y_grid = forward_sampling_rollout(agent, u_ff, return_samples=True)
-    assert lib.gpmpc_debug_last_rollout_path() == 1
-    assert agent._plan(use_grad=True).desc.grid_n1 == 9, "the facade did not detect the reference's training grid"
+    assert lib.gpmpc_debug_last_rollout_path() == path
+    assert agent._plan(use_grad=not nograd).desc.grid_n1 == 9, "the facade did not detect the reference's training grid"
     monkeypatch.setenv("GPMPC_DISABLE_GRID_ROOT", "1")
     agent2, _ = make_agents(sg, p, erv=agent.epistimic_random_vector.cpu().numpy())
     X_chol, Y_chol = forward_sampling_rollout(agent2, u_ff, return_samples=True)
-    assert lib.gpmpc_debug_last_rollout_path() == 1
+    assert lib.gpmpc_debug_last_rollout_path() == path
     Xo, Yo = ao.forward_sampling_rollout(oagent, u_ff, return_samples=True)
     print(f"{pname} Ns={Ns} H={H}: grid root vs Cholesky root max abs diff X {np.abs(X_grid - X_chol).max():.2e} "
           f"Y {np.abs(Y_grid - Y_chol).max():.2e}; vs oracle {relerr(X_grid, Xo):.2e} / {relerr(X_chol, Xo):.2e}")
