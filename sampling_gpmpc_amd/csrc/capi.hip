@@ -194,6 +194,22 @@ __global__ __launch_bounds__(256) void plan_kernel(GpParams gp, const double* __
             m1[r] = (gp.os[o] * dinv) * (dinv * acc);
             m2[r] = (gp.os[o] * dinv) * (gp.os[o] * dinv);
         }
+        if (n0 + n1 <= 16) {                                 // mode-I table (gpmpc_device.hpp: plan_tabi_*)
+            __syncthreads();
+            __threadfence_block();
+            double* tab = L + plan_tabi_offset(n, n0, n1);
+            const int nt_d = plan_tabi_doubles(n0, n1);
+            for (int e = tid; e < nt_d; e += nt) {
+                double v = 0.0;
+                if (e < n0) v = X_r[(long)(e * n1) * D + 0];
+                else if (e < n0 + n1) v = X_r[(long)(e - n0) * D + 1];
+                else if (e >= plan_tabi_qa(n0, n1) && e < plan_tabi_qa(n0, n1) + n0 * n0) v = Qa[e - plan_tabi_qa(n0, n1)];
+                else if (e >= plan_tabi_qb(n0, n1) && e < plan_tabi_qb(n0, n1) + n1 * n1) v = Qb[e - plan_tabi_qb(n0, n1)];
+                else if (e >= plan_tabi_m1(n0, n1) && e < plan_tabi_m1(n0, n1) + n0 * n1) v = m1[e - plan_tabi_m1(n0, n1)];
+                else if (e >= plan_tabi_m2(n0, n1) && e < plan_tabi_m2(n0, n1) + n0 * n1) v = m2[e - plan_tabi_m2(n0, n1)];
+                tab[e] = v;
+            }
+        }
     }
 }
 

@@ -39,9 +39,25 @@ struct EnvParams {
 // W = D^-1/2 (Qa (x) Qb)^T satisfies W^T W = (K_rr + s2 I)^-1 and can stand in for L_rr^-1 everywhere (the Schur
 // complement, the posterior mean and covariance only see W^T W).  W k_r for a separable kernel row costs n0 + n1 pivots
 // instead of N_r.  dsc[r] = os / sqrt(D_r) (the outputscale of k_r folded in), wE = W y_r.
+// Mode-I table (rollout_indep.hip), appended to the grid root: the tables the grid-root mode-I kernel streams through
+// scalar loads, packed in units of 8 doubles (one s_load_dwordx16 each), 64-byte aligned inside the plan:
+//   [ axis: axis-0 points (n0), axis-1 points (n1), pad to 16 | Qa flat (n0*n0) pad 8 | Qb flat (n1*n1) pad 8
+//     | m1 flat (n0*n1) pad 8 | m2 flat (n0*n1) pad 8 ], the unit count rounded up to even
+__host__ __device__ constexpr int plan_tabi_c8(int n) { return (n + 7) / 8; }
+__host__ __device__ constexpr int plan_tabi_qa(int, int) { return 16; }
+__host__ __device__ constexpr int plan_tabi_qb(int n0, int n1) { return plan_tabi_qa(n0, n1) + 8 * plan_tabi_c8(n0 * n0); }
+__host__ __device__ constexpr int plan_tabi_m1(int n0, int n1) { return plan_tabi_qb(n0, n1) + 8 * plan_tabi_c8(n1 * n1); }
+__host__ __device__ constexpr int plan_tabi_m2(int n0, int n1) { return plan_tabi_m1(n0, n1) + 8 * plan_tabi_c8(n0 * n1); }
+__host__ __device__ constexpr int plan_tabi_doubles(int n0, int n1) {
+    return 16 * ((plan_tabi_m2(n0, n1) + 8 * plan_tabi_c8(n0 * n1) + 15) / 16);
+}
+__host__ __device__ inline long plan_tabi_offset(int n_r, int n0, int n1) {       // doubles from the output's plan start
+    return (2L * n_r * n_r + 2L * n_r + (long)n0 * n0 + (long)n1 * n1 + 4L * n0 * n1 + 7) & ~7L;
+}
 __host__ __device__ inline long plan_doubles_per_output(int n_r, int n0 = 0, int n1 = 0) {
+    if (n0 > 0 && n1 > 0 && n0 + n1 <= 16) return plan_tabi_offset(n_r, n0, n1) + plan_tabi_doubles(n0, n1);
     const long grid = (n0 > 0 && n1 > 0) ? ((long)n0 * n0 + (long)n1 * n1 + 4L * n0 * n1 + 1) & ~1L : 0;
-    return 2L * n_r * n_r + 2L * n_r + grid;
+    return (2L * n_r * n_r + 2L * n_r + grid + 7) & ~7L;
 }
 __device__ inline const double* plan_L(const double* plan, const GpParams& gp, int o) { return plan + o * gp.plan_stride; }
 __device__ inline const double* plan_LinvT(const double* plan, const GpParams& gp, int o) {
@@ -72,6 +88,9 @@ __device__ inline const double* plan_grid_m1(const double* plan, const GpParams&
 }
 __device__ inline const double* plan_grid_m2(const double* plan, const GpParams& gp, int o) {
     return plan_grid_m1(plan, gp, o) + (long)gp.grid_n0 * gp.grid_n1;
+}
+__device__ inline const double* plan_grid_tabi(const double* plan, const GpParams& gp, int o) {
+    return plan + o * gp.plan_stride + plan_tabi_offset(gp.n_r, gp.grid_n0, gp.grid_n1);
 }
 __host__ __device__ inline bool plan_has_grid_root(int grid_n0, int grid_n1, int real_has_grad) {
     return grid_n0 > 0 && grid_n1 > 0 && grid_n0 <= 16 && grid_n1 <= 16 && !real_has_grad;

@@ -14,6 +14,8 @@
 #include "gpmpc_host.hpp"
 #include "rollout_args.hpp"
 
+#include <type_traits>
+
 namespace gpmpc {
 
 typedef double double2_i __attribute__((ext_vector_type(2)));
@@ -162,18 +164,58 @@ __global__ __launch_bounds__(256) void rollout_indep_kernel(const RolloutArgs a)
 // The real inputs are the tensor grid meshgrid(axis0[N0], axis1[N1]) with value-only labels, so
 //   (K_rr + s2 I)^-1 = W^T W,  W = D^-1/2 (Qa (x) Qb)^T,  k_r = os (ea (x) eb)   =>   W k_r = dsc . (A (x) B),
 //   A = Qa^T ea (N0 x N0),  B = Qb^T eb (N1 x N1),
-//   mu = sum_a A_a sum_c m1[a][c] B_c,      k_r^T (K_rr + s2 I)^-1 k_r = sum_a A_a^2 sum_c m2[a][c] B_c^2
-// with m1 = dsc . wE and m2 = dsc^2 from the plan: N0^2 + N1^2 + 2 N0 N1 + 2 N0 (+ N0 + N1 squares) = 220 FMA per
-// output and step (car) instead of the 1035 + 90 of the triangular product above - the posterior mean and variance
-// only see W^T W, so the two forms agree to round-off (tests/test_hip_parity.py compares both with the oracle).
+//   mu = sum_c B_c sum_a m1[a][c] A_a,      k_r^T (K_rr + s2 I)^-1 k_r = sum_c B_c^2 sum_a m2[a][c] A_a^2
+// with m1 = dsc . wE and m2 = dsc^2 from the plan: N0^2 + N1^2 + 2 N0 N1 + 2 N1 = 214 FMA per output and step (car)
+// instead of the 1035 + 90 of the triangular product above - the posterior mean and variance only see W^T W, so the
+// two forms agree to round-off (tests/test_hip_parity.py compares both with the oracle).
 // Mapping: one SAMPLE per lane, one OUTPUT per wave (workgroup = G_NY waves = 64 samples; the outputs of a step meet
-// in a double-buffered LDS exchange, one barrier per step).  Every matrix entry is uniform across the wave and the
-// per-output tables are 1.9 KB, so they are read with scalar loads (constant address space -> s_load, K$-resident)
-// and enter the FMAs as SGPR operands: no LDS or vector-memory traffic for the factor at all.
+// in a double-buffered LDS exchange, one barrier per step).  Every table entry is uniform across the wave and an
+// output's tables are 1.9 KB (plan_tabi_*: packed in units of 8 doubles), so they are STREAMED THROUGH SCALAR LOADS
+// (s_load_dwordx16, K$-resident) and enter the FMAs as SGPR operands: no LDS or vector-memory traffic for the factor.
+// Scalar loads return out of order (a wait is always lgkmcnt(0)), so the stream is hand-pipelined: wait for group g
+// (two units), issue group g+1, consume group g.  The loads are inline asm - left to the compiler, the ~400 SGPRs of
+// loop-invariant table entries are hoisted and spilled to VGPR lanes, or the loads sink to their uses one by one.
 // ---------------------------------------------------------------------------------------------------------------
 typedef const double __attribute__((address_space(4))) cdouble_t;
+typedef double v8d_t __attribute__((ext_vector_type(8)));
 __device__ __forceinline__ const cdouble_t* as_uniform(const double* p) {
     return reinterpret_cast<const cdouble_t*>(reinterpret_cast<uintptr_t>(p));
+}
+template <int UNIT>
+__device__ __forceinline__ v8d_t sload_unit(const cdouble_t* base) {
+    v8d_t r;
+    asm volatile("s_load_dwordx16 %0, %1, %2" : "=&s"(r) : "s"(base), "n"(UNIT * 64));
+    return r;
+}
+__device__ __forceinline__ void swait_units(v8d_t& a, v8d_t& b) {
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(a), "+s"(b));
+}
+// units 2G, 2G+1 (already requested: c0, c1) .. 2NG-1: f(integral_constant<flat index>, value) for every table entry
+template <int G, int NG, class F>
+__device__ __forceinline__ void stream_table(const cdouble_t* base, v8d_t c0, v8d_t c1, F&& f) {
+    swait_units(c0, c1);
+    v8d_t n0, n1;
+    if constexpr (G + 1 < NG) {
+        n0 = sload_unit<2 * G + 2>(base);
+        n1 = sload_unit<2 * G + 3>(base);
+    }
+    f(std::integral_constant<int, 16 * G + 0>{}, c0[0]);
+    f(std::integral_constant<int, 16 * G + 1>{}, c0[1]);
+    f(std::integral_constant<int, 16 * G + 2>{}, c0[2]);
+    f(std::integral_constant<int, 16 * G + 3>{}, c0[3]);
+    f(std::integral_constant<int, 16 * G + 4>{}, c0[4]);
+    f(std::integral_constant<int, 16 * G + 5>{}, c0[5]);
+    f(std::integral_constant<int, 16 * G + 6>{}, c0[6]);
+    f(std::integral_constant<int, 16 * G + 7>{}, c0[7]);
+    f(std::integral_constant<int, 16 * G + 8>{}, c1[0]);
+    f(std::integral_constant<int, 16 * G + 9>{}, c1[1]);
+    f(std::integral_constant<int, 16 * G + 10>{}, c1[2]);
+    f(std::integral_constant<int, 16 * G + 11>{}, c1[3]);
+    f(std::integral_constant<int, 16 * G + 12>{}, c1[4]);
+    f(std::integral_constant<int, 16 * G + 13>{}, c1[5]);
+    f(std::integral_constant<int, 16 * G + 14>{}, c1[6]);
+    f(std::integral_constant<int, 16 * G + 15>{}, c1[7]);
+    if constexpr (G + 1 < NG) stream_table<G + 1, NG>(base, n0, n1, f);
 }
 
 // exp(x) for x <= 0 (the arithmetic of expn_neg, gpmpc_device.hpp, as a single chain: with several waves per SIMD the
@@ -195,37 +237,34 @@ __device__ __forceinline__ double exp_neg1(double x) {
     return ldexp(fma(fma(b2, r4, b1), r4, b0), (int)n);
 }
 
-template <int N>
-__device__ __forceinline__ void load_row(const cdouble_t* p, double (&r)[N]) {
-#pragma unroll
-    for (int k = 0; k < N; ++k) r[k] = p[k];
-}
-// a use of the row in SGPRs: the compiler's s_waitcnt for the row's scalar loads lands here
-template <int N>
-__device__ __forceinline__ void touch_row(double (&r)[N]) {
-#pragma unroll
-    for (int k = 0; k < N; ++k) asm volatile("" : "+s"(r[k]));
-}
-
 template <int ENV, int N0, int N1, int G_NY>
 __global__ __launch_bounds__(64 * G_NY) void rollout_indep_grid_kernel(const RolloutArgs a) {
-    constexpr int NR = N0 * N1;
     constexpr int NX = (ENV == GPMPC_ENV_PENDULUM1D) ? 2 : 4;
     constexpr int NU = (ENV == GPMPC_ENV_PENDULUM1D) ? 1 : 2;
+    constexpr int QA = plan_tabi_qa(N0, N1), QB = plan_tabi_qb(N0, N1), M1 = plan_tabi_m1(N0, N1), M2 = plan_tabi_m2(N0, N1);
+    constexpr int NGRP = plan_tabi_doubles(N0, N1) / 16;
+    static_assert(N0 + N1 <= 16, "the axis points share the first two table units");
     __shared__ double ybuf[2][G_NY][kWave];
+    __shared__ double xtile[8][NX][kWave];                                // eight steps of the workgroup's trajectories
     __shared__ int s_info[kWave];
     const GpParams& gp = a.gp;
     const int lane = threadIdx.x & 63;
     const int o = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);       // this wave's output
+    // X_traj is (Ns, nx, H+1): a lane storing its state every step writes 8 bytes into a different cache line per
+    // lane and step (the lines are evicted long before the next step fills them: ~8x write amplification).  The states
+    // of eight steps are staged in LDS instead and written out by the whole workgroup as 64-byte row segments.
+    auto flush_tile = [&](int t0, int cnt) {
+        for (int e = threadIdx.x; e < kWave * NX * 8; e += blockDim.x) {
+            const int tt = e & 7, r = e >> 3, d = r % NX, sl = r / NX;
+            const long smp = (long)blockIdx.x * kWave + sl;
+            if (tt < cnt && smp < a.Ns) a.X_traj[(smp * NX + d) * (a.H + 1) + t0 + tt] = xtile[tt][d][sl];
+        }
+    };
     const long sraw = (long)blockIdx.x * kWave + lane;
     const bool active = sraw < a.Ns;
     const long s = active ? sraw : a.Ns - 1;
     const int H = a.H;
-    const cdouble_t* Xr = as_uniform(a.X_r);
-    const cdouble_t* Qa = as_uniform(plan_grid_Qa(a.plan, gp, o));
-    const cdouble_t* Qb = as_uniform(plan_grid_Qb(a.plan, gp, o));
-    const cdouble_t* m1 = as_uniform(plan_grid_m1(a.plan, gp, o));
-    const cdouble_t* m2 = as_uniform(plan_grid_m2(a.plan, gp, o));
+    const cdouble_t* tab = as_uniform(plan_grid_tabi(a.plan, gp, o));
     const cdouble_t* uff = as_uniform(a.u_ff);
     const double il0 = gp.inv_l2[o][0], il1 = gp.inv_l2[o][1], os = gp.os[o];
     if (threadIdx.x < kWave) s_info[threadIdx.x] = 0;
@@ -237,6 +276,7 @@ __global__ __launch_bounds__(64 * G_NY) void rollout_indep_grid_kernel(const Rol
 
 #pragma unroll 1
     for (int t = 0; t < H; ++t) {
+        const v8d_t ax0 = sload_unit<0>(tab), ax1 = sload_unit<1>(tab);   // the axis points: needed first
         double u[NU], xi[2];
 #pragma unroll
         for (int i = 0; i < NU; ++i) {
@@ -252,82 +292,40 @@ __global__ __launch_bounds__(64 * G_NY) void rollout_indep_grid_kernel(const Rol
         }
         xi[0] = (ENV == GPMPC_ENV_PENDULUM1D) ? x[0] : x[2];
         xi[1] = u[0];
-        if (active && o == 0) {
+        if (o == 0) {
 #pragma unroll
-            for (int d = 0; d < NX; ++d) a.X_traj[(s * NX + d) * (H + 1) + t] = x[d];
-            if (a.Xi) {
+            for (int d = 0; d < NX; ++d) xtile[t & 7][d][lane] = x[d];
+            if (active && a.Xi) {
                 a.Xi[(s * H + t) * 2 + 0] = xi[0];
                 a.Xi[(s * H + t) * 2 + 1] = xi[1];
             }
         }
         const double z = a.z[(long)t * a.z_step_stride + (s * G_NY + o)];
-        // axis factors of the separable kernel row, then their images under the axis eigenvectors
-        double ea[N0], eb[N1];
-#pragma unroll
-        for (int q = 0; q < N0; ++q) {
-            const double r = Xr[(q * N1) * 2 + 0] - xi[0];
-            ea[q] = exp_neg1(-0.5 * r * r * il0);
-        }
-#pragma unroll
-        for (int c = 0; c < N1; ++c) {
-            const double r = Xr[c * 2 + 1] - xi[1];
-            eb[c] = exp_neg1(-0.5 * r * r * il1);
-        }
-        // Row-wise products with the table rows prefetched one row ahead (scalar loads return out of order, so a wait is
-        // always lgkmcnt(0): the row in use is touched - which places the wait - BEFORE the next row's load is issued,
-        // and the scheduling barriers keep at most two rows live in SGPRs).
-        double A[N0], B[N1];
-        {
-            double rc[N0], rn[N0];
-            load_row<N0>(Qa, rc);
-#pragma unroll
-            for (int i = 0; i < N0; ++i) {
-                touch_row<N0>(rc);
-                __builtin_amdgcn_sched_barrier(0);
-                if (i + 1 < N0) load_row<N0>(Qa + (i + 1) * N0, rn);
-#pragma unroll
-                for (int k = 0; k < N0; ++k) A[k] = (i == 0) ? rc[k] * ea[0] : fma(rc[k], ea[i], A[k]);
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int k = 0; k < N0; ++k) rc[k] = rn[k];
+
+        double ea[N0], eb[N1], A[N0], B[N1], tm[N1], tv[N1], A2[N0];
+        stream_table<0, NGRP>(tab, ax0, ax1, [&](auto fc, double v) {
+            constexpr int f = decltype(fc)::value;
+            if constexpr (f < N0) {                                       // axis-0 point f: its kernel factor
+                const double r = v - xi[0];
+                ea[f] = exp_neg1(-0.5 * r * r * il0);
+            } else if constexpr (f < N0 + N1) {
+                const double r = v - xi[1];
+                eb[f - N0] = exp_neg1(-0.5 * r * r * il1);
+            } else if constexpr (f >= QA && f < QA + N0 * N0) {           // A_k += Qa[i][k] ea_i
+                constexpr int i = (f - QA) / N0, k = (f - QA) % N0;
+                A[k] = (i == 0) ? v * ea[0] : fma(v, ea[i], A[k]);
+            } else if constexpr (f >= QB && f < QB + N1 * N1) {           // B_k += Qb[j][k] eb_j
+                constexpr int j = (f - QB) / N1, k = (f - QB) % N1;
+                B[k] = (j == 0) ? v * eb[0] : fma(v, eb[j], B[k]);
+            } else if constexpr (f >= M1 && f < M1 + N0 * N1) {           // tm_c += m1[a][c] A_a
+                constexpr int i = (f - M1) / N1, c = (f - M1) % N1;
+                tm[c] = (i == 0) ? v * A[0] : fma(v, A[i], tm[c]);
+            } else if constexpr (f >= M2 && f < M2 + N0 * N1) {           // tv_c += m2[a][c] A_a^2
+                constexpr int i = (f - M2) / N1, c = (f - M2) % N1;
+                if constexpr (c == 0) A2[i] = A[i] * A[i];
+                tv[c] = (i == 0) ? v * A2[0] : fma(v, A2[i], tv[c]);
             }
-        }
-        double tm[N1], tv[N1];
-        {
-            double rc[N1], rn[N1], pc[N1], pn[N1];
-            load_row<N1>(Qb, rc);
-#pragma unroll
-            for (int j = 0; j < N1; ++j) {
-                touch_row<N1>(rc);
-                __builtin_amdgcn_sched_barrier(0);
-                if (j + 1 < N1) load_row<N1>(Qb + (j + 1) * N1, rn);
-                else load_row<N1>(m1, rn), load_row<N1>(m2, pn);
-#pragma unroll
-                for (int k = 0; k < N1; ++k) B[k] = (j == 0) ? rc[k] * eb[0] : fma(rc[k], eb[j], B[k]);
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int k = 0; k < N1; ++k) rc[k] = rn[k];
-            }
-#pragma unroll
-            for (int k = 0; k < N1; ++k) pc[k] = pn[k];
-            // tm[c] = sum_a m1[a][c] A_a, tv[c] = sum_a m2[a][c] A_a^2 (2 N1 independent chains)
-#pragma unroll
-            for (int i = 0; i < N0; ++i) {
-                touch_row<N1>(rc);
-                touch_row<N1>(pc);
-                __builtin_amdgcn_sched_barrier(0);
-                if (i + 1 < N0) load_row<N1>(m1 + (i + 1) * N1, rn), load_row<N1>(m2 + (i + 1) * N1, pn);
-                const double a2 = A[i] * A[i];
-#pragma unroll
-                for (int c = 0; c < N1; ++c) {
-                    tm[c] = (i == 0) ? rc[c] * A[0] : fma(rc[c], A[i], tm[c]);
-                    tv[c] = (i == 0) ? pc[c] * a2 : fma(pc[c], a2, tv[c]);
-                }
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int c = 0; c < N1; ++c) rc[c] = rn[c], pc[c] = pn[c];
-            }
-        }
+        });
         double mu = 0.0, ss = 0.0;
 #pragma unroll
         for (int c = 0; c < N1; ++c) {
@@ -356,6 +354,11 @@ __global__ __launch_bounds__(64 * G_NY) void rollout_indep_grid_kernel(const Rol
 #pragma unroll
             for (int oo = 0; oo < G_NY; ++oo) g[oo] = ybuf[t & 1][oo][lane];
         }
+        if ((t & 7) == 7) {                                               // uniform
+            if constexpr (G_NY == 1) __syncthreads();
+            flush_tile(t - 7, 8);
+            __syncthreads();                                              // the tile is rewritten from the next step on
+        }
         if (ENV == GPMPC_ENV_PENDULUM1D) {
             const double x0n = x[0] + x[1] * a.env.dt;
             x[1] = x[1] + g[0];
@@ -369,12 +372,13 @@ __global__ __launch_bounds__(64 * G_NY) void rollout_indep_grid_kernel(const Rol
         }
     }
     if (info_acc) atomicOr(&s_info[lane], info_acc);
-    __syncthreads();
-    if (active && o == 0) {
+    if (o == 0) {
 #pragma unroll
-        for (int d = 0; d < NX; ++d) a.X_traj[(s * NX + d) * (H + 1) + H] = x[d];
-        a.info[s] = s_info[lane];
+        for (int d = 0; d < NX; ++d) xtile[H & 7][d][lane] = x[d];
     }
+    __syncthreads();
+    flush_tile(H & ~7, (H & 7) + 1);
+    if (active && o == 0) a.info[s] = s_info[lane];
 }
 
 

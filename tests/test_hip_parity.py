@@ -85,8 +85,15 @@ def test_plan_matches_dense_cholesky(sg, pname, use_grad):
     buf = plan.buf.cpu()
     n0, n1 = int(plan.desc.grid_n0), int(plan.desc.grid_n1)
     assert (n0, n1) == ((4, 9) if "pendulum" in pname else (5, 9)), "training grid not detected"
-    grid = (n0 * n0 + n1 * n1 + 4 * n0 * n1 + 1) & ~1            # the plan's grid-root block (gpmpc_device.hpp)
-    per = 2 * n * n + 2 * n + grid
+    # the plan's grid-root block and the mode-I table behind it (gpmpc_device.hpp: plan_doubles_per_output)
+    c8 = lambda v: (v + 7) // 8
+    tab_qa = 16
+    tab_qb = tab_qa + 8 * c8(n0 * n0)
+    tab_m1 = tab_qb + 8 * c8(n1 * n1)
+    tab_m2 = tab_m1 + 8 * c8(n0 * n1)
+    tab_len = 16 * ((tab_m2 + 8 * c8(n0 * n1) + 15) // 16)
+    tab_ofs = (2 * n * n + 2 * n + n0 * n0 + n1 * n1 + 4 * n0 * n1 + 7) & ~7
+    per = tab_ofs + tab_len
     for o in range(hy.ell.shape[0]):
         K = scaled_rbf_kernel(X, X, hy.ell[o], hy.outputscale[o], use_grad)
         T = hy.T
@@ -119,6 +126,17 @@ def test_plan_matches_dense_cholesky(sg, pname, use_grad):
         m1, m2 = g[n0 * n0 + n1 * n1 + 2 * n:][:n], g[n0 * n0 + n1 * n1 + 3 * n:][:n]
         np.testing.assert_allclose(m1.numpy(), (dsc * wE).numpy(), rtol=1e-14)
         np.testing.assert_allclose(m2.numpy(), (dsc * dsc).numpy(), rtol=1e-14)
+        # mode-I table: axis points, Qa, Qb, m1, m2 packed in units of 8 doubles, zero padded
+        tab = blk[tab_ofs:]
+        Xc = X.cpu()
+        ref = torch.zeros(tab_len, dtype=torch.float64)
+        ref[:n0] = Xc[::n1, 0]
+        ref[n0:n0 + n1] = Xc[:n1, 1]
+        ref[tab_qa:tab_qa + n0 * n0] = Qa.reshape(-1)
+        ref[tab_qb:tab_qb + n1 * n1] = Qb.reshape(-1)
+        ref[tab_m1:tab_m1 + n] = m1
+        ref[tab_m2:tab_m2 + n] = m2
+        np.testing.assert_array_equal(tab.numpy(), ref.numpy())
 
 
 @pytest.mark.parametrize("tag,pname", [("R_pendulum1D", "params_pendulum1D_samples"),
