@@ -66,7 +66,7 @@ __device__ void jacobi_eig16_wave(double* A, int n, double* V) {
 template <int D>
 __global__ __launch_bounds__(256) void plan_kernel(GpParams gp, const double* __restrict__ X_r,
                                                    const double* __restrict__ Y_r, double* __restrict__ plan,
-                                                   int* __restrict__ info) {
+                                                   int* __restrict__ info, int no_rec) {
     extern __shared__ __attribute__((aligned(16))) double A[];
     __shared__ int s_fail;
     const int o = blockIdx.x;
@@ -194,15 +194,37 @@ __global__ __launch_bounds__(256) void plan_kernel(GpParams gp, const double* __
             m1[r] = (gp.os[o] * dinv) * (dinv * acc);
             m2[r] = (gp.os[o] * dinv) * (gp.os[o] * dinv);
         }
-        if (n0 + n1 <= 16) {                                 // mode-I table (gpmpc_device.hpp: plan_tabi_*)
+        if (n0 + n1 <= 14) {                                 // mode-I table (gpmpc_device.hpp: plan_tabi_*)
             __syncthreads();
             __threadfence_block();
             double* tab = L + plan_tabi_offset(n, n0, n1);
             const int nt_d = plan_tabi_doubles(n0, n1);
+            // equispaced axes (the reference's linspace grids): x_q = x_0 + q h up to round-off, and the recurrence
+            // exp(-il (r_0 + k h)^2 / 2) = E_0 rho^k G_k stays in range (il ((n-1) h)^2 <= 200, rollout_indep.hip)
+            const double xa0 = X_r[0], xb0 = X_r[1];
+            const double ha = (n0 > 1) ? (X_r[(long)((n0 - 1) * n1) * D + 0] - xa0) / (n0 - 1) : 0.0;
+            const double hb = (n1 > 1) ? (X_r[(long)(n1 - 1) * D + 1] - xb0) / (n1 - 1) : 0.0;
+            bool eq = !no_rec;
+            for (int q = 0; q < n0; ++q) {
+                const double xq = X_r[(long)(q * n1) * D + 0];
+                eq = eq && fabs(xq - (xa0 + q * ha)) <= 1.5e-14 * fmax(fabs(xa0), fabs(xa0 + (n0 - 1) * ha));
+            }
+            for (int q = 0; q < n1; ++q) {
+                const double xq = X_r[(long)q * D + 1];
+                eq = eq && fabs(xq - (xb0 + q * hb)) <= 1.5e-14 * fmax(fabs(xb0), fabs(xb0 + (n1 - 1) * hb));
+            }
+            eq = eq && inv_l2[0] * (n0 - 1) * (n0 - 1) * ha * ha <= 200.0 && inv_l2[1] * (n1 - 1) * (n1 - 1) * hb * hb <= 200.0;
+            const int ax = plan_tabi_axis(n0, n1);
             for (int e = tid; e < nt_d; e += nt) {
                 double v = 0.0;
-                if (e < n0) v = X_r[(long)(e * n1) * D + 0];
-                else if (e < n0 + n1) v = X_r[(long)(e - n0) * D + 1];
+                if (e == 0) v = xa0;
+                else if (e == 1) v = eq ? inv_l2[0] * ha : __builtin_nan("");
+                else if (e == 2) v = xb0;
+                else if (e == 3) v = inv_l2[1] * hb;
+                else if (e < 4 + (n0 - 1)) { const double k = e - 3; v = exp(-0.5 * inv_l2[0] * ha * ha * k * k); }
+                else if (e < 4 + (n0 - 1) + (n1 - 1)) { const double k = e - 3 - (n0 - 1); v = exp(-0.5 * inv_l2[1] * hb * hb * k * k); }
+                else if (e >= ax && e < ax + n0) v = X_r[(long)((e - ax) * n1) * D + 0];
+                else if (e >= ax + n0 && e < ax + n0 + n1) v = X_r[(long)(e - ax - n0) * D + 1];
                 else if (e >= plan_tabi_qa(n0, n1) && e < plan_tabi_qa(n0, n1) + n0 * n0) v = Qa[e - plan_tabi_qa(n0, n1)];
                 else if (e >= plan_tabi_qb(n0, n1) && e < plan_tabi_qb(n0, n1) + n1 * n1) v = Qb[e - plan_tabi_qb(n0, n1)];
                 else if (e >= plan_tabi_m1(n0, n1) && e < plan_tabi_m1(n0, n1) + n0 * n1) v = m1[e - plan_tabi_m1(n0, n1)];
@@ -335,8 +357,10 @@ int gpmpc_plan_build(const gpmpc_gp_desc_t* gp, const double* X_r, const double*
     if (gp->D != 2) return fail(GPMPC_E_UNSUPPORTED, "only D = 2 is instantiated");
     auto kern = plan_kernel<2>;
     GPMPC_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    // GPMPC_DISABLE_EXP_RECURRENCE=1: the mode-I table is marked "axes not equispaced" (tests: the direct-exponential path)
+    const char* er = std::getenv("GPMPC_DISABLE_EXP_RECURRENCE");
     hipLaunchKernelGGL(kern, dim3(gp->g_ny), dim3(256), lds, (hipStream_t)stream, p, X_r, Y_r, (double*)plan,
-                       (int*)info);
+                       (int*)info, (er && er[0] == '1') ? 1 : 0);
     GPMPC_HIP_CHECK(hipGetLastError());
     return GPMPC_OK;
 }

@@ -41,10 +41,15 @@ struct EnvParams {
 // instead of N_r.  dsc[r] = os / sqrt(D_r) (the outputscale of k_r folded in), wE = W y_r.
 // Mode-I table (rollout_indep.hip), appended to the grid root: the tables the grid-root mode-I kernel streams through
 // scalar loads, packed in units of 8 doubles (one s_load_dwordx16 each), 64-byte aligned inside the plan:
-//   [ axis: axis-0 points (n0), axis-1 points (n1), pad to 16 | Qa flat (n0*n0) pad 8 | Qb flat (n1*n1) pad 8
-//     | m1 flat (n0*n1) pad 8 | m2 flat (n0*n1) pad 8 ], the unit count rounded up to even
+//   [ rec (16): x_first(axis 0), il0*h0, x_first(axis 1), il1*h1, then G0_k = exp(-il0 (k h0)^2 / 2), k = 1..n0-1, and
+//               G1_k, k = 1..n1-1 - the constants of the equispaced-axis recurrence for the kernel factors
+//               (il0*h0 = NaN: the axes are not equispaced / the recurrence is out of range, use the axis points)
+//     | axis (16): axis-0 points (n0), axis-1 points (n1)
+//     | Qa flat (n0*n0) pad 8 | Qb flat (n1*n1) pad 8 | m1 flat (n0*n1) pad 8 | m2 flat (n0*n1) pad 8 ],
+//   the unit count rounded up to even
 __host__ __device__ constexpr int plan_tabi_c8(int n) { return (n + 7) / 8; }
-__host__ __device__ constexpr int plan_tabi_qa(int, int) { return 16; }
+__host__ __device__ constexpr int plan_tabi_axis(int, int) { return 16; }
+__host__ __device__ constexpr int plan_tabi_qa(int, int) { return 32; }
 __host__ __device__ constexpr int plan_tabi_qb(int n0, int n1) { return plan_tabi_qa(n0, n1) + 8 * plan_tabi_c8(n0 * n0); }
 __host__ __device__ constexpr int plan_tabi_m1(int n0, int n1) { return plan_tabi_qb(n0, n1) + 8 * plan_tabi_c8(n1 * n1); }
 __host__ __device__ constexpr int plan_tabi_m2(int n0, int n1) { return plan_tabi_m1(n0, n1) + 8 * plan_tabi_c8(n0 * n1); }
@@ -55,7 +60,7 @@ __host__ __device__ inline long plan_tabi_offset(int n_r, int n0, int n1) {     
     return (2L * n_r * n_r + 2L * n_r + (long)n0 * n0 + (long)n1 * n1 + 4L * n0 * n1 + 7) & ~7L;
 }
 __host__ __device__ inline long plan_doubles_per_output(int n_r, int n0 = 0, int n1 = 0) {
-    if (n0 > 0 && n1 > 0 && n0 + n1 <= 16) return plan_tabi_offset(n_r, n0, n1) + plan_tabi_doubles(n0, n1);
+    if (n0 > 0 && n1 > 0 && n0 + n1 <= 14) return plan_tabi_offset(n_r, n0, n1) + plan_tabi_doubles(n0, n1);
     const long grid = (n0 > 0 && n1 > 0) ? ((long)n0 * n0 + (long)n1 * n1 + 4L * n0 * n1 + 1) & ~1L : 0;
     return (2L * n_r * n_r + 2L * n_r + grid + 7) & ~7L;
 }

@@ -243,7 +243,7 @@ __global__ __launch_bounds__(64 * G_NY) void rollout_indep_grid_kernel(const Rol
     constexpr int NU = (ENV == GPMPC_ENV_PENDULUM1D) ? 1 : 2;
     constexpr int QA = plan_tabi_qa(N0, N1), QB = plan_tabi_qb(N0, N1), M1 = plan_tabi_m1(N0, N1), M2 = plan_tabi_m2(N0, N1);
     constexpr int NGRP = plan_tabi_doubles(N0, N1) / 16;
-    static_assert(N0 + N1 <= 16, "the axis points share the first two table units");
+    static_assert(N0 + N1 <= 14 && QA == 32, "table groups 0 / 1 hold the recurrence constants / the axis points");
     __shared__ double ybuf[2][G_NY][kWave];
     __shared__ double xtile[8][NX][kWave];                                // eight steps of the workgroup's trajectories
     __shared__ int s_info[kWave];
@@ -276,7 +276,6 @@ __global__ __launch_bounds__(64 * G_NY) void rollout_indep_grid_kernel(const Rol
 
 #pragma unroll 1
     for (int t = 0; t < H; ++t) {
-        const v8d_t ax0 = sload_unit<0>(tab), ax1 = sload_unit<1>(tab);   // the axis points: needed first
         double u[NU], xi[2];
 #pragma unroll
         for (int i = 0; i < NU; ++i) {
@@ -292,6 +291,12 @@ __global__ __launch_bounds__(64 * G_NY) void rollout_indep_grid_kernel(const Rol
         }
         xi[0] = (ENV == GPMPC_ENV_PENDULUM1D) ? x[0] : x[2];
         xi[1] = u[0];
+        // An asm-loaded unit must not stay live across branches or register pressure: between the request and the wait
+        // its SGPRs hold stale data, and a compiler-inserted spill or copy there would save garbage.  Requests are
+        // therefore issued in straight-line code right before the work that hides them (tests/test_host_logic.py scans
+        // the ISA for reads of a requested unit before its wait).
+        v8d_t rc0 = sload_unit<0>(tab), rc1 = sload_unit<1>(tab);         // the recurrence constants
+        swait_units(rc0, rc1);
         if (o == 0) {
 #pragma unroll
             for (int d = 0; d < NX; ++d) xtile[t & 7][d][lane] = x[d];
@@ -302,16 +307,55 @@ __global__ __launch_bounds__(64 * G_NY) void rollout_indep_grid_kernel(const Rol
         }
         const double z = a.z[(long)t * a.z_step_stride + (s * G_NY + o)];
 
-        double ea[N0], eb[N1], A[N0], B[N1], tm[N1], tv[N1], A2[N0];
-        stream_table<0, NGRP>(tab, ax0, ax1, [&](auto fc, double v) {
+        // ---- axis factors ea_q = exp(-il0 (xa_q - xi0)^2 / 2), eb_c likewise ------------------------------------------
+        // Equispaced axes (the reference's linspace grids; the plan checks): with r_0 = x_0 - xi, x_k = x_0 + k h,
+        //   exp(-il (r_0 + k h)^2 / 2) = E_0 rho^k G_k,   E_0 = exp(-il r_0^2 / 2), rho = exp(-il h r_0), G_k = exp(-il (k h)^2 / 2)
+        // i.e. TWO exponentials per axis and 2 (N - 1) + log-depth multiplies instead of N exponentials; G_k comes from
+        // the plan.  Range: the plan admits the recurrence only for il ((N-1) h)^2 <= 200, and |il h r_0| (N-1) is clamped
+        // to 700 - beyond that every factor of the axis is < 1e-271 and E_0 underflows to exactly 0, so the clamped
+        // product is 0 as well.  Otherwise (il0*h0 = NaN in the table) the axis points are fetched and N exponentials run.
+        double ea[N0], eb[N1];
+        if (rc0[1] == rc0[1]) {                                           // uniform
+            const double rec[16] = {rc0[0], rc0[1], rc0[2], rc0[3], rc0[4], rc0[5], rc0[6], rc0[7],
+                                    rc1[0], rc1[1], rc1[2], rc1[3], rc1[4], rc1[5], rc1[6], rc1[7]};
+            const double r0a = rec[0] - xi[0], r0b = rec[2] - xi[1];
+            constexpr double capa = (N0 > 1) ? 700.0 / (N0 - 1) : 700.0, capb = (N1 > 1) ? 700.0 / (N1 - 1) : 700.0;
+            const double aa = fmin(fmax(-rec[1] * r0a, -capa), capa), ab = fmin(fmax(-rec[3] * r0b, -capb), capb);
+            const double E0a = exp_neg1(-0.5 * r0a * r0a * il0), E0b = exp_neg1(-0.5 * r0b * r0b * il1);
+            double pa[N0], pb[N1];                                        // rho^k, log depth
+            pa[0] = 1.0, pb[0] = 1.0;
+            if constexpr (N0 > 1) pa[1] = exp_neg1(aa);
+            if constexpr (N1 > 1) pb[1] = exp_neg1(ab);
+#pragma unroll
+            for (int k = 2; k < N0; ++k) pa[k] = pa[k / 2] * pa[k - k / 2];
+#pragma unroll
+            for (int k = 2; k < N1; ++k) pb[k] = pb[k / 2] * pb[k - k / 2];
+            ea[0] = E0a, eb[0] = E0b;
+#pragma unroll
+            for (int k = 1; k < N0; ++k) ea[k] = (E0a * rec[3 + k]) * pa[k];
+#pragma unroll
+            for (int k = 1; k < N1; ++k) eb[k] = (E0b * rec[3 + (N0 - 1) + k]) * pb[k];
+        } else {
+            v8d_t ax0 = sload_unit<2>(tab), ax1 = sload_unit<3>(tab);
+            swait_units(ax0, ax1);
+            const double axv[16] = {ax0[0], ax0[1], ax0[2], ax0[3], ax0[4], ax0[5], ax0[6], ax0[7],
+                                    ax1[0], ax1[1], ax1[2], ax1[3], ax1[4], ax1[5], ax1[6], ax1[7]};
+#pragma unroll
+            for (int q = 0; q < N0; ++q) {
+                const double r = axv[q] - xi[0];
+                ea[q] = exp_neg1(-0.5 * r * r * il0);
+            }
+#pragma unroll
+            for (int c = 0; c < N1; ++c) {
+                const double r = axv[N0 + c] - xi[1];
+                eb[c] = exp_neg1(-0.5 * r * r * il1);
+            }
+        }
+
+        double A[N0], B[N1], tm[N1], tv[N1], A2[N0];
+        stream_table<2, NGRP>(tab, sload_unit<4>(tab), sload_unit<5>(tab), [&](auto fc, double v) {
             constexpr int f = decltype(fc)::value;
-            if constexpr (f < N0) {                                       // axis-0 point f: its kernel factor
-                const double r = v - xi[0];
-                ea[f] = exp_neg1(-0.5 * r * r * il0);
-            } else if constexpr (f < N0 + N1) {
-                const double r = v - xi[1];
-                eb[f - N0] = exp_neg1(-0.5 * r * r * il1);
-            } else if constexpr (f >= QA && f < QA + N0 * N0) {           // A_k += Qa[i][k] ea_i
+            if constexpr (f >= QA && f < QA + N0 * N0) {                  // A_k += Qa[i][k] ea_i
                 constexpr int i = (f - QA) / N0, k = (f - QA) % N0;
                 A[k] = (i == 0) ? v * ea[0] : fma(v, ea[i], A[k]);
             } else if constexpr (f >= QB && f < QB + N1 * N1) {           // B_k += Qb[j][k] eb_j
@@ -339,9 +383,10 @@ __global__ __launch_bounds__(64 * G_NY) void rollout_indep_grid_kernel(const Rol
             info_acc |= GPMPC_INFO_VAR_CLAMPED;
         }
         if (S < 0.0) info_acc |= GPMPC_INFO_NEG_1x1;
-        double y = fma(sqrt(S), z, mu);
+        const double sq = sqrt(S);                                       // S < 0: NaN, as the reference's 1x1 root
+        double y = fma(sq, z, mu);
         if (a.var_zero_thr >= 0.0 && var <= a.var_zero_thr) y = mu;
-        const double sd = a.beta * sqrt(var);
+        const double sd = a.beta * ((var == S) ? sq : sqrt(var));
         y = fmin(fmax(y, mu - sd), mu + sd);
         if (active && a.Y) a.Y[(s * G_NY + o) * H + t] = y;
 

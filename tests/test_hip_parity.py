@@ -87,7 +87,7 @@ def test_plan_matches_dense_cholesky(sg, pname, use_grad):
     assert (n0, n1) == ((4, 9) if "pendulum" in pname else (5, 9)), "training grid not detected"
     # the plan's grid-root block and the mode-I table behind it (gpmpc_device.hpp: plan_doubles_per_output)
     c8 = lambda v: (v + 7) // 8
-    tab_qa = 16
+    tab_qa = 32
     tab_qb = tab_qa + 8 * c8(n0 * n0)
     tab_m1 = tab_qb + 8 * c8(n1 * n1)
     tab_m2 = tab_m1 + 8 * c8(n0 * n1)
@@ -130,8 +130,16 @@ def test_plan_matches_dense_cholesky(sg, pname, use_grad):
         tab = blk[tab_ofs:]
         Xc = X.cpu()
         ref = torch.zeros(tab_len, dtype=torch.float64)
-        ref[:n0] = Xc[::n1, 0]
-        ref[n0:n0 + n1] = Xc[:n1, 1]
+        il = 1.0 / hy.ell[o].cpu() ** 2
+        ha, hb = (Xc[-1, 0] - Xc[0, 0]) / (n0 - 1), (Xc[n1 - 1, 1] - Xc[0, 1]) / (n1 - 1)
+        ref[0], ref[1], ref[2], ref[3] = Xc[0, 0], il[0] * ha, Xc[0, 1], il[1] * hb
+        ka, kb = torch.arange(1, n0, dtype=torch.float64), torch.arange(1, n1, dtype=torch.float64)
+        ref[4:4 + n0 - 1] = torch.exp(-0.5 * il[0] * (ka * ha) ** 2)
+        ref[3 + n0:3 + n0 + n1 - 1] = torch.exp(-0.5 * il[1] * (kb * hb) ** 2)
+        np.testing.assert_allclose(tab[:16].numpy(), ref[:16].numpy(), rtol=1e-14, atol=0)   # recurrence constants
+        ref[:16] = tab[:16]
+        ref[16:16 + n0] = Xc[::n1, 0]
+        ref[16 + n0:16 + n0 + n1] = Xc[:n1, 1]
         ref[tab_qa:tab_qa + n0 * n0] = Qa.reshape(-1)
         ref[tab_qb:tab_qb + n1 * n1] = Qb.reshape(-1)
         ref[tab_m1:tab_m1 + n] = m1
@@ -714,4 +722,32 @@ def test_prepare_dynamics_set_against_oracle(sg):
     assert (agent.rejection_trace[-1].cpu().numpy() == left).all()
     np.testing.assert_allclose(agent.Hallcinated_X_train.cpu().numpy(), oagent.Hallcinated_X_train.numpy(), rtol=1e-9, atol=1e-12)
     np.testing.assert_allclose(agent.Hallcinated_Y_train.cpu().numpy(), oagent.Hallcinated_Y_train.numpy(), rtol=1e-9, atol=1e-12)
-    assert not np.array_equal(oagent.Hallcinated_X_train.numpy(), hx_before.numpy()), "rejected samples keep their data"
+    assert not np.array_equal(oagent.Hallcinated_X_train.numpy(), hx_before.numpy()), "rejected samples keep their data"@pytest.mark.gpu
+@pytest.mark.parametrize("pname,Ns,H", [("params_car_residual_fs", 200, 40), ("params_pendulum1D_samples", 130, 30)])
+def test_mode_i_exp_recurrence_vs_direct_exponentials(sg, pname, Ns, H, monkeypatch):
+    """Mode I on the equispaced training grid: the kernel factors come from the recurrence E_0 rho^k G_k (two
+    exponentials per axis, constants in the plan's mode-I table) or, with GPMPC_DISABLE_EXP_RECURRENCE=1 (the plan then
+    marks the axes "not equispaced"), from one exponential per axis point.  Same arithmetic up to round-off; both match
+    the oracle."""
+    from sampling_gpmpc_amd.rollout import forward_sampling_rollout
+    p = fs_params(pname, Ns, H, nograd=True)
+    agent, oagent = make_agents(sg, p)
+    u_ff = synthetic_u_ff(agent.nu, H)
+    lib = sg._lib.load()
+    X_rec, Y_rec = forward_sampling_rollout(agent, u_ff, return_samples=True)
+    assert lib.gpmpc_debug_last_rollout_path() == 2
+    monkeypatch.setenv("GPMPC_DISABLE_EXP_RECURRENCE", "1")
+    agent2, _ = make_agents(sg, p, erv=agent.epistimic_random_vector.cpu().numpy())
+    X_dir, Y_dir = forward_sampling_rollout(agent2, u_ff, return_samples=True)
+    assert lib.gpmpc_debug_last_rollout_path() == 2
+    Xo, Yo = ao.forward_sampling_rollout(oagent, u_ff, return_samples=True)
+    print(f"{pname} Ns={Ns} H={H}: recurrence vs direct max abs diff X {np.abs(X_rec - X_dir).max():.2e} "
+          f"Y {np.abs(Y_rec - Y_dir).max():.2e}; vs oracle {relerr(X_rec, Xo):.2e} / {relerr(X_dir, Xo):.2e}")
+    assert np.abs(Y_rec - Y_dir).max() > 0.0, "bit-identical results: the knob is not wired"
+    assert relerr(X_rec, Xo) < RTOL_TRAJ and relerr(X_dir, Xo) < RTOL_TRAJ
+    np.testing.assert_allclose(X_rec, X_dir, rtol=1e-9, atol=1e-11)
+    np.testing.assert_allclose(Y_rec, Y_dir, rtol=1e-7, atol=1e-11)
+    np.testing.assert_allclose(Y_rec, Yo, rtol=1e-4, atol=1e-8)
+
+
+
