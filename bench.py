@@ -44,6 +44,8 @@ def parse():
     ap.add_argument("--ns", type=int, default=1024, help="samples per GPU (BASELINE configs[1]: 1024)")
     ap.add_argument("--horizon", type=int, default=30)
     ap.add_argument("--cpu-sample", type=int, default=256, help="samples of the CPU-oracle baseline (0 = skip)")
+    ap.add_argument("--reach-ns", type=int, default=32768,
+                    help="samples per GPU of the informational reachable-set leg (configs[3], mode I; 0 = skip)")
     return ap.parse_args()
 
 
@@ -62,6 +64,70 @@ def cpu_baseline(Ns_cpu, H, u_ff):
     dt = time.perf_counter() - t0
     assert np.isfinite(X).all()
     return Ns_cpu * H / dt, dt
+
+
+def reachable_set_leg(a, rank, world, dist, sg, _lib, RolloutRunner, fs_params, synthetic_u_ff):
+    """Second, informational leg (not `value`): BASELINE.json's "reachable-set wall-clock" on configs[3] as shipped
+    (params_car_residual_fs, forward sampling on the real data only = mode I, T = 1, H = 40), 32768 samples per GPU
+    (the per-GPU shard of Ns = 262144 on 8 GPUs): one rollout launch + the all-gather of the tube per repetition,
+    base samples resident in HBM, max over ranks.  Any failure is reported in the JSON instead of raised; the ranks
+    agree on skipping before they enter the collective."""
+    if a.reach_ns <= 0:
+        return None
+    res, ok, runner, tube = {"workload": "BASELINE configs[3] as shipped: params_car_residual_fs, mode I (T=1), "
+                             "Ns=%d per GPU, H=40; rollout + all-gather of X_traj" % a.reach_ns}, 1, None, None
+    try:
+        Ns, H = a.reach_ns, 40
+        p = fs_params("params_car_residual_fs", Ns, H, nograd=True)
+        p["common"]["use_cuda"] = True
+        p["agent"]["base_sample_generator"] = "vectorized"
+        torch.manual_seed(777 + rank)
+        agent = sg.Agent(p, sg.make_env(p))
+        u_ff = synthetic_u_ff(agent.nu, H)
+        erv = agent.epistimic_random_vector
+        per = Ns * agent.g_ny
+        runner = RolloutRunner(agent, u_ff, erv.reshape(-1)[per:], erv.shape[1] * per, H, _lib.MODE_INDEPENDENT, True)
+        if world > 1:
+            tube = torch.empty(world * Ns, agent.nx, H + 1, dtype=torch.float64, device="cuda")
+        runner.launch()
+        torch.cuda.synchronize()
+    except Exception as e:                                    # noqa: BLE001 - reported, never fatal for the bench line
+        ok, res["error"] = 0, repr(e)[:300]
+    if world > 1:
+        flag = torch.tensor([ok], dtype=torch.int32, device="cuda")
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        ok = int(flag.item())
+    if not ok:
+        res.setdefault("error", "skipped: another rank failed to set the workload up")
+        return res
+    reps = 10
+
+    def one():
+        X = runner.launch()
+        if world > 1:
+            dist.all_gather_into_tensor(tube, X)
+
+    for _ in range(2):
+        one()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        one()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([wall], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        wall = float(t.item())
+    finite = bool(torch.isfinite(runner.X_traj).all())
+    res.update({"Ns_per_gpu": a.reach_ns, "Ns_total": world * a.reach_ns, "H": 40, "n_gpus": world, "reps": reps,
+                "wallclock_ms": wall / reps * 1e3, "trajectory_steps_per_s": world * a.reach_ns * 40 * reps / wall,
+                "finite": finite, "kernel": "rollout_indep_grid_kernel<car,5,9,3>"})
+    return res
 
 
 def main():
@@ -142,6 +208,8 @@ def main():
     bits = int(runner.info.max().item())
     assert torch.isfinite(runner.X_traj).all() and not (bits & (_lib.INFO_TRAIN_CHOL_FAIL | _lib.INFO_ROOT_FAIL)), bits
 
+    reach = reachable_set_leg(a, rank, world, dist, sg, _lib, RolloutRunner, fs_params, synthetic_u_ff)
+
     if rank == 0:
         name, cus, _ = _lib.device_info(local_rank)
         units = world * Ns * H                                  # sampled trajectory-steps per step
@@ -190,6 +258,7 @@ def main():
                                    "host_cpus": os.cpu_count()}
         else:
             out["cpu_baseline"] = None
+        out["reachable_set"] = reach
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
