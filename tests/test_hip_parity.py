@@ -222,6 +222,44 @@ def test_rollout_sample_subset_invariance_full_size(sg):
     assert X[:, 1, -1].std() > 1e-4
 
 
+@pytest.mark.parametrize("pname,Ns,H,nograd", [("params_car_residual_fs", 262144, 40, True),     # BASELINE configs[3] as shipped
+                                               ("params_car_residual_fs", 4096, 40, False)])     # configs[2]
+def test_car_rollout_full_size_properties(sg, pname, Ns, H, nograd):
+    """BASELINE full sizes of the car workloads (mode I, Ns=262144: the true-reachable-set launch of one GPU; mode R,
+    Ns=4096): finite, error-free info words, every sample independent of what else is in the launch (bit-exact on
+    re-launched subsets, incl. one that straddles workgroups and the ragged last one) and a 12-sample subset equal to
+    the oracle."""
+    from sampling_gpmpc_amd.rollout import rollout_device
+    from sampling_gpmpc_amd import _lib
+    p = fs_params(pname, Ns, H, nograd=nograd, beta=(None if nograd else 3.0))
+    p["agent"]["base_sample_generator"] = "vectorized"
+    torch.manual_seed(11)
+    pg = {**p, "common": {**p["common"], "use_cuda": True}}
+    agent = sg.Agent(pg, sg.make_env(pg))
+    u_ff = synthetic_u_ff(agent.nu, H)
+    T = 1 if nograd else 3
+    mode = _lib.MODE_INDEPENDENT if nograd else _lib.MODE_RECONDITIONED
+    erv = agent.epistimic_random_vector
+    per_slab = Ns * agent.g_ny * T
+    z = erv.reshape(-1)[per_slab:]
+    full = rollout_device(agent, u_ff, z, erv.shape[1] * per_slab, H=H, mode=mode, use_model_without_derivatives=nograd)
+    X = full.X_traj
+    assert X.shape == (Ns, 4, H + 1) and bool(torch.isfinite(X).all())
+    assert int(full.info.max().item()) & (_lib.INFO_TRAIN_CHOL_FAIL | _lib.INFO_ROOT_FAIL) == 0
+    for lo, hi in ((0, 5), (Ns // 2 - 37, Ns // 2 + 91), (Ns - 3, Ns)):
+        sub = rollout_device(agent, u_ff, z, erv.shape[1] * per_slab, H=H, mode=mode,
+                             use_model_without_derivatives=nograd, sample_slice=(lo, hi))
+        assert torch.equal(sub.X_traj, X[lo:hi]), (lo, hi)
+    lo = Ns // 3
+    po = fs_params(pname, 12, H, nograd=nograd, beta=(None if nograd else 3.0))
+    oagent = ao.OracleAgent(po, ao.make_oracle_env(po), erv[:, :, lo:lo + 12].cpu())
+    Xo = ao.forward_sampling_rollout(oagent, u_ff)
+    e = relerr(X[lo:lo + 12].cpu().numpy(), Xo)
+    print(f"{pname} Ns={Ns} mode {'I' if nograd else 'R'}: 12-sample subset vs oracle rel err {e:.2e}")
+    assert e < RTOL_TRAJ
+    assert float(X[:, 1, -1].std()) > 1e-6                    # a genuine spread
+
+
 def test_joint_draw_against_reference_golden(sg):
     """Mode J as the SQP loop drives it (two iterations; the second conditions on the first's 8 sampled points)."""
     d = np.load(os.path.join(GOLDEN, "agent_e2e_J_pendulum1D.npz"))
