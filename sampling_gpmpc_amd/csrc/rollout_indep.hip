@@ -15,8 +15,29 @@
 #include "rollout_args.hpp"
 
 #include <type_traits>
+#include <utility>
 
 namespace gpmpc {
+
+__device__ long long g_indep_phase_cycles[16];
+#ifdef GPMPC_PHASE_TIMERS
+#define IPHASE_DECL                                   \
+    long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};       \
+    long long tph = __builtin_readcyclecounter()
+#define IPHASE(idx)                                              \
+    do {                                                         \
+        const long long _n = __builtin_readcyclecounter();       \
+        ph[idx] += _n - tph;                                     \
+        tph = _n;                                                \
+    } while (0)
+#define IPHASE_STORE                                             \
+    if (blockIdx.x == 0 && threadIdx.x == 0)                     \
+        for (int i = 0; i < 8; ++i) g_indep_phase_cycles[i] = ph[i]
+#else
+#define IPHASE_DECL
+#define IPHASE(idx)
+#define IPHASE_STORE
+#endif
 
 typedef double double2_i __attribute__((ext_vector_type(2)));
 
@@ -170,52 +191,42 @@ __global__ __launch_bounds__(256) void rollout_indep_kernel(const RolloutArgs a)
 // two forms agree to round-off (tests/test_hip_parity.py compares both with the oracle).
 // Mapping: one SAMPLE per lane, one OUTPUT per wave (workgroup = G_NY waves = 64 samples; the outputs of a step meet
 // in a double-buffered LDS exchange, one barrier per step).  Every table entry is uniform across the wave and an
-// output's tables are 1.9 KB (plan_tabi_*: packed in units of 8 doubles), so they are STREAMED THROUGH SCALAR LOADS
-// (s_load_dwordx16, K$-resident) and enter the FMAs as SGPR operands: no LDS or vector-memory traffic for the factor.
-// Scalar loads return out of order (a wait is always lgkmcnt(0)), so the stream is hand-pipelined: wait for group g
-// (two units), issue group g+1, consume group g.  The loads are inline asm - left to the compiler, the ~400 SGPRs of
-// loop-invariant table entries are hoisted and spilled to VGPR lanes, or the loads sink to their uses one by one.
+// output's tables are 1.9 KB (plan_tabi_*: 248 doubles), so they are REGISTER RESIDENT: 15 VGPR pairs, each holding 16
+// entries replicated in the four DPP rows, loaded once before the step loop, and every FMA reads its entry as a DPP
+// row_newbcast operand.  The step loop touches no table memory at all.  (Measured on the way, git history: the tables
+// streamed through hand-pipelined s_load_dwordx16 into SGPR operands - scalar loads return out of order, so every wait
+// is lgkmcnt(0) and a wave can hide a load only behind the 16 FMAs of the previous group: 15 exposed K$ round trips
+// per step, 0.67 ms at Ns = 262144 and 0.114 ms at 32768; LDS broadcast reads are bound by the LDS pipe, 3.0 ms.)
 // ---------------------------------------------------------------------------------------------------------------
-typedef const double __attribute__((address_space(4))) cdouble_t;
-typedef double v8d_t __attribute__((ext_vector_type(8)));
-__device__ __forceinline__ const cdouble_t* as_uniform(const double* p) {
-    return reinterpret_cast<const cdouble_t*>(reinterpret_cast<uintptr_t>(p));
+constexpr int kIndepMaxH = 256;                                          // input sequence staged in LDS
+// Table access: the table lives in VGPRs, entry f in register f / 16, replicated in every DPP row of 16 lanes (lane l
+// holds entry 16 r + (l & 15)).  v_fmac_f64_dpp with row_newbcast:(f % 16) reads it as a
+// wave-uniform operand.  The table registers are never written inside the step loop, so the DPP read-after-VALU-write
+// hazard (two wait states) cannot arise.
+template <int F, int NREG>
+__device__ __forceinline__ void fmac_tab(double& acc, const double (&T)[NREG], double x) {                 // acc += tab[F] * x
+    asm("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(T[F / 16]), "v"(x), "n"(F % 16));
 }
-template <int UNIT>
-__device__ __forceinline__ v8d_t sload_unit(const cdouble_t* base) {
-    v8d_t r;
-    asm volatile("s_load_dwordx16 %0, %1, %2" : "=&s"(r) : "s"(base), "n"(UNIT * 64));
+// (gfx950 has no DPP form of v_mul_f64 / v_add_f64: products and differences against a table entry go through the fmac)
+template <int F, int NREG>
+__device__ __forceinline__ double mul_tab(const double (&T)[NREG], double x) {                            // tab[F] * x
+    double r = 0.0;
+    fmac_tab<F>(r, T, x);
     return r;
 }
-__device__ __forceinline__ void swait_units(v8d_t& a, v8d_t& b) {
-    asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(a), "+s"(b));
+template <int F, int NREG>
+__device__ __forceinline__ double sub_from_tab(const double (&T)[NREG], double x) {                       // tab[F] - x
+    double r = -x;
+    fmac_tab<F>(r, T, 1.0);
+    return r;
 }
-// units 2G, 2G+1 (already requested: c0, c1) .. 2NG-1: f(integral_constant<flat index>, value) for every table entry
-template <int G, int NG, class F>
-__device__ __forceinline__ void stream_table(const cdouble_t* base, v8d_t c0, v8d_t c1, F&& f) {
-    swait_units(c0, c1);
-    v8d_t n0, n1;
-    if constexpr (G + 1 < NG) {
-        n0 = sload_unit<2 * G + 2>(base);
-        n1 = sload_unit<2 * G + 3>(base);
-    }
-    f(std::integral_constant<int, 16 * G + 0>{}, c0[0]);
-    f(std::integral_constant<int, 16 * G + 1>{}, c0[1]);
-    f(std::integral_constant<int, 16 * G + 2>{}, c0[2]);
-    f(std::integral_constant<int, 16 * G + 3>{}, c0[3]);
-    f(std::integral_constant<int, 16 * G + 4>{}, c0[4]);
-    f(std::integral_constant<int, 16 * G + 5>{}, c0[5]);
-    f(std::integral_constant<int, 16 * G + 6>{}, c0[6]);
-    f(std::integral_constant<int, 16 * G + 7>{}, c0[7]);
-    f(std::integral_constant<int, 16 * G + 8>{}, c1[0]);
-    f(std::integral_constant<int, 16 * G + 9>{}, c1[1]);
-    f(std::integral_constant<int, 16 * G + 10>{}, c1[2]);
-    f(std::integral_constant<int, 16 * G + 11>{}, c1[3]);
-    f(std::integral_constant<int, 16 * G + 12>{}, c1[4]);
-    f(std::integral_constant<int, 16 * G + 13>{}, c1[5]);
-    f(std::integral_constant<int, 16 * G + 14>{}, c1[6]);
-    f(std::integral_constant<int, 16 * G + 15>{}, c1[7]);
-    if constexpr (G + 1 < NG) stream_table<G + 1, NG>(base, n0, n1, f);
+template <int... I, class F>
+__device__ __forceinline__ void static_for_impl(std::integer_sequence<int, I...>, F&& f) {
+    (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+    static_for_impl(std::make_integer_sequence<int, N>{}, f);
 }
 
 // exp(x) for x <= 0 (the arithmetic of expn_neg, gpmpc_device.hpp, as a single chain: with several waves per SIMD the
@@ -242,70 +253,92 @@ __global__ __launch_bounds__(64 * G_NY) void rollout_indep_grid_kernel(const Rol
     constexpr int NX = (ENV == GPMPC_ENV_PENDULUM1D) ? 2 : 4;
     constexpr int NU = (ENV == GPMPC_ENV_PENDULUM1D) ? 1 : 2;
     constexpr int QA = plan_tabi_qa(N0, N1), QB = plan_tabi_qb(N0, N1), M1 = plan_tabi_m1(N0, N1), M2 = plan_tabi_m2(N0, N1);
-    constexpr int NGRP = plan_tabi_doubles(N0, N1) / 16;
     static_assert(N0 + N1 <= 14 && QA == 32, "table groups 0 / 1 hold the recurrence constants / the axis points");
     __shared__ double ybuf[2][G_NY][kWave];
-    __shared__ double xtile[8][NX][kWave];                                // eight steps of the workgroup's trajectories
+    __shared__ __attribute__((aligned(16))) double xtile[8][kWave * NX + 8];   // eight steps of the workgroup's trajectories
+    __shared__ double uffs[kIndepMaxH * NU];                              // the input sequence
+    __shared__ __attribute__((aligned(16))) double fbk[NX + NU * NX];     // x_goal, K (row-major)
     __shared__ int s_info[kWave];
     const GpParams& gp = a.gp;
     const int lane = threadIdx.x & 63;
     const int o = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);       // this wave's output
     // X_traj is (Ns, nx, H+1): a lane storing its state every step writes 8 bytes into a different cache line per
     // lane and step (the lines are evicted long before the next step fills them: ~8x write amplification).  The states
-    // of eight steps are staged in LDS instead and written out by the whole workgroup as 64-byte row segments.
+    // of eight steps are staged in LDS instead (xtile[step][sample * NX + d], step stride padded for the transposed read)
+    // and written out by the whole workgroup as 64-byte row segments: thread -> (step tt = tid & 7, row tid >> 3 + k * RPI),
+    // the row of global sample smp, dimension d being row (smp * NX + d) of X_traj viewed as (Ns * NX, H + 1).
     auto flush_tile = [&](int t0, int cnt) {
-        for (int e = threadIdx.x; e < kWave * NX * 8; e += blockDim.x) {
-            const int tt = e & 7, r = e >> 3, d = r % NX, sl = r / NX;
-            const long smp = (long)blockIdx.x * kWave + sl;
-            if (tt < cnt && smp < a.Ns) a.X_traj[(smp * NX + d) * (a.H + 1) + t0 + tt] = xtile[tt][d][sl];
+        const int tt = threadIdx.x & 7, RPI = blockDim.x >> 3;
+        int r = threadIdx.x >> 3;
+        const long rows_left = (a.Ns - (long)blockIdx.x * kWave) * NX;    // rows of this workgroup that exist
+        double* dst = a.X_traj + ((long)blockIdx.x * kWave * NX + r) * (a.H + 1) + t0 + tt;
+        const long dstep = (long)RPI * (a.H + 1);
+        if (tt < cnt) {
+            for (; r < kWave * NX; r += RPI, dst += dstep)
+                if (r < rows_left) *dst = xtile[tt][r];
         }
     };
     const long sraw = (long)blockIdx.x * kWave + lane;
     const bool active = sraw < a.Ns;
     const long s = active ? sraw : a.Ns - 1;
     const int H = a.H;
-    const cdouble_t* tab = as_uniform(plan_grid_tabi(a.plan, gp, o));
-    const cdouble_t* uff = as_uniform(a.u_ff);
+    constexpr int NREG = plan_tabi_doubles(N0, N1) / 16;
+    const double* tabg = plan_grid_tabi(a.plan, gp, o);
+    double T[NREG];                                                       // the output's tables (see fmac_tab)
+#pragma unroll
+    for (int r = 0; r < NREG; ++r) T[r] = (r == 1) ? 0.0 : tabg[16 * r + (lane & 15)];      // group 1 = axis points: fallback only
+    const bool rec_ok = tabg[1] == tabg[1];                               // equispaced axes (plan): recurrence constants valid
     const double il0 = gp.inv_l2[o][0], il1 = gp.inv_l2[o][1], os = gp.os[o];
     if (threadIdx.x < kWave) s_info[threadIdx.x] = 0;
+    // The input sequence and the feedback law are staged in LDS once: read from the kernel arguments / HBM inside the
+    // step loop they are a chain of ~7 dependent scalar-load round trips at the head of every step (pointer, element,
+    // x_goal, a row of K, ...), which nothing in a wave's own instruction stream hides.
+    for (int e = threadIdx.x; e < H * NU; e += blockDim.x) uffs[e] = a.u_ff[e];
+    if (threadIdx.x < NX) fbk[threadIdx.x] = a.env.x_goal[threadIdx.x];
+    if (threadIdx.x < NU * NX) fbk[NX + threadIdx.x] = a.env.K[threadIdx.x / NX][threadIdx.x % NX];
+    const bool use_fb = a.env.use_feedback != 0;
+    // Base samples: one 8-byte read per lane and step, requested at the head of the step and used at its end.  (A
+    // chunked prefetch - eight steps ahead through registers and a per-lane LDS column - was measured and made no
+    // difference: the read's latency is already covered by the ~2000 issue cycles between request and use.)
+    const double* zp = a.z + (s * G_NY + o);                             // this lane's base sample of step t: zp[t * stride]
+    const long zstride = a.z_step_stride;
+    __syncthreads();
 
     double x[NX];
 #pragma unroll
     for (int d = 0; d < NX; ++d) x[d] = a.x0[(a.x0_per_sample ? s * NX : 0) + d];
     int info_acc = 0;
+    const double sqrt_floor = sqrt(gp.var_floor);
 
+    IPHASE_DECL;
 #pragma unroll 1
     for (int t = 0; t < H; ++t) {
         double u[NU], xi[2];
+        const double z = zp[(long)t * zstride];
 #pragma unroll
-        for (int i = 0; i < NU; ++i) {
-            const double uf = uff[t * NU + i];
-            if (a.env.use_feedback) {
+        for (int i = 0; i < NU; ++i) u[i] = uffs[t * NU + i];
+        if (use_fb) {                                                     // uniform
+            double dx[NX];
+#pragma unroll
+            for (int j = 0; j < NX; ++j) dx[j] = fbk[j] - x[j];
+#pragma unroll
+            for (int i = 0; i < NU; ++i) {
                 double acc = 0.0;
 #pragma unroll
-                for (int j = 0; j < NX; ++j) acc += (a.env.x_goal[j] - x[j]) * a.env.K[i][j];
-                u[i] = -acc + uf;
-            } else {
-                u[i] = uf;
+                for (int j = 0; j < NX; ++j) acc += dx[j] * fbk[NX + i * NX + j];
+                u[i] = -acc + u[i];
             }
         }
         xi[0] = (ENV == GPMPC_ENV_PENDULUM1D) ? x[0] : x[2];
         xi[1] = u[0];
-        // An asm-loaded unit must not stay live across branches or register pressure: between the request and the wait
-        // its SGPRs hold stale data, and a compiler-inserted spill or copy there would save garbage.  Requests are
-        // therefore issued in straight-line code right before the work that hides them (tests/test_host_logic.py scans
-        // the ISA for reads of a requested unit before its wait).
-        v8d_t rc0 = sload_unit<0>(tab), rc1 = sload_unit<1>(tab);         // the recurrence constants
-        swait_units(rc0, rc1);
         if (o == 0) {
 #pragma unroll
-            for (int d = 0; d < NX; ++d) xtile[t & 7][d][lane] = x[d];
+            for (int d = 0; d < NX; ++d) xtile[t & 7][lane * NX + d] = x[d];
             if (active && a.Xi) {
                 a.Xi[(s * H + t) * 2 + 0] = xi[0];
                 a.Xi[(s * H + t) * 2 + 1] = xi[1];
             }
         }
-        const double z = a.z[(long)t * a.z_step_stride + (s * G_NY + o)];
 
         // ---- axis factors ea_q = exp(-il0 (xa_q - xi0)^2 / 2), eb_c likewise ------------------------------------------
         // Equispaced axes (the reference's linspace grids; the plan checks): with r_0 = x_0 - xi, x_k = x_0 + k h,
@@ -314,13 +347,13 @@ __global__ __launch_bounds__(64 * G_NY) void rollout_indep_grid_kernel(const Rol
         // the plan.  Range: the plan admits the recurrence only for il ((N-1) h)^2 <= 200, and |il h r_0| (N-1) is clamped
         // to 700 - beyond that every factor of the axis is < 1e-271 and E_0 underflows to exactly 0, so the clamped
         // product is 0 as well.  Otherwise (il0*h0 = NaN in the table) the axis points are fetched and N exponentials run.
+        IPHASE(0);
         double ea[N0], eb[N1];
-        if (rc0[1] == rc0[1]) {                                           // uniform
-            const double rec[16] = {rc0[0], rc0[1], rc0[2], rc0[3], rc0[4], rc0[5], rc0[6], rc0[7],
-                                    rc1[0], rc1[1], rc1[2], rc1[3], rc1[4], rc1[5], rc1[6], rc1[7]};
-            const double r0a = rec[0] - xi[0], r0b = rec[2] - xi[1];
+        if (rec_ok) {                                                     // uniform
+            // table group 0: x_first(axis 0), il0 h0, x_first(axis 1), il1 h1, G0_1.., G1_1..
+            const double r0a = sub_from_tab<0>(T, xi[0]), r0b = sub_from_tab<2>(T, xi[1]);
             constexpr double capa = (N0 > 1) ? 700.0 / (N0 - 1) : 700.0, capb = (N1 > 1) ? 700.0 / (N1 - 1) : 700.0;
-            const double aa = fmin(fmax(-rec[1] * r0a, -capa), capa), ab = fmin(fmax(-rec[3] * r0b, -capb), capb);
+            const double aa = fmin(fmax(-mul_tab<1>(T, r0a), -capa), capa), ab = fmin(fmax(-mul_tab<3>(T, r0b), -capb), capb);
             const double E0a = exp_neg1(-0.5 * r0a * r0a * il0), E0b = exp_neg1(-0.5 * r0b * r0b * il1);
             double pa[N0], pb[N1];                                        // rho^k, log depth
             pa[0] = 1.0, pb[0] = 1.0;
@@ -331,44 +364,48 @@ __global__ __launch_bounds__(64 * G_NY) void rollout_indep_grid_kernel(const Rol
 #pragma unroll
             for (int k = 2; k < N1; ++k) pb[k] = pb[k / 2] * pb[k - k / 2];
             ea[0] = E0a, eb[0] = E0b;
-#pragma unroll
-            for (int k = 1; k < N0; ++k) ea[k] = (E0a * rec[3 + k]) * pa[k];
-#pragma unroll
-            for (int k = 1; k < N1; ++k) eb[k] = (E0b * rec[3 + (N0 - 1) + k]) * pb[k];
+            static_for<N0 - 1>([&](auto kc) {
+                constexpr int k = decltype(kc)::value + 1;
+                ea[k] = mul_tab<3 + k>(T, E0a) * pa[k];
+            });
+            static_for<N1 - 1>([&](auto kc) {
+                constexpr int k = decltype(kc)::value + 1;
+                eb[k] = mul_tab<3 + (N0 - 1) + k>(T, E0b) * pb[k];
+            });
         } else {
-            v8d_t ax0 = sload_unit<2>(tab), ax1 = sload_unit<3>(tab);
-            swait_units(ax0, ax1);
-            const double axv[16] = {ax0[0], ax0[1], ax0[2], ax0[3], ax0[4], ax0[5], ax0[6], ax0[7],
-                                    ax1[0], ax1[1], ax1[2], ax1[3], ax1[4], ax1[5], ax1[6], ax1[7]};
+            const double* axg = tabg + plan_tabi_axis(N0, N1);
 #pragma unroll
             for (int q = 0; q < N0; ++q) {
-                const double r = axv[q] - xi[0];
+                const double r = axg[q] - xi[0];
                 ea[q] = exp_neg1(-0.5 * r * r * il0);
             }
 #pragma unroll
             for (int c = 0; c < N1; ++c) {
-                const double r = axv[N0 + c] - xi[1];
+                const double r = axg[N0 + c] - xi[1];
                 eb[c] = exp_neg1(-0.5 * r * r * il1);
             }
         }
 
+        IPHASE(1);
         double A[N0], B[N1], tm[N1], tv[N1], A2[N0];
-        stream_table<2, NGRP>(tab, sload_unit<4>(tab), sload_unit<5>(tab), [&](auto fc, double v) {
-            constexpr int f = decltype(fc)::value;
-            if constexpr (f >= QA && f < QA + N0 * N0) {                  // A_k += Qa[i][k] ea_i
-                constexpr int i = (f - QA) / N0, k = (f - QA) % N0;
-                A[k] = (i == 0) ? v * ea[0] : fma(v, ea[i], A[k]);
-            } else if constexpr (f >= QB && f < QB + N1 * N1) {           // B_k += Qb[j][k] eb_j
-                constexpr int j = (f - QB) / N1, k = (f - QB) % N1;
-                B[k] = (j == 0) ? v * eb[0] : fma(v, eb[j], B[k]);
-            } else if constexpr (f >= M1 && f < M1 + N0 * N1) {           // tm_c += m1[a][c] A_a
-                constexpr int i = (f - M1) / N1, c = (f - M1) % N1;
-                tm[c] = (i == 0) ? v * A[0] : fma(v, A[i], tm[c]);
-            } else if constexpr (f >= M2 && f < M2 + N0 * N1) {           // tv_c += m2[a][c] A_a^2
-                constexpr int i = (f - M2) / N1, c = (f - M2) % N1;
-                if constexpr (c == 0) A2[i] = A[i] * A[i];
-                tv[c] = (i == 0) ? v * A2[0] : fma(v, A2[i], tv[c]);
-            }
+#pragma unroll
+        for (int k = 0; k < N0; ++k) A[k] = 0.0;
+#pragma unroll
+        for (int k = 0; k < N1; ++k) B[k] = 0.0, tm[k] = 0.0, tv[k] = 0.0;
+        static_for<N0 * N0>([&](auto ec) {                                // A_k += Qa[i][k] ea_i
+            constexpr int e = decltype(ec)::value, i = e / N0, k = e % N0;
+            fmac_tab<QA + e>(A[k], T, ea[i]);
+        });
+        static_for<N1 * N1>([&](auto ec) {                                // B_k += Qb[j][k] eb_j
+            constexpr int e = decltype(ec)::value, j = e / N1, k = e % N1;
+            fmac_tab<QB + e>(B[k], T, eb[j]);
+        });
+#pragma unroll
+        for (int i = 0; i < N0; ++i) A2[i] = A[i] * A[i];
+        static_for<N0 * N1>([&](auto ec) {                                // tm_c += m1[a][c] A_a, tv_c += m2[a][c] A_a^2
+            constexpr int e = decltype(ec)::value, i = e / N1, c = e % N1;
+            fmac_tab<M1 + e>(tm[c], T, A[i]);
+            fmac_tab<M2 + e>(tv[c], T, A2[i]);
         });
         double mu = 0.0, ss = 0.0;
 #pragma unroll
@@ -376,6 +413,7 @@ __global__ __launch_bounds__(64 * G_NY) void rollout_indep_grid_kernel(const Rol
             mu = fma(tm[c], B[c], mu);
             ss = fma(tv[c], B[c] * B[c], ss);
         }
+        IPHASE(2);
         const double S = os - ss;
         double var = S;
         if (var < gp.var_floor) {
@@ -386,10 +424,11 @@ __global__ __launch_bounds__(64 * G_NY) void rollout_indep_grid_kernel(const Rol
         const double sq = sqrt(S);                                       // S < 0: NaN, as the reference's 1x1 root
         double y = fma(sq, z, mu);
         if (a.var_zero_thr >= 0.0 && var <= a.var_zero_thr) y = mu;
-        const double sd = a.beta * ((var == S) ? sq : sqrt(var));
+        const double sd = a.beta * ((S >= gp.var_floor) ? sq : sqrt_floor);   // sqrt(var): var = max(S, floor)
         y = fmin(fmax(y, mu - sd), mu + sd);
         if (active && a.Y) a.Y[(s * G_NY + o) * H + t] = y;
 
+        IPHASE(3);
         double g[G_NY];
         if constexpr (G_NY == 1) {
             g[0] = y;
@@ -399,6 +438,7 @@ __global__ __launch_bounds__(64 * G_NY) void rollout_indep_grid_kernel(const Rol
 #pragma unroll
             for (int oo = 0; oo < G_NY; ++oo) g[oo] = ybuf[t & 1][oo][lane];
         }
+        IPHASE(4);
         if ((t & 7) == 7) {                                               // uniform
             if constexpr (G_NY == 1) __syncthreads();
             flush_tile(t - 7, 8);
@@ -415,11 +455,13 @@ __global__ __launch_bounds__(64 * G_NY) void rollout_indep_grid_kernel(const Rol
             x[2] = x[2] + vv * g[G_NY > 2 ? 2 : 0];
             x[3] = x[3] + u[NU - 1] * a.env.dt;
         }
+        IPHASE(5);
     }
+    IPHASE_STORE;
     if (info_acc) atomicOr(&s_info[lane], info_acc);
     if (o == 0) {
 #pragma unroll
-        for (int d = 0; d < NX; ++d) xtile[H & 7][d][lane] = x[d];
+        for (int d = 0; d < NX; ++d) xtile[H & 7][lane * NX + d] = x[d];
     }
     __syncthreads();
     flush_tile(H & ~7, (H & 7) + 1);
@@ -440,7 +482,8 @@ int rollout_indep_launch(const gpmpc_gp_desc_t* gp, const gpmpc_env_desc_t* env,
     // the grid root of the plan unless disabled (GPMPC_DISABLE_GRID_ROOT=1 keeps the triangular L_rr^-1 form, used by
     // the tests to compare the two)
     const char* eg = std::getenv("GPMPC_DISABLE_GRID_ROOT");
-    const bool grid_root = !(eg && eg[0] == '1') && plan_has_grid_root(gp->grid_n0, gp->grid_n1, gp->real_has_grad);
+    const bool grid_root = !(eg && eg[0] == '1') && plan_has_grid_root(gp->grid_n0, gp->grid_n1, gp->real_has_grad) &&
+                           args.H <= kIndepMaxH;
     if (grid_root) {
         const dim3 grid((unsigned)((args.Ns + 63) / 64));
         if (env->env_id == GPMPC_ENV_CAR_RESIDUAL)
@@ -459,3 +502,8 @@ int rollout_indep_launch(const gpmpc_gp_desc_t* gp, const gpmpc_env_desc_t* env,
 }
 
 }  // namespace gpmpc
+
+extern "C" int gpmpc_debug_read_indep_phases(long long* out /*[host] 16*/) {
+    GPMPC_HIP_CHECK(hipMemcpyFromSymbol(out, HIP_SYMBOL(gpmpc::g_indep_phase_cycles), 16 * sizeof(long long)));
+    return GPMPC_OK;
+}
