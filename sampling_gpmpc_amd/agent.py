@@ -97,6 +97,9 @@ class Agent(object):
         self.model_i_samples = None
         self.likelihood = None
         self.mpc_iter = 0
+        # samples sharded over ranks (sampling_gpmpc_amd.distributed.make_sharded_agent): the process group through which
+        # the reference's cross-sample couplings are reduced; None = this Agent holds every sample
+        self.dist_group, self.shard, self.ns_global = None, None, self.ns
         self._plans = {}          # T -> RealDataPlan (real block factorised once per label layout)
         self._ws_cache = {}
         self._reset_hallucinated()
@@ -156,7 +159,12 @@ class Agent(object):
             dist_norm = torch.linalg.vector_norm(newX[:, :, None, :, :] - X_cond[:, :, :, None, :], dim=-1)
             filt = torch.any(dist_norm <= min_distance, dim=2)                     # (Ns, g_ny, m)
             newY = torch.where(filt.unsqueeze(-1), torch.full_like(newY, float("nan")), newY)
-            keep = ~torch.any(torch.all(filt, dim=0), dim=0)                       # filtered in ALL samples -> drop
+            if self.dist_group is not None:                                        # samples sharded over ranks
+                from .distributed import filtered_in_all_samples
+                all_s = filtered_in_all_samples(filt, self.dist_group)
+            else:
+                all_s = torch.all(filt, dim=0)
+            keep = ~torch.any(all_s, dim=0)                                        # filtered in ALL samples -> drop
             newX, newY = newX[:, :, keep, :], newY[:, :, keep, :]
         self.Hallcinated_X_train = torch.cat([self.Hallcinated_X_train, newX], 2)
         self.Hallcinated_Y_train = torch.cat([self.Hallcinated_Y_train, newY], 2)
@@ -370,7 +378,11 @@ class Agent(object):
             self.train_forward_sampling_dynGP()
             xu_hat = torch.cat([torch.stack([x_next] * self.nx, dim=1)[:, :, None, :],
                                 torch.tile(U_soln[[i + 1]], dims=(n_sample, self.nx, 1, 1))], dim=-1)
-        if torch.sum(samples_left) > 0:
+        if self.dist_group is not None:                                            # samples sharded over ranks
+            from .distributed import replace_rejected_samples
+            self.Hallcinated_X_train, self.Hallcinated_Y_train = replace_rejected_samples(
+                self.Hallcinated_X_train, self.Hallcinated_Y_train, samples_left, self.ns_global, rng, self.dist_group)
+        elif torch.sum(samples_left) > 0:
             n_rep = int(torch.sum(samples_left == 0).item())
             remaining = torch.arange(n_sample)[(samples_left > 0).cpu()].numpy()
             dead = samples_left == 0

@@ -4,9 +4,21 @@ RCCL over xGMI on ROCm, "gloo" is used by the CPU tests).
 The path shards trivially: samples are independent given the shared real data, the shared input
 sequence and their own base samples.  Rank r owns the contiguous global samples ``[r*Ns/G, (r+1)*Ns/G)``; the plan
 (real-data factor, ~20 KB) is replicated; base samples are addressed by GLOBAL sample index, so the assembled tube is
-identical for every GPU count.  The only collective is ONE all-gather of the ``(Ns/G, nx, H+1)`` float64 trajectory
-shards per rollout (the reference has no collective at all: it scales out with a SLURM job array and merges pickles
-offline, ``benchmarking/euler_job.sh:5-11``, ``generate_convex_hull.py:76-83``).
+identical for every GPU count.  The only collective of the rollout is ONE all-gather of the ``(Ns/G, nx, H+1)``
+float64 trajectory shards (the reference has no collective at all: it scales out with a SLURM job array and merges
+pickles offline, ``benchmarking/euler_job.sh:5-11``, ``generate_convex_hull.py:76-83``).
+
+The closed loop (mode J) shards the same way - every rank runs an ``Agent`` over its slice of the
+samples (``make_sharded_agent``) and the Jacobians go to the solver's host (``gather_jacobians``).  The reference has
+three places where samples are NOT independent; an Agent with ``dist_group`` set routes them through the helpers below
+so that the sharded run equals the single-process one:
+  * ``src/agent.py:186-191`` drops a new point when it was min-distance filtered in ALL samples
+    (``filtered_in_all_samples``: one all-reduce(MIN) of a (g_ny, m) mask);
+  * gpytorch's NaN-mask policy collapses the batch to the slots observed in every sample (App. A.4): the same mask
+    (the NaN pattern is the filter pattern), so the same reduction covers it;
+  * ``src/agent.py:418-436`` overwrites the hallucinated data of rejected samples with randomly chosen survivors'
+    (``replace_rejected_samples``: all-gather of the survivor mask and of the hallucinated tensors; every rank draws the
+    same indices from an identically seeded ``RandomState``).
 """
 from __future__ import annotations
 
@@ -82,3 +94,85 @@ def sharded_forward_sampling_rollout(agent, u_ff, x0=None, group=None) -> torch.
         return res.X_traj
 
     return sharded_rollout(local, agent.ns, group)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# closed loop (mode J): per-rank Agents over sample shards and the reference's cross-sample couplings
+# ---------------------------------------------------------------------------------------------------------------------
+def make_sharded_agent(agent_cls, params, env_model, group=None):
+    """An ``Agent`` over this rank's contiguous shard of the ``num_dyn_samples`` GLOBAL samples.
+
+    Every rank generates the full base-sample tensor from the same generator state (the constructor does, exactly as
+    the single-process Agent would) and keeps its slice, so sample ``s`` sees the same draws for every world size.
+    The returned agent has ``dist_group`` / ``shard`` / ``ns_global`` set; its methods return shard-sized arrays."""
+    import copy
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    Ns = int(params["agent"]["num_dyn_samples"])
+    lo, hi = shard_range(Ns, rank, world)
+    full = agent_cls(params, env_model)                   # global base samples (and global-size empty tensors)
+    erv = full.epistimic_random_vector[:, :, lo:hi].contiguous()
+    p_loc = copy.deepcopy(params)
+    p_loc["agent"]["num_dyn_samples"] = hi - lo
+    gen_state = torch.get_rng_state()
+    agent = agent_cls(p_loc, env_model)
+    torch.set_rng_state(gen_state)                        # the shard constructor's own draws do not advance the stream
+    agent.epistimic_random_vector = erv
+    agent.dist_group = group if group is not None else dist.group.WORLD
+    agent.shard, agent.ns_global = (lo, hi), Ns
+    return agent
+
+
+def filtered_in_all_samples(filt_local: torch.Tensor, group=None) -> torch.Tensor:
+    """``filt_local`` (Ns_local, g_ny, m) bool: point filtered for that sample/output.  Returns the (g_ny, m) bool mask
+    "filtered in ALL samples" over the GLOBAL sample set (reference ``src/agent.py:186``: ``torch.all(filt, dim=0)``)."""
+    loc = torch.all(filt_local, dim=0).to(torch.int32) if filt_local.shape[0] > 0 else \
+        torch.ones(filt_local.shape[1:], dtype=torch.int32, device=filt_local.device)
+    dist.all_reduce(loc, op=dist.ReduceOp.MIN, group=group)
+    return loc.bool()
+
+
+def all_gather_samples(x_local: torch.Tensor, Ns: int, group=None) -> torch.Tensor:
+    """Concatenate per-rank tensors whose dim 0 is the (contiguously sharded) sample axis; ragged shards are padded."""
+    return all_gather_tube(x_local, Ns, group)
+
+
+def replace_rejected_samples(X_local: torch.Tensor, Y_local: torch.Tensor, left_local: torch.Tensor, Ns: int, rng,
+                             group=None):
+    """Survivor replacement of ``prepare_dynamics_set`` (reference ``src/agent.py:418-436``) for sharded samples.
+
+    ``left_local`` (Ns_local,) is nonzero for samples that stayed inside the tube.  If any sample of the GLOBAL set
+    survived, the hallucinated rows of every rejected sample are overwritten with those of survivors drawn by
+    ``rng.choice(remaining, n_rep)`` - drawn twice, once for X and once for Y, exactly as the reference does.  ``rng``
+    must be identically seeded on every rank (a ``numpy.random.RandomState``).  Returns the updated local X, Y."""
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    lo, hi = shard_range(Ns, rank, world)
+    left = all_gather_samples(left_local.reshape(-1, 1).to(torch.int64), Ns, group).reshape(-1)
+    if int(left.sum().item()) == 0:
+        return X_local, Y_local
+    Xg = all_gather_samples(X_local, Ns, group)
+    Yg = all_gather_samples(Y_local, Ns, group)
+    dead = (left == 0).cpu()
+    n_rep = int(dead.sum().item())
+    remaining = torch.arange(Ns)[~dead].numpy()
+    pick_x = rng.choice(remaining, n_rep).tolist()
+    pick_y = rng.choice(remaining, n_rep).tolist()
+    Xg[dead.to(Xg.device)] = Xg[pick_x]
+    Yg[dead.to(Yg.device)] = Yg[pick_y]
+    return Xg[lo:hi].contiguous(), Yg[lo:hi].contiguous()
+
+
+def gather_jacobians(arrays, Ns: int, group=None, dst: int = 0):
+    """Assemble the solver-side numpy arrays of ``dyn_fg_jacobians`` (``gp_val, y_grad, u_grad``, sample axis first)
+    from the per-rank shards on rank ``dst`` (the closed loop moves Jacobians to the solver's
+    host, not between GPUs).  Returns the full arrays on ``dst`` and ``None`` elsewhere."""
+    import numpy as np
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    out = []
+    for a in arrays:
+        parts = [None] * world if rank == dst else None
+        dist.gather_object(np.ascontiguousarray(a), parts, dst=dst, group=group)
+        out.append(np.concatenate(parts, axis=0) if rank == dst else None)
+    if rank == dst:
+        assert all(o.shape[0] == Ns for o in out)
+        return tuple(out)
+    return None

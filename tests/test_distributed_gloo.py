@@ -77,3 +77,98 @@ def test_shard_range_partitions():
             assert all(r[k][1] == r[k + 1][0] for k in range(world - 1))
             sizes = [hi - lo for lo, hi in r]
             assert max(sizes) - min(sizes) <= 1
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# closed loop: the reference's cross-sample couplings under sample sharding
+# ---------------------------------------------------------------------------------------------------------------------
+def _coupling_worker(rank, world, port, Ns, payload, out_q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.set_num_threads(2)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import copy
+    import sampling_gpmpc_amd as sg
+    from sampling_gpmpc_amd.distributed import (shard_range, filtered_in_all_samples, replace_rejected_samples,
+                                                gather_jacobians, make_sharded_agent)
+    lo, hi = shard_range(Ns, rank, world)
+    filt, X, Y, left, jac, newX, newY, params, seed = payload
+    res = {"rank": rank}
+    res["all_s"] = filtered_in_all_samples(filt[lo:hi]).numpy()
+    Xr, Yr = replace_rejected_samples(X[lo:hi].clone(), Y[lo:hi].clone(), left[lo:hi], Ns, np.random.RandomState(5))
+    res["X"], res["Y"] = Xr.numpy(), Yr.numpy()
+    g = gather_jacobians([a[lo:hi] for a in jac], Ns)
+    res["jac"] = g
+    # the Agent wiring: min-distance filter of update_hallucinated_Dyn_dataset with samples sharded over ranks
+    torch.manual_seed(seed)
+    agent = make_sharded_agent(sg.Agent, copy.deepcopy(params), sg.make_env(params))
+    assert agent.ns == hi - lo and agent.ns_global == Ns and agent.shard == (lo, hi)
+    agent.update_hallucinated_Dyn_dataset(newX[lo:hi], newY[lo:hi])
+    agent.update_hallucinated_Dyn_dataset(newX[lo:hi] + 0.01, newY[lo:hi])          # close to the first batch: filtered
+    res["hX"], res["hY"] = agent.Hallcinated_X_train.numpy(), agent.Hallcinated_Y_train.numpy()
+    res["erv"] = agent.epistimic_random_vector.numpy()
+    out_q.put(res)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("Ns", [6, 7])
+def test_cross_sample_couplings_sharded_equal_single_process(Ns):
+    import copy
+    import sampling_gpmpc_amd as sg
+    from tests.helpers import load_params
+    world, g_ny, m, n, D, T = 2, 1, 5, 4, 2, 3
+    gen = torch.Generator().manual_seed(100 + Ns)
+    filt = torch.rand(Ns, g_ny, m, generator=gen) < 0.6
+    filt[:, :, 1] = True                                          # one point filtered in every sample
+    X = torch.randn(Ns, g_ny, n, D, generator=gen, dtype=torch.float64)
+    Y = torch.randn(Ns, g_ny, n, T, generator=gen, dtype=torch.float64)
+    left = (torch.rand(Ns, generator=gen) < 0.5).to(torch.int64)
+    left[0], left[-1] = 1, 0                                      # at least one survivor, one rejected sample
+    jac = [np.arange(Ns * 2 * 3, dtype=np.float64).reshape(Ns, 2, 3, 1), np.random.RandomState(1).randn(Ns, 2, 3, 2)]
+    params = copy.deepcopy(load_params("params_pendulum1D_samples"))
+    params["common"]["use_cuda"] = False
+    params["agent"]["num_dyn_samples"] = Ns
+    params["optimizer"]["H"] = m
+    params["common"]["num_MPC_itrs"], params["optimizer"]["SEMPC"]["max_sqp_iter"] = 2, 2
+    params["agent"]["Dyn_gp_min_data_dist"] = 0.05
+    newX = torch.randn(Ns, g_ny, m, D, generator=gen, dtype=torch.float64) + torch.tensor([2.5, 0.0])
+    newX[:, :, 2, :] = torch.tensor([2.1, -5.0], dtype=torch.float64)      # ON a real grid point: filtered in every sample
+    newY = torch.randn(Ns, g_ny, m, T, generator=gen, dtype=torch.float64)
+    seed = 4242
+    # single-process references
+    all_ref = torch.all(filt, dim=0).numpy()
+    rng = np.random.RandomState(5)
+    Xs, Ys = X.clone(), Y.clone()
+    dead = left == 0
+    remaining = torch.arange(Ns)[left > 0].numpy()
+    n_rep = int(dead.sum())
+    Xs[dead] = Xs[rng.choice(remaining, n_rep).tolist()]
+    Ys[dead] = Ys[rng.choice(remaining, n_rep).tolist()]
+    torch.manual_seed(seed)
+    ref_agent = sg.Agent(copy.deepcopy(params), sg.make_env(params))
+    ref_agent.update_hallucinated_Dyn_dataset(newX, newY)
+    ref_agent.update_hallucinated_Dyn_dataset(newX + 0.01, newY)
+    assert ref_agent.Hallcinated_X_train.shape[2] < 2 * m, "the all-samples drop did not trigger in the reference run"
+
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    payload = (filt, X, Y, left, jac, newX, newY, params, seed)
+    procs = [ctx.Process(target=_coupling_worker, args=(r, world, port, Ns, payload, q)) for r in range(world)]
+    for pr in procs:
+        pr.start()
+    got = sorted((q.get(timeout=180) for _ in range(world)), key=lambda r: r["rank"])
+    for pr in procs:
+        pr.join(timeout=60)
+        assert pr.exitcode == 0
+    for r in got:
+        np.testing.assert_array_equal(r["all_s"], all_ref)
+    np.testing.assert_array_equal(np.concatenate([r["X"] for r in got]), Xs.numpy())
+    np.testing.assert_array_equal(np.concatenate([r["Y"] for r in got]), Ys.numpy())
+    assert got[1]["jac"] is None
+    for a, b in zip(got[0]["jac"], jac):
+        np.testing.assert_array_equal(a, b)
+    np.testing.assert_array_equal(np.concatenate([r["hX"] for r in got]), ref_agent.Hallcinated_X_train.numpy())
+    np.testing.assert_array_equal(np.concatenate([r["hY"] for r in got]), ref_agent.Hallcinated_Y_train.numpy())
+    np.testing.assert_array_equal(np.concatenate([r["erv"] for r in got], axis=2), ref_agent.epistimic_random_vector.numpy())
