@@ -241,6 +241,9 @@ def main():
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / FP64_PEAK_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_hbm_bytes_per_launch": MIN_HBM_BYTES_PER_TRAJ_STEP["pendulum1D_R_H30"] * Ns * H,
+                         "hbm_gbps": (traffic / (kern_ms * 1e-3) / 1e9) if traffic else None,
+                         "hbm_frac_of_8TBps": (traffic / (kern_ms * 1e-3) / 8e12) if traffic else None,
+                         "mfma_busy": 0.0,      # SQ_VALU_MFMA_BUSY_CYCLES = 0 (profiles/): three right-hand sides cannot fill an FP64 MFMA tile
                          "kernel": "rollout_fast_kernel<3,36,1,pendulum1D,L_hh in LDS,grid root>", "kernel_ms": kern_ms,
                          "timed_region_ms_per_step_hip_events": region_ms,
                          "flop_per_launch": flop,

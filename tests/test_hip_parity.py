@@ -479,6 +479,46 @@ def test_sharded_rollout_single_rank_rccl(sg):
     np.testing.assert_array_equal(tube.cpu().numpy(), X)
 
 
+def test_sharded_closed_loop_single_rank_rccl(sg):
+    """The sharded closed-loop path (make_sharded_agent + min-distance filter reduced through RCCL + gather_jacobians)
+    with a world of one rank equals the plain Agent, two SQP iterations."""
+    import copy
+    import torch.distributed as dist
+    from sampling_gpmpc_amd.distributed import make_sharded_agent, gather_jacobians
+    Ns, H = 6, 5
+    p = load_params("params_pendulum1D_samples")
+    p["common"]["use_cuda"] = True
+    p["agent"]["num_dyn_samples"], p["optimizer"]["H"] = Ns, H
+    p["common"]["num_MPC_itrs"], p["optimizer"]["SEMPC"]["max_sqp_iter"] = 1, 2
+    p["agent"]["Dyn_gp_min_data_dist"] = 0.02
+    torch.manual_seed(9)
+    plain = sg.Agent(copy.deepcopy(p), sg.make_env(p))
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ["MASTER_PORT"] = "29537"
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        torch.manual_seed(9)
+        sharded = make_sharded_agent(sg.Agent, copy.deepcopy(p), sg.make_env(p))
+        assert sharded.dist_group is not None and sharded.shard == (0, Ns)
+        assert torch.equal(sharded.epistimic_random_vector, plain.epistimic_random_vector)
+        g = torch.Generator().manual_seed(5)
+        x0 = np.array(p["env"]["start"], dtype=np.float64)
+        for it in range(2):
+            x_h = np.tile(x0, (H, Ns)) + 0.05 * torch.randn(H, Ns * plain.nx, generator=g, dtype=F64).numpy()
+            u_h = 0.3 * torch.randn(H, Ns, plain.nu, generator=g, dtype=F64).numpy()
+            outs = []
+            for ag in (plain, sharded):
+                ag.train_hallucinated_dynGP(it)
+                outs.append(ag.dyn_fg_jacobians(ag.get_batch_x_hat_u_diff(x_h, u_h), it))
+            full = gather_jacobians(outs[1], Ns)
+            for a, b in zip(outs[0], full):
+                np.testing.assert_array_equal(a, b)
+            assert torch.equal(plain.Hallcinated_X_train, sharded.Hallcinated_X_train)
+            np.testing.assert_array_equal(plain.Hallcinated_Y_train.cpu().numpy(), sharded.Hallcinated_Y_train.cpu().numpy())
+    finally:
+        dist.destroy_process_group()
+
+
 @pytest.mark.parametrize("pname,Ns,H,nograd", [("params_pendulum1D_samples", 16, 12, False),
                                                ("params_car_residual_fs", 9, 10, False),
                                                ("params_car_residual_fs", 70, 9, True)])
