@@ -180,3 +180,39 @@ def test_sequential_conditioning_on_exact_draws_equals_the_joint_draw():
     y2 = gp2(xs[:, :, 1:]).sample(z[:, :, 1:])
     np.testing.assert_allclose(y1.numpy(), joint[:, :, :1].numpy(), rtol=1e-10, atol=1e-12)
     np.testing.assert_allclose(y2.numpy(), joint[:, :, 1:].numpy(), rtol=1e-5, atol=1e-7)
+
+
+def test_value_only_posterior_against_scikit_learn():
+    """The value-only (T = 1) GP algebra of the oracle - ARD RBF convention exp(-r^2 / (2 l^2)), outputscale as a
+    multiplier, noise on the diagonal, zero mean, posterior mean and covariance, Cholesky-root sampling - against
+    scikit-learn's GaussianProcessRegressor (an independent third-party exact-GP implementation; hyper-parameters
+    fixed, optimizer off) on the car's 5 x 9 training grid with the shipped hyper-parameters of every output."""
+    from sklearn.gaussian_process import GaussianProcessRegressor
+    from sklearn.gaussian_process.kernels import RBF, ConstantKernel
+    from tests.helpers import load_params
+    from oracle import agent_oracle as ao
+    p = load_params("params_car_residual_fs")
+    p["common"]["use_cuda"] = False
+    env = ao.make_oracle_env(p)
+    X, Y = env.initial_training_data()                       # (45, 2), (3, 45, 3); value-only: column 0
+    hy = go.GPHyper.from_params(p, use_grad=False)
+    rs = np.random.RandomState(3)
+    Xs = np.stack([rs.uniform(-1.2, 1.2, 7), rs.uniform(-0.7, 0.7, 7)], axis=1)
+    for o in range(hy.ell.shape[0]):
+        hyp = go.GPHyper(hy.ell[[o]], hy.outputscale[[o]], hy.noise_diag, hy.jitter, False)
+        gp = go.OracleGP(X.reshape(1, 1, -1, 2).to(F64), Y[o, :, [0]].reshape(1, 1, -1, 1).to(F64), hyp)
+        post = gp(torch.tensor(Xs).reshape(1, 1, -1, 2))
+        kern = ConstantKernel(float(hy.outputscale[o]), "fixed") * RBF(hy.ell[o].numpy(), "fixed")
+        sk = GaussianProcessRegressor(kernel=kern, alpha=float(hy.noise_diag[0]), optimizer=None, normalize_y=False)
+        sk.fit(X.numpy(), Y[o, :, 0].numpy())
+        mu, cov = sk.predict(Xs, return_cov=True)
+        np.testing.assert_allclose(post.mean.reshape(-1).numpy(), mu, rtol=1e-8, atol=1e-10 * np.abs(mu).max())
+        np.testing.assert_allclose(post.covariance_matrix[0, 0].numpy(), cov, rtol=1e-6, atol=1e-9 * np.abs(cov).max())
+        # Cholesky-root sampling with given base samples == mean + chol(cov) z on scikit-learn's covariance
+        z = torch.tensor(rs.randn(7)).reshape(1, 1, 7, 1)
+        Lc = np.linalg.cholesky(cov + 0.0 * np.eye(7))
+        y_sk = mu + Lc @ z.reshape(-1).numpy()
+        info = go.FactorInfo()
+        R = go.root_decomposition(post.covariance_matrix, hyp.jitter, info)
+        if float(info.jitter_added.max()) == 0.0:               # un-jittered branch: same root
+            np.testing.assert_allclose(post.sample(z).reshape(-1).numpy(), y_sk, rtol=1e-6, atol=1e-9)
