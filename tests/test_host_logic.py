@@ -189,3 +189,14 @@ def test_on_disk_formats_roundtrip(tmp_path):
     with pytest.raises(ValueError):
         io.save_x_traj(str(tmp_path), 1, np.zeros((3, 4)))
 
+
+def test_inline_asm_dpp_table_reads_have_no_valu_write_hazard():
+    """rollout_indep_grid_kernel reads its register-resident tables as the DPP source of inline-asm v_fmac_f64_dpp; the
+    compiler cannot insert the two wait states a VALU-written DPP source needs into inline asm, so the ISA is scanned
+    for a write of a table register right in front of such a read (tools/check_dpp_hazard.py)."""
+    import subprocess, sys, shutil
+    if not (shutil.which("hipcc") or os.path.exists("/opt/rocm/bin/hipcc")):
+        pytest.skip("hipcc not available")
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(repo, "tools", "check_dpp_hazard.py")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
