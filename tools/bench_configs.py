@@ -35,6 +35,9 @@ if __name__ == "__main__":
         for h in (10, 15, 20, 43):
             run("params_pendulum1D_samples", 4096, h, False, 10)
         sys.exit(0)
+    if "--car" in sys.argv:
+        run("params_car_residual_fs", 4096, 40, False, 5)
+        sys.exit(0)
     if "--mode-i" in sys.argv:
         run("params_car_residual_fs", 32768, 40, True, 10)
         run("params_car_residual_fs", 262144, 40, True, 10)
