@@ -39,8 +39,8 @@ struct EnvParams {
 // W = D^-1/2 (Qa (x) Qb)^T satisfies W^T W = (K_rr + s2 I)^-1 and can stand in for L_rr^-1 everywhere (the Schur
 // complement, the posterior mean and covariance only see W^T W).  W k_r for a separable kernel row costs n0 + n1 pivots
 // instead of N_r.  dsc[r] = os / sqrt(D_r) (the outputscale of k_r folded in), wE = W y_r.
-// Mode-I table (rollout_indep.hip), appended to the grid root: the tables the grid-root mode-I kernel streams through
-// scalar loads, packed in units of 8 doubles (one s_load_dwordx16 each), 64-byte aligned inside the plan:
+// Mode-I table (rollout_indep.hip), appended to the grid root: the tables the grid-root mode-I kernel keeps in
+// registers (16 entries per VGPR pair), packed in units of 8 doubles, 64-byte aligned inside the plan:
 //   [ rec (16): x_first(axis 0), il0*h0, x_first(axis 1), il1*h1, then G0_k = exp(-il0 (k h0)^2 / 2), k = 1..n0-1, and
 //               G1_k, k = 1..n1-1 - the constants of the equispaced-axis recurrence for the kernel factors
 //               (il0*h0 = NaN: the axes are not equispaced / the recurrence is out of range, use the axis points)

@@ -288,6 +288,22 @@ __global__ __launch_bounds__(64 * G_NY) void rollout_indep_grid_kernel(const Rol
 #pragma unroll
     for (int r = 0; r < NREG; ++r) T[r] = (r == 1) ? 0.0 : tabg[16 * r + (lane & 15)];      // group 1 = axis points: fallback only
     const bool rec_ok = tabg[1] == tabg[1];                               // equispaced axes (plan): recurrence constants valid
+    if (rec_ok) {
+        // the recurrence yields ea_i = E_0 rho^i G_i: the constant G_i is folded into row i of Qa (Qb likewise) once, here
+#pragma unroll
+        for (int r = QA / 16; r <= (M1 - 1) / 16; ++r) {
+            const int f = 16 * r + (lane & 15);
+            double gf = 1.0;
+            if (f >= QA && f < QA + N0 * N0) {
+                const int i = (f - QA) / N0;
+                if (i > 0) gf = tabg[3 + i];
+            } else if (f >= QB && f < QB + N1 * N1) {
+                const int j = (f - QB) / N1;
+                if (j > 0) gf = tabg[3 + (N0 - 1) + j];
+            }
+            T[r] *= gf;
+        }
+    }
     const double il0 = gp.inv_l2[o][0], il1 = gp.inv_l2[o][1], os = gp.os[o];
     if (threadIdx.x < kWave) s_info[threadIdx.x] = 0;
     // The input sequence and the feedback law are staged in LDS once: read from the kernel arguments / HBM inside the
@@ -350,7 +366,7 @@ __global__ __launch_bounds__(64 * G_NY) void rollout_indep_grid_kernel(const Rol
         IPHASE(0);
         double ea[N0], eb[N1];
         if (rec_ok) {                                                     // uniform
-            // table group 0: x_first(axis 0), il0 h0, x_first(axis 1), il1 h1, G0_1.., G1_1..
+            // table group 0: x_first(axis 0), il0 h0, x_first(axis 1), il1 h1 (G0_k, G1_k: folded into Qa / Qb)
             const double r0a = sub_from_tab<0>(T, xi[0]), r0b = sub_from_tab<2>(T, xi[1]);
             constexpr double capa = (N0 > 1) ? 700.0 / (N0 - 1) : 700.0, capb = (N1 > 1) ? 700.0 / (N1 - 1) : 700.0;
             const double aa = fmin(fmax(-mul_tab<1>(T, r0a), -capa), capa), ab = fmin(fmax(-mul_tab<3>(T, r0b), -capb), capb);
@@ -364,14 +380,10 @@ __global__ __launch_bounds__(64 * G_NY) void rollout_indep_grid_kernel(const Rol
 #pragma unroll
             for (int k = 2; k < N1; ++k) pb[k] = pb[k / 2] * pb[k - k / 2];
             ea[0] = E0a, eb[0] = E0b;
-            static_for<N0 - 1>([&](auto kc) {
-                constexpr int k = decltype(kc)::value + 1;
-                ea[k] = mul_tab<3 + k>(T, E0a) * pa[k];
-            });
-            static_for<N1 - 1>([&](auto kc) {
-                constexpr int k = decltype(kc)::value + 1;
-                eb[k] = mul_tab<3 + (N0 - 1) + k>(T, E0b) * pb[k];
-            });
+#pragma unroll
+            for (int k = 1; k < N0; ++k) ea[k] = E0a * pa[k];             // G_k lives in the table rows (see the prologue)
+#pragma unroll
+            for (int k = 1; k < N1; ++k) eb[k] = E0b * pb[k];
         } else {
             const double* axg = tabg + plan_tabi_axis(N0, N1);
 #pragma unroll
