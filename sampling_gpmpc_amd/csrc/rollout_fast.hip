@@ -628,6 +628,23 @@ __global__ __launch_bounds__(GPMPC_FAST_MAXTHREADS, 1) void rollout_fast_kernel(
             }
         }
         wave_sync_lds();
+        // The rows this step appends (base = n_h .. n_h + T - 1) get v_r^T as their L_hr rows, and v_r is in kvs from here
+        // on: the owning lanes fetch it NOW - their rows do not exist yet (ex0 is false: whatever they compute below is
+        // discarded, and it stays finite) - instead of at the end of the step, where the 18 LDS reads and their wait sat
+        // on the serial spine between the sampling and the next step.
+        if (n_h < kWave && t + 1 < H) {                                   // uniform: a new row lives in bank 0 (registers)
+            const int a0e = lane - n_h;
+            if (a0e >= 0 && a0e < T) {
+                const double* src = kvs + a0e * NRP;
+#pragma unroll
+                for (int ip = 0; ip < NPAIR; ++ip) {
+                    const double2_t vv = *reinterpret_cast<const double2_t*>(src + 2 * ip);
+                    Lhr0[2 * ip] = vv.x;
+                    Lhr0[2 * ip + 1] = vv.y;
+                }
+                if (NR & 1) Lhr0[NR - 1] = src[NR - 1];
+            }
+        }
         FPHASE(1);
 
         if (n_h > 0) {
@@ -865,15 +882,7 @@ __global__ __launch_bounds__(GPMPC_FAST_MAXTHREADS, 1) void rollout_fast_kernel(
                 if (base < kWave) {                                       // uniform: a new row lives in bank 0 (registers)
                     // only the three owning lanes execute the loads (exec-masked): no select against the old row, and
                     // the loads can land directly in the registers that hold the row
-                    if (new0) {
-                        const double* src = kvs + a0 * NRP;
-#pragma unroll
-                        for (int ip = 0; ip < NPAIR; ++ip) {
-                            const double2_t vv = *reinterpret_cast<const double2_t*>(src + 2 * ip);
-                            Lhr0[2 * ip] = vv.x;
-                            Lhr0[2 * ip + 1] = vv.y;
-                        }
-                        if (NR & 1) Lhr0[NR - 1] = src[NR - 1];
+                    if (new0) {                                           // (the L_hr row itself was fetched after phase 1)
                         if constexpr (LHH_LDS) {
                             // ... and read the diagonal-block segment of their new row back (entries at / right of the
                             // diagonal: the zero pair); same wave, LDS operations complete in order
