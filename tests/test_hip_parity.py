@@ -260,6 +260,29 @@ def test_car_rollout_full_size_properties(sg, pname, Ns, H, nograd):
     assert float(X[:, 1, -1].std()) > 1e-6                    # a genuine spread
 
 
+@pytest.mark.parametrize("pname,Ns,H,feedback,x0", [
+    ("params_car_residual_fs", 70, 40, False, None),                        # open loop (no feedback law)
+    ("params_car_residual_fs", 9, 40, True, [0.5, 1.2, 0.1, 9.0]),          # another start state
+    ("params_car_residual_fs", 6, 300, True, None),                         # H > 256: the triangular kernel takes over
+    ("params_pendulum1D_samples", 66, 33, False, [2.4, -0.5]),
+])
+def test_mode_i_variants_against_oracle(sg, pname, Ns, H, feedback, x0):
+    """Mode I beyond the shipped configuration: without the feedback law, from another start state, and with a horizon
+    longer than the grid kernel stages in LDS (rollout_indep_launch falls back to the triangular kernel)."""
+    from sampling_gpmpc_amd.rollout import forward_sampling_rollout
+    p = fs_params(pname, Ns, H, nograd=True, feedback=feedback)
+    agent, oagent = make_agents(sg, p)
+    u_ff = synthetic_u_ff(agent.nu, H)
+    if H > 100:
+        u_ff = u_ff * 0.2                                                   # keep the long car rollout near the data
+    X, Y = forward_sampling_rollout(agent, u_ff, x0=x0, return_samples=True)
+    assert sg._lib.load().gpmpc_debug_last_rollout_path() == 2
+    Xo, Yo = ao.forward_sampling_rollout(oagent, u_ff, x0=x0, return_samples=True)
+    print(f"{pname} Ns={Ns} H={H} feedback={feedback} x0={x0}: rel err X_traj {relerr(X, Xo):.2e}, Y {relerr(Y, Yo):.2e}")
+    assert np.isfinite(X).all() and relerr(X, Xo) < RTOL_TRAJ
+    np.testing.assert_allclose(Y, Yo, rtol=1e-4, atol=1e-8)
+
+
 def test_joint_draw_against_reference_golden(sg):
     """Mode J as the SQP loop drives it (two iterations; the second conditions on the first's 8 sampled points)."""
     d = np.load(os.path.join(GOLDEN, "agent_e2e_J_pendulum1D.npz"))
