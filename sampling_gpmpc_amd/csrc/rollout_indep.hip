@@ -198,7 +198,7 @@ __global__ __launch_bounds__(256) void rollout_indep_kernel(const RolloutArgs a)
 // is lgkmcnt(0) and a wave can hide a load only behind the 16 FMAs of the previous group: 15 exposed K$ round trips
 // per step, 0.67 ms at Ns = 262144 and 0.114 ms at 32768; LDS broadcast reads are bound by the LDS pipe, 3.0 ms.)
 // ---------------------------------------------------------------------------------------------------------------
-constexpr int kIndepMaxH = 256;                                          // input sequence staged in LDS
+constexpr int kIndepMaxH = 256;                                          // input sequence staged in LDS up to this horizon
 // Table access: the table lives in VGPRs, entry f in register f / 16, replicated in every DPP row of 16 lanes (lane l
 // holds entry 16 r + (l & 15)).  v_fmac_f64_dpp with row_newbcast:(f % 16) reads it as a
 // wave-uniform operand.  The table registers are never written inside the step loop, so the DPP read-after-VALU-write
@@ -309,7 +309,8 @@ __global__ __launch_bounds__(64 * G_NY) void rollout_indep_grid_kernel(const Rol
     // The input sequence and the feedback law are staged in LDS once: read from the kernel arguments / HBM inside the
     // step loop they are a chain of ~7 dependent scalar-load round trips at the head of every step (pointer, element,
     // x_goal, a row of K, ...), which nothing in a wave's own instruction stream hides.
-    for (int e = threadIdx.x; e < H * NU; e += blockDim.x) uffs[e] = a.u_ff[e];
+    const bool uff_lds = H <= kIndepMaxH;                                 // longer horizons read the sequence from memory
+    for (int e = threadIdx.x; e < H * NU && uff_lds; e += blockDim.x) uffs[e] = a.u_ff[e];
     if (threadIdx.x < NX) fbk[threadIdx.x] = a.env.x_goal[threadIdx.x];
     if (threadIdx.x < NU * NX) fbk[NX + threadIdx.x] = a.env.K[threadIdx.x / NX][threadIdx.x % NX];
     const bool use_fb = a.env.use_feedback != 0;
@@ -332,7 +333,7 @@ __global__ __launch_bounds__(64 * G_NY) void rollout_indep_grid_kernel(const Rol
         double u[NU], xi[2];
         const double z = zp[(long)t * zstride];
 #pragma unroll
-        for (int i = 0; i < NU; ++i) u[i] = uffs[t * NU + i];
+        for (int i = 0; i < NU; ++i) u[i] = uff_lds ? uffs[t * NU + i] : a.u_ff[t * NU + i];
         if (use_fb) {                                                     // uniform
             double dx[NX];
 #pragma unroll
@@ -494,8 +495,7 @@ int rollout_indep_launch(const gpmpc_gp_desc_t* gp, const gpmpc_env_desc_t* env,
     // the grid root of the plan unless disabled (GPMPC_DISABLE_GRID_ROOT=1 keeps the triangular L_rr^-1 form, used by
     // the tests to compare the two)
     const char* eg = std::getenv("GPMPC_DISABLE_GRID_ROOT");
-    const bool grid_root = !(eg && eg[0] == '1') && plan_has_grid_root(gp->grid_n0, gp->grid_n1, gp->real_has_grad) &&
-                           args.H <= kIndepMaxH;
+    const bool grid_root = !(eg && eg[0] == '1') && plan_has_grid_root(gp->grid_n0, gp->grid_n1, gp->real_has_grad);
     if (grid_root) {
         const dim3 grid((unsigned)((args.Ns + 63) / 64));
         if (env->env_id == GPMPC_ENV_CAR_RESIDUAL)

@@ -263,12 +263,12 @@ def test_car_rollout_full_size_properties(sg, pname, Ns, H, nograd):
 @pytest.mark.parametrize("pname,Ns,H,feedback,x0", [
     ("params_car_residual_fs", 70, 40, False, None),                        # open loop (no feedback law)
     ("params_car_residual_fs", 9, 40, True, [0.5, 1.2, 0.1, 9.0]),          # another start state
-    ("params_car_residual_fs", 6, 300, True, None),                         # H > 256: the triangular kernel takes over
+    ("params_car_residual_fs", 6, 300, True, None),                         # H > 256: the input sequence is read from memory
     ("params_pendulum1D_samples", 66, 33, False, [2.4, -0.5]),
 ])
 def test_mode_i_variants_against_oracle(sg, pname, Ns, H, feedback, x0):
     """Mode I beyond the shipped configuration: without the feedback law, from another start state, and with a horizon
-    longer than the grid kernel stages in LDS (rollout_indep_launch falls back to the triangular kernel)."""
+    longer than the grid kernel stages in LDS (the input sequence is then read from memory)."""
     from sampling_gpmpc_amd.rollout import forward_sampling_rollout
     p = fs_params(pname, Ns, H, nograd=True, feedback=feedback)
     agent, oagent = make_agents(sg, p)
