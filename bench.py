@@ -107,23 +107,27 @@ def reachable_set_leg(a, rank, world, dist, sg, _lib, RolloutRunner, fs_params, 
         if world > 1:
             dist.all_gather_into_tensor(tube, X)
 
-    for _ in range(2):
-        one()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(reps):
-        one()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    wall = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([wall], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        wall = float(t.item())
-    finite = bool(torch.isfinite(runner.X_traj).all())
+    try:
+        for _ in range(2):
+            one()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            one()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        wall = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([wall], dtype=torch.float64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            wall = float(t.item())
+        finite = bool(torch.isfinite(runner.X_traj).all())
+    except Exception as e:                                    # noqa: BLE001 - the headline line must still be printed
+        res["error"] = repr(e)[:300]
+        return res
     res.update({"Ns_per_gpu": a.reach_ns, "Ns_total": world * a.reach_ns, "H": 40, "n_gpus": world, "reps": reps,
                 "wallclock_ms": wall / reps * 1e3, "trajectory_steps_per_s": world * a.reach_ns * 40 * reps / wall,
                 "finite": finite, "kernel": "rollout_indep_grid_kernel<car,5,9,3>"})
