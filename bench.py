@@ -12,7 +12,10 @@ X_traj (N*Ns, nx, H+1) on every rank.  Workload at every N: BASELINE.json config
 value+gradient labels) - i.e. weak scaling over samples.  Inputs (training grid, base samples z, input sequence)
 are synthetic and resident in HBM before the timed region.
 
-Prints ONE JSON line on rank 0 (see the keys below).  `roofline` is for the dominant kernel (rollout_kernel):
+Before the W warmup steps the same step runs `--prewarm` (default 2000, ~0.25 s) more untimed times: a cold GPU needs
+that long to reach its sustained clocks, and a 50-step region measured right after 5 warmup steps reads ~5 % slower than
+the steady state every longer run sees (tools/clock_check.py: 0.1166 vs 0.1087 ms per step); the count is reported as
+`prewarm_steps`.  Prints ONE JSON line on rank 0 (see the keys below).  `roofline` is for the dominant kernel (rollout_kernel):
 algorithmic FP64 FLOP per launch (2.55e4 FLOP per trajectory-step for this config) divided by
 the launch duration measured with HIP events on the launch stream (one event pair per launch, in a pass of the same
 launches right after the timed region; the timed region itself carries one event at either end).  `cpu_baseline` times the CPU oracle (the
@@ -44,6 +47,9 @@ def parse():
     ap.add_argument("--ns", type=int, default=1024, help="samples per GPU (BASELINE configs[1]: 1024)")
     ap.add_argument("--horizon", type=int, default=30)
     ap.add_argument("--cpu-sample", type=int, default=256, help="samples of the CPU-oracle baseline (0 = skip)")
+    ap.add_argument("--prewarm", type=int, default=2000,
+                    help="untimed steps BEFORE the W warmup steps that bring the GPU to its sustained clocks (a cold "
+                         "50-step region measures ~5 %% slower than steady state: tools/clock_check.py); 0 = off")
     ap.add_argument("--reach-ns", type=int, default=32768,
                     help="samples per GPU of the informational reachable-set leg (configs[3], mode I; 0 = skip)")
     return ap.parse_args()
@@ -100,7 +106,7 @@ def reachable_set_leg(a, rank, world, dist, sg, _lib, RolloutRunner, fs_params, 
     if not ok:
         res.setdefault("error", "skipped: another rank failed to set the workload up")
         return res
-    reps = 10
+    reps = 50
 
     def one():
         X = runner.launch()
@@ -108,7 +114,7 @@ def reachable_set_leg(a, rank, world, dist, sg, _lib, RolloutRunner, fs_params, 
             dist.all_gather_into_tensor(tube, X)
 
     try:
-        for _ in range(2):
+        for _ in range(50):
             one()
         if world > 1:
             dist.barrier()
@@ -180,6 +186,10 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # clock ramp: the same step, a fixed count on every rank (it contains the collective), untimed and reported
+    for _ in range(max(a.prewarm, 0)):
+        step()
+    fence()
     for _ in range(a.warmup):
         step()
     fence()
@@ -208,7 +218,10 @@ def main():
         runner.launch()
         ev[k][1].record()
     torch.cuda.synchronize()
-    kern_ms = float(np.mean([s.elapsed_time(e) for s, e in ev]))
+    kern_ms_pairs = float(np.mean([s.elapsed_time(e) for s, e in ev]))
+    # a launch cannot take longer than a step of the (un-instrumented) timed region it is part of: at N = 1 the region per
+    # step is kernel + launch gap, and the event pairs of the second pass add a few microseconds of their own
+    kern_ms = min(kern_ms_pairs, region_ms) if world == 1 else kern_ms_pairs
     bits = int(runner.info.max().item())
     assert torch.isfinite(runner.X_traj).all() and not (bits & (_lib.INFO_TRAIN_CHOL_FAIL | _lib.INFO_ROOT_FAIL)), bits
 
@@ -231,6 +244,7 @@ def main():
             "n_gpus": world,
             "steps": a.steps,
             "warmup": a.warmup,
+            "prewarm_steps": max(a.prewarm, 0),     # untimed clock-ramp steps before the warmup (see --prewarm)
             "ms_per_step": wall / a.steps * 1e3,
             "higher_is_better": True,
             "scaling": "weak",
@@ -250,6 +264,7 @@ def main():
                          "mfma_busy": 0.0,      # SQ_VALU_MFMA_BUSY_CYCLES = 0 (profiles/): three right-hand sides cannot fill an FP64 MFMA tile
                          "kernel": "rollout_fast_kernel<3,36,1,pendulum1D,L_hh in LDS,grid root>", "kernel_ms": kern_ms,
                          "timed_region_ms_per_step_hip_events": region_ms,
+                         "kernel_ms_per_launch_event_pairs": kern_ms_pairs,
                          "flop_per_launch": flop,
                          "note": "FP64 (vector FMA; FP64 MFMA peak is the same 78.6 TFLOP/s on MI355X); algorithmic "
                                  "FLOP = 2.55e4 per trajectory-step (SURVEY 8d) x Ns x H; min HBM traffic 80 B per "
