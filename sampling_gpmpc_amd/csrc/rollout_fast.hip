@@ -467,6 +467,10 @@ __global__ __launch_bounds__(GPMPC_FAST_MAXTHREADS, 1) void rollout_fast_kernel(
     // its full latency (the three z loads were serialised behind s_waitcnt vmcnt(0), which also waits for the
     // trajectory stores of the step).  With L_hh in LDS the loop then contains no vector-memory load at all.
     // layout: register c, lane t = component c of step t (H <= 43 < 64), so a pick is two v_readlane, no register select
+    constexpr bool TRAJ_REGS = (G_NY == 1);
+    double xq[TRAJ_REGS ? NX : 1];                                // state of step `lane` (see the step loop)
+#pragma unroll
+    for (int d = 0; d < (TRAJ_REGS ? NX : 1); ++d) xq[d] = 0.0;
     double zq[T], uq[NU];
 #pragma unroll
     for (int c = 0; c < T; ++c) zq[c] = (lane < H) ? a.z[(long)lane * a.z_step_stride + (s * G_NY + o) * T + c] : 0.0;
@@ -496,18 +500,25 @@ __global__ __launch_bounds__(GPMPC_FAST_MAXTHREADS, 1) void rollout_fast_kernel(
             xi[0] = (ENV == GPMPC_ENV_PENDULUM1D) ? x[0] : x[2];
             xi[1] = u[0];
         }
-#ifdef GPMPC_ABLATE_STORES
-        if (lane == 0 && o == 0 && t < 0) {
-#else
-        if (lane == 0 && o == 0) {
-#endif
+        if constexpr (TRAJ_REGS) {
+            // the trajectory is collected one step per lane (H + 1 <= 44 lanes) and written once, coalesced, after the
+            // loop: no exec-masked store region and no address arithmetic inside the step.  (Pendulum only: the car
+            // kernel has no registers left for it.)
 #pragma unroll
-            for (int d = 0; d < NX; ++d) a.X_traj[(s * NX + d) * (H + 1) + t] = x[d];
+            for (int d = 0; d < NX; ++d) xq[d] = (lane == t) ? x[d] : xq[d];
+        }
+#ifndef GPMPC_ABLATE_STORES
+        if (lane == 0 && o == 0) {
+            if constexpr (!TRAJ_REGS) {
+#pragma unroll
+                for (int d = 0; d < NX; ++d) a.X_traj[(s * NX + d) * (H + 1) + t] = x[d];
+            }
             if (a.Xi) {
 #pragma unroll
                 for (int d = 0; d < D; ++d) a.Xi[(s * H + t) * D + d] = xi[d];
             }
         }
+#endif
 
         // ---- kernel entries: the row against the real data (lane = real point) and this lane's rows of k_h ----------
         // one basic block: the exponentials are independent dependency chains and interleave.  The lane's row of
@@ -978,9 +989,16 @@ __global__ __launch_bounds__(GPMPC_FAST_MAXTHREADS, 1) void rollout_fast_kernel(
         FPHASE(7);
     }
 
-    if (lane == 0 && o == 0) {
+    if constexpr (TRAJ_REGS) {
+        if (o == 0 && lane <= H) {
 #pragma unroll
-        for (int d = 0; d < NX; ++d) a.X_traj[(s * NX + d) * (H + 1) + H] = x[d];
+            for (int d = 0; d < NX; ++d) a.X_traj[(s * NX + d) * (H + 1) + lane] = (lane == H) ? x[d] : xq[d];
+        }
+    } else {
+        if (lane == 0 && o == 0) {
+#pragma unroll
+            for (int d = 0; d < NX; ++d) a.X_traj[(s * NX + d) * (H + 1) + H] = x[d];
+        }
     }
     if constexpr (G_NY == 1) {
         if (lane == 0) a.info[s] = info_acc;
