@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define GPMPC_ABI_VERSION 2
+#define GPMPC_ABI_VERSION 3
 
 #define GPMPC_MAX_NY 4   /* GP outputs            (reference agent.g_dim.ny : 1 pendulum1D, 3 car)          */
 #define GPMPC_MAX_D  4   /* GP input dimension    (g_nx + g_nu : 2 in all shipped configs)                 */
@@ -46,9 +46,18 @@ extern "C" {
 /* info bits (per batch element) */
 #define GPMPC_INFO_TRAIN_CHOL_FAIL   0x0001 /* non-positive pivot while factorising K_oo + Sigma (A.5)      */
 #define GPMPC_INFO_ROOT_JITTER_MASK  0x000e /* (info >> 1) & 7 = highest retry level reached, 0 = none      */
-#define GPMPC_INFO_ROOT_FAIL         0x0010 /* all 3 jitter retries failed -> caller must take eigh path   */
+#define GPMPC_INFO_ROOT_FAIL         0x0010 /* all 3 jitter retries failed for THIS chain (-> eigh root)     */
 #define GPMPC_INFO_VAR_CLAMPED       0x0020 /* a posterior variance was raised to the 1e-10 floor (A.8)     */
 #define GPMPC_INFO_NEG_1x1           0x0040 /* 1x1 covariance negative -> sqrt gives NaN (as gpytorch)      */
+#define GPMPC_INFO_ROOT_EIGH         0x0080 /* y was drawn with the eigendecomposition root (A.7 step 4)    */
+#define GPMPC_INFO_EIGH_NOCONV       0x0100 /* the Jacobi eigensolver hit its sweep limit (result still used) */
+
+/* root_mode of gpmpc_joint_sample */
+#define GPMPC_ROOT_AUTO      0   /* gpytorch: Cholesky with the jitter chain; if ANY chain of the batch fails all  */
+                                 /* three retries, the WHOLE batch is drawn with the eigendecomposition root       */
+#define GPMPC_ROOT_EIGH      1   /* eigendecomposition root for every chain (a sharded batch whose failing chain   */
+                                 /* lives on another rank; tests)                                                  */
+#define GPMPC_ROOT_CHOLESKY  2   /* never fall back: failing chains return NaN samples + GPMPC_INFO_ROOT_FAIL      */
 
 /* environment ids: the per-step maps of reference src/environments/{pendulum1D,car_model_residual}.py        */
 #define GPMPC_ENV_PENDULUM1D   0
@@ -155,7 +164,9 @@ int    gpmpc_rollout(const gpmpc_gp_desc_t* gp, const gpmpc_env_desc_t* env, con
  * gpmpc_joint_sample - joint posterior draw at m test points per (sample, output), conditioning on the shared
  * real data plus per-sample hallucinated data.
  * Replaces: reference src/agent.py:629-708 (sample_gp): model_i(x_input) [gpytorch ExactGP eval call, SURVEY App.
- * A.4-A.6], .sample(base_samples) [A.7 root with jitter-on-failure], .variance [A.8], the optional
+ * A.4-A.6], .sample(base_samples) [A.7 root: Cholesky with jitter-on-failure, then the eigendecomposition root
+ * R = U sqrt(max(lambda, 0)) for the whole batch - the branch params_car_residual.yaml:51 (Dyn_gp_jitter 1e-20)
+ * takes on every draw; second kernel of the same call, no host round trip], .variance [A.8], the optional
  * variance-is-zero replacement and the beta clip.  The min-data-distance overwrite (src/agent.py:666-698) stays in
  * the facade (disabled in every shipped config).
  *   X_h     [dev] (Ns, g_ny, n_h, D)   Hallcinated_X_train (NULL if n_h == 0)
@@ -165,8 +176,12 @@ int    gpmpc_rollout(const gpmpc_gp_desc_t* gp, const gpmpc_env_desc_t* env, con
  *   X_s     [dev] (Ns, g_ny, m, D)     test inputs (g_xu_hat)
  *   z       [dev] (Ns, g_ny, m, T)     base samples
  *   mean, var, y [dev] (Ns, g_ny, m, T) out (var floored; y post-processed as above)
- *   covar   [dev] (Ns, g_ny, m*T, m*T) or NULL   out: posterior covariance (for the eigh fallback / debugging)
+ *   covar   [dev] (Ns, g_ny, m*T, m*T) or NULL   out: posterior covariance (model_i_call.covariance_matrix)
+ *   root    [dev] (Ns, g_ny, m*T, m*T) or NULL   out, eigh branch only: the root R actually used (columns ordered by
+ *                                      ascending eigenvalue like torch.linalg.eigh; column signs are solver specific)
+ *   root_mode  GPMPC_ROOT_*
  *   info    [dev] (Ns, g_ny) int32
+ *   limits: m*T <= 256 and n_ho + 1 + m*T <= 1024 label rows per chain (GPMPC_E_UNSUPPORTED beyond)
  */
 size_t gpmpc_joint_workspace_bytes(const gpmpc_gp_desc_t* gp, int64_t Ns, int32_t n_ho, int32_t m);
 int    gpmpc_joint_sample(const gpmpc_gp_desc_t* gp, const void* plan, const double* X_r,
@@ -174,7 +189,8 @@ int    gpmpc_joint_sample(const gpmpc_gp_desc_t* gp, const void* plan, const dou
                           const int32_t* h_slots, int32_t n_ho,
                           int32_t m, const double* X_s, const double* z,
                           double var_zero_thr, double beta, int32_t apply_clip,
-                          double* mean, double* var, double* y, double* covar, int32_t* info,
+                          double* mean, double* var, double* y, double* covar, double* root,
+                          int32_t root_mode, int32_t* info,
                           void* ws, size_t ws_bytes, void* stream);
 
 /*

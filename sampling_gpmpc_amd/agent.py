@@ -100,6 +100,7 @@ class Agent(object):
         # samples sharded over ranks (sampling_gpmpc_amd.distributed.make_sharded_agent): the process group through which
         # the reference's cross-sample couplings are reduced; None = this Agent holds every sample
         self.dist_group, self.shard, self.ns_global = None, None, self.ns
+        self.debug_keep_root = False   # tests: keep the eigendecomposition root of the last joint draw (model_i_call.root)
         self._plans = {}          # T -> RealDataPlan (real block factorised once per label layout)
         self._ws_cache = {}
         self._reset_hallucinated()
@@ -224,7 +225,7 @@ class Agent(object):
             hy = torch.empty(self.ns, self.g_ny, 0, 1, dtype=F64, device=self.torch_device)
         else:
             hx, hy = self.Hallcinated_X_train, self.Hallcinated_Y_train
-        self.model_i = HipGPModel(plan, hx, hy, self.batch_shape, self._ws_cache)
+        self.model_i = HipGPModel(plan, hx, hy, self.batch_shape, self._ws_cache, dist_group=self.dist_group)
         self.likelihood = plan.hyper
         if sqp_iter == 0:
             self._reset_hallucinated()
@@ -234,15 +235,18 @@ class Agent(object):
         plan = self._plan(use_grad=True)
         hx = torch.concat([self.FS_X_train_batch, self.Hallcinated_X_train], dim=2)
         hy = torch.concat([self.FS_Y_train_batch, self.Hallcinated_Y_train], dim=2)
-        self.model_i = HipGPModel(plan, hx, hy, self.batch_shape, self._ws_cache)
+        self.model_i = HipGPModel(plan, hx, hy, self.batch_shape, self._ws_cache, dist_group=self.dist_group)
         self.likelihood = plan.hyper
 
     def sample_gp(self, x_input, base_samples=None):
-        """Joint posterior draw + post-processing (reference ``src/agent.py:629-730``) in one kernel launch."""
+        """Joint posterior draw + post-processing (reference ``src/agent.py:629-730``) in one ``gpmpc_joint_sample`` call
+        (posterior + Cholesky root with the jitter chain; the eigendecomposition root for the whole batch when a chain
+        fails every retry, as with the shipped car_residual jitter of 1e-20)."""
         ag = self.params["agent"]
         self.model_i_call = self.model_i(x_input)
         y = self.model_i_call._sample(base_samples, clip=(ag["Dyn_gp_min_data_dist"] < 0.0),
-                                      beta=ag["Dyn_gp_beta"], var_zero_thr=ag["Dyn_gp_variance_is_zero"])
+                                      beta=ag["Dyn_gp_beta"], var_zero_thr=ag["Dyn_gp_variance_is_zero"],
+                                      want_root=self.debug_keep_root)
         if ag["Dyn_gp_min_data_dist"] >= 0.0:
             # overwrite by the closest observed training label when a test input is too close to it (:666-698),
             # then clip (:701-708).  Off in every shipped config; plain device tensor ops.

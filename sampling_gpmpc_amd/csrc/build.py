@@ -3,6 +3,8 @@
 
     python sampling_gpmpc_amd/csrc/build.py [--force] [--verbose]
 """
+import hashlib
+import json
 import os
 import subprocess
 import sys
@@ -11,7 +13,8 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 REPO = os.path.dirname(os.path.dirname(HERE))
 SOURCES = ["capi.hip", "rollout.hip", "rollout_fast.hip", "rollout_indep.hip", "joint.hip", "assemble.hip"]
-HEADERS = ["gpmpc_device.hpp", "gpmpc_host.hpp", "rollout_args.hpp", os.path.join(REPO, "include", "gpmpc_hip.h")]
+HEADERS = ["gpmpc_device.hpp", "gpmpc_host.hpp", "rollout_args.hpp", "joint_eigh.hpp",
+           os.path.join(REPO, "include", "gpmpc_hip.h")]
 OUT = os.path.join(os.path.dirname(HERE), "libgpmpc_hip.so")
 OBJDIR = os.path.join(HERE, "build")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
@@ -27,12 +30,36 @@ if os.environ.get("GPMPC_PHASE_TIMERS") == "1":      # debug build: per-phase s_
 EXTRA_FLAGS = {"rollout_fast.hip": os.environ.get("GPMPC_FAST_FLAGS", "-mllvm -disable-machine-licm").split()}
 
 
+STAMP = os.path.join(OBJDIR, "flags.stamp")
+
+
 def _mtime(p):
     return os.path.getmtime(p) if os.path.exists(p) else 0.0
 
 
+def flags_digest():
+    """Hash of everything besides the sources that decides what the objects contain: compiler, common flags (incl. the
+    GPMPC_EXTRA_DEFS / GPMPC_PHASE_TIMERS experiment knobs) and the per-file flags.  An ablation or instrumentation
+    build (tools/*.sh) therefore never survives as the "up to date" library of a later default build."""
+    blob = json.dumps({"hipcc": HIPCC, "flags": FLAGS, "extra": EXTRA_FLAGS}, sort_keys=True)
+    return hashlib.sha256(blob.encode()).hexdigest()
+
+
+def is_default_build():
+    """True when no experiment knob is set in the environment (what tests, bench.py and build() expect to load)."""
+    return not (os.environ.get("GPMPC_EXTRA_DEFS") or os.environ.get("GPMPC_PHASE_TIMERS") == "1"
+                or os.environ.get("GPMPC_FAST_FLAGS") is not None)
+
+
 def build(force=False, verbose=False):
     os.makedirs(OBJDIR, exist_ok=True)
+    digest = flags_digest()
+    try:
+        with open(STAMP) as f:
+            stale_flags = f.read().strip() != digest
+    except OSError:
+        stale_flags = True
+    force = force or stale_flags
     hdr_t = max(_mtime(h if os.path.isabs(h) else os.path.join(HERE, h)) for h in HEADERS)
     hdr_t = max(hdr_t, _mtime(os.path.abspath(__file__)))
     jobs = []
@@ -53,6 +80,8 @@ def build(force=False, verbose=False):
             print(r.stderr)
     with ThreadPoolExecutor(max_workers=4) as ex:
         list(ex.map(cc, jobs))
+    with open(STAMP, "w") as f:
+        f.write(digest + "\n")
     objs = [os.path.join(OBJDIR, s.replace(".hip", ".o")) for s in SOURCES]
     if jobs or not os.path.exists(OUT):
         cmd = [HIPCC, "-shared", "-fPIC", "--offload-arch=gfx950", "-o", OUT] + objs

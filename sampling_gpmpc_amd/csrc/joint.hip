@@ -18,7 +18,10 @@
 //                        test rows become V^T = (L^-1 K_o*)^T             
 //   * mean = V^T w, covariance S = K** - V^T V, variance = diag(S) floored (A.8)
 //   * root = Cholesky of S with the jitter-on-failure chain (A.7), y = mean + R z, post-processing of sample_gp.
+//   * S is left in a per-chain buffer: when any chain of the batch fails all retries, joint_eigh_kernel
+//     (joint_eigh.hpp, launched right behind this kernel) redraws the whole batch with the eigendecomposition root.
 #include "gpmpc_host.hpp"
+#include "joint_eigh.hpp"
 
 namespace gpmpc {
 
@@ -45,6 +48,8 @@ struct JointArgs {
     double* ws;
     long ws_chain_stride;   // doubles
     int ld;                 // rows of M (padded)
+    double* Sall;           // [chains][mT*mT] posterior covariance, column-major, lower part valid
+    int* any_fail;          // set when a chain's jitter chain failed (read by joint_eigh_kernel)
 };
 
 // Blocked left-looking step shared by the three phases.  For the column block whose pivot rows are
@@ -271,12 +276,12 @@ __global__ __launch_bounds__(NT, WPE) void joint_kernel(const JointArgs a) {
     const long nchains = a.Ns * gp.g_ny;
 
     double* M = a.ws + (long)blockIdx.x * a.ws_chain_stride;     // [n_o][ld]   column-major, thread == row
-    double* Sm = M + (long)n_o * ld;                              // [mT][mT]    column-major, lower part valid
-    double* Rm = Sm + (long)mT * mT;                              // [mT][mT]    factor attempts
+    double* Rm = M + (long)n_o * ld;                              // [mT][mT]    factor attempts
     double* muv = Rm + (long)mT * mT;                             // [mT]
     double* yv = muv + mT;                                        // [mT]   mean + R z
 
     for (long chain = blockIdx.x; chain < nchains; chain += gridDim.x) {
+        double* Sm = a.Sall + chain * (long)mT * mT;             // [mT][mT]    column-major, lower part valid
         const long s = chain / gp.g_ny;
         const int o = (int)(chain - s * gp.g_ny);
         const double* LinvT = plan_LinvT(a.plan, gp, o);
@@ -583,7 +588,10 @@ __global__ __launch_bounds__(NT, WPE) void joint_kernel(const JointArgs a) {
             }
         }
         info_acc |= (level << 1);
-        if (!rooted) info_acc |= GPMPC_INFO_ROOT_FAIL;
+        if (!rooted) {
+            info_acc |= GPMPC_INFO_ROOT_FAIL;
+            if (tid == 0) atomicOr(a.any_fail, 1);
+        }
         __syncthreads();
 
         JPH(6);
@@ -661,12 +669,37 @@ static long joint_chain_doubles(int n_r, int n_ho, int m, int T, int* ld_out) {
     int ld = n_ho + 1 + mT;
     ld = (ld + 3) & ~3;
     if (ld_out) *ld_out = ld;
-    return (long)(n_r + n_ho) * ld + 2L * mT * mT + 2L * mT + 4;
+    return (long)(n_r + n_ho) * ld + 1L * mT * mT + 2L * mT + 4;
 }
 
 static long joint_grid(long nchains) {
     const long cap = 256L * 16;
     return nchains < cap ? nchains : cap;
+}
+
+// workspace layout (doubles): [joint slots | S of every chain | eigh slots | flags]
+struct JointWs {
+    long grid, stride, s_off, egrid, estride, e_off, f_off, total;
+    int ld;
+};
+
+static long eigh_grid(long nchains) {
+    const long cap = 256L * 4;
+    return nchains < cap ? nchains : cap;
+}
+
+static JointWs joint_ws_layout(int n_r, int n_ho, int m, int T, long nchains) {
+    JointWs w;
+    const long mT = (long)m * T;
+    w.grid = joint_grid(nchains);
+    w.stride = joint_chain_doubles(n_r, n_ho, m, T, &w.ld);
+    w.s_off = w.grid * w.stride;
+    w.egrid = eigh_grid(nchains);
+    w.estride = eigh_slot_doubles((int)mT);
+    w.e_off = w.s_off + nchains * mT * mT;
+    w.f_off = w.e_off + (mT > 1 ? w.egrid * w.estride : 0);
+    w.total = w.f_off + 32;
+    return w;
 }
 
 }  // namespace gpmpc
@@ -682,15 +715,15 @@ int gpmpc_debug_read_joint_phases(long long* out /*[host] 16*/) {
 
 size_t gpmpc_joint_workspace_bytes(const gpmpc_gp_desc_t* gp, int64_t Ns, int32_t n_ho, int32_t m) {
     if (check_gp(gp) != GPMPC_OK) return 0;
-    const long per = joint_chain_doubles(observed_real_slots(gp), n_ho, m, gp->T, nullptr);
-    return align_up((size_t)joint_grid(Ns * gp->g_ny) * per * sizeof(double), 256);
+    const JointWs w = joint_ws_layout(observed_real_slots(gp), n_ho, m, gp->T, Ns * gp->g_ny);
+    return align_up((size_t)w.total * sizeof(double), 256);
 }
 
 int gpmpc_joint_sample(const gpmpc_gp_desc_t* gp, const void* plan, const double* X_r, int64_t Ns, int32_t n_h,
                        const double* X_h, const double* Y_h, const int32_t* h_slots, int32_t n_ho, int32_t m,
                        const double* X_s, const double* z, double var_zero_thr, double beta, int32_t apply_clip,
-                       double* mean, double* var, double* y, double* covar, int32_t* info, void* ws,
-                       size_t ws_bytes, void* stream) {
+                       double* mean, double* var, double* y, double* covar, double* root, int32_t root_mode,
+                       int32_t* info, void* ws, size_t ws_bytes, void* stream) {
     if (int rc = check_gp(gp)) return rc;
     if (!plan || !X_r || !X_s || !z || !mean || !var || !y || !info || !ws)
         return fail(GPMPC_E_ARG, "gpmpc_joint_sample: NULL pointer");
@@ -700,7 +733,9 @@ int gpmpc_joint_sample(const gpmpc_gp_desc_t* gp, const void* plan, const double
     if (gp->D != 2) return fail(GPMPC_E_UNSUPPORTED, "only D = 2 is instantiated");
     const int mT = m * gp->T;
     if (mT > 256) return fail(GPMPC_E_UNSUPPORTED, "joint: m*T > 256");
-    if (n_ho + 1 + mT > 1024) return fail(GPMPC_E_UNSUPPORTED, "joint: more than 1024 label rows per chain");
+    if (n_ho + 1 + mT > 2048) return fail(GPMPC_E_UNSUPPORTED, "joint: more than 2048 label rows per chain");
+    if (root_mode < GPMPC_ROOT_AUTO || root_mode > GPMPC_ROOT_CHOLESKY)
+        return fail(GPMPC_E_ARG, "gpmpc_joint_sample: root_mode must be GPMPC_ROOT_AUTO / _EIGH / _CHOLESKY");
     JointArgs a;
     a.gp = make_gp_params(gp);
     a.plan = (const double*)plan;
@@ -723,11 +758,16 @@ int gpmpc_joint_sample(const gpmpc_gp_desc_t* gp, const void* plan, const double
     a.covar = covar;
     a.info = (int*)info;
     a.ws = (double*)ws;
-    a.ws_chain_stride = joint_chain_doubles(a.gp.n_r, n_ho, m, gp->T, &a.ld);
-    const long grid = joint_grid(Ns * gp->g_ny);
-    if (ws_bytes < (size_t)grid * a.ws_chain_stride * sizeof(double))
+    const JointWs w = joint_ws_layout(a.gp.n_r, n_ho, m, gp->T, Ns * gp->g_ny);
+    a.ws_chain_stride = w.stride;
+    a.ld = w.ld;
+    const long grid = w.grid;
+    if (ws_bytes < (size_t)w.total * sizeof(double))
         return fail(GPMPC_E_WORKSPACE, "gpmpc_joint_sample: workspace too small");
+    a.Sall = (double*)ws + w.s_off;
+    a.any_fail = (int*)((double*)ws + w.f_off);
     hipStream_t st = (hipStream_t)stream;
+    GPMPC_HIP_CHECK(hipMemsetAsync(a.any_fail, 0, sizeof(int), st));
     const int nrow = n_ho + 1 + mT;
     // one label row per thread and a workgroup just wide enough for the rows (more chains per CU when they are short:
     // iteration 0 of config 5 has 121 rows; iteration 0 of every later MPC step conditions on the previous step's
@@ -738,7 +778,8 @@ int gpmpc_joint_sample(const gpmpc_gp_desc_t* gp, const void* plan, const double
         if (nrow <= 128) hipLaunchKernelGGL((joint_kernel<TT, 16, 1, 128, GPMPC_JOINT_WPE>), g, dim3(128), 0, st, a);      \
         else if (nrow <= 256) hipLaunchKernelGGL((joint_kernel<TT, 16, 1, 256, GPMPC_JOINT_WPE>), g, dim3(256), 0, st, a); \
         else if (nrow <= 512) hipLaunchKernelGGL((joint_kernel<TT, 16, 1, 512, GPMPC_JOINT_WPE>), g, dim3(512), 0, st, a); \
-        else hipLaunchKernelGGL((joint_kernel<TT, 16, 1, 1024, 4>), g, dim3(1024), 0, st, a);               \
+        else if (nrow <= 1024) hipLaunchKernelGGL((joint_kernel<TT, 16, 1, 1024, 4>), g, dim3(1024), 0, st, a);            \
+        else hipLaunchKernelGGL((joint_kernel<TT, 16, 2, 1024, 4>), g, dim3(1024), 0, st, a);               \
     } while (0)
     if (gp->T == 1) {
         GPMPC_JOINT_LAUNCH(1);
@@ -749,6 +790,37 @@ int gpmpc_joint_sample(const gpmpc_gp_desc_t* gp, const void* plan, const double
     }
 #undef GPMPC_JOINT_LAUNCH
     GPMPC_HIP_CHECK(hipGetLastError());
+    // eigendecomposition root for the whole batch when a chain failed all jitter retries (or on request); the kernel
+    // returns at once when the flag is clear
+    if (mT > 1 && root_mode != GPMPC_ROOT_CHOLESKY) {
+        EighArgs e;
+        e.gp = a.gp;
+        e.Ns = Ns;
+        e.m = m;
+        e.z = z;
+        e.var_zero_thr = var_zero_thr;
+        e.beta = beta;
+        e.apply_clip = apply_clip;
+        e.mean = mean;
+        e.var = var;
+        e.y = y;
+        e.info = (int*)info;
+        e.Sall = a.Sall;
+        e.any_fail = a.any_fail;
+        e.force = (root_mode == GPMPC_ROOT_EIGH);
+        e.ws = (double*)ws + w.e_off;
+        e.ws_slot_stride = w.estride;
+        e.root = root;
+        const bool global_G = (getenv("GPMPC_EIGH_GLOBAL_G") != nullptr);     // test knob: Gram matrix in HBM/L2
+        const int np = (mT + 1) & ~1;
+        e.lds_cap = global_G ? 0 : (np < EIGH_LDS_RANK ? np : EIGH_LDS_RANK);
+        e.tol_mult = 16.0;
+        const size_t lds = (size_t)e.lds_cap * e.lds_cap * sizeof(double);
+        const dim3 ge((unsigned)w.egrid);
+        if (gp->T == 1) hipLaunchKernelGGL((joint_eigh_kernel<1>), ge, dim3(EIGH_NT), lds, st, e);
+        else hipLaunchKernelGGL((joint_eigh_kernel<3>), ge, dim3(EIGH_NT), lds, st, e);
+        GPMPC_HIP_CHECK(hipGetLastError());
+    }
     return GPMPC_OK;
 }
 

@@ -118,12 +118,13 @@ class HipPosterior:
         self._model = model
         self._x = x.to(dtype=F64).contiguous()
         assert self._x.dim() == 4 and tuple(self._x.shape[:2]) == tuple(model.batch_shape)
-        self._mean = self._var = self._covar = None
+        self._mean = self._var = self._covar = self._root = None
         self.last_info = None
+        self.used_eigh = False
 
     # -- one kernel launch ----------------------------------------------------------------------------------
     def _run(self, z: Optional[torch.Tensor], clip: bool, beta: float = 0.0, var_zero_thr: float = -1.0,
-             want_covar: bool = False):
+             want_covar: bool = False, want_root: bool = False, root_mode: int = _lib.ROOT_AUTO):
         mdl = self._model
         lib = _lib.load()
         hy = mdl.hyper
@@ -137,6 +138,7 @@ class HipPosterior:
             raise RuntimeError(f"base_samples shape {tuple(z.shape)} does not match the mean shape {shape}")
         mean, var, y = (torch.empty(shape, dtype=F64, device=dev) for _ in range(3))
         covar = torch.empty((Ns, g_ny, m * hy.T, m * hy.T), dtype=F64, device=dev) if want_covar else None
+        root = torch.zeros((Ns, g_ny, m * hy.T, m * hy.T), dtype=F64, device=dev) if want_root else None
         info = torch.zeros((Ns, g_ny), dtype=torch.int32, device=dev)
         n_ho = int(mdl.h_slots.numel())
         ws_bytes = lib.gpmpc_joint_workspace_bytes(mdl.plan.desc, Ns, n_ho, m)
@@ -146,13 +148,17 @@ class HipPosterior:
             _lib.dptr(mdl.hall_X) if mdl.n_h else None, _lib.dptr(mdl.hall_Y) if mdl.n_h else None,
             _lib.dptr(mdl.h_slots) if n_ho else None, n_ho, m, _lib.dptr(self._x), _lib.dptr(z),
             float(var_zero_thr), float(beta), int(bool(clip)), _lib.dptr(mean), _lib.dptr(var), _lib.dptr(y),
-            _lib.dptr(covar), _lib.dptr(info), _lib.dptr(ws), ws.numel() * 8, _lib.current_stream_ptr())
+            _lib.dptr(covar), _lib.dptr(root), int(root_mode), _lib.dptr(info), _lib.dptr(ws), ws.numel() * 8,
+            _lib.current_stream_ptr())
         _lib.check(rc, "gpmpc_joint_sample")
         self._mean, self._var = mean, var
         if want_covar:
             self._covar = covar
+        if want_root:
+            self._root = root
         bits = _or_reduce(info)
         self.last_info = info
+        self.used_eigh = bool(bits & _lib.INFO_ROOT_EIGH)
         if bits & _lib.INFO_TRAIN_CHOL_FAIL:
             raise NotPSDError("Cholesky of the training covariance (real + hallucinated data) failed")
         if bits & _lib.INFO_VAR_CLAMPED:
@@ -161,6 +167,13 @@ class HipPosterior:
             warnings.warn(f"posterior covariance not p.d. - added jitter of up to "
                           f"{hy.jitter * 10 ** (((bits & _lib.INFO_ROOT_JITTER_MASK) >> 1) - 1):.1e} to the diagonal",
                           NumericalWarning)
+        if bits & _lib.INFO_ROOT_EIGH:
+            # gpytorch: NotPSDError inside root_decomposition -> eigh root for the WHOLE batch (A.7 step 4); drawn by
+            # the second kernel of the same gpmpc_joint_sample call
+            warnings.warn("Cholesky of the posterior covariance failed after 3 jitter retries; using the "
+                          "eigendecomposition root for the whole batch", NumericalWarning)
+        if bits & _lib.INFO_EIGH_NOCONV:
+            warnings.warn("Jacobi eigensolver of the posterior covariance hit its sweep limit", NumericalWarning)
         return y, bits
 
     # -- distribution surface -----------------------------------------------------------------------------------
@@ -195,29 +208,28 @@ class HipPosterior:
         None draws z internally like gpytorch does (``randn``, device generator)."""
         return self._sample(base_samples, clip=False)
 
-    def _sample(self, base_samples, clip, beta=0.0, var_zero_thr=-1.0):
+    def _sample(self, base_samples, clip, beta=0.0, var_zero_thr=-1.0, want_root=False):
         Ns, g_ny, m, _ = self._x.shape
         T = self._model.hyper.T
         if base_samples is None:
             base_samples = torch.randn(Ns, g_ny, m, T, dtype=F64, device=self._x.device)
-        y, bits = self._run(base_samples, clip, beta, var_zero_thr)
-        if bits & _lib.INFO_ROOT_FAIL:
-            # gpytorch: NotPSDError inside root_decomposition -> eigh root for the WHOLE batch (A.7 step 4).
-            # Off the default path; uses the device eigensolver (rocSOLVER via torch.linalg.eigh).
-            warnings.warn("Cholesky of the posterior covariance failed after 3 jitter retries; using the "
-                          "eigendecomposition root for the whole batch", NumericalWarning)
-            S = self.covariance_matrix
-            evals, evecs = torch.linalg.eigh(S)
-            R = evecs * evals.clamp_min(0.0).sqrt().unsqueeze(-2)
-            z = base_samples.to(device=S.device, dtype=F64).reshape(Ns, g_ny, m * T, 1)
-            y = ((R @ z).squeeze(-1) + self._mean.reshape(Ns, g_ny, m * T)).reshape(Ns, g_ny, m, T)
-            if var_zero_thr >= 0.0:
-                zero = torch.all(self._var <= var_zero_thr, dim=-1, keepdim=True)
-                y = torch.where(zero, self._mean, y)
-            if clip:
-                sd = beta * torch.sqrt(self._var)
-                y = torch.min(torch.max(y, self._mean - sd), self._mean + sd)
+        y, bits = self._run(base_samples, clip, beta, var_zero_thr, want_root=want_root)
+        group = self._model.dist_group
+        if group is not None and m * T > 1:
+            # the eigh fallback is a property of the WHOLE batch (all ranks' chains): a rank none of whose chains failed
+            # redraws with the eigendecomposition root when a chain on another rank did
+            import torch.distributed as dist
+            flag = torch.tensor([1 if self.used_eigh else 0], dtype=torch.int32, device=self._x.device)
+            dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=group)
+            if int(flag.item()) and not self.used_eigh:
+                y, bits = self._run(base_samples, clip, beta, var_zero_thr, want_root=want_root,
+                                    root_mode=_lib.ROOT_EIGH)
         return y
+
+    @property
+    def root(self) -> Optional[torch.Tensor]:
+        """The eigendecomposition root of the last draw (only kept when the draw asked for it; tests)."""
+        return self._root
 
 
 def _or_reduce(info: torch.Tensor) -> int:
@@ -226,7 +238,7 @@ def _or_reduce(info: torch.Tensor) -> int:
         return 0
     v = info.flatten()
     # OR == max per bit: one small reduction per flag bit, a single transfer
-    packed = torch.stack([(v & b).max() for b in (0x1, 0x2, 0x4, 0x8, 0x10, 0x20, 0x40)])
+    packed = torch.stack([(v & b).max() for b in (0x1, 0x2, 0x4, 0x8, 0x10, 0x20, 0x40, 0x80, 0x100)])
     bits = 0
     for x in packed.tolist():
         bits |= int(x)
@@ -237,8 +249,9 @@ class HipGPModel:
     """Conditioning set = shared real data (factorised plan) + per-sample hallucinated data."""
 
     def __init__(self, plan: RealDataPlan, hall_X: torch.Tensor, hall_Y: torch.Tensor, batch_shape,
-                 ws_cache: Optional[dict] = None):
+                 ws_cache: Optional[dict] = None, dist_group=None):
         self.plan = plan
+        self.dist_group = dist_group
         self.hyper = plan.hyper
         self.batch_shape = torch.Size(batch_shape)
         Ns, g_ny = self.batch_shape
@@ -250,6 +263,12 @@ class HipGPModel:
         if self.n_h:
             # gpytorch "mask" policy: a label slot that is NaN in ANY batch element is dropped for the whole batch
             nan_any = torch.isnan(self.hall_Y).reshape(Ns * g_ny, self.n_h * self.hyper.T).any(dim=0)
+            if dist_group is not None:
+                # ... in any batch element of ANY rank: the batch is the whole (sharded) sample set
+                import torch.distributed as dist
+                flag = nan_any.to(torch.int32)
+                dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=dist_group)
+                nan_any = flag.bool()
             self.h_slots = torch.nonzero(~nan_any).flatten().to(torch.int32).contiguous()
         else:
             self.h_slots = torch.empty(0, dtype=torch.int32, device=dev)

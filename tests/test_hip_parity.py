@@ -823,7 +823,10 @@ def test_prepare_dynamics_set_against_oracle(sg):
     assert (agent.rejection_trace[-1].cpu().numpy() == left).all()
     np.testing.assert_allclose(agent.Hallcinated_X_train.cpu().numpy(), oagent.Hallcinated_X_train.numpy(), rtol=1e-9, atol=1e-12)
     np.testing.assert_allclose(agent.Hallcinated_Y_train.cpu().numpy(), oagent.Hallcinated_Y_train.numpy(), rtol=1e-9, atol=1e-12)
-    assert not np.array_equal(oagent.Hallcinated_X_train.numpy(), hx_before.numpy()), "rejected samples keep their data"@pytest.mark.gpu
+    assert not np.array_equal(oagent.Hallcinated_X_train.numpy(), hx_before.numpy()), "rejected samples keep their data"
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("pname,Ns,H", [("params_car_residual_fs", 200, 40), ("params_pendulum1D_samples", 130, 30)])
 def test_mode_i_exp_recurrence_vs_direct_exponentials(sg, pname, Ns, H, monkeypatch):
     """Mode I on the equispaced training grid: the kernel factors come from the recurrence E_0 rho^k G_k (two
