@@ -684,7 +684,7 @@ struct JointWs {
 };
 
 static long eigh_grid(long nchains) {
-    const long cap = 256L * 4;
+    const long cap = 256L * 10;           // one wave per chain, ~9 resident per CU (LDS bound)
     return nchains < cap ? nchains : cap;
 }
 
@@ -710,6 +710,11 @@ extern "C" {
 
 int gpmpc_debug_read_joint_phases(long long* out /*[host] 16*/) {
     GPMPC_HIP_CHECK(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_joint_phase), 16 * sizeof(long long)));
+    return GPMPC_OK;
+}
+
+int gpmpc_debug_read_eigh_phases(long long* out /*[host] 8*/) {
+    GPMPC_HIP_CHECK(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_eigh_phase), 8 * sizeof(long long)));
     return GPMPC_OK;
 }
 
@@ -815,10 +820,15 @@ int gpmpc_joint_sample(const gpmpc_gp_desc_t* gp, const void* plan, const double
         const int np = (mT + 1) & ~1;
         e.lds_cap = global_G ? 0 : (np < EIGH_LDS_RANK ? np : EIGH_LDS_RANK);
         e.tol_mult = 16.0;
-        const size_t lds = (size_t)e.lds_cap * e.lds_cap * sizeof(double);
-        const dim3 ge((unsigned)w.egrid);
-        if (gp->T == 1) hipLaunchKernelGGL((joint_eigh_kernel<1>), ge, dim3(EIGH_NT), lds, st, e);
-        else hipLaunchKernelGGL((joint_eigh_kernel<3>), ge, dim3(EIGH_NT), lds, st, e);
+        const size_t lds = (size_t)(eigh_packed(e.lds_cap) + 2) * sizeof(double);   // + the pad slot of the dummy blocks
+        const dim3 ge((unsigned)w.egrid), be(64);
+        if (gp->T == 1) {
+            if (mT <= 128) hipLaunchKernelGGL((joint_eigh_kernel<1, 2>), ge, be, lds, st, e);
+            else hipLaunchKernelGGL((joint_eigh_kernel<1, 4>), ge, be, lds, st, e);
+        } else {
+            if (mT <= 128) hipLaunchKernelGGL((joint_eigh_kernel<3, 2>), ge, be, lds, st, e);
+            else hipLaunchKernelGGL((joint_eigh_kernel<3, 4>), ge, be, lds, st, e);
+        }
         GPMPC_HIP_CHECK(hipGetLastError());
     }
     return GPMPC_OK;

@@ -6,21 +6,27 @@
 // root_decomposition() falls back, for the WHOLE batch, to
 //        evals, evecs = eigh(S);   R = evecs * sqrt(clamp(evals, 0));   y = mean + R z        (ascending evals)
 //
-// What runs here, one 256-thread workgroup per (sample, output) chain, thread == test slot (n = m*T <= 256):
+// What runs here: ONE WAVE per (sample, output) chain (64-thread workgroups, no barrier anywhere on the LDS path; the
+// CU overlaps ~9 chains), n = m*T <= 256 test slots, lane owns rows lane, lane+64, ...:
 //   A. diagonally pivoted Cholesky  S ~= L L^T  (left-looking, L is n x r, stops when the largest residual diagonal
-//      entry is <= tol): S has numerical rank r ~ 30..60 of n = 120, everything below tol is the round-off noise of
+//      entry is <= tol): S has numerical rank r ~ 30..60 of n = 120; everything below tol is the round-off noise of
 //      S = K** - V^T V itself (its eigenvalues there are +-1e-16 and their eigenvectors arbitrary, also for LAPACK);
 //   B. G = L^T L  (r x r, FP64 MFMA 16x16x4) - G has exactly the non-zero eigenvalues of L L^T;
-//   C. cyclic two-sided Jacobi on G with the round-robin ordering: every round rotates r/2 disjoint index pairs, the
-//      symmetric update is done 2x2 block by 2x2 block (block (I,K) only needs the rotations of pairs I and K, so a
-//      round is two barriers), G lives in LDS (upper triangle); the rotation tangents are logged to the workspace;
+//   C. cyclic two-sided Jacobi on G, round-robin ordering IN POSITION SPACE: the matrix is kept permuted so that the
+//      pairs of every round are the fixed positions (a, rp-1-a); a round rotates the rp/2 disjoint pairs, updates the
+//      symmetric matrix 2x2 block by 2x2 block (block (I,K) only needs the rotations of pairs I and K) and writes every
+//      entry to the position its indices take in the next round (position 0 fixed, the others shift by one).  All
+//      addresses are therefore round independent: each lane precomputes the read / write slots of its <= 7 blocks once,
+//      a round is "read my blocks - rotate - write them shifted" on the packed upper triangle in LDS (<= 12.8 KB).
+//      After every sweep (rp-1 rounds) the positions are back where they started.  Rotation tangents are logged;
 //   D. eigenvalues = diag(G) (>= 0 by construction: no clamp needed), ascending rank -> which base sample belongs to
-//      which eigenvector (R's columns are ordered like eigh's: the n-r zero columns first); t = W z~ by applying the
-//      logged rotations in reverse order to the permuted base-sample vector (W itself is never formed);
+//      which eigenvector (R's columns are ordered like eigh's: the n-r zero columns first); t = W z~ by replaying the
+//      logged rounds in reverse on the permuted base-sample vector (W itself is never formed);
 //   E. y = mean + L t  (R = L W: column j is sqrt(lambda_j) u_j), then the post-processing of sample_gp;
-//   F. only when the caller asks for the root (tests): W from the log, R = L W written out.
+//   F. only when the caller asks for the root (tests): column j of R = L (W e_j), one replay per column.
 // L W has the columns sqrt(lambda_j) u_j of the eigh root up to their signs (solver specific in LAPACK too) and up to
 // the noise directions; tests align the signs per column and compare the samples.
+// Ranks beyond EIGH_LDS_RANK take the same algorithm with G double-buffered in the HBM/L2 workspace.
 #pragma once
 #include <cfloat>
 #include <cstdlib>
@@ -41,300 +47,336 @@ struct EighArgs {
     const double* Sall;      // [chains][n*n]  column-major, lower part valid
     const int* any_fail;     // device flag set by joint_kernel when a chain's jitter chain failed
     int force;
-    double* ws;              // per slot: L [n*n] | G [np*np] | rotation log [EIGH_MAX_SWEEPS/2 * np*np]
+    double* ws;              // per slot: L [n*n] | 2 x packed G [np*(np+1)/2] | rotation log [EIGH_MAX_SWEEPS/2 * np*np]
     long ws_slot_stride;
     double* root;            // optional [chains][n][n] row-major
-    int lds_cap;             // largest (even) rank whose Gram matrix fits the dynamic LDS
+    int lds_cap;             // largest (even) rank whose packed Gram matrix fits the dynamic LDS
     double tol_mult;         // pivoted-Cholesky stop: residual diagonal <= tol_mult * eps * max prior variance
 };
 
-constexpr int EIGH_NT = 256;
+__device__ long long g_eigh_phase[8];
+#ifdef GPMPC_PHASE_TIMERS
+#define EPH(idx) do { const long long _n = __builtin_readcyclecounter(); eph[idx] += _n - et; et = _n; } while (0)
+#else
+#define EPH(idx)
+#endif
+
 constexpr int EIGH_MAX_SWEEPS = 16;
-constexpr int EIGH_LDS_RANK = 60;      // Gram matrices up to 60 x 60 (28.8 KB) stay in LDS: four workgroups per CU
+constexpr int EIGH_LDS_RANK = 56;      // packed 56 x 56 Gram matrix = 12.8 KB of LDS per chain: ~9 chains per CU
+constexpr int EIGH_PB = 8;             // candidate pivots per pass of the pivoted Cholesky
+constexpr double EIGH_PIVOT_THRESHOLD = 1.0 / 16.0;   // accepted pivot >= this x the largest residual diagonal left
+constexpr int EIGH_MAXIT = 7;          // off-diagonal 2x2 blocks per lane at the LDS rank cap: ceil(14 * 28 / 64)
 
 typedef double double4_e __attribute__((ext_vector_type(4)));
+typedef double double2_e __attribute__((ext_vector_type(2)));
 typedef __attribute__((address_space(3))) double lds_double;
 
+__host__ __device__ inline long eigh_packed(int np) { return (long)np * (np + 1) / 2; }
 __host__ __device__ inline long eigh_slot_doubles(int n) {
     const long np = (n + 1) & ~1;
-    return (long)n * n + np * np + (long)(EIGH_MAX_SWEEPS / 2) * np * np + 8;
+    return (long)n * n + 2 * eigh_packed((int)np) + (long)(EIGH_MAX_SWEEPS / 2) * np * np + 8;
 }
 
-// pair i of round rho in the round-robin schedule over rp (even) indices: every index appears once per round, every
-// pair once per sweep of rp-1 rounds
-__device__ __forceinline__ void rr_pair(int i, int rho, int rp, int& p, int& q) {
-    int a_, b_;
-    if (i == 0) {
-        a_ = rp - 1;
-        b_ = rho;
-    } else {
-        a_ = (rho + i) % (rp - 1);
-        b_ = (rho + rp - 1 - i) % (rp - 1);
+// packed upper triangle, row a holds columns a..rp-1
+__device__ __forceinline__ int tri_idx(int a, int b, int rp) { return a * rp - (a * (a - 1)) / 2 + (b - a); }
+__device__ __forceinline__ int sym_idx(int a, int b, int rp) { return a <= b ? tri_idx(a, b, rp) : tri_idx(b, a, rp); }
+// where the index at position a sits in the next round (round-robin: position 0 fixed, the others shift by one)
+__device__ __forceinline__ int rr_shift(int a, int rp) { return a == 0 ? 0 : (a == rp - 1 ? 1 : a + 1); }
+
+// block b of the folded enumeration of the h (h + 1) / 2 blocks I <= K; false for the padding slots of odd h
+__device__ __forceinline__ bool rr_block(int b, int h, int& I, int& K) {
+    const int u = b / (h + 1), off = b - u * (h + 1);
+    if (off < h - u) {
+        I = u;
+        K = u + off;
+        return true;
     }
-    p = min(a_, b_);
-    q = max(a_, b_);
+    I = h - 1 - u;
+    K = I + (off - (h - u));
+    return I != u;
 }
 
-// Phases B..F for one chain; GP is `double*` (G in the HBM/L2 workspace) or `lds_double*` (G in LDS).
-template <int T, class GP>
-__device__ __forceinline__ int eigh_tail(const EighArgs& a, long chain, int n, int r, const double* __restrict__ Lm,
-                                         GP G, double* __restrict__ rlog, double* e_vec, double (*e_cs)[2],
-                                         short (*e_pq)[2], short* e_rank, double* e_y, int* e_cnt) {
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int rp = (r + 1) & ~1, h = rp / 2, ldg = rp;
-    int info = GPMPC_INFO_ROOT_EIGH;
-    long gtot = 0;
-    if (r > 0) {
-        // ---- B. G = L^T L (upper triangle), FP64 MFMA: A[i][k] = L[k0+k][I*16+i], B[k][j] = L[k0+k][J*16+j] -------
-        const int ntile = (rp + 15) / 16, npairs = ntile * (ntile + 1) / 2;
-        for (int tp = wv; tp < npairs; tp += EIGH_NT / 64) {
-            int I = 0, rem = tp;
-            while (rem >= ntile - I) {
-                rem -= ntile - I;
-                ++I;
-            }
-            const int J = I + rem;
+__device__ __forceinline__ double wave_max_nonneg(double v) {     // max over the wave of values >= 0 (0 is neutral)
+    double t = fmax(v, dpp_f64<0x111, 0xf, 0xf>(v));
+    t = fmax(t, dpp_f64<0x112, 0xf, 0xf>(v));
+    t = fmax(t, dpp_f64<0x113, 0xf, 0xf>(v));
+    t = fmax(t, dpp_f64<0x114, 0xf, 0xe>(t));
+    t = fmax(t, dpp_f64<0x118, 0xf, 0xc>(t));
+    t = fmax(t, dpp_f64<0x142, 0xa, 0xf>(t));
+    t = fmax(t, dpp_f64<0x143, 0xc, 0xf>(t));
+    return readlane_f64(t, 63);
+}
+
+// Jacobi rotation annihilating g_pq: tangent t (0 = skip), c, s with J = [[c, s], [-s, c]] on the (p, q) plane.
+// Division free (two rsqrt_fast): with x = dq^2 + 4 gpq^2, cos(2 theta) = |dq| / sqrt(x) =: C2, u = (1 + C2) / 2:
+//     c = sqrt(u),   s = sign(dq) gpq / sqrt(x) / c,   t = s / c = sign(dq) gpq / sqrt(x) / u
+// (the textbook t = sign(zeta) / (|zeta| + sqrt(1 + zeta^2)), zeta = dq / (2 gpq), without its division and two IEEE
+// square roots: the rotation sits on the serial spine of every round)
+__device__ __forceinline__ bool jacobi_rot(double gpp, double gqq, double gpq, double thr, double& t, double& c, double& s) {
+    const bool rot = fabs(gpq) > thr;
+    const double dq = gqq - gpp;
+    const double x = rot ? fma(dq, dq, 4.0 * gpq * gpq) : 1.0;
+    const double rinv = rsqrt_fast(x);
+    const double u = fma(0.5, fabs(dq) * rinv, 0.5);             // in [0.5, 1]
+    const double ic = rsqrt_fast(u);
+    double sg = gpq * rinv;
+    sg = (dq < 0.0) ? -sg : sg;
+    c = rot ? u * ic : 1.0;
+    s = rot ? sg * ic : 0.0;
+    t = rot ? s * ic : 0.0;
+    return rot;
+}
+
+// G <- J^T G J on one 2x2 block (rows pair I, columns pair K)
+__device__ __forceinline__ void rot_block(double cI, double sI, double cK, double sK, double b00, double b01, double b10,
+                                          double b11, double& n00, double& n01, double& n10, double& n11) {
+    const double r00 = cI * b00 - sI * b10, r01 = cI * b01 - sI * b11;
+    const double r10 = sI * b00 + cI * b10, r11 = sI * b01 + cI * b11;
+    n00 = cK * r00 - sK * r01;
+    n01 = sK * r00 + cK * r01;
+    n10 = cK * r10 - sK * r11;
+    n11 = sK * r10 + cK * r11;
+}
+
+// ---- B. G = L^T L (packed upper triangle), FP64 MFMA: A[i][k] = L[k0+k][I*16+i], B[k][j] = L[k0+k][J*16+j] -----------
+template <class GP>
+__device__ __forceinline__ void eigh_gram(const double* __restrict__ Lm, int n, int r, int rp, GP G) {
+    const int lane = threadIdx.x & 63;
+    const int ntile = (rp + 15) / 16;
+    for (int I = 0; I < ntile; ++I) {
+        for (int J = I; J < ntile; ++J) {
             const int ca = I * 16 + (lane & 15), cb = J * 16 + (lane & 15), kr = lane >> 4;
             const bool va = ca < r, vb = cb < r;
             const double* pa = Lm + (long)(va ? ca : 0) * n;
             const double* pb = Lm + (long)(vb ? cb : 0) * n;
             double4_e acc = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll 4
-            for (int k0 = 0; k0 < n; k0 += 4) {
-                const int row = k0 + kr;
-                const bool vr = row < n;
-                const double av = (va && vr) ? pa[row] : 0.0;
-                const double bv = (vb && vr) ? pb[row] : 0.0;
-                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
+            for (int k0 = 0; k0 < n; k0 += 16) {
+                double av[4], bv[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int row = k0 + 4 * u + kr;
+                    const bool vr = row < n;
+                    av[u] = (va && vr) ? pa[row] : 0.0;
+                    bv[u] = (vb && vr) ? pb[row] : 0.0;
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u], bv[u], acc, 0, 0, 0);
             }
 #pragma unroll
             for (int v = 0; v < 4; ++v) {                        // D: col = lane & 15, row = (lane >> 4) + 4 v
                 const int ra = I * 16 + kr + 4 * v, cc = J * 16 + (lane & 15);
-                if (ra <= cc && cc < rp) G[ra * ldg + cc] = acc[v];
-            }
-        }
-        __syncthreads();
-
-        // ---- C. cyclic Jacobi, round-robin ordering, 2x2-block symmetric update ---------------------------------
-        const double thr = DBL_EPSILON * G[0];                   // G[0][0] = squared norm of the first (largest) column
-        const int nround = rp - 1;
-        const int nitem = ((h + 1) / 2) * (h + 1);
-        bool conv = false;
-        int sweeps = 0;
-        for (; sweeps < EIGH_MAX_SWEEPS && !conv; ++sweeps) {
-            if (tid == 0) *e_cnt = 0;
-            __syncthreads();
-            for (int rho = 0; rho < nround; ++rho, ++gtot) {
-                if (tid < h) {
-                    int p, q;
-                    rr_pair(tid, rho, rp, p, q);
-                    const double gpp = G[p * ldg + p], gqq = G[q * ldg + q], gpq = G[p * ldg + q];
-                    double t = 0.0, c = 1.0, s = 0.0;
-                    if (fabs(gpq) > thr) {
-                        const double zeta = (gqq - gpp) / (2.0 * gpq);
-                        t = copysign(1.0, zeta) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
-                        c = 1.0 / sqrt(1.0 + t * t);
-                        s = t * c;
-                        atomicAdd(e_cnt, 1);
-                    }
-                    e_cs[tid][0] = c;
-                    e_cs[tid][1] = s;
-                    e_pq[tid][0] = (short)p;
-                    e_pq[tid][1] = (short)q;
-                    rlog[gtot * h + tid] = t;
-                }
-                __syncthreads();
-                for (int b = tid; b < nitem; b += EIGH_NT) {
-                    const int u = b / (h + 1), off = b - u * (h + 1);
-                    int I, K;
-                    bool ok = true;
-                    if (off < h - u) {
-                        I = u;
-                        K = u + off;
-                    } else {
-                        I = h - 1 - u;
-                        K = I + (off - (h - u));
-                        ok = (I != u);
-                    }
-                    if (!ok) continue;
-                    const double cI = e_cs[I][0], sI = e_cs[I][1];
-                    const int pI = e_pq[I][0], qI = e_pq[I][1];
-                    if (I == K) {
-                        if (sI != 0.0) {
-                            const double t = sI / cI, gpq = G[pI * ldg + qI];
-                            G[pI * ldg + pI] -= t * gpq;
-                            G[qI * ldg + qI] += t * gpq;
-                            G[pI * ldg + qI] = 0.0;
-                        }
-                    } else {
-                        const double cK = e_cs[K][0], sK = e_cs[K][1];
-                        if (sI == 0.0 && sK == 0.0) continue;
-                        const int pK = e_pq[K][0], qK = e_pq[K][1];
-                        const int i00 = min(pI, pK) * ldg + max(pI, pK), i01 = min(pI, qK) * ldg + max(pI, qK);
-                        const int i10 = min(qI, pK) * ldg + max(qI, pK), i11 = min(qI, qK) * ldg + max(qI, qK);
-                        const double b00 = G[i00], b01 = G[i01], b10 = G[i10], b11 = G[i11];
-                        const double r00 = cI * b00 - sI * b10, r01 = cI * b01 - sI * b11;
-                        const double r10 = sI * b00 + cI * b10, r11 = sI * b01 + cI * b11;
-                        G[i00] = cK * r00 - sK * r01;
-                        G[i01] = sK * r00 + cK * r01;
-                        G[i10] = cK * r10 - sK * r11;
-                        G[i11] = sK * r10 + cK * r11;
-                    }
-                }
-                __syncthreads();
-            }
-            conv = (*e_cnt == 0);
-            __syncthreads();
-        }
-        if (!conv) info |= GPMPC_INFO_EIGH_NOCONV;
-
-        // ---- D. ascending rank of the eigenvalues; t = W z~ (logged rotations, reverse order) --------------------
-        double lam = 0.0;
-        if (tid < r) {
-            lam = G[tid * ldg + tid];
-            e_y[tid] = lam;
-        }
-        __syncthreads();
-        if (tid < rp) {
-            double zt = 0.0;
-            if (tid < r) {
-                int cnt = 0;
-                for (int i = 0; i < r; ++i) {
-                    const double li = e_y[i];
-                    cnt += (li < lam || (li == lam && i < tid)) ? 1 : 0;
-                }
-                e_rank[tid] = (short)cnt;
-                zt = a.z[chain * (long)n + (n - r + cnt)];
-            }
-            e_vec[tid] = zt;
-        }
-        __syncthreads();
-        for (long g1 = gtot; g1 > 0; g1 -= 8) {
-            double tq[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const long gg = g1 - 1 - u;
-                tq[u] = (gg >= 0 && tid < h) ? rlog[gg * h + tid] : 0.0;
-            }
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const long gg = g1 - 1 - u;
-                if (gg >= 0) {                                   // uniform
-                    if (tid < h && tq[u] != 0.0) {
-                        int p, q;
-                        rr_pair(tid, (int)(gg % nround), rp, p, q);
-                        const double c = 1.0 / sqrt(1.0 + tq[u] * tq[u]), s = tq[u] * c;
-                        const double vp = e_vec[p], vq = e_vec[q];
-                        e_vec[p] = c * vp + s * vq;
-                        e_vec[q] = c * vq - s * vp;
-                    }
-                    __syncthreads();
-                }
+                if (ra <= cc && cc < rp) G[tri_idx(ra, cc, rp)] = acc[v];
             }
         }
     }
-
-    // ---- E. y = mean + L t, post-processing of sample_gp (reference src/agent.py:646-708) ----------------------------
-    if (tid < n) {
-        double acc = 0.0;
-        for (int j0 = 0; j0 < r; j0 += 8) {
-            double l8[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) l8[u] = Lm[(long)min(j0 + u, r - 1) * n + tid];
-#pragma unroll
-            for (int u = 0; u < 8; ++u)
-                if (j0 + u < r) acc = fma(l8[u], e_vec[j0 + u], acc);
-        }
-        e_y[tid] = acc + a.mean[chain * (long)n + tid];
-    }
-    __syncthreads();
-    for (int j = tid; j < a.m; j += EIGH_NT) {
-        double vv[T], mm[T];
-        bool all_zero = (a.var_zero_thr >= 0.0);
-#pragma unroll
-        for (int b = 0; b < T; ++b) {
-            const long off = chain * (long)n + j * T + b;
-            vv[b] = a.var[off];
-            mm[b] = a.mean[off];
-            all_zero = all_zero && (vv[b] <= a.var_zero_thr);
-        }
-#pragma unroll
-        for (int b = 0; b < T; ++b) {
-            double yb = all_zero ? mm[b] : e_y[j * T + b];
-            if (a.apply_clip) {
-                const double sd = a.beta * sqrt(vv[b]);
-                yb = fmin(fmax(yb, mm[b] - sd), mm[b] + sd);
-            }
-            a.y[chain * (long)n + j * T + b] = yb;
-        }
-    }
-
-    // ---- F. optional: the root itself, R = L W with eigh's column order (tests) --------------------------------------
-    if (a.root) {
-        double* Rout = a.root + chain * (long)n * n;
-        __syncthreads();
-        if (r > 0) {
-            for (int e = tid; e < rp * rp; e += EIGH_NT) G[e] = (e / rp == e % rp) ? 1.0 : 0.0;
-            __syncthreads();
-            const int nround = rp - 1;
-            for (long gg = gtot - 1; gg >= 0; --gg) {               // V <- J_g V, ends as W
-                if (tid < h) {
-                    const double t = rlog[gg * h + tid];
-                    const double c = 1.0 / sqrt(1.0 + t * t);
-                    int p, q;
-                    rr_pair(tid, (int)(gg % nround), rp, p, q);
-                    e_cs[tid][0] = c;
-                    e_cs[tid][1] = t * c;
-                    e_pq[tid][0] = (short)p;
-                    e_pq[tid][1] = (short)q;
-                }
-                __syncthreads();
-                for (int e = tid; e < h * rp; e += EIGH_NT) {
-                    const int i = e / rp, col = e - i * rp;
-                    const double c = e_cs[i][0], s = e_cs[i][1];
-                    if (s != 0.0) {
-                        const int p = e_pq[i][0], q = e_pq[i][1];
-                        const double vp = G[p * ldg + col], vq = G[q * ldg + col];
-                        G[p * ldg + col] = c * vp + s * vq;
-                        G[q * ldg + col] = c * vq - s * vp;
-                    }
-                }
-                __syncthreads();
-            }
-        }
-        if (tid < n) {
-            for (int c = 0; c < n - r; ++c) Rout[(long)tid * n + c] = 0.0;
-            for (int j = 0; j < r; ++j) {
-                double acc = 0.0;
-                for (int k = 0; k < r; ++k) acc = fma(Lm[(long)k * n + tid], (double)G[k * ldg + j], acc);
-                Rout[(long)tid * n + (n - r + e_rank[j])] = acc;
-            }
-        }
-        __syncthreads();
-    }
-    return info;
 }
 
-template <int T>
-__global__ __launch_bounds__(EIGH_NT, 4) void joint_eigh_kernel(const EighArgs a) {
-    extern __shared__ __attribute__((aligned(16))) double e_dyn[];
+// ---- C (LDS). all sweeps; returns the number of rounds logged -------------------------------------------------------
+// block b of the folded enumeration of the h (h - 1) / 2 OFF-DIAGONAL blocks I < K
+__device__ __forceinline__ bool rr_block_off(int b, int h, int& I, int& K) {
+    const int hh = h - 1;                                        // rows I = 0..h-2, row I has hh - I blocks
+    const int u = b / h, off = b - u * h;
+    if (off < hh - u) {
+        I = u;
+        K = I + 1 + off;
+        return true;
+    }
+    I = hh - 1 - u;
+    K = I + 1 + (off - (hh - u));
+    return I != u;
+}
+
+// G has eigh_packed(rp) entries plus ONE pad slot: lanes with fewer than MAXIT blocks run dummy blocks on the pad slot
+// with the identity rotation e_cs[h] - a round has no branch besides "lane < h owns a pair".  The lane that owns pair i
+// computes its rotation AND updates the pair's diagonal block (g_pp, g_pq, g_qq: textbook update); the off-diagonal 2x2
+// blocks are spread over the wave.
+template <int MAXIT>
+__device__ __forceinline__ long eigh_jacobi_lds(lds_double* G, int rp, double* __restrict__ rlog, double (*e_cs)[2],
+                                                bool& conv, int& sweeps) {
+    const int lane = threadIdx.x & 63;
+    const int h = rp / 2, nslots = (h / 2) * h;                  // ceil((h - 1) / 2) * h
+    const int pad = (int)eigh_packed(rp);
+    // this lane's blocks: packed slots read (ri) and written (wi: the slots of the shifted positions)
+    int ri[MAXIT][4], wi[MAXIT][4], bI[MAXIT], bK[MAXIT];
+#pragma unroll
+    for (int it = 0; it < MAXIT; ++it) {
+        const int b = lane + 64 * it;
+        int I = 0, K = 1;
+        const bool ok = (b < nslots) && rr_block_off(b, h, I, K);
+        bI[it] = ok ? I : h;
+        bK[it] = ok ? K : h;
+        const int pI = I, qI = rp - 1 - I, pK = K, qK = rp - 1 - K;
+        const int sp = rr_shift(pI, rp), sq = rr_shift(qI, rp), tp = rr_shift(pK, rp), tq = rr_shift(qK, rp);
+        ri[it][0] = ok ? sym_idx(pI, pK, rp) : pad;
+        ri[it][1] = ok ? sym_idx(pI, qK, rp) : pad;
+        ri[it][2] = ok ? sym_idx(qI, pK, rp) : pad;
+        ri[it][3] = ok ? sym_idx(qI, qK, rp) : pad;
+        wi[it][0] = ok ? sym_idx(sp, tp, rp) : pad;
+        wi[it][1] = ok ? sym_idx(sp, tq, rp) : pad;
+        wi[it][2] = ok ? sym_idx(sq, tp, rp) : pad;
+        wi[it][3] = ok ? sym_idx(sq, tq, rp) : pad;
+    }
+    const bool own = lane < h;
+    const int p1 = own ? lane : 0, q1 = rp - 1 - p1;             // this lane's pair
+    const int dpp_ = tri_idx(p1, p1, rp), dpq_ = tri_idx(p1, q1, rp), dqq_ = tri_idx(q1, q1, rp);
+    const int sp1 = rr_shift(p1, rp), sq1 = rr_shift(q1, rp);
+    const int wpp_ = own ? sym_idx(sp1, sp1, rp) : pad, wpq_ = own ? sym_idx(sp1, sq1, rp) : pad;
+    const int wqq_ = own ? sym_idx(sq1, sq1, rp) : pad;
+    if (lane == 0) {
+        G[pad] = 0.0;
+        e_cs[h][0] = 1.0;
+        e_cs[h][1] = 0.0;
+    }
+    const double thr = DBL_EPSILON * G[0];                       // G[0][0] = squared norm of the first (largest) column
+    const int nround = rp - 1;
+    long g = 0;
+    conv = false;
+    for (sweeps = 0; sweeps < EIGH_MAX_SWEEPS && !conv; ++sweeps) {
+        bool rot_any = false;
+        for (int rho = 0; rho < nround; ++rho, ++g) {
+            // every read of the round precedes every write (a block's write slot is another block's read slot); one
+            // wave, LDS operations complete in order: no barrier.  The block reads are in flight under the rotation.
+            const double gpp = G[dpp_], gqq = G[dqq_], gpq = G[dpq_];
+            double b[MAXIT][4];
+#pragma unroll
+            for (int it = 0; it < MAXIT; ++it)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) b[it][e] = G[ri[it][e]];
+            double t, c, s;
+            const bool rot = jacobi_rot(gpp, gqq, gpq, thr, t, c, s) && own;
+            rot_any |= rot;
+            if (own) {
+                e_cs[lane][0] = c;
+                e_cs[lane][1] = s;
+                rlog[g * h + lane] = t;
+            }
+            G[wpp_] = fma(-t, gpq, gpp);
+            G[wqq_] = fma(t, gpq, gqq);
+            G[wpq_] = rot ? 0.0 : gpq;
+#pragma unroll
+            for (int it = 0; it < MAXIT; ++it) {
+                const double2_e ci = *reinterpret_cast<const double2_e*>(e_cs[bI[it]]);
+                const double2_e ck = *reinterpret_cast<const double2_e*>(e_cs[bK[it]]);
+                double n00, n01, n10, n11;
+                rot_block(ci.x, ci.y, ck.x, ck.y, b[it][0], b[it][1], b[it][2], b[it][3], n00, n01, n10, n11);
+                G[wi[it][0]] = n00;
+                G[wi[it][1]] = n01;
+                G[wi[it][2]] = n10;
+                G[wi[it][3]] = n11;
+            }
+        }
+        conv = !__any(rot_any);
+    }
+    return g;
+}
+
+// ---- C (HBM/L2). same rounds with the packed matrix double-buffered in the workspace (ranks beyond the LDS cap) -----
+__device__ __forceinline__ long eigh_jacobi_global(double*& Gc, double*& Gn, int rp, double* __restrict__ rlog,
+                                                   double (*e_cs)[2], bool& conv, int& sweeps) {
+    const int lane = threadIdx.x & 63;
+    const int h = rp / 2, nslots = ((h + 1) / 2) * (h + 1);
+    const double thr = DBL_EPSILON * Gc[0];
+    const int nround = rp - 1;
+    long g = 0;
+    conv = false;
+    for (sweeps = 0; sweeps < EIGH_MAX_SWEEPS && !conv; ++sweeps) {
+        bool rot_any = false;
+        for (int rho = 0; rho < nround; ++rho, ++g) {
+            for (int i = lane; i < h; i += 64) {
+                const int p = i, q = rp - 1 - i;
+                double t, c, s;
+                rot_any |= jacobi_rot(Gc[tri_idx(p, p, rp)], Gc[tri_idx(q, q, rp)], Gc[tri_idx(p, q, rp)], thr, t, c, s);
+                e_cs[i][0] = c;
+                e_cs[i][1] = s;
+                rlog[g * h + i] = t;
+            }
+            __syncthreads();
+            for (int b = lane; b < nslots; b += 64) {
+                int I, K;
+                if (!rr_block(b, h, I, K)) continue;
+                const int pI = I, qI = rp - 1 - I, pK = K, qK = rp - 1 - K;
+                const int sp = rr_shift(pI, rp), sq = rr_shift(qI, rp), tp = rr_shift(pK, rp), tq = rr_shift(qK, rp);
+                const double cI = e_cs[I][0], sI = e_cs[I][1], cK = e_cs[K][0], sK = e_cs[K][1];
+                const double b00 = Gc[sym_idx(pI, pK, rp)], b01 = Gc[sym_idx(pI, qK, rp)];
+                const double b10 = Gc[sym_idx(qI, pK, rp)], b11 = Gc[sym_idx(qI, qK, rp)];
+                double n00, n01, n10, n11;
+                if (I == K) {
+                    const double tt = sI / cI;
+                    n00 = b00 - tt * b01;
+                    n11 = b11 + tt * b01;
+                    n01 = n10 = (sI != 0.0) ? 0.0 : b01;
+                } else {
+                    rot_block(cI, sI, cK, sK, b00, b01, b10, b11, n00, n01, n10, n11);
+                }
+                Gn[sym_idx(sp, tp, rp)] = n00;
+                Gn[sym_idx(sp, tq, rp)] = n01;
+                Gn[sym_idx(sq, tp, rp)] = n10;
+                Gn[sym_idx(sq, tq, rp)] = n11;
+            }
+            __syncthreads();
+            double* tmp = Gc;
+            Gc = Gn;
+            Gn = tmp;
+        }
+        conv = !__any(rot_any);
+    }
+    return g;
+}
+
+// v <- Q_1 ... Q_K v: the logged rounds in reverse (Q_g = J_g Pi: un-shift the positions, then rotate the pairs)
+__device__ __forceinline__ void eigh_replay(double* e_vec, const double* __restrict__ rlog, long gtot, int rp) {
+    const int lane = threadIdx.x & 63;
+    const int h = rp / 2;
+    const int i0 = lane, i1 = lane + 64;                         // h <= 128: at most two pairs per lane
+    const bool v0 = i0 < h, v1 = i1 < h;
+    const int a0 = v0 ? rr_shift(i0, rp) : 0, b0 = v0 ? rr_shift(rp - 1 - i0, rp) : 0;
+    const int a1 = v1 ? rr_shift(i1, rp) : 0, b1 = v1 ? rr_shift(rp - 1 - i1, rp) : 0;
+    for (long g1 = gtot; g1 > 0; g1 -= 8) {
+        double tq0[8], tq1[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const long gg = g1 - 1 - u;
+            tq0[u] = (gg >= 0 && v0) ? rlog[gg * h + i0] : 0.0;
+            tq1[u] = (gg >= 0 && v1) ? rlog[gg * h + i1] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            if (g1 - 1 - u >= 0) {                                // uniform
+                double up0 = 0.0, uq0 = 0.0, up1 = 0.0, uq1 = 0.0;
+                if (v0) up0 = e_vec[a0], uq0 = e_vec[b0];
+                if (v1) up1 = e_vec[a1], uq1 = e_vec[b1];
+                if (v0) {
+                    const double c = rsqrt_fast(fma(tq0[u], tq0[u], 1.0)), s = tq0[u] * c;
+                    e_vec[i0] = c * up0 + s * uq0;
+                    e_vec[rp - 1 - i0] = c * uq0 - s * up0;
+                }
+                if (v1) {
+                    const double c = rsqrt_fast(fma(tq1[u], tq1[u], 1.0)), s = tq1[u] * c;
+                    e_vec[i1] = c * up1 + s * uq1;
+                    e_vec[rp - 1 - i1] = c * uq1 - s * up1;
+                }
+            }
+        }
+    }
+}
+
+template <int T, int RPL>
+__global__ __launch_bounds__(64, 2) void joint_eigh_kernel(const EighArgs a) {
+    extern __shared__ __attribute__((aligned(16))) double e_dyn[];   // packed Gram matrix (LDS path)
     __shared__ double e_vec[256];                                // pivot row / rotated base samples
     __shared__ double e_y[256];                                  // eigenvalues / raw sample
-    __shared__ double e_cs[128][2];
-    __shared__ short e_pq[128][2];
+    __shared__ __attribute__((aligned(16))) double e_cs[128][2];
     __shared__ short e_rank[256];
-    __shared__ double e_rv[EIGH_NT / 64];
-    __shared__ int e_ri[EIGH_NT / 64];
-    __shared__ int e_cnt;
     if (!a.force && *a.any_fail == 0) return;                    // no chain of the batch failed: Cholesky roots stand
     const GpParams& gp = a.gp;
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int lane = threadIdx.x;
     const int n = a.m * T;
     const long nchains = a.Ns * gp.g_ny;
     double* Lm = a.ws + (long)blockIdx.x * a.ws_slot_stride;     // [n][n] column-major, r columns used
     const int np = (n + 1) & ~1;
-    double* Gg = Lm + (long)n * n;
-    double* rlog = Gg + (long)np * np;
+    double* Gg0 = Lm + (long)n * n;
+    double* Gg1 = Gg0 + eigh_packed(np);
+    double* rlog = Gg1 + eigh_packed(np);
 
     for (long chain = blockIdx.x; chain < nchains; chain += gridDim.x) {
         const int o = (int)(chain % gp.g_ny);
@@ -345,73 +387,291 @@ __global__ __launch_bounds__(EIGH_NT, 4) void joint_eigh_kernel(const EighArgs a
             for (int d = 0; d < T - 1; ++d) kmax = fmax(kmax, gp.os[o] * gp.inv_l2[o][d]);
         }
         const double tol = a.tol_mult * DBL_EPSILON * kmax;
+        long long eph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        long long et = __builtin_readcyclecounter();
+        (void)eph;
+        (void)et;
 
-        // ---- A. diagonally pivoted Cholesky, left-looking; thread == row ------------------------------------------
-        const double NEG_INF = -__builtin_huge_val();
-        double d = NEG_INF;
-        if (tid < n) d = Sm[(long)tid * n + tid];
-        int r = 0;
-        for (int k = 0; k < n; ++k) {
-            double bv = d;
-            int bi = tid;
+        // ---- A. diagonally pivoted Cholesky, left-looking, EIGH_PB pivots per pass; lane owns rows lane + 64 i --------
+        // A pass picks the EIGH_PB largest residual diagonal entries as candidates, forms their EIGH_PB columns
+        // against all previous columns at once (every own-row entry of L is loaded once per pass instead of once per
+        // pivot: the loads' latency, not their volume, bounds this phase), then eliminates the candidates against each
+        // other in registers, greedily by their exact current residual; a candidate whose residual has dropped to <=
+        // tol is dropped, and the pass ends when the best candidate left is below 1/16 of the largest residual of ANY
+        // row (threshold pivoting: ~10 passes for rank 50, the residual S - L L^T as small as with one pivot per pass).
+        double d[RPL];
+        bool pivoted[RPL];
 #pragma unroll
-            for (int off = 32; off; off >>= 1) {
-                const double ov = __shfl_xor(bv, off, 64);
-                const int oi = __shfl_xor(bi, off, 64);
-                if (ov > bv || (ov == bv && oi < bi)) {
-                    bv = ov;
-                    bi = oi;
-                }
-            }
-            if (lane == 0) {
-                e_rv[wv] = bv;
-                e_ri[wv] = bi;
-            }
-            __syncthreads();
-            bv = e_rv[0];
-            bi = e_ri[0];
-#pragma unroll
-            for (int w = 1; w < EIGH_NT / 64; ++w) {
-                const double ov = e_rv[w];
-                const int oi = e_ri[w];
-                if (ov > bv || (ov == bv && oi < bi)) {
-                    bv = ov;
-                    bi = oi;
-                }
-            }
-            const int p = bi;
-            const double dp = bv;
-            if (!(dp > tol)) break;                              // uniform
-            for (int j = tid; j < k; j += EIGH_NT) e_vec[j] = Lm[(long)j * n + p];
-            double v = 0.0;
-            if (tid < n) v = (tid >= p) ? Sm[(long)p * n + tid] : Sm[(long)tid * n + p];
-            __syncthreads();
-            if (tid < n) {
-                for (int j0 = 0; j0 < k; j0 += 8) {
-                    double l8[8];
-#pragma unroll
-                    for (int u = 0; u < 8; ++u) l8[u] = Lm[(long)min(j0 + u, k - 1) * n + tid];
-#pragma unroll
-                    for (int u = 0; u < 8; ++u)
-                        if (j0 + u < k) v = fma(-l8[u], e_vec[j0 + u], v);
-                }
-                const double sd = sqrt(dp);
-                const bool done = (d == NEG_INF);                // row pivoted earlier: its residual is exactly zero
-                const double l = (tid == p) ? sd : (done ? 0.0 : v / sd);
-                Lm[(long)k * n + tid] = l;
-                d = (tid == p || done) ? NEG_INF : d - l * l;
-            }
-            r = k + 1;
+        for (int i = 0; i < RPL; ++i) {
+            const int t = lane + 64 * i;
+            d[i] = (t < n) ? Sm[(long)t * n + t] : 0.0;
+            pivoted[i] = !(t < n);
         }
-        __syncthreads();
+        int r = 0;
+        while (r < n) {
+            // candidates: repeated arg max; the row index rides in the low mantissa byte (ties -> lowest row)
+            bool taken[RPL];
+#pragma unroll
+            for (int i = 0; i < RPL; ++i) taken[i] = pivoted[i];
+            int cand[EIGH_PB], nc = 0;
+#pragma unroll
+            for (int c = 0; c < EIGH_PB; ++c) {
+                cand[c] = 0;
+                double key = 0.0;
+#pragma unroll
+                for (int i = 0; i < RPL; ++i) {
+                    if (!taken[i] && d[i] > tol) {
+                        const unsigned long long kb = (__builtin_bit_cast(unsigned long long, d[i]) & ~0xFFull) |
+                                                      (unsigned long long)(255 - (lane + 64 * i));
+                        key = fmax(key, __builtin_bit_cast(double, kb));
+                    }
+                }
+                key = wave_max_nonneg(key);
+                if (key > 0.0 && nc == c) {                      // uniform
+                    const int p = 255 - (int)(__builtin_bit_cast(unsigned long long, key) & 0xFFull);
+                    cand[c] = p;
+                    nc = c + 1;
+#pragma unroll
+                    for (int i = 0; i < RPL; ++i)
+                        if (lane + 64 * i == p) taken[i] = true;
+                }
+            }
+            if (nc == 0) break;                                  // largest residual <= tol: done
+            if (lane < EIGH_PB) e_rank[lane] = (short)cand[0];
+#pragma unroll
+            for (int c = 1; c < EIGH_PB; ++c)
+                if (lane == c) e_rank[lane] = (short)cand[c];
+            // candidate columns of S
+            double acc[RPL][EIGH_PB];
+#pragma unroll
+            for (int i = 0; i < RPL; ++i) {
+                const int t = min(lane + 64 * i, n - 1);
+#pragma unroll
+                for (int c = 0; c < EIGH_PB; ++c) {
+                    const int p = cand[c];
+                    acc[i][c] = (c < nc) ? ((t >= p) ? Sm[(long)p * n + t] : Sm[(long)t * n + p]) : 0.0;
+                }
+            }
+            // minus the previous columns: chunks of 32 columns, the candidates' rows of L staged in LDS ([column][cand])
+            for (int c0 = 0; c0 < r; c0 += 32) {
+                const int cw = min(32, r - c0);
+                for (int e = lane; e < 32 * EIGH_PB; e += 64) {
+                    const int jj = e / EIGH_PB, c = e - jj * EIGH_PB;
+                    e_y[e] = (jj < cw && c < nc) ? Lm[(long)(c0 + jj) * n + e_rank[c]] : 0.0;
+                }
+                for (int j0 = 0; j0 < cw; j0 += 8) {
+                    double l8[8][RPL];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const long col = (long)(c0 + min(j0 + u, cw - 1)) * n;
+#pragma unroll
+                        for (int i = 0; i < RPL; ++i) l8[u][i] = Lm[col + min(lane + 64 * i, n - 1)];
+                    }
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        if (j0 + u < cw) {                       // uniform
+                            double lp[EIGH_PB];
+#pragma unroll
+                            for (int c = 0; c < EIGH_PB; c += 2) {
+                                const double2_e pr = *reinterpret_cast<const double2_e*>(&e_y[(j0 + u) * EIGH_PB + c]);
+                                lp[c] = pr.x, lp[c + 1] = pr.y;
+                            }
+#pragma unroll
+                            for (int i = 0; i < RPL; ++i)
+#pragma unroll
+                                for (int c = 0; c < EIGH_PB; ++c) acc[i][c] = fma(-l8[u][i], lp[c], acc[i][c]);
+                        }
+                    }
+                }
+            }
+            // eliminate the candidates against each other, greedily by their current residual
+            unsigned used = 0;
+            for (int q = 0; q < nc; ++q) {
+                int cs_ = -1;
+                double best = tol;
+#pragma unroll
+                for (int c = 0; c < EIGH_PB; ++c) {
+                    if (c < nc && !(used & (1u << c))) {
+                        const int p = cand[c];
+                        double dsel = d[0];
+#pragma unroll
+                        for (int i = 1; i < RPL; ++i)
+                            if ((p >> 6) == i) dsel = d[i];
+                        const double dc = readlane_f64(dsel, p & 63);     // exact residual of the candidate row
+                        if (dc > best) {
+                            best = dc;
+                            cs_ = c;
+                        }
+                    }
+                }
+                if (cs_ < 0) break;                              // every remaining candidate dropped to <= tol
+                // threshold pivoting: a pivot far below the largest residual left (it may sit at the noise floor of S
+                // while 1e-9 residuals remain) would amplify that noise into the other rows - end the pass instead
+                double gmax = 0.0;
+#pragma unroll
+                for (int i = 0; i < RPL; ++i)
+                    if (!pivoted[i]) gmax = fmax(gmax, d[i]);
+                gmax = wave_max_nonneg(fmax(gmax, 0.0));
+                if (best < EIGH_PIVOT_THRESHOLD * gmax) break;
+                used |= 1u << cs_;
+                int p = 0;
+                double col[RPL];
+#pragma unroll
+                for (int i = 0; i < RPL; ++i) col[i] = 0.0;
+#pragma unroll
+                for (int c = 0; c < EIGH_PB; ++c) {
+                    if (c == cs_) {                              // uniform select
+                        p = cand[c];
+#pragma unroll
+                        for (int i = 0; i < RPL; ++i) col[i] = acc[i][c];
+                    }
+                }
+                double inv;
+                const double sd = sqrt_rsqrt_fast(best, inv);
+#pragma unroll
+                for (int i = 0; i < RPL; ++i) {
+                    const int t = lane + 64 * i;
+                    const double l = (t == p) ? sd : (pivoted[i] ? 0.0 : col[i] * inv);   // pivoted rows: residual exactly 0
+                    col[i] = l;
+                    if (t < n) Lm[(long)r * n + t] = l;
+                    if (t == p) pivoted[i] = true;
+                    d[i] -= l * l;
+                }
+                // the other candidates' columns lose their component along the new column
+#pragma unroll
+                for (int c = 0; c < EIGH_PB; ++c) {
+                    if (c < nc && !(used & (1u << c))) {         // uniform
+                        const int pc = cand[c];
+                        double lsel = col[0];
+#pragma unroll
+                        for (int i = 1; i < RPL; ++i)
+                            if ((pc >> 6) == i) lsel = col[i];
+                        const double lpc = readlane_f64(lsel, pc & 63);
+#pragma unroll
+                        for (int i = 0; i < RPL; ++i) acc[i][c] = fma(-col[i], lpc, acc[i][c]);
+                    }
+                }
+                ++r;
+            }
+        }
+        EPH(0);
 
         const int rp = (r + 1) & ~1;
-        int info;
-        if (rp <= a.lds_cap)
-            info = eigh_tail<T>(a, chain, n, r, Lm, (lds_double*)e_dyn, rlog, e_vec, e_cs, e_pq, e_rank, e_y, &e_cnt);
-        else
-            info = eigh_tail<T>(a, chain, n, r, Lm, Gg, rlog, e_vec, e_cs, e_pq, e_rank, e_y, &e_cnt);
-        if (tid == 0) a.info[chain] |= info;
+        int info = GPMPC_INFO_ROOT_EIGH;
+        long gtot = 0;
+        if (r > 0) {
+            bool conv;
+            int sweeps;
+            if (rp <= a.lds_cap) {
+                lds_double* G = (lds_double*)e_dyn;
+                eigh_gram(Lm, n, r, rp, G);
+                EPH(1);
+                const int h = rp / 2, nsl = (h / 2) * h;
+                if (nsl <= 128) gtot = eigh_jacobi_lds<2>(G, rp, rlog, e_cs, conv, sweeps);
+                else if (nsl <= 256) gtot = eigh_jacobi_lds<4>(G, rp, rlog, e_cs, conv, sweeps);
+                else gtot = eigh_jacobi_lds<EIGH_MAXIT>(G, rp, rlog, e_cs, conv, sweeps);
+                for (int i = lane; i < r; i += 64) e_y[i] = G[tri_idx(i, i, rp)];
+            } else {
+                double *Gc = Gg0, *Gn = Gg1;
+                eigh_gram(Lm, n, r, rp, Gc);
+                __syncthreads();
+                EPH(1);
+                gtot = eigh_jacobi_global(Gc, Gn, rp, rlog, e_cs, conv, sweeps);
+                for (int i = lane; i < r; i += 64) e_y[i] = Gc[tri_idx(i, i, rp)];
+            }
+            if (!conv) info |= GPMPC_INFO_EIGH_NOCONV;
+            EPH(2);
+#ifdef GPMPC_PHASE_TIMERS
+            eph[6] = sweeps;
+#endif
+            __syncthreads();
+            // ---- D. ascending rank of the eigenvalues; t = W z~ ----------------------------------------------------
+            for (int i = lane; i < rp; i += 64) {
+                double zt = 0.0;
+                if (i < r) {
+                    const double lam = e_y[i];
+                    int cnt = 0;
+                    for (int j = 0; j < r; ++j) {
+                        const double lj = e_y[j];
+                        cnt += (lj < lam || (lj == lam && j < i)) ? 1 : 0;
+                    }
+                    e_rank[i] = (short)cnt;
+                    zt = a.z[chain * (long)n + (n - r + cnt)];
+                }
+                e_vec[i] = zt;
+            }
+            __syncthreads();
+            eigh_replay(e_vec, rlog, gtot, rp);
+            __syncthreads();
+        }
+        EPH(3);
+
+        // ---- E. y = mean + L t, post-processing of sample_gp (reference src/agent.py:646-708) ------------------------
+#pragma unroll
+        for (int i = 0; i < RPL; ++i) {
+            const int t = lane + 64 * i;
+            if (t < n) {
+                double acc = 0.0;
+                for (int j0 = 0; j0 < r; j0 += 8) {
+                    double l8[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) l8[u] = Lm[(long)min(j0 + u, r - 1) * n + t];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u)
+                        if (j0 + u < r) acc = fma(l8[u], e_vec[j0 + u], acc);
+                }
+                e_y[t] = acc + a.mean[chain * (long)n + t];
+            }
+        }
+        __syncthreads();
+        for (int j = lane; j < a.m; j += 64) {
+            double vv[T], mm[T];
+            bool all_zero = (a.var_zero_thr >= 0.0);
+#pragma unroll
+            for (int b = 0; b < T; ++b) {
+                const long off = chain * (long)n + j * T + b;
+                vv[b] = a.var[off];
+                mm[b] = a.mean[off];
+                all_zero = all_zero && (vv[b] <= a.var_zero_thr);
+            }
+#pragma unroll
+            for (int b = 0; b < T; ++b) {
+                double yb = all_zero ? mm[b] : e_y[j * T + b];
+                if (a.apply_clip) {
+                    const double sd = a.beta * sqrt(vv[b]);
+                    yb = fmin(fmax(yb, mm[b] - sd), mm[b] + sd);
+                }
+                a.y[chain * (long)n + j * T + b] = yb;
+            }
+        }
+        EPH(4);
+
+        // ---- F. optional: the root itself, R = L W with eigh's column order (tests) ------------------------------------
+        if (a.root) {
+            double* Rout = a.root + chain * (long)n * n;
+            for (int t = lane; t < n; t += 64)
+                for (int c = 0; c < n - r; ++c) Rout[(long)t * n + c] = 0.0;
+            for (int j = 0; j < r; ++j) {
+                __syncthreads();
+                for (int i = lane; i < rp; i += 64) e_vec[i] = (i == j) ? 1.0 : 0.0;
+                __syncthreads();
+                eigh_replay(e_vec, rlog, gtot, rp);
+                __syncthreads();
+                const int col = n - r + e_rank[j];
+                for (int t = lane; t < n; t += 64) {
+                    double acc = 0.0;
+                    for (int k = 0; k < r; ++k) acc = fma(Lm[(long)k * n + t], e_vec[k], acc);
+                    Rout[(long)t * n + col] = acc;
+                }
+            }
+        }
+#ifdef GPMPC_PHASE_TIMERS
+        if (blockIdx.x == 0 && lane == 0) {
+            eph[7] = r;
+            for (int i = 0; i < 8; ++i) g_eigh_phase[i] = eph[i];
+        }
+#endif
+        if (lane == 0) a.info[chain] |= info;
         __syncthreads();
     }
 }

@@ -135,7 +135,7 @@ def test_eigh_whole_batch_fallback_and_root_modes(sg):
         R = post.root.cpu()
         S = post.covariance_matrix.cpu()
     ev, U = torch.linalg.eigh(S)
-    Splus = (U * ev.clamp_min(0)) @ U.transpose(-1, -2)
+    Splus = (U * ev.clamp_min(0).unsqueeze(-2)) @ U.transpose(-1, -2)
     assert float((R @ R.transpose(-1, -2) - Splus).abs().max()) < 1e-8 * float(S.abs().max())
     # same distribution, different root: the two draws differ but both reproduce their own root
     zz = z.reshape(Ns, 3, -1, 1).cpu()

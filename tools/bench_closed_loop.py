@@ -22,7 +22,7 @@ def main():
     ap.add_argument("--horizon", type=int, default=40)
     ap.add_argument("--iters", type=int, default=4)
     ap.add_argument("--mpc-steps", type=int, default=4)
-    ap.add_argument("--jitter", type=float, default=1e-9, help="keeps the car on the Cholesky branch (YAML: 1e-20 -> eigh)")
+    ap.add_argument("--jitter", type=float, default=None, help="override Dyn_gp_jitter (default: as shipped, 1e-20 -> eigh root)")
     a = ap.parse_args()
     p = load_params(a.params)
     p["common"]["use_cuda"] = True
@@ -30,7 +30,8 @@ def main():
     p["agent"]["true_dyn_as_sample"] = False
     p["agent"]["base_sample_generator"] = "vectorized"
     p["common"]["num_MPC_itrs"], p["optimizer"]["SEMPC"]["max_sqp_iter"] = 1, a.iters
-    p["agent"]["Dyn_gp_jitter"] = a.jitter
+    if a.jitter is not None:
+        p["agent"]["Dyn_gp_jitter"] = a.jitter
     torch.manual_seed(3)
     agent = sg.Agent(p, sg.make_env(p))
     Ns, H, nx, nu = a.ns, a.horizon, agent.nx, agent.nu
