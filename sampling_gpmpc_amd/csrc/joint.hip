@@ -684,7 +684,9 @@ struct JointWs {
 };
 
 static long eigh_grid(long nchains) {
-    const long cap = 256L * 10;           // one wave per chain, ~9 resident per CU (LDS bound)
+    static const char* env = getenv("GPMPC_EIGH_SLOTS_PER_CU");       // experiment knob (tools/eigh_sweep.sh)
+    const long per_cu = env ? atol(env) : 10;            // one wave per chain, ~8 resident per CU (LDS / VGPR bound)
+    const long cap = 256L * (per_cu > 0 ? per_cu : 10);
     return nchains < cap ? nchains : cap;
 }
 
@@ -716,6 +718,16 @@ int gpmpc_debug_read_joint_phases(long long* out /*[host] 16*/) {
 int gpmpc_debug_read_eigh_phases(long long* out /*[host] 8*/) {
     GPMPC_HIP_CHECK(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_eigh_phase), 8 * sizeof(long long)));
     return GPMPC_OK;
+}
+
+// occupancy of the eigh kernel as the runtime computes it (blocks of one wave per CU) for an m*T-slot covariance
+int gpmpc_debug_eigh_occupancy(int mT, size_t extra_lds) {
+    const int np = (mT + 1) & ~1;
+    const int cap = np < EIGH_LDS_RANK ? np : EIGH_LDS_RANK;
+    const size_t lds = (size_t)eigh_lds_doubles(mT, cap) * sizeof(double) + extra_lds;
+    int nb = -1;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, joint_eigh_kernel<3, 2>, 64, lds) != hipSuccess) return -1;
+    return nb;
 }
 
 size_t gpmpc_joint_workspace_bytes(const gpmpc_gp_desc_t* gp, int64_t Ns, int32_t n_ho, int32_t m) {
@@ -820,7 +832,7 @@ int gpmpc_joint_sample(const gpmpc_gp_desc_t* gp, const void* plan, const double
         const int np = (mT + 1) & ~1;
         e.lds_cap = global_G ? 0 : (np < EIGH_LDS_RANK ? np : EIGH_LDS_RANK);
         e.tol_mult = 16.0;
-        const size_t lds = (size_t)(eigh_packed(e.lds_cap) + 2) * sizeof(double);   // + the pad slot of the dummy blocks
+        const size_t lds = (size_t)eigh_lds_doubles(mT, e.lds_cap) * sizeof(double);
         const dim3 ge((unsigned)w.egrid), be(64);
         if (gp->T == 1) {
             if (mT <= 128) hipLaunchKernelGGL((joint_eigh_kernel<1, 2>), ge, be, lds, st, e);

@@ -55,6 +55,7 @@ struct EighArgs {
 };
 
 __device__ long long g_eigh_phase[8];
+__device__ int g_eigh_stat[4];         // phase-timer builds: max rank, chains on the HBM/L2 path
 #ifdef GPMPC_PHASE_TIMERS
 #define EPH(idx) do { const long long _n = __builtin_readcyclecounter(); eph[idx] += _n - et; et = _n; } while (0)
 #else
@@ -62,16 +63,22 @@ __device__ long long g_eigh_phase[8];
 #endif
 
 constexpr int EIGH_MAX_SWEEPS = 16;
-constexpr int EIGH_LDS_RANK = 56;      // packed 56 x 56 Gram matrix = 12.8 KB of LDS per chain: ~9 chains per CU
+constexpr double EIGH_TINY_ROT = 1e-8; // a sweep whose largest rotation tangent is below this is the last one
+constexpr int EIGH_LDS_RANK = 64;      // packed 64 x 64 Gram matrix = 16.6 KB of LDS per chain: ~7 chains per CU
 constexpr int EIGH_PB = 8;             // candidate pivots per pass of the pivoted Cholesky
 constexpr double EIGH_PIVOT_THRESHOLD = 1.0 / 16.0;   // accepted pivot >= this x the largest residual diagonal left
-constexpr int EIGH_MAXIT = 7;          // off-diagonal 2x2 blocks per lane at the LDS rank cap: ceil(14 * 28 / 64)
+constexpr int EIGH_MAXIT = 8;          // off-diagonal 2x2 blocks per lane at the LDS rank cap: 16 * 32 / 64
 
 typedef double double4_e __attribute__((ext_vector_type(4)));
 typedef double double2_e __attribute__((ext_vector_type(2)));
 typedef __attribute__((address_space(3))) double lds_double;
 
 __host__ __device__ inline long eigh_packed(int np) { return (long)np * (np + 1) / 2; }
+// dynamic LDS of one chain (doubles) for an n x n covariance with the Gram matrix of ranks <= cap in LDS
+__host__ __device__ inline long eigh_lds_doubles(int n, int cap) {
+    const long np = (n + 1) & ~1;
+    return eigh_packed(cap) + 2 + 2 * (np / 2 + 2) + (n > 256 ? n : 256) + np + (np + 3) / 4 + 2;
+}
 __host__ __device__ inline long eigh_slot_doubles(int n) {
     const long np = (n + 1) & ~1;
     return (long)n * n + 2 * eigh_packed((int)np) + (long)(EIGH_MAX_SWEEPS / 2) * np * np + 8;
@@ -233,6 +240,7 @@ __device__ __forceinline__ long eigh_jacobi_lds(lds_double* G, int rp, double* _
     conv = false;
     for (sweeps = 0; sweeps < EIGH_MAX_SWEEPS && !conv; ++sweeps) {
         bool rot_any = false;
+        double tmax = 0.0;
         for (int rho = 0; rho < nround; ++rho, ++g) {
             // every read of the round precedes every write (a block's write slot is another block's read slot); one
             // wave, LDS operations complete in order: no barrier.  The block reads are in flight under the rotation.
@@ -245,6 +253,7 @@ __device__ __forceinline__ long eigh_jacobi_lds(lds_double* G, int rp, double* _
             double t, c, s;
             const bool rot = jacobi_rot(gpp, gqq, gpq, thr, t, c, s) && own;
             rot_any |= rot;
+            tmax = fmax(tmax, rot ? fabs(t) : 0.0);
             if (own) {
                 e_cs[lane][0] = c;
                 e_cs[lane][1] = s;
@@ -265,7 +274,9 @@ __device__ __forceinline__ long eigh_jacobi_lds(lds_double* G, int rp, double* _
                 G[wi[it][3]] = n11;
             }
         }
-        conv = !__any(rot_any);
+        // done when nothing was rotated - or when every rotation of the sweep was tiny: the entries it leaves behind are
+        // O(t^2) relative (quadratic convergence), far below thr; saves the sweep that would only confirm it
+        conv = !__any(rot_any) || !__any(tmax > EIGH_TINY_ROT);
     }
     return g;
 }
@@ -362,15 +373,17 @@ __device__ __forceinline__ void eigh_replay(double* e_vec, const double* __restr
 
 template <int T, int RPL>
 __global__ __launch_bounds__(64, 2) void joint_eigh_kernel(const EighArgs a) {
-    extern __shared__ __attribute__((aligned(16))) double e_dyn[];   // packed Gram matrix (LDS path)
-    __shared__ double e_vec[256];                                // pivot row / rotated base samples
-    __shared__ double e_y[256];                                  // eigenvalues / raw sample
-    __shared__ __attribute__((aligned(16))) double e_cs[128][2];
-    __shared__ short e_rank[256];
+    // dynamic LDS, sized by the launch (eigh_lds_doubles): packed Gram matrix + pad slot | rotations (c, s) | staging /
+    // eigenvalues / raw sample | rotated base samples | ranks, candidates
+    extern __shared__ __attribute__((aligned(16))) double e_dyn[];
     if (!a.force && *a.any_fail == 0) return;                    // no chain of the batch failed: Cholesky roots stand
     const GpParams& gp = a.gp;
     const int lane = threadIdx.x;
     const int n = a.m * T;
+    double (*e_cs)[2] = reinterpret_cast<double (*)[2]>(e_dyn + eigh_packed(a.lds_cap) + 2);
+    double* e_y = e_dyn + eigh_packed(a.lds_cap) + 2 + 2 * (((n + 1) & ~1) / 2 + 2);
+    double* e_vec = e_y + (n > 256 ? n : 256);
+    short* e_rank = reinterpret_cast<short*>(e_vec + ((n + 1) & ~1));
     const long nchains = a.Ns * gp.g_ny;
     double* Lm = a.ws + (long)blockIdx.x * a.ws_slot_stride;     // [n][n] column-major, r columns used
     const int np = (n + 1) & ~1;
@@ -389,6 +402,9 @@ __global__ __launch_bounds__(64, 2) void joint_eigh_kernel(const EighArgs a) {
         const double tol = a.tol_mult * DBL_EPSILON * kmax;
         long long eph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         long long et = __builtin_readcyclecounter();
+#ifdef GPMPC_PHASE_TIMERS
+        const long long rt0 = __builtin_amdgcn_s_memrealtime();      // constant 100 MHz: cycles / ticks = shader clock
+#endif
         (void)eph;
         (void)et;
 
@@ -558,6 +574,12 @@ __global__ __launch_bounds__(64, 2) void joint_eigh_kernel(const EighArgs a) {
 
         const int rp = (r + 1) & ~1;
         int info = GPMPC_INFO_ROOT_EIGH;
+#ifdef GPMPC_PHASE_TIMERS
+        if (lane == 0) {
+            atomicMax((int*)&g_eigh_stat[0], r);
+            if (rp > a.lds_cap) atomicAdd((int*)&g_eigh_stat[1], 1);
+        }
+#endif
         long gtot = 0;
         if (r > 0) {
             bool conv;
@@ -569,6 +591,7 @@ __global__ __launch_bounds__(64, 2) void joint_eigh_kernel(const EighArgs a) {
                 const int h = rp / 2, nsl = (h / 2) * h;
                 if (nsl <= 128) gtot = eigh_jacobi_lds<2>(G, rp, rlog, e_cs, conv, sweeps);
                 else if (nsl <= 256) gtot = eigh_jacobi_lds<4>(G, rp, rlog, e_cs, conv, sweeps);
+                else if (nsl <= 384) gtot = eigh_jacobi_lds<6>(G, rp, rlog, e_cs, conv, sweeps);
                 else gtot = eigh_jacobi_lds<EIGH_MAXIT>(G, rp, rlog, e_cs, conv, sweeps);
                 for (int i = lane; i < r; i += 64) e_y[i] = G[tri_idx(i, i, rp)];
             } else {
@@ -666,9 +689,11 @@ __global__ __launch_bounds__(64, 2) void joint_eigh_kernel(const EighArgs a) {
             }
         }
 #ifdef GPMPC_PHASE_TIMERS
-        if (blockIdx.x == 0 && lane == 0) {
+        if ((chain == 0 || chain == 1000) && lane == 0) {    // chain 1000 runs with the CU fully loaded, chain 0 too
             eph[7] = r;
+            eph[5] = __builtin_amdgcn_s_memrealtime() - rt0;
             for (int i = 0; i < 8; ++i) g_eigh_phase[i] = eph[i];
+            g_eigh_phase[4] = g_eigh_stat[0] * 100000LL + g_eigh_stat[1];
         }
 #endif
         if (lane == 0) a.info[chain] |= info;

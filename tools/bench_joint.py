@@ -54,13 +54,16 @@ def run(pname, Ns, H, iters, jitter=None):
             names = ["realcols", "init", "update", "factor", "solve", "mean+S", "root", "sample"]
             print("   phases(cycles):", {n: out[i] for i, n in enumerate(names)})
             out = (C.c_longlong * 8)(); sg._lib.load().gpmpc_debug_read_eigh_phases(out)
-            names = ["pivchol", "gram", "jacobi", "reverse", "sample", "root_out", "sweeps", "rank"]
-            print("   eigh phases(cycles, block 0 last chain):", {n: out[i] for i, n in enumerate(names)})
+            names = ["pivchol", "gram", "jacobi", "reverse", "sample", "ticks_100MHz", "sweeps", "rank"]
+            cyc = sum(out[i] for i in range(5))
+            print("   eigh phases(cycles, chain 0 or 1000):", {n: out[i] for i, n in enumerate(names)},
+                  f"=> {cyc} cycles in {out[5] * 10} ns: shader clock {cyc / max(out[5], 1) / 10:.2f} GHz")
         print(f"{pname:26s} Ns={Ns} H={H} k={it}: n_o={agent.model_i.plan.n_r + n_h*3:4d} m*T={H*3}: sample_gp {1e3*(t1-t0):8.2f} ms (best of 3) "
               f"({Ns*H/(t1-t0)/1e6:7.2f} M traj-steps/s), max jitter level {lvl}, eigh root={eigh}, finite={bool(torch.isfinite(y).all())}", flush=True)
 
 if __name__ == "__main__":
-    run("params_pendulum1D_samples", 1024, 30, 2)
+    if "--car-only" not in sys.argv:
+        run("params_pendulum1D_samples", 1024, 30, 2)
     run("params_car_residual", 1024, 40, 4)                     # as shipped: Dyn_gp_jitter 1e-20 -> eigendecomposition root
     if "--cholesky-branch" in sys.argv:
         run("params_car_residual", 1024, 40, 4, jitter=1e-9)    # comparison: the car kept on the Cholesky branch
