@@ -9,18 +9,23 @@ A "step" is one pass of the hot path over one batch: the full H-step re-conditio
 dynamics functions (one gpmpc_rollout launch) plus, for N > 1, the RCCL all-gather that assembles the reachable tube
 X_traj (N*Ns, nx, H+1) on every rank.  Workload at every N: BASELINE.json configs[1] per GPU - pendulum1D
 (params_pendulum1D_samples), Ns = 1024 samples per GPU, H = 30, sequential re-conditioned rollout (mode R, T = 3
-value+gradient labels) - i.e. weak scaling over samples.  Inputs (training grid, base samples z, input sequence)
-are synthetic and resident in HBM before the timed region.
+value+gradient labels) - i.e. weak scaling over samples.  Inputs (training grid, base samples z, input sequence) are
+synthetic and resident in HBM before the timed region; every rank generates ONLY its own shard
+of the base samples (counter-based stream keyed by global sample id).
 
-Before the W warmup steps the same step runs `--prewarm` (default 2000, ~0.25 s) more untimed times: a cold GPU needs
-that long to reach its sustained clocks, and a 50-step region measured right after 5 warmup steps reads ~5 % slower than
-the steady state every longer run sees (tools/clock_check.py: 0.1166 vs 0.1087 ms per step); the count is reported as
-`prewarm_steps`.  Prints ONE JSON line on rank 0 (see the keys below).  `roofline` is for the dominant kernel (rollout_kernel):
-algorithmic FP64 FLOP per launch (2.55e4 FLOP per trajectory-step for this config) divided by
-the launch duration measured with HIP events on the launch stream (one event pair per launch, in a pass of the same
-launches right after the timed region; the timed region itself carries one event at either end).  `cpu_baseline` times the CPU oracle (the
-reference-faithful from-scratch algorithm, torch CPU FP64) on rank 0 at N = 1 on a bounded sample of the same
-workload.
+For N > 1 the all-gather of rollout r runs on a side stream while rollout r+1 runs on the launch stream (two
+trajectory / tube buffers, sampling_gpmpc_amd.distributed.OverlappedTubeGather); the timed region ends when the last
+gather has completed.  `gather` in the JSON reports the collective alone and what of it stays exposed per step.
+
+Measurement order: W warmup steps -> K steps timed COLD (`cold.ms_per_step`: what a fresh process sees; the GPU has not
+reached its sustained clocks yet) -> `--prewarm` (default 2000, ~0.25 s) untimed steps -> W warmup steps -> EXACTLY K
+steps between two fences (barrier + synchronize): `value` / `ms_per_step`, max over ranks.  Prints ONE JSON line on rank
+0.  `roofline` is for the dominant kernel: algorithmic FP64 FLOP per launch divided by the launch
+duration measured with HIP events on the launch stream (one event pair per launch, in a pass of the same launches right
+after the timed region).  `cpu_baseline` times the CPU oracle (the reference-faithful from-scratch algorithm, torch CPU
+FP64) on rank 0 at N = 1 on a bounded sample of the same workload, at the best of several thread counts.  `extra`
+(N = 1) carries BASELINE configs[2] (car, mode R) and configs[4]'s per-GPU shard (car closed loop AS SHIPPED, mode J,
+SQP iterations k = 0..3), each with its own roofline object.
 """
 import argparse
 import json
@@ -34,8 +39,6 @@ sys.path.insert(0, REPO)
 import numpy as np
 import torch
 
-FLOP_PER_TRAJ_STEP = {"pendulum1D_R_H30": 2.55e4}     # SURVEY.md section 8(d), append-row algorithm
-MIN_HBM_BYTES_PER_TRAJ_STEP = {"pendulum1D_R_H30": 80}
 FP64_PEAK_TFLOPS = 78.6                                # MI355X FP64 vector == matrix peak (vendor figure)
 
 
@@ -48,48 +51,153 @@ def parse():
     ap.add_argument("--horizon", type=int, default=30)
     ap.add_argument("--cpu-sample", type=int, default=256, help="samples of the CPU-oracle baseline (0 = skip)")
     ap.add_argument("--prewarm", type=int, default=2000,
-                    help="untimed steps BEFORE the W warmup steps that bring the GPU to its sustained clocks (a cold "
-                         "50-step region measures ~5 %% slower than steady state: tools/clock_check.py); 0 = off")
+                    help="untimed steps before the second warmup that bring the GPU to its sustained clocks (the cold "
+                         "region is measured before them and reported as well); 0 = off")
     ap.add_argument("--reach-ns", type=int, default=32768,
                     help="samples per GPU of the informational reachable-set leg (configs[3], mode I; 0 = skip)")
+    ap.add_argument("--no-extra", action="store_true", help="skip the configs[2] / configs[4] legs (N = 1 only)")
     return ap.parse_args()
 
 
+def roofline(flop_per_launch, kernel_ms, kernel, hbm_bytes_algorithmic, note=None, **more):
+    ach = flop_per_launch / (kernel_ms * 1e-3) / 1e12
+    r = {"bound": "fp64_valu", "achieved": ach, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / FP64_PEAK_TFLOPS,
+         "kernel": kernel, "kernel_ms": kernel_ms, "flop_per_launch": flop_per_launch,
+         "algorithmic_hbm_bytes_per_launch": hbm_bytes_algorithmic,
+         "algorithmic_hbm_gbps": hbm_bytes_algorithmic / (kernel_ms * 1e-3) / 1e9}
+    if note:
+        r["note"] = note
+    r.update(more)
+    return r
+
+
 def cpu_baseline(Ns_cpu, H, u_ff):
-    """Time the oracle (reference-faithful: Ns-tiled real data, dense kernel rebuild, from-scratch Cholesky per step)."""
+    """Time the oracle (reference-faithful: Ns-tiled real data, dense kernel rebuild, from-scratch Cholesky per step) at
+    the best of several torch thread counts (probed on a quarter-size sample), on the bounded sample."""
     from oracle import agent_oracle as ao
-    from tests.helpers import fs_params
     import sampling_gpmpc_amd as sg
-    p = fs_params("params_pendulum1D_samples", Ns_cpu, H)
-    p["agent"]["base_sample_generator"] = "vectorized"
-    torch.manual_seed(99)
-    erv = sg.random_vector_within_bounds(p, 1, 3)
-    agent = ao.OracleAgent(p, ao.make_oracle_env(p), erv)
-    t0 = time.perf_counter()
-    X = ao.forward_sampling_rollout(agent, u_ff)
-    dt = time.perf_counter() - t0
-    assert np.isfinite(X).all()
-    return Ns_cpu * H / dt, dt
+    from sampling_gpmpc_amd.workloads import fs_params
+
+    def run(ns, threads):
+        torch.set_num_threads(threads)
+        p = fs_params("params_pendulum1D_samples", ns, H)
+        p["agent"]["base_sample_generator"] = "counter"
+        erv = sg.random_vector_within_bounds(p, 1, 3)
+        agent = ao.OracleAgent(p, ao.make_oracle_env(p), erv)
+        t0 = time.perf_counter()
+        X = ao.forward_sampling_rollout(agent, u_ff)
+        dt = time.perf_counter() - t0
+        assert np.isfinite(X).all()
+        return ns * H / dt, dt
+
+    ncpu = os.cpu_count() or 8
+    default_threads = torch.get_num_threads()
+    probe = {}
+    for th in sorted({t for t in (8, 16, 32, 64, 128) if t <= ncpu}):
+        probe[th] = run(max(Ns_cpu // 4, 16), th)[0]
+    best = max(probe, key=probe.get)
+    v, dt = run(Ns_cpu, best)
+    torch.set_num_threads(default_threads)
+    return v, dt, best, {str(k): round(x, 1) for k, x in probe.items()}
 
 
-def reachable_set_leg(a, rank, world, dist, sg, _lib, RolloutRunner, fs_params, synthetic_u_ff):
+def time_launches(fn, reps):
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
+    for k in range(reps):
+        ev[k][0].record()
+        fn()
+        ev[k][1].record()
+    torch.cuda.synchronize()
+    t = [s.elapsed_time(e) for s, e in ev]
+    return float(np.mean(t)), float(np.min(t))
+
+
+def extra_car_rollout(sg, _lib, RolloutRunner, wl):
+    """BASELINE configs[2]: params_car_residual, Ns=4096, H=40, sequential re-conditioned rollout (mode R, T=3)."""
+    Ns, H = 4096, 40
+    p = wl.fs_params("params_car_residual", Ns, H, nograd=False)
+    p["common"]["use_cuda"] = True
+    p["agent"]["base_sample_generator"] = "counter"
+    agent = sg.Agent(p, sg.make_env(p))
+    erv = agent.epistimic_random_vector
+    per = Ns * agent.g_ny * 3
+    runner = RolloutRunner(agent, wl.synthetic_u_ff(agent.nu, H), erv.reshape(-1)[per:], erv.shape[1] * per, H,
+                           _lib.MODE_RECONDITIONED, False)
+    for _ in range(100):
+        runner.launch()
+    torch.cuda.synchronize()
+    ms, ms_min = time_launches(runner.launch, 30)
+    bits = int(runner.info.max().item())
+    ok = bool(torch.isfinite(runner.X_traj).all()) and not (bits & (_lib.INFO_TRAIN_CHOL_FAIL | _lib.INFO_ROOT_FAIL))
+    flop = wl.flop_mode_r(3, 3, 45, 45, H) * Ns * H
+    return {"workload": "BASELINE configs[2]: params_car_residual, mode R (T=3), Ns=4096, H=40, 1 GPU",
+            "value": Ns * H / (ms * 1e-3), "unit": "trajectory-steps/s", "ms_per_rollout": ms, "finite": ok,
+            "roofline": roofline(flop, ms, "rollout_fast_kernel<3,45,3,car_residual,grid root>",
+                                 wl.min_hbm_bytes(4, 3, 3) * Ns * H)}
+
+
+def extra_closed_loop(sg, _lib, wl):
+    """BASELINE configs[4] on its per-GPU shard, AS SHIPPED (params_car_residual.yaml incl. Dyn_gp_jitter 1e-20 -> the
+    eigendecomposition root): Ns = 8192 / 8 = 1024, H = 40, joint draw per SQP iteration k = 0..3 (reference
+    src/solver.py:84-94); linearisation points from the deterministic surrogate of SURVEY.md 8d (sample mean of the
+    previous iteration's prediction)."""
+    import warnings
+    Ns, H, iters = 1024, 40, 4
+    p = wl.closed_loop_params("params_car_residual", Ns, H, 1, iters)
+    p["common"]["use_cuda"] = True
+    p["agent"]["base_sample_generator"] = "counter"
+    agent = sg.Agent(p, sg.make_env(p))
+    x0 = np.asarray(p["env"]["start"], dtype=np.float64)[: agent.nx]
+    u_h = wl.synthetic_u_ff(agent.nu, H)
+    x_h = np.tile(x0, (H, Ns))
+    agent.mpc_iteration(0)
+    out = []
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for k in range(iters):
+            agent.train_hallucinated_dynGP(k)
+            bx = agent.get_batch_x_hat(x_h, u_h)
+            g_xu = agent.env_model.get_g_xu_hat(bx).contiguous()
+            z = agent.epistimic_random_vector[0][k]
+            for _ in range(3 if k else 40):                     # k = 0 also brings the clocks up
+                agent.sample_gp(g_xu, base_samples=z)
+            torch.cuda.synchronize()
+            ms, ms_min = time_launches(lambda: agent.sample_gp(g_xu, base_samples=z), 4)
+            gp_val, _, _ = agent.dyn_fg_jacobians(bx, k)        # the real call: appends the draw to the hallucinated set
+            info = agent.model_i_call.last_info
+            n_o = agent.model_i.plan.n_r + 3 * agent.model_i.n_h
+            flop = wl.flop_mode_j(3, 3, 45, H, k) * Ns
+            out.append({"k": k, "n_o": int(n_o), "ms_per_draw": ms_min, "trajectory_steps_per_s": Ns * H / (ms_min * 1e-3),
+                        "eigh_root": bool((info & _lib.INFO_ROOT_EIGH).all().item()),
+                        "finite": bool(np.isfinite(gp_val).all()),
+                        "roofline": roofline(flop, ms_min, "joint_kernel<3,16,1,NT,4> + joint_eigh_kernel<3,2>",
+                                             8 * (2 * 4 + 2 * 3 * 3) * Ns * H,
+                                             note="joint draw incl. the facade's info reduction; FLOP = SURVEY 8d mode-J "
+                                                  "formula (Cholesky-branch algebra; the eigendecomposition is extra work)")})
+            mean_next = gp_val[:, :, :, 0].mean(axis=0).T
+            x_h = np.tile(np.vstack([x0[None, :], mean_next[:-1]]), (1, Ns))
+    return {"workload": "BASELINE configs[4] per-GPU shard as shipped: params_car_residual (Dyn_gp_jitter 1e-20), mode J, "
+                        "Ns=1024 (8192 / 8 GPUs), H=40, SQP iterations k=0..3", "iterations": out}
+
+
+def reachable_set_leg(a, rank, world, dist, sg, _lib, RolloutRunner, wl):
     """Second, informational leg (not `value`): BASELINE.json's "reachable-set wall-clock" on configs[3] as shipped
     (params_car_residual_fs, forward sampling on the real data only = mode I, T = 1, H = 40), 32768 samples per GPU
     (the per-GPU shard of Ns = 262144 on 8 GPUs): one rollout launch + the all-gather of the tube per repetition,
-    base samples resident in HBM, max over ranks.  Any failure is reported in the JSON instead of raised; the ranks
-    agree on skipping before they enter the collective."""
+    base samples of the rank's shard resident in HBM, max over ranks.  Any failure is reported in the JSON instead of
+    raised; the ranks agree on skipping before they enter the collective."""
     if a.reach_ns <= 0:
         return None
     res, ok, runner, tube = {"workload": "BASELINE configs[3] as shipped: params_car_residual_fs, mode I (T=1), "
                              "Ns=%d per GPU, H=40; rollout + all-gather of X_traj" % a.reach_ns}, 1, None, None
     try:
         Ns, H = a.reach_ns, 40
-        p = fs_params("params_car_residual_fs", Ns, H, nograd=True)
+        p = wl.fs_params("params_car_residual_fs", Ns, H, nograd=True)
         p["common"]["use_cuda"] = True
-        p["agent"]["base_sample_generator"] = "vectorized"
-        torch.manual_seed(777 + rank)
+        p["agent"]["base_sample_generator"] = "counter"
+        p["agent"]["base_sample_offset"] = rank * Ns           # global sample id of this rank's first sample
         agent = sg.Agent(p, sg.make_env(p))
-        u_ff = synthetic_u_ff(agent.nu, H)
+        u_ff = wl.synthetic_u_ff(agent.nu, H)
         erv = agent.epistimic_random_vector
         per = Ns * agent.g_ny
         runner = RolloutRunner(agent, u_ff, erv.reshape(-1)[per:], erv.shape[1] * per, H, _lib.MODE_INDEPENDENT, True)
@@ -131,12 +239,18 @@ def reachable_set_leg(a, rank, world, dist, sg, _lib, RolloutRunner, fs_params, 
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             wall = float(t.item())
         finite = bool(torch.isfinite(runner.X_traj).all())
+        kms, _ = time_launches(runner.launch, 20)
     except Exception as e:                                    # noqa: BLE001 - the headline line must still be printed
         res["error"] = repr(e)[:300]
         return res
     res.update({"Ns_per_gpu": a.reach_ns, "Ns_total": world * a.reach_ns, "H": 40, "n_gpus": world, "reps": reps,
                 "wallclock_ms": wall / reps * 1e3, "trajectory_steps_per_s": world * a.reach_ns * 40 * reps / wall,
-                "finite": finite, "kernel": "rollout_indep_grid_kernel<car,5,9,3>"})
+                "finite": finite,
+                "roofline": roofline(wl.flop_mode_i(3, 45) * a.reach_ns * 40, kms, "rollout_indep_grid_kernel<car,5,9,3>",
+                                     wl.min_hbm_bytes(4, 3, 1) * a.reach_ns * 40,
+                                     note="FLOP = SURVEY 8d count of the triangular algorithm (8.3e3 per trajectory-step); the "
+                                          "grid-root kernel executes ~1.5e3, so frac can exceed what the pipe could do on "
+                                          "the counted algorithm")})
     return res
 
 
@@ -159,84 +273,91 @@ def main():
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
 
     import sampling_gpmpc_amd as sg
-    from sampling_gpmpc_amd import _lib
+    from sampling_gpmpc_amd import _lib, workloads as wl
+    from sampling_gpmpc_amd.distributed import OverlappedTubeGather
     from sampling_gpmpc_amd.rollout import RolloutRunner
-    from tests.helpers import fs_params, synthetic_u_ff
 
     Ns, H = a.ns, a.horizon
-    p = fs_params("params_pendulum1D_samples", Ns, H)
+    p = wl.fs_params("params_pendulum1D_samples", Ns, H)
     p["common"]["use_cuda"] = True
-    p["agent"]["base_sample_generator"] = "vectorized"
-    torch.manual_seed(123456 + rank)            # every rank owns different samples (global sample id = rank*Ns + s)
+    p["agent"]["base_sample_generator"] = "counter"       # the rank draws ITS shard only, keyed by global sample id
+    p["agent"]["base_sample_offset"] = rank * Ns
     agent = sg.Agent(p, sg.make_env(p))
-    u_ff = synthetic_u_ff(1, H)
-    erv = agent.epistimic_random_vector         # (H, 2, Ns, 1, 1, 3) on the device
+    u_ff = wl.synthetic_u_ff(1, H)
+    erv = agent.epistimic_random_vector         # (H, 2, Ns, 1, 1, 3) on the device: this rank's samples only
     per_slab = Ns * 3
     z = erv.reshape(-1)[per_slab:]
     runner = RolloutRunner(agent, u_ff, z, erv.shape[1] * per_slab, H, _lib.MODE_RECONDITIONED, False)
-    tube = torch.empty(world * Ns, agent.nx, H + 1, dtype=torch.float64, device="cuda") if world > 1 else None
+    pipe = OverlappedTubeGather(Ns, agent.nx, H) if world > 1 else None
 
-    def step():
-        X = runner.launch()
-        if world > 1:
-            dist.all_gather_into_tensor(tube, X)
+    def run_steps(n, r0=0):
+        """n steps; for N > 1: rollout r on the launch stream, its all-gather on the side stream (overlaps rollout r+1)"""
+        if pipe is None:
+            for _ in range(n):
+                runner.launch()
+            return
+        for r in range(r0, r0 + n):
+            pipe.before_rollout(r)
+            runner.launch(out=pipe.buffer(r))
+            pipe.submit(r)
+        pipe.finish()
 
     def fence():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    # clock ramp: the same step, a fixed count on every rank (it contains the collective), untimed and reported
-    for _ in range(max(a.prewarm, 0)):
-        step()
-    fence()
-    for _ in range(a.warmup):
-        step()
-    fence()
-    # timed region: EXACTLY a.steps steps between two fences; one HIP event at either end on the launch stream (per-launch
-    # events inside the loop cost ~6 us per step: every record is a queue packet the next dispatch waits for)
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    t0 = time.perf_counter()
-    ev0.record()
-    for k in range(a.steps):
-        X = runner.launch()
+    def timed(n):
+        fence()
+        t0 = time.perf_counter()
+        run_steps(n)
+        fence()
+        wall = time.perf_counter() - t0
         if world > 1:
-            dist.all_gather_into_tensor(tube, X)
-    ev1.record()
+            t = torch.tensor([wall], dtype=torch.float64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            wall = float(t.item())
+        return wall
+
+    # cold: what a fresh process sees (W warmup steps, then K timed steps, clocks not yet ramped)
+    run_steps(a.warmup)
+    wall_cold = timed(a.steps)
+    # clock ramp: the same step, a fixed count on every rank (it contains the collective), untimed and reported
+    run_steps(max(a.prewarm, 0))
     fence()
-    wall = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([wall], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        wall = float(t.item())
-    region_ms = ev0.elapsed_time(ev1) / a.steps             # per step over the timed region (includes the collective)
+    run_steps(a.warmup)
+    # timed region: EXACTLY a.steps steps between two fences
+    wall = timed(a.steps)
     # the rollout kernel's launch duration, one HIP event pair per launch (what rocprofv3 --kernel-trace reports per
     # dispatch): a second, untimed pass of the same launches, so that the instrumentation stays out of the timed region
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(a.steps)]
-    for k in range(a.steps):
-        ev[k][0].record()
-        runner.launch()
-        ev[k][1].record()
-    torch.cuda.synchronize()
-    kern_ms_pairs = float(np.mean([s.elapsed_time(e) for s, e in ev]))
+    kern_ms_pairs, _ = time_launches(runner.launch, a.steps)
     # a launch cannot take longer than a step of the (un-instrumented) timed region it is part of: at N = 1 the region per
     # step is kernel + launch gap, and the event pairs of the second pass add a few microseconds of their own
-    kern_ms = min(kern_ms_pairs, region_ms) if world == 1 else kern_ms_pairs
+    kern_ms = min(kern_ms_pairs, wall / a.steps * 1e3) if world == 1 else kern_ms_pairs
+    gather = None
+    if world > 1:
+        tube = pipe.tube(0)
+        for _ in range(20):
+            dist.all_gather_into_tensor(tube, pipe.buffer(0))
+        fence()
+        g_ms, _ = time_launches(lambda: dist.all_gather_into_tensor(tube, pipe.buffer(0)), 50)
+        gather = {"collective": "all_gather_into_tensor of (Ns, nx, H+1) f64 shards, RCCL", "bytes_per_rank": Ns * agent.nx * (H + 1) * 8,
+                  "standalone_ms": g_ms, "exposed_ms_per_step": max(wall / a.steps * 1e3 - kern_ms, 0.0),
+                  "overlapped_with_next_rollout": True}
+    X_last = runner.X_traj if pipe is None else pipe.buffer(a.steps - 1)
     bits = int(runner.info.max().item())
-    assert torch.isfinite(runner.X_traj).all() and not (bits & (_lib.INFO_TRAIN_CHOL_FAIL | _lib.INFO_ROOT_FAIL)), bits
+    assert torch.isfinite(X_last).all() and not (bits & (_lib.INFO_TRAIN_CHOL_FAIL | _lib.INFO_ROOT_FAIL)), bits
 
-    reach = reachable_set_leg(a, rank, world, dist, sg, _lib, RolloutRunner, fs_params, synthetic_u_ff)
+    reach = reachable_set_leg(a, rank, world, dist, sg, _lib, RolloutRunner, wl)
 
     if rank == 0:
         name, cus, _ = _lib.device_info(local_rank)
         units = world * Ns * H                                  # sampled trajectory-steps per step
-        traffic, traffic_src = None, None
-        tf = os.path.join(REPO, "profiles", "latest_traffic.json")
+        prof, tf = {}, os.path.join(REPO, "profiles", "latest_traffic.json")
         if os.path.exists(tf) and Ns == 1024 and H == 30:     # PMC counters cannot be read in-process: last profiled run
-            tj = json.load(open(tf))
-            traffic, traffic_src = tj["hbm_bytes_per_launch_gfx950_corrected"], tj["source"]
-        flop = FLOP_PER_TRAJ_STEP["pendulum1D_R_H30"] * Ns * H  # per launch (one GPU)
-        achieved = flop / (kern_ms * 1e-3) / 1e12
+            prof = json.load(open(tf))
+        traffic = prof.get("hbm_bytes_per_launch_gfx950_corrected")
+        flop = wl.flop_mode_r(1, 3, 36, 36, H) * Ns * H         # per launch (one GPU): 2.55e4 per trajectory-step at H = 30
         out = {
             "metric": "sampled trajectory-steps/sec (Ns*H per wall second)",
             "value": units * a.steps / wall,
@@ -244,8 +365,10 @@ def main():
             "n_gpus": world,
             "steps": a.steps,
             "warmup": a.warmup,
-            "prewarm_steps": max(a.prewarm, 0),     # untimed clock-ramp steps before the warmup (see --prewarm)
+            "prewarm_steps": max(a.prewarm, 0),     # untimed clock-ramp steps between the cold and the reported region
             "ms_per_step": wall / a.steps * 1e3,
+            "cold": {"ms_per_step": wall_cold / a.steps * 1e3, "value": units * a.steps / wall_cold,
+                     "note": "the same K steps right after the W warmup steps of a fresh process, before the clock ramp"},
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
@@ -254,33 +377,45 @@ def main():
             "config": {"workload": "BASELINE configs[1]: params_pendulum1D_samples, sequential re-conditioned rollout "
                                    "(mode R, value+gradient labels T=3), Ns=%d per GPU, H=%d" % (Ns, H),
                        "Ns_per_gpu": Ns, "H": H, "Ns_total": world * Ns,
-                       "parallelism": "samples sharded over %d GPU(s), RCCL all-gather of X_traj per rollout" % world,
+                       "parallelism": "samples sharded over %d GPU(s); base samples generated per shard; RCCL all-gather of "
+                                      "X_traj per rollout on a side stream, overlapping the next rollout" % world,
                        "device": name, "cus": cus},
-            "roofline": {"bound": "mfma", "achieved": achieved, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / FP64_PEAK_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
-                         "algorithmic_hbm_bytes_per_launch": MIN_HBM_BYTES_PER_TRAJ_STEP["pendulum1D_R_H30"] * Ns * H,
-                         "hbm_gbps": (traffic / (kern_ms * 1e-3) / 1e9) if traffic else None,
-                         "hbm_frac_of_8TBps": (traffic / (kern_ms * 1e-3) / 8e12) if traffic else None,
-                         "mfma_busy": 0.0,      # SQ_VALU_MFMA_BUSY_CYCLES = 0 (profiles/): three right-hand sides cannot fill an FP64 MFMA tile
-                         "kernel": "rollout_fast_kernel<3,36,1,pendulum1D,L_hh in LDS,grid root>", "kernel_ms": kern_ms,
-                         "timed_region_ms_per_step_hip_events": region_ms,
-                         "kernel_ms_per_launch_event_pairs": kern_ms_pairs,
-                         "flop_per_launch": flop,
-                         "note": "FP64 (vector FMA; FP64 MFMA peak is the same 78.6 TFLOP/s on MI355X); algorithmic "
-                                 "FLOP = 2.55e4 per trajectory-step (SURVEY 8d) x Ns x H; min HBM traffic 80 B per "
-                                 "trajectory-step, i.e. the kernel is latency/FLOP bound, not HBM bound"},
+            "roofline": roofline(
+                flop, kern_ms, "rollout_fast_kernel<3,36,1,pendulum1D,L_hh in LDS,grid root>",
+                wl.min_hbm_bytes(2, 1, 3) * Ns * H,
+                note="FP64 vector FMA (the FP64 MFMA peak is the same 78.6 TFLOP/s on MI355X; three right-hand sides cannot "
+                     "fill an FP64 MFMA tile, no MFMA is issued); algorithmic FLOP = 2.55e4 per trajectory-step (SURVEY 8d) "
+                     "x Ns x H; min HBM traffic 80 B per trajectory-step: latency / issue bound, not HBM bound",
+                traffic=traffic, traffic_source=prof.get("source"),
+                hbm_gbps=(traffic / (kern_ms * 1e-3) / 1e9) if traffic else None,
+                hbm_frac_of_8TBps=(traffic / (kern_ms * 1e-3) / 8e12) if traffic else None,
+                # executed work (SQ counters of the last profiled run): VALU instructions x 64 lanes x 2 FLOP as if every one
+                # were an FP64 FMA, over the measured launch time - how busy the FP64 pipe is with ANY instruction
+                executed_flop_frac=(prof["valu_insts_per_launch"] * 128 / (kern_ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS)
+                if prof.get("valu_insts_per_launch") else None,
+                valu_active_frac=prof.get("valu_active_frac"),
+                mfma_busy=0.0,
+                kernel_ms_per_launch_event_pairs=kern_ms_pairs),
+            "gather": gather,
         }
         if world == 1 and a.cpu_sample > 0:
-            v, dt = cpu_baseline(a.cpu_sample, H, u_ff)
-            out["cpu_baseline"] = {"value": v, "unit": "trajectory-steps/s", "cores": torch.get_num_threads(),
-                                   "kind": "port",
+            v, dt, th, probe = cpu_baseline(a.cpu_sample, H, u_ff)
+            out["cpu_baseline"] = {"value": v, "unit": "trajectory-steps/s", "cores": th, "kind": "port",
                                    "sample": "same workload, Ns=%d of %d samples, full H=%d horizon, %.1f s of CPU work "
                                              "(oracle: reference-faithful from-scratch batched Cholesky per step, torch "
                                              "CPU FP64; gpytorch itself is not installable on the box)" % (a.cpu_sample, Ns, H, dt),
-                                   "host_cpus": os.cpu_count()}
+                                   "thread_probe_steps_per_s": probe, "host_cpus": os.cpu_count()}
         else:
             out["cpu_baseline"] = None
         out["reachable_set"] = reach
+        if world == 1 and not a.no_extra:
+            extra = []
+            for fn, args in ((extra_car_rollout, (sg, _lib, RolloutRunner, wl)), (extra_closed_loop, (sg, _lib, wl))):
+                try:
+                    extra.append(fn(*args))
+                except Exception as e:                            # noqa: BLE001 - never fatal for the bench line
+                    extra.append({"workload": fn.__name__, "error": repr(e)[:300]})
+            out["extra"] = extra
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

@@ -38,6 +38,10 @@ def random_vector_within_bounds(params, g_ny: int, T: int, device="cpu", mode: O
     reference does, so a seeded run reproduces its stream exactly (the reference draws on its compute device; CUDA
     generator streams are not reproducible on ROCm, so the draw is pinned to the CPU generator here).
     mode "vectorized": same distribution, candidates drawn in blocks (for Ns in the 1e5 range).
+    mode "counter": same distribution from a counter-based stream keyed by (seed, mpc step, SQP iteration, GLOBAL sample
+    id, attempt): ``agent.base_sample_offset`` (default 0) is the global id of this Agent's first sample, so a rank of a
+    sample-sharded run generates exactly its own shard - on its own device, nothing of the other shards - and the
+    assembled run is the same for every GPU count (``sampling_gpmpc_amd.distributed``).
     """
     H = params["optimizer"]["H"]
     n_dyn = params["agent"]["num_dyn_samples"]
@@ -66,9 +70,63 @@ def random_vector_within_bounds(params, g_ny: int, T: int, device="cpu", mode: O
             n = min(cand.shape[0], total - filled)
             flat[filled:filled + n] = cand[:n]
             filled += n
+    elif mode == "counter":
+        return counter_base_samples(n_mpc, n_itrs, n_dyn, g_ny, H, T, beta,
+                                    seed=int(params["agent"].get("base_sample_seed", 123456)),
+                                    offset=int(params["agent"].get("base_sample_offset", 0)), device=device)
     else:
         raise ValueError(f"unknown base_sample_generator {mode!r}")
     return out.to(device)
+
+
+_M64 = (1 << 64) - 1
+
+
+def _s64(v: int) -> int:
+    """Python int -> the int64 with the same 64 bits."""
+    v &= _M64
+    return v - (1 << 64) if v >= (1 << 63) else v
+
+
+def _lsr(x: torch.Tensor, k: int) -> torch.Tensor:
+    """Logical right shift of an int64 tensor (torch's >> is arithmetic)."""
+    return (x >> k) & ((1 << (64 - k)) - 1)
+
+
+def _mix64(x: torch.Tensor) -> torch.Tensor:
+    """splitmix64 finaliser; int64 arithmetic wraps, which is the mod 2^64 arithmetic the mixer is defined in."""
+    x = (x ^ _lsr(x, 30)) * _s64(0xBF58476D1CE4E5B9)
+    x = (x ^ _lsr(x, 27)) * _s64(0x94D049BB133111EB)
+    return x ^ _lsr(x, 31)
+
+
+def counter_base_samples(n_mpc, n_itrs, n_dyn, g_ny, H, T, beta, seed=123456, offset=0, device="cpu") -> torch.Tensor:
+    """``(n_mpc, n_itrs, n_dyn, g_ny, H, T)`` truncated-normal vectors with the whole-vector rejection rule of reference
+    ``src/agent.py:84-100``, each vector a pure function of (seed, j, i, offset + s): attempt ``a`` of a vector draws its
+    ``V = g_ny H T`` entries from the hashed counters ``2 (a V + e)``, ``2 (a V + e) + 1`` (Box-Muller), and the first
+    attempt with every entry in [-beta, beta] is kept.  Generated on ``device`` one (j, i) slab at a time."""
+    V = g_ny * H * T
+    dev = torch.device(device)
+    out = torch.empty(n_mpc, n_itrs, n_dyn, V, dtype=F64, device=dev)
+    sid = torch.arange(offset, offset + n_dyn, dtype=torch.int64, device=dev)
+    e2 = 2 * torch.arange(V, dtype=torch.int64, device=dev)
+    two_pi = 2.0 * 3.141592653589793
+    for j in range(n_mpc):
+        for i in range(n_itrs):
+            key = _mix64(sid * _s64(0x9E3779B97F4A7C15) + _s64(seed * 0xD1B54A32D192ED03 + (j * n_itrs + i) * 0x8CB92BA72F3D8DD7))
+            slab = out[j, i]
+            pending = torch.arange(n_dyn, device=dev)
+            attempt = 0
+            while pending.numel():
+                c = key[pending].unsqueeze(1) + (e2 + 2 * attempt * V).unsqueeze(0) * _s64(0xDA942042E4DD58B5)
+                u1 = (_lsr(_mix64(c), 11).to(F64) + 0.5) * (1.0 / 9007199254740992.0)
+                u2 = (_lsr(_mix64(c + _s64(0xDA942042E4DD58B5)), 11).to(F64) + 0.5) * (1.0 / 9007199254740992.0)
+                w = torch.sqrt(-2.0 * torch.log(u1)) * torch.cos(two_pi * u2)
+                ok = (w.abs() <= beta).all(dim=1)
+                slab[pending[ok]] = w[ok]
+                pending = pending[~ok]
+                attempt += 1
+    return out.reshape(n_mpc, n_itrs, n_dyn, g_ny, H, T)
 
 
 class Agent(object):

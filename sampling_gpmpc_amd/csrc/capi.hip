@@ -353,7 +353,10 @@ int gpmpc_plan_build(const gpmpc_gp_desc_t* gp, const double* X_r, const double*
     if (!X_r || !Y_r || !plan || !info) return fail(GPMPC_E_ARG, "gpmpc_plan_build: NULL pointer");
     GpParams p = make_gp_params(gp);
     const size_t lds = (size_t)p.n_r * p.n_r * sizeof(double);
-    if (lds > 160 * 1024 - 64) return fail(GPMPC_E_UNSUPPORTED, "plan: n_r too large for the LDS-resident factorisation");
+    // 160 KiB per workgroup minus the kernel's static LDS (the four 16 x 16 Jacobi scratch tiles = 8 KiB, flags)
+    constexpr size_t PLAN_STATIC_LDS = 4 * 16 * 16 * sizeof(double) + 256;
+    if (lds + PLAN_STATIC_LDS > 160 * 1024)
+        return fail(GPMPC_E_UNSUPPORTED, "plan: n_r too large for the LDS-resident factorisation (n_r^2 * 8 B + 8.25 KiB > 160 KiB)");
     if (gp->D != 2) return fail(GPMPC_E_UNSUPPORTED, "only D = 2 is instantiated");
     auto kern = plan_kernel<2>;
     GPMPC_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));

@@ -58,6 +58,53 @@ def all_gather_tube(X_local: torch.Tensor, Ns: int, group=None) -> torch.Tensor:
     return torch.cat([buf[r * nmax: r * nmax + (hi - lo)] for r, (lo, hi) in enumerate(sizes)], dim=0)
 
 
+class OverlappedTubeGather:
+    """The tube all-gather of rollout r on a side stream while rollout r+1 runs on the launch stream.
+
+    Two trajectory buffers and two tube buffers alternate: ``buffer(r)`` is where rollout r writes; ``submit(r)`` (called
+    on the launch stream right after the rollout was enqueued) makes the side stream wait for it and enqueues the
+    collective there; ``before_rollout(r)`` makes the launch stream wait for the gather that last read ``buffer(r)``.
+    ``tube(r)`` is valid after ``wait(r)`` / ``finish()``.  Equal shards only (the bench shape); ragged shards use
+    ``all_gather_tube``."""
+
+    def __init__(self, ns_local: int, nx: int, H: int, group=None, device=None):
+        self.group = group
+        self.world = dist.get_world_size(group)
+        dev = torch.device("cuda", torch.cuda.current_device()) if device is None else device
+        self.X = [torch.empty(ns_local, nx, H + 1, dtype=torch.float64, device=dev) for _ in range(2)]
+        self.T = [torch.empty(self.world * ns_local, nx, H + 1, dtype=torch.float64, device=dev) for _ in range(2)]
+        self.comm = torch.cuda.Stream(device=dev)
+        self.rolled = [torch.cuda.Event() for _ in range(2)]
+        self.gathered = [torch.cuda.Event() for _ in range(2)]
+        self._pending = [False, False]
+
+    def buffer(self, r: int) -> torch.Tensor:
+        return self.X[r & 1]
+
+    def tube(self, r: int) -> torch.Tensor:
+        return self.T[r & 1]
+
+    def before_rollout(self, r: int) -> None:
+        if self._pending[r & 1]:
+            torch.cuda.current_stream().wait_event(self.gathered[r & 1])
+
+    def submit(self, r: int) -> None:
+        b = r & 1
+        self.rolled[b].record()                              # on the launch stream
+        with torch.cuda.stream(self.comm):
+            self.comm.wait_event(self.rolled[b])
+            dist.all_gather_into_tensor(self.T[b], self.X[b], group=self.group)
+            self.gathered[b].record()
+        self._pending[b] = True
+
+    def wait(self, r: int) -> None:
+        if self._pending[r & 1]:
+            torch.cuda.current_stream().wait_event(self.gathered[r & 1])
+
+    def finish(self) -> None:
+        torch.cuda.current_stream().wait_stream(self.comm)
+
+
 def sharded_rollout(local_rollout: Callable[[int, int], torch.Tensor], Ns: int, group=None) -> torch.Tensor:
     """Run ``local_rollout(lo, hi) -> X_traj[lo:hi]`` for this rank's shard of global samples and all-gather.
 
@@ -70,11 +117,12 @@ def sharded_rollout(local_rollout: Callable[[int, int], torch.Tensor], Ns: int, 
 
 
 def sharded_forward_sampling_rollout(agent, u_ff, x0=None, group=None) -> torch.Tensor:
-    """Forward-sampling rollout of ``agent.ns`` GLOBAL samples, sharded over the process group.
+    """Forward-sampling rollout of the GLOBAL sample set, sharded over the process group; returns the full tube on
+    every rank (device tensor).
 
-    Every rank holds the same ``agent`` configuration and the same base-sample tensor (seeded identically, or
-    broadcast); each launches ``gpmpc_rollout`` on its own contiguous slice and the shards are all-gathered over
-    RCCL.  Returns the full tube on every rank (device tensor)."""
+    ``agent`` is either a SHARDED agent (``make_sharded_agent``: it holds only its own samples and their base samples -
+    per-rank HBM for ``z`` is 1/G of the global tensor, nothing is generated twice) or, for small runs, an agent over
+    all samples with the same base-sample tensor on every rank (each rank then launches its contiguous slice)."""
     import numpy as np
     from . import _lib
     from .rollout import rollout_device
@@ -87,6 +135,10 @@ def sharded_forward_sampling_rollout(agent, u_ff, x0=None, group=None) -> torch.
     erv = agent.epistimic_random_vector.to(device=agent.torch_device, dtype=torch.float64).contiguous()
     per_slab = agent.ns * agent.g_ny * T
     z = erv.reshape(-1)[per_slab:]
+    if agent.shard is not None:                           # the agent IS the shard
+        res = rollout_device(agent, u_ff, z, erv.shape[1] * per_slab, H=H, mode=mode,
+                             use_model_without_derivatives=nograd, x0=x0, want_samples=False)
+        return all_gather_tube(res.X_traj, agent.ns_global, group)
 
     def local(lo, hi):
         res = rollout_device(agent, u_ff, z, erv.shape[1] * per_slab, H=H, mode=mode,
@@ -102,21 +154,33 @@ def sharded_forward_sampling_rollout(agent, u_ff, x0=None, group=None) -> torch.
 def make_sharded_agent(agent_cls, params, env_model, group=None):
     """An ``Agent`` over this rank's contiguous shard of the ``num_dyn_samples`` GLOBAL samples.
 
-    Every rank generates the full base-sample tensor from the same generator state (the constructor does, exactly as
-    the single-process Agent would) and keeps its slice, so sample ``s`` sees the same draws for every world size.
+    ``agent.base_sample_generator: counter`` (the scalable way): the rank generates exactly its own shard from the
+    counter-based stream keyed by global sample id - on its own device, no other shard is ever materialised, and sample
+    ``s`` sees the same draws for every world size.  The sequential generators ("reference": the reference's call-for-call
+    stream, "vectorized") can only be sliced after the fact: the full tensor is drawn ONCE on the host from the global
+    generator state (exactly what the single-process Agent draws) and only the slice goes to the device.
     The returned agent has ``dist_group`` / ``shard`` / ``ns_global`` set; its methods return shard-sized arrays."""
     import copy
+    from .agent import random_vector_within_bounds
     rank, world = dist.get_rank(group), dist.get_world_size(group)
     Ns = int(params["agent"]["num_dyn_samples"])
     lo, hi = shard_range(Ns, rank, world)
-    full = agent_cls(params, env_model)                   # global base samples (and global-size empty tensors)
-    erv = full.epistimic_random_vector[:, :, lo:hi].contiguous()
     p_loc = copy.deepcopy(params)
     p_loc["agent"]["num_dyn_samples"] = hi - lo
-    gen_state = torch.get_rng_state()
-    agent = agent_cls(p_loc, env_model)
-    torch.set_rng_state(gen_state)                        # the shard constructor's own draws do not advance the stream
-    agent.epistimic_random_vector = erv
+    if params["agent"].get("base_sample_generator") == "counter":
+        p_loc["agent"]["base_sample_offset"] = int(params["agent"].get("base_sample_offset", 0)) + lo
+        agent = agent_cls(p_loc, env_model)               # draws its shard only
+    else:
+        g_ny = params["agent"]["g_dim"]["ny"]
+        D = params["agent"]["g_dim"]["nx"] + params["agent"]["g_dim"]["nu"]
+        T = 1 if params["env"]["use_model_without_derivatives"] else 1 + D
+        erv = random_vector_within_bounds(params, g_ny, T, device="cpu")[:, :, lo:hi].contiguous()   # host, once
+        tiny = copy.deepcopy(p_loc)                       # the shard constructor must not draw from the global stream
+        tiny["agent"]["base_sample_generator"] = "counter"
+        tiny["common"]["num_MPC_itrs"], tiny["optimizer"]["SEMPC"]["max_sqp_iter"] = 1, 1
+        agent = agent_cls(tiny, env_model)
+        agent.params = p_loc
+        agent.epistimic_random_vector = erv.to(agent.torch_device)
     agent.dist_group = group if group is not None else dist.group.WORLD
     agent.shard, agent.ns_global = (lo, hi), Ns
     return agent

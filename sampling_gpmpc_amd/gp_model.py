@@ -24,6 +24,8 @@ import torch
 from . import _lib
 
 F64 = torch.float64
+MAX_JOINT_ROWS = 2048            # gpmpc_joint_sample: n_ho + 1 + m*T label rows per chain (include/gpmpc_hip.h)
+MAX_JOINT_TEST_SLOTS = 256       # m*T
 
 
 class NumericalWarning(RuntimeWarning):
@@ -141,6 +143,13 @@ class HipPosterior:
         root = torch.zeros((Ns, g_ny, m * hy.T, m * hy.T), dtype=F64, device=dev) if want_root else None
         info = torch.zeros((Ns, g_ny), dtype=torch.int32, device=dev)
         n_ho = int(mdl.h_slots.numel())
+        if n_ho + 1 + m * hy.T > MAX_JOINT_ROWS or m * hy.T > MAX_JOINT_TEST_SLOTS:
+            raise _lib.GpmpcError(
+                f"joint draw needs {n_ho} hallucinated + 1 + {m * hy.T} test label rows per chain; the kernels are "
+                f"instantiated for <= {MAX_JOINT_ROWS} rows and <= {MAX_JOINT_TEST_SLOTS} test slots (m*T).  In the SQP "
+                f"loop the hallucinated set grows by H*T rows per iteration and is reset at sqp_iter == 0: with H*T = "
+                f"{m * hy.T} that is at most {(MAX_JOINT_ROWS - 1 - m * hy.T) // max(m * hy.T, 1)} iterations after the "
+                f"reset (the reference's max_sqp_iter of 150 is not reachable: its cost grows with the cube of the rows).")
         ws_bytes = lib.gpmpc_joint_workspace_bytes(mdl.plan.desc, Ns, n_ho, m)
         ws = mdl._workspace(ws_bytes)
         rc = lib.gpmpc_joint_sample(
@@ -245,6 +254,20 @@ def _or_reduce(info: torch.Tensor) -> int:
     return bits
 
 
+def _observed_slots(hall_Y: torch.Tensor, dist_group=None) -> torch.Tensor:
+    """Observed hallucinated label slots (ascending, slot = point * T + task).  gpytorch's "mask" policy drops a slot that
+    is NaN in ANY batch element; with the samples sharded over ranks the batch is the whole sample
+    set, so the NaN flags are OR-ed over the process group."""
+    Ns, g_ny, n_h, T = hall_Y.shape
+    nan_any = torch.isnan(hall_Y).reshape(Ns * g_ny, n_h * T).any(dim=0)
+    if dist_group is not None:
+        import torch.distributed as dist
+        flag = nan_any.to(torch.int32)
+        dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=dist_group)
+        nan_any = flag.bool()
+    return torch.nonzero(~nan_any).flatten().to(torch.int32).contiguous()
+
+
 class HipGPModel:
     """Conditioning set = shared real data (factorised plan) + per-sample hallucinated data."""
 
@@ -261,15 +284,7 @@ class HipGPModel:
         self.n_h = int(self.hall_X.shape[2])
         assert tuple(self.hall_X.shape[:2]) == (Ns, g_ny) and self.hall_Y.shape[-1] == self.hyper.T
         if self.n_h:
-            # gpytorch "mask" policy: a label slot that is NaN in ANY batch element is dropped for the whole batch
-            nan_any = torch.isnan(self.hall_Y).reshape(Ns * g_ny, self.n_h * self.hyper.T).any(dim=0)
-            if dist_group is not None:
-                # ... in any batch element of ANY rank: the batch is the whole (sharded) sample set
-                import torch.distributed as dist
-                flag = nan_any.to(torch.int32)
-                dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=dist_group)
-                nan_any = flag.bool()
-            self.h_slots = torch.nonzero(~nan_any).flatten().to(torch.int32).contiguous()
+            self.h_slots = _observed_slots(self.hall_Y, dist_group)
         else:
             self.h_slots = torch.empty(0, dtype=torch.int32, device=dev)
         self._ws_cache = ws_cache if ws_cache is not None else {}

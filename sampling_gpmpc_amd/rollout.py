@@ -139,6 +139,12 @@ def forward_sampling_rollout(agent: Agent, u_ff, x0=None, return_samples: bool =
     erv = agent.epistimic_random_vector
     if not fused_rollout_supported(agent):
         return forward_sampling_stepwise(agent, u_ff, x0=x0, return_samples=return_samples)
+    nograd_ = bool(p["env"]["use_model_without_derivatives"])
+    if agent.Hallcinated_X_train.shape[2] != 0 and not nograd_:
+        # The reference loop's train_hallucinated_dynGP(1) never resets: a second call on the same agent (or a call after
+        # closed-loop iterations) conditions on the points already there.  The fused kernel starts every chain from the
+        # real data only, so such calls go through the per-step harness, which does condition on them.
+        return forward_sampling_stepwise(agent, u_ff, x0=x0, return_samples=return_samples)
     if p["optimizer"]["H"] != 1 or erv.shape[0] < H or erv.shape[1] < 2:
         raise ValueError("forward sampling needs optimizer.H == 1, num_MPC_itrs >= H_traj and max_sqp_iter >= 2 "
                          "(reference simulate_forward_sampling_car.py indexes epistimic_random_vector[H_idx][1])")
@@ -227,9 +233,16 @@ class RolloutRunner:
                       self.z.data_ptr(), self.z_step_stride, _lib.dptr(self.X_traj), _lib.dptr(self.Y),
                       _lib.dptr(self.Xi), _lib.dptr(self.info), _lib.dptr(self.ws), self.ws.numel() * 8)
 
-    def launch(self, stream_ptr: Optional[int] = None):
+    def launch(self, stream_ptr: Optional[int] = None, out: Optional[torch.Tensor] = None):
+        """One rollout launch; ``out`` (same shape / dtype / device as ``X_traj``) redirects the trajectory output, e.g.
+        into the alternating buffers of ``distributed.OverlappedTubeGather``."""
         st = _lib.current_stream_ptr() if stream_ptr is None else stream_ptr
-        rc = self.lib.gpmpc_rollout(*self._args, st)
+        args = self._args
+        if out is not None:
+            if out.shape != self.X_traj.shape or out.dtype != F64 or not out.is_contiguous():
+                raise ValueError("out must be a contiguous float64 tensor shaped like X_traj")
+            args = args[:15] + (_lib.dptr(out),) + args[16:]
+        rc = self.lib.gpmpc_rollout(*args, st)
         if rc != 0:
             _lib.check(rc, "gpmpc_rollout")
-        return self.X_traj
+        return self.X_traj if out is None else out

@@ -172,3 +172,65 @@ def test_cross_sample_couplings_sharded_equal_single_process(Ns):
     np.testing.assert_array_equal(np.concatenate([r["hX"] for r in got]), ref_agent.Hallcinated_X_train.numpy())
     np.testing.assert_array_equal(np.concatenate([r["hY"] for r in got]), ref_agent.Hallcinated_Y_train.numpy())
     np.testing.assert_array_equal(np.concatenate([r["erv"] for r in got], axis=2), ref_agent.epistimic_random_vector.numpy())
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# per-shard base samples (counter-based stream keyed by GLOBAL sample id) and the rank-spanning NaN mask
+# ---------------------------------------------------------------------------------------------------------------------
+def _counter_worker(rank, world, port, Ns, H, out_q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.set_num_threads(2)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import sampling_gpmpc_amd as sg
+    from oracle import agent_oracle as ao
+    from sampling_gpmpc_amd.distributed import all_gather_tube, make_sharded_agent, shard_range
+    p = fs_params("params_pendulum1D_samples", Ns, H)
+    p["agent"]["base_sample_generator"] = "counter"
+    p["agent"]["base_sample_seed"] = 77
+    agent = make_sharded_agent(sg.Agent, p, sg.make_env(p))
+    lo, hi = shard_range(Ns, rank, world)
+    assert agent.shard == (lo, hi) and agent.epistimic_random_vector.shape[2] == hi - lo   # HBM for z: 1/G per rank
+    # the rank's rollout on ITS shard (the oracle plays the kernel on CPU), then the collective
+    pl = fs_params("params_pendulum1D_samples", hi - lo, H)
+    oagent = ao.OracleAgent(pl, ao.make_oracle_env(pl), agent.epistimic_random_vector)
+    X_local = torch.from_numpy(ao.forward_sampling_rollout(oagent, synthetic_u_ff(1, H)))
+    tube = all_gather_tube(X_local, Ns)
+    # gpytorch's NaN mask spans the WHOLE batch: a slot that is NaN only in a sample of rank 0 is dropped on every rank
+    from sampling_gpmpc_amd.gp_model import _observed_slots
+    hy = torch.zeros(hi - lo, 1, 4, 3, dtype=torch.float64)
+    if lo == 0:
+        hy[0, 0, 2, 1] = float("nan")
+    slots = _observed_slots(hy, agent.dist_group)
+    out_q.put((rank, tube.numpy(), agent.epistimic_random_vector.numpy(), slots.numpy()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [1, 2, 3])
+def test_counter_base_samples_make_the_run_independent_of_the_world_size(world):
+    """Every rank draws only its own shard of the base samples, yet the assembled tube is bit-identical for 1, 2 and 3
+    ranks (even and ragged shards) - and identical to the single-process run on the same stream."""
+    Ns, H = 7, 4
+    import sampling_gpmpc_amd as sg
+    from oracle import agent_oracle as ao
+    p = fs_params("params_pendulum1D_samples", Ns, H)
+    p["agent"]["base_sample_generator"] = "counter"
+    p["agent"]["base_sample_seed"] = 77
+    erv = sg.random_vector_within_bounds(p, 1, 3)
+    assert float(erv.abs().max()) <= p["agent"]["Dyn_gp_beta"]
+    X_ref = ao.forward_sampling_rollout(ao.OracleAgent(p, ao.make_oracle_env(p), erv), synthetic_u_ff(1, H))
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_counter_worker, args=(r, world, port, Ns, H, q)) for r in range(world)]
+    for pr in procs:
+        pr.start()
+    got = sorted((q.get(timeout=180) for _ in range(world)), key=lambda r: r[0])
+    for pr in procs:
+        pr.join(timeout=60)
+        assert pr.exitcode == 0
+    np.testing.assert_array_equal(np.concatenate([g[2] for g in got], axis=2), erv.numpy())
+    for _, tube, _, slots in got:
+        np.testing.assert_array_equal(tube, X_ref)
+        assert slots.tolist() == [s for s in range(12) if s != 2 * 3 + 1]

@@ -326,7 +326,8 @@ def test_joint_draw_against_reference_golden(sg):
 @pytest.mark.parametrize("pname,Ns,H,iters", [
     ("params_pendulum1D_samples", 16, 30, 2),     # 91 / 181 label rows: 128- and 256-thread workgroups
     ("params_car_residual", 8, 12, 3),
-    ("params_pendulum1D_samples", 6, 30, 7),      # up to 631 rows: 512-thread workgroups, then four rows per thread
+    ("params_pendulum1D_samples", 6, 30, 7),      # up to 631 rows: 512-thread workgroups, then 1024 threads
+    ("params_pendulum1D_samples", 3, 30, 13),     # up to 1171 rows: two rows per thread (beyond 1024 rows)
 ])
 def test_joint_draw_against_oracle(sg, pname, Ns, H, iters):
     """sample_gp / dyn_fg_jacobians over several SQP iterations vs the oracle (mean, variance, covariance, samples)."""
@@ -855,3 +856,40 @@ def test_mode_i_exp_recurrence_vs_direct_exponentials(sg, pname, Ns, H, monkeypa
 
 
 
+
+
+def test_joint_row_limit_is_reported_up_front(sg):
+    """More label rows per chain than the joint kernels are instantiated for (2048): a clear error before any launch
+    (the reference's max_sqp_iter = 150 would need 22 500 rows at the shipped car horizon)."""
+    p = load_params("params_pendulum1D_samples")
+    p["agent"]["num_dyn_samples"], p["optimizer"]["H"] = 2, 10
+    p["common"]["num_MPC_itrs"], p["optimizer"]["SEMPC"]["max_sqp_iter"] = 1, 1
+    agent, _ = make_agents(sg, p)
+    agent.train_hallucinated_dynGP(0)
+    dev = agent.torch_device
+    agent.Hallcinated_X_train = torch.rand(2, 1, 700, 2, dtype=F64, device=dev)
+    agent.Hallcinated_Y_train = torch.rand(2, 1, 700, 3, dtype=F64, device=dev)
+    agent.train_hallucinated_dynGP(1)
+    x = torch.rand(2, 1, 10, 2, dtype=F64, device=dev)
+    with pytest.raises(sg._lib.GpmpcError, match="2048 rows"):
+        agent.model_i(x).mean
+
+
+def test_second_fused_rollout_conditions_on_existing_points(sg):
+    """reference simulate_forward_sampling_car.py:118 calls train_hallucinated_dynGP(1), which never resets: a second
+    rollout on the same agent conditions on the first one's points.  The fused call must not silently start from the
+    real data only: it is routed through the per-step harness."""
+    from sampling_gpmpc_amd.rollout import forward_sampling_rollout
+    p = fs_params("params_pendulum1D_samples", 5, 6, nograd=False)
+    agent, oagent = make_agents(sg, p)
+    u_ff = synthetic_u_ff(1, 6)
+    X1 = forward_sampling_rollout(agent, u_ff)
+    Xo1 = ao.forward_sampling_rollout(oagent, u_ff)
+    assert relerr(X1, Xo1) < RTOL_TRAJ
+    assert agent.Hallcinated_X_train.shape[2] == 6
+    X2 = forward_sampling_rollout(agent, u_ff)                    # conditions on the 6 points of the first rollout
+    Xo2 = ao.forward_sampling_rollout(oagent, u_ff)
+    print(f"second rollout on the same agent: rel err {relerr(X2, Xo2):.2e}; differs from the first by {relerr(X2, X1):.2e}")
+    assert relerr(X2, Xo2) < RTOL_TRAJ
+    assert relerr(X2, X1) > 1e-6
+    assert agent.Hallcinated_X_train.shape[2] == 12
