@@ -19,7 +19,7 @@ from typing import Optional
 import numpy as np
 import torch
 
-from .gp_oracle import F64, GPHyper, OracleGP
+from .gp_oracle import F64, GPHyper, OracleGP, OracleSemantics
 
 
 # ----------------------------------------------------------------------------------------------------------------
@@ -221,9 +221,12 @@ def get_reachable_set_ball(params, V_k):
 # Agent (only the hot-path methods)
 # ----------------------------------------------------------------------------------------------------------------
 class OracleAgent:
-    def __init__(self, params, env, epistimic_random_vector: Optional[torch.Tensor] = None):
+    def __init__(self, params, env, epistimic_random_vector: Optional[torch.Tensor] = None,
+                 semantics: Optional[OracleSemantics] = None):
         """reference ``src/agent.py:18-74``.  Base samples are an *input* (generated by the caller with
-        ``random_vector_within_bounds`` for reference-exact runs)."""
+        ``random_vector_within_bounds`` for reference-exact runs).  ``semantics``: the switchable gpytorch behaviours
+        (``gp_oracle.OracleSemantics``; defaults = what the HIP kernels implement)."""
+        self.semantics = semantics if semantics is not None else OracleSemantics()
         self.params, self.env_model = params, env
         ag = params["agent"]
         self.g_nx, self.g_nu, self.g_ny = ag["g_dim"]["nx"], ag["g_dim"]["nu"], ag["g_dim"]["ny"]
@@ -249,6 +252,13 @@ class OracleAgent:
     def mpc_iteration(self, i):
         self.mpc_iter = i
 
+    def update_current_state(self, state):          # :157-162
+        self.current_state = state
+        self.current_location = state[: self.nx]
+
+    def get_next_to_go_loc(self):                   # :529-530
+        return np.array([2])
+
     def concatenate_real_hallucinated_data(self):   # :274-281
         return (torch.concat([self.Dyn_gp_X_train_batch, self.Hallcinated_X_train], dim=2),
                 torch.concat([self.Dyn_gp_Y_train_batch, self.Hallcinated_Y_train], dim=2))
@@ -259,6 +269,7 @@ class OracleAgent:
         else:
             data_X, data_Y = self.concatenate_real_hallucinated_data()
         hyper = GPHyper.from_params(self.params, use_grad=not use_model_without_derivatives)
+        hyper.semantics = self.semantics
         if not use_model_without_derivatives and self.in_dim_y == 1:
             # the reference would build a T=1+D likelihood against T=1 labels here; not a runnable combination
             raise RuntimeError("in_dim_y == 1 requires use_model_without_derivatives=True")
@@ -270,7 +281,9 @@ class OracleAgent:
     def train_forward_sampling_dynGP(self):           # :283-329  real ++ forward-sampling ++ hallucinated data
         data_X = torch.concat([self.Dyn_gp_X_train_batch, self.FS_X_train_batch, self.Hallcinated_X_train], dim=2)
         data_Y = torch.concat([self.Dyn_gp_Y_train_batch, self.FS_Y_train_batch, self.Hallcinated_Y_train], dim=2)
-        self.model_i = OracleGP(data_X, data_Y, GPHyper.from_params(self.params, use_grad=True))
+        hyper = GPHyper.from_params(self.params, use_grad=True)
+        hyper.semantics = self.semantics
+        self.model_i = OracleGP(data_X, data_Y, hyper)
 
     def prepare_dynamics_set(self, X_soln, U_soln, X_kp1, base_samples=None, rng=None):   # :331-443
         """Forward sampling with rejection.  ``base_samples``: list of (Ns, g_ny, 1, T) tensors, one per propagation

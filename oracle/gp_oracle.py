@@ -48,6 +48,37 @@ class NotPSDError(RuntimeError):
     """All jitter retries failed (linear_operator.utils.errors.NotPSDError is a RuntimeError too)."""
 
 
+@dataclass
+class OracleSemantics:
+    """The gpytorch / linear_operator behaviours this restatement cannot verify here (hard part 1),
+    each one switchable.  The DEFAULTS are the reading of gpytorch 1.13 / linear_operator 0.5.x the HIP kernels
+    implement; ``tests/golden/make_goldens.py --real-gpytorch`` reports which setting the genuine library matches when
+    it is run on a machine that has it.
+
+    jitter_policy ............ "failed_elements": retry i adds ``jitter * 10**i`` (total) to the diagonal of the batch
+                               elements whose previous attempt failed (psd_safe_cholesky since linear_operator 0.1);
+                               "whole_batch": ... of EVERY batch element as soon as one fails (gpytorch <= 1.5);
+                               "always": the first attempt already carries ``jitter`` (no un-jittered try).
+    eigh_fallback ............ "whole_batch": when any element is still not p.d. after the retries, the root of every
+                               element is the eigendecomposition root (NotPSDError is raised for the whole operator);
+                               "failed_elements": only the failing elements take it, the others keep their Cholesky root.
+    variance_floor ........... lower clamp of ``.variance`` (gpytorch.settings.min_variance, 1e-10 for float64); None = off.
+    nan_mask_batch_collapse .. True: a label slot that is NaN in ANY batch element is dropped for the WHOLE batch (the
+                               mask is reduced over the batch dimensions); False: every batch element drops its own slots.
+    """
+    jitter_policy: str = "failed_elements"
+    eigh_fallback: str = "whole_batch"
+    variance_floor: Optional[float] = MIN_VARIANCE_F64
+    nan_mask_batch_collapse: bool = True
+
+    def __post_init__(self):
+        assert self.jitter_policy in ("failed_elements", "whole_batch", "always")
+        assert self.eigh_fallback in ("whole_batch", "failed_elements")
+
+
+DEFAULT_SEMANTICS = OracleSemantics()
+
+
 # ----------------------------------------------------------------------------------------------------------------
 # A.2  kernel:  sigma^2 * RBF (value-only)  or  sigma^2 * RBFKernelGrad (value + gradient), interleaved ordering
 # ----------------------------------------------------------------------------------------------------------------
@@ -99,26 +130,34 @@ class FactorInfo:
     tries: int = 0
 
 
-def psd_safe_cholesky(A: torch.Tensor, jitter: float, info_out: Optional[FactorInfo] = None) -> torch.Tensor:
+def psd_safe_cholesky(A: torch.Tensor, jitter: float, info_out: Optional[FactorInfo] = None,
+                      sem: OracleSemantics = DEFAULT_SEMANTICS) -> torch.Tensor:
     """linear_operator.utils.cholesky.psd_safe_cholesky restated (A.7 steps 2-3).
 
     Plain ``cholesky_ex``; if any batch element fails, up to three retries adding ``jitter * 10**i`` (total) to the
-    diagonal of the batch elements that failed the *previous* attempt, re-factorising the whole batch each time.
+    diagonal of the batch elements that failed the *previous* attempt (``sem.jitter_policy``), re-factorising the whole
+    batch each time.  On NotPSDError the exception carries the last factor and info (``.L``, ``.info``) for the
+    per-element eigh fallback.
     """
-    L, info = torch.linalg.cholesky_ex(A)
+    A0 = A
+    if sem.jitter_policy == "always":
+        A0 = A.clone()
+        A0.diagonal(dim1=-1, dim2=-2).add_(jitter)
+    L, info = torch.linalg.cholesky_ex(A0)
     if info_out is not None:
         info_out.first_info = info.clone()
-        info_out.jitter_added = torch.zeros(A.shape[:-2], dtype=A.dtype)
+        info_out.jitter_added = torch.full(A.shape[:-2], jitter if sem.jitter_policy == "always" else 0.0, dtype=A.dtype)
         info_out.tries = 0
     if not torch.any(info):
         return L
     if torch.isnan(A).any():
         raise ValueError("cholesky_cpu: NaN in input")          # NanError in the library
-    Aprime = A.clone()
-    jitter_prev = 0.0
+    Aprime = A0.clone()
+    jitter_prev = jitter if sem.jitter_policy == "always" else 0.0
     for i in range(CHOLESKY_MAX_TRIES):
-        jitter_new = jitter * (10 ** i)
-        add = (info > 0).to(A.dtype) * (jitter_new - jitter_prev)
+        jitter_new = jitter * (10 ** (i + 1 if sem.jitter_policy == "always" else i))
+        who = (info > 0) if sem.jitter_policy != "whole_batch" else torch.ones_like(info, dtype=torch.bool)
+        add = who.to(A.dtype) * (jitter_new - jitter_prev)
         Aprime.diagonal(dim1=-1, dim2=-2).add_(add.unsqueeze(-1))
         if info_out is not None:
             info_out.jitter_added = info_out.jitter_added + add
@@ -127,20 +166,27 @@ def psd_safe_cholesky(A: torch.Tensor, jitter: float, info_out: Optional[FactorI
         L, info = torch.linalg.cholesky_ex(Aprime)
         if not torch.any(info):
             return L
-    raise NotPSDError(f"Matrix not positive definite after repeatedly adding jitter up to {jitter_new:.1e}.")
+    err = NotPSDError(f"Matrix not positive definite after repeatedly adding jitter up to {jitter_new:.1e}.")
+    err.L, err.info = L, info
+    raise err
 
 
-def root_decomposition(S: torch.Tensor, jitter: float, info_out: Optional[FactorInfo] = None) -> torch.Tensor:
+def root_decomposition(S: torch.Tensor, jitter: float, info_out: Optional[FactorInfo] = None,
+                       sem: OracleSemantics = DEFAULT_SEMANTICS) -> torch.Tensor:
     """LinearOperator.root_decomposition(method="cholesky") restated (A.7 steps 1-4)."""
     if S.shape[-1] == 1:
         return S.sqrt()                                          # 1x1: plain sqrt, no jitter, NaN if negative
     try:
-        return psd_safe_cholesky(S, jitter, info_out)
-    except NotPSDError:
-        evals, evecs = torch.linalg.eigh(S)                      # whole batch falls back
+        return psd_safe_cholesky(S, jitter, info_out, sem)
+    except NotPSDError as e:
+        evals, evecs = torch.linalg.eigh(S)
         if info_out is not None:
             info_out.used_eigh = True
-        return evecs * evals.clamp_min(0.0).sqrt().unsqueeze(-2)
+        R = evecs * evals.clamp_min(0.0).sqrt().unsqueeze(-2)
+        if sem.eigh_fallback == "whole_batch":
+            return R                                             # whole batch falls back
+        failed = (e.info > 0).reshape(e.info.shape + (1, 1))
+        return torch.where(failed, R, e.L)
 
 
 # ----------------------------------------------------------------------------------------------------------------
@@ -154,6 +200,7 @@ class GPHyper:
     noise_diag: torch.Tensor    # (T,)        task_noises.val[t]*multiplier + Dyn_gp_noise
     jitter: float               # Dyn_gp_jitter
     use_grad: bool = True
+    semantics: OracleSemantics = field(default_factory=OracleSemantics)
 
     @property
     def T(self) -> int:
@@ -175,16 +222,18 @@ class GPHyper:
 class OraclePosterior:
     """Stand-in for the MultitaskMultivariateNormal returned by ``model_i(x)``."""
 
-    def __init__(self, mean: torch.Tensor, covar: torch.Tensor, jitter: float):
+    def __init__(self, mean: torch.Tensor, covar: torch.Tensor, jitter: float,
+                 sem: OracleSemantics = DEFAULT_SEMANTICS):
         self.mean = mean                    # (Ns, g_ny, m, T)
         self.covariance_matrix = covar      # (Ns, g_ny, m*T, m*T)
         self._jitter = jitter
+        self._sem = sem
         self.root_info = FactorInfo()
 
     @property
     def variance(self) -> torch.Tensor:     # A.8: diag, no jitter, floor 1e-10
         v = self.covariance_matrix.diagonal(dim1=-1, dim2=-2).reshape(self.mean.shape)
-        return v.clamp_min(MIN_VARIANCE_F64)
+        return v if self._sem.variance_floor is None else v.clamp_min(self._sem.variance_floor)
 
     @property
     def stddev(self) -> torch.Tensor:
@@ -195,7 +244,7 @@ class OraclePosterior:
         return self.mean - s2, self.mean + s2
 
     def root(self) -> torch.Tensor:
-        return root_decomposition(self.covariance_matrix, self._jitter, self.root_info)
+        return root_decomposition(self.covariance_matrix, self._jitter, self.root_info, self._sem)
 
     def sample(self, base_samples: Optional[torch.Tensor] = None) -> torch.Tensor:
         """A.7: y = mu + R z with z the given base samples flattened interleaved, or internal randn."""
@@ -231,6 +280,27 @@ class OracleGP:
         y = self.train_targets
         return ~torch.any(torch.isnan(y.reshape(-1, y.shape[-2] * y.shape[-1])), dim=0)
 
+    def _per_element(self, x: torch.Tensor) -> "OraclePosterior":
+        """``nan_mask_batch_collapse = False``: every batch element conditions on its own observed slots (a loop of
+        single-element models; only for the small comparison runs of the semantics switches)."""
+        import copy
+        sem = copy.copy(self.hyper.semantics)
+        sem.nan_mask_batch_collapse = True
+        Ns, g_ny = self.batch_shape
+        means, covs = [], []
+        for s_ in range(Ns):
+            mo, co = [], []
+            for o in range(g_ny):
+                h = GPHyper(self.hyper.ell[o:o + 1], self.hyper.outputscale[o:o + 1], self.hyper.noise_diag,
+                            self.hyper.jitter, self.hyper.use_grad, sem)
+                one = OracleGP(self.train_inputs[0][s_:s_ + 1, o:o + 1], self.train_targets[s_:s_ + 1, o:o + 1], h)
+                post = one(x[s_:s_ + 1, o:o + 1])
+                mo.append(post.mean)
+                co.append(post.covariance_matrix)
+            means.append(torch.cat(mo, dim=1))
+            covs.append(torch.cat(co, dim=1))
+        return OraclePosterior(torch.cat(means, dim=0), torch.cat(covs, dim=0), self.hyper.jitter, self.hyper.semantics)
+
     def _ell_os(self):
         h = self.hyper
         ell = h.ell.reshape(1, *h.ell.shape)                      # (1, g_ny, D) -> broadcast over Ns
@@ -247,7 +317,7 @@ class OracleGP:
             K = scaled_rbf_kernel(X, X, ell, osc, h.use_grad)     # (Ns, g_ny, N*T, N*T), dense, every call
             K = K + torch.diag(h.noise_diag.repeat(N))            # kron(I_N, diag(noise))  (A.3)
             Koo = K[..., obs, :][..., :, obs]
-            L = psd_safe_cholesky(Koo, h.jitter, self.train_info)  # A.5
+            L = psd_safe_cholesky(Koo, h.jitter, self.train_info, h.semantics)  # A.5
             yo = Y.reshape(*Y.shape[:-2], N * T)[..., obs].unsqueeze(-1)
             alpha = torch.cholesky_solve(yo, L)                   # mean is zero
             self._cache = (obs, L, alpha)
@@ -255,6 +325,8 @@ class OracleGP:
 
     def __call__(self, x: torch.Tensor) -> OraclePosterior:
         h = self.hyper
+        if not h.semantics.nan_mask_batch_collapse and bool(torch.isnan(self.train_targets).any()):
+            return self._per_element(x)
         obs, L, alpha = self._train_cache()
         X = self.train_inputs[0]
         T = self.train_targets.shape[-1]
@@ -265,4 +337,4 @@ class OracleGP:
         mean = (K_so @ alpha).squeeze(-1).reshape(*x.shape[:-2], m, T)
         corr = torch.cholesky_solve(K_so.transpose(-1, -2), L)               # (K_oo+S)^-1 K_o*
         covar = K_ss + K_so @ corr.mul(-1)                                   # A.6
-        return OraclePosterior(mean, covar, h.jitter)
+        return OraclePosterior(mean, covar, h.jitter, h.semantics)

@@ -21,6 +21,17 @@ What is captured, and from which reference code:
 * ``conditioning_gp.npz`` ... reference ``extra/conditioning_gp.py`` executed as is (numpy RBF posterior sampler,
                               value-only) - an in-reference cross-check of kernel + Cholesky conditioning + sampling.
 * ``configs`` ............... the three runnable reference YAMLs re-serialised into sampling_gpmpc_amd/params/.
+* ``formats_check.npz`` ..... files written by ``sampling_gpmpc_amd.io_formats`` (``data.pkl``, ``X_traj_list_<k>.pkl``,
+                              ``data_X_traj_<idx>.pkl``) read back by the reference's own loader lines
+                              (``benchmarking/simulate_forward_sampling_car.py:91-98``, ``extra/cdc_plt.py:162-176``,
+                              ``benchmarking/generate_convex_hull.py:76-83``), executed from the reference sources here;
+                              what they produced is the fixture (``python tests/golden/make_goldens.py --only formats``).
+
+``--real-gpytorch``: the one-command pin of the GP algebra for a machine that HAS gpytorch (this image does not; the script
+then says so and exits with status 3 without touching anything).  It drives the reference's real ``src/agent.py`` with the
+GENUINE library through the same end-to-end cases, writes ``agent_e2e_*_gpytorch.npz`` next to the stub-generated files,
+prints a per-tensor difference against the oracle, and tries the ``OracleSemantics`` switches to say which setting the
+library matches (``tests/test_oracle_golden.py`` picks the files up when they exist).
 """
 import contextlib
 import copy
@@ -88,7 +99,146 @@ def quiet(fn, *a, **k):
         return fn(*a, **k)
 
 
+def formats_fixture():
+    """Write with sampling_gpmpc_amd.io_formats, read with the reference's loader lines (taken from its sources at run time)."""
+    import pickle
+    import re
+    from sampling_gpmpc_amd import io_formats as io
+    g = torch.Generator().manual_seed(21)
+    Ns, nx, nu, H, g_ny = 5, 2, 1, 6, 1
+    X_traj = torch.randn(Ns, nx, H + 1, generator=g, dtype=torch.float64).numpy()
+    U = torch.randn(H, nu, generator=g, dtype=torch.float64).numpy()
+    data = {"state_traj": [torch.randn(H + 1, Ns * nx, generator=g, dtype=torch.float64).numpy() for _ in range(2)],
+            "input_traj": [U * 0.5, U], "mean_state_traj": [], "true_state_traj": [X_traj[0].T.copy(), X_traj[1].T.copy()],
+            "physical_state_traj": [np.zeros(Ns * nx), np.ones(Ns * nx)], "solver_time": [0.1, 0.2],
+            "gp_model_after_solve_train_X": [torch.zeros(Ns, g_ny, 3, 2)], "gp_model_after_solve_train_Y": [torch.zeros(Ns, g_ny, 3, 3)],
+            "tilde_eps_list": [np.arange(4.0)], "ci_list": [0.5]}
+    out = {"X_traj": X_traj, "U": U, "input_traj_0": data["input_traj"][0], "input_traj_1": data["input_traj"][1]}
+    with tempfile.TemporaryDirectory() as td:
+        io.save_data_pkl(td, data)
+        io.save_x_traj_list(td, 3, X_traj, U, g_ny)
+        for idx in (1, 2):
+            io.save_x_traj(td, idx, X_traj + idx)
+        # (1) reference benchmarking/simulate_forward_sampling_car.py:91-98, executed from its source: data.pkl -> the
+        #     open-loop input sequence the forward-sampling harness replays
+        src = open(f"{REF}/benchmarking/simulate_forward_sampling_car.py").read().split("\n")
+        code = "\n".join(src[90:98])                      # `with open(input_data_path, "rb") ...` .. `input_gpmpc_input_traj = ...`
+        assert "pickle.load(input_data_file)" in code and "input_gpmpc_input_traj" in code, "reference lines moved"
+        ns = {"pickle": pickle, "input_data_path": f"{td}/data.pkl", "np": np}
+        exec(code, ns)
+        out["ref_input_traj_last"] = np.asarray(ns["input_gpmpc_input_traj"])
+        # (2) reference extra/cdc_plt.py:162-176: X_traj_list_<k>.pkl -> (H+1, N, g_ny, 1, nx+nu) array, state_traj slice
+        with open(f"{td}/X_traj_list_3.pkl", "rb") as a_file:
+            sampling_gpmpc_data = pickle.load(a_file)
+        sampling_gpmpc_data_np = np.array([np.array(x.cpu()) for x in sampling_gpmpc_data])       # cdc_plt.py:169-171
+        H_GT, N_samples, nx_, _, nxu = sampling_gpmpc_data_np.shape                                 # cdc_plt.py:172
+        out["ref_list_shape"] = np.array(sampling_gpmpc_data_np.shape)
+        out["ref_state_traj"] = sampling_gpmpc_data_np[:, :, 0, 0, 0:2]                             # cdc_plt.py:176
+        # (3) reference benchmarking/generate_convex_hull.py:76-83, executed from its source: the per-job tube files are
+        #     concatenated over the sample axis
+        src = open(f"{REF}/benchmarking/generate_convex_hull.py").read().split("\n")
+        code = "\n".join(src[75:83]).replace("range(1)", "range(1, 3)")
+        assert "data_X_traj_" in code and "np.vstack(input_gpmpc_data_list)" in code, "reference lines moved"
+
+        class _A:
+            i = "job"
+        os.makedirs(f"{td}/job", exist_ok=True)
+        for idx in (1, 2):
+            os.replace(f"{td}/data_X_traj_{idx}.pkl", f"{td}/job/data_X_traj_{idx}.pkl")
+        ns = {"pickle": pickle, "np": np, "save_path": td + "/", "args": _A, "input_gpmpc_data_list": [], "print": lambda *a: None}
+        exec(code, ns)
+        out["ref_merged"] = np.asarray(ns["X_traj"])
+    np.savez(f"{HERE}/formats_check.npz", **out)
+    print("formats_check.npz written: data.pkl / X_traj_list_3.pkl / data_X_traj_{1,2}.pkl read back by the reference's loaders")
+
+
+def real_gpytorch_pin():
+    """Needs a machine with gpytorch==1.13 (reference requirements.txt:6).  See the module docstring."""
+    try:
+        import gpytorch                                                              # noqa: F401
+    except Exception as e:                                                           # noqa: BLE001
+        print(f"--real-gpytorch: `import gpytorch` failed ({e!r}).  Nothing was written.  Install gpytorch==1.13 "
+              f"(reference requirements.txt:6) next to /root/reference and rerun this command; parity of the GP algebra "
+              f"stays 'unpinned' until then.")
+        return 3
+    import itertools
+    import src.agent as ref_agent
+    from src.environments.pendulum1D import Pendulum as RefPendulum1D
+    from src.environments.car_model_residual import CarKinematicsModel as RefCar
+    from oracle import agent_oracle as ao
+    from oracle.gp_oracle import OracleSemantics
+    torch.set_default_dtype(torch.float64)
+    report = []
+    cases = [("R_pendulum1D", RefPendulum1D, "params_pendulum1D_samples", 8, 10, False, True),
+             ("I_car", RefCar, "params_car_residual_fs", 8, 8, True, True),
+             ("R_car", RefCar, "params_car_residual_fs", 4, 8, False, True)]
+    for tag, cls, pname, Ns, Ht, nograd, fb in cases:
+        p = load_params(pname)
+        p["common"]["use_cuda"] = False
+        p["agent"]["num_dyn_samples"], p["optimizer"]["H"] = Ns, 1
+        p["common"]["num_MPC_itrs"], p["optimizer"]["SEMPC"]["max_sqp_iter"] = Ht, 2
+        p["env"]["use_model_without_derivatives"], p["agent"]["feedback"]["use"] = nograd, fb
+        torch.manual_seed(123456)
+        agent = quiet(ref_agent.Agent, p, cls(p))
+        u_ff = np.linspace(-1, 1, Ht).reshape(Ht, 1) if agent.nu == 1 else \
+            np.stack([0.05 * np.sin(2 * np.pi * np.arange(Ht) / Ht), np.zeros(Ht)], axis=1)
+        X_ref, Y_ref = fs_loop(agent, p, u_ff)
+        erv = agent.epistimic_random_vector.clone()
+        np.savez(f"{HERE}/agent_e2e_{tag}_gpytorch.npz", Ns=Ns, H_traj=Ht, nograd=nograd, feedback=fb, u_ff=u_ff,
+                 beta=p["agent"]["Dyn_gp_beta"], epistimic_random_vector=erv.numpy(), X_traj=X_ref, Y=Y_ref)
+        best = None
+        for jp, ef, nm in itertools.product(("failed_elements", "whole_batch", "always"), ("whole_batch", "failed_elements"),
+                                            (True, False)):
+            sem = OracleSemantics(jitter_policy=jp, eigh_fallback=ef, nan_mask_batch_collapse=nm)
+            oa = ao.OracleAgent(p, ao.make_oracle_env(p), erv, semantics=sem)
+            Xo, Yo = ao.forward_sampling_rollout(oa, u_ff, return_samples=True)
+            err = float(np.max(np.abs(Xo - X_ref)) / np.max(np.abs(X_ref)))
+            report.append(f"{tag:14s} jitter_policy={jp:16s} eigh_fallback={ef:16s} nan_collapse={nm!s:5s}: "
+                          f"rel err X_traj {err:.3e}  Y {float(np.max(np.abs(Yo - Y_ref))):.3e}")
+            if best is None or err < best[0]:
+                best = (err, sem)
+        report.append(f"{tag:14s} best match: {best[1]} ({best[0]:.3e})")
+    txt = "\n".join(report)
+    print(txt)
+    with open(f"{HERE}/gpytorch_pin_report.txt", "w") as f:
+        f.write(txt + "\n")
+    return 0
+
+
+def fs_loop(agent, p, u_ff):
+    """reference benchmarking/simulate_forward_sampling_car.py:108-138, same calls in the same order."""
+    ns, nx = agent.ns, agent.nx
+    K = np.array(p["optimizer"]["terminal_tightening"]["K"])
+    x_equi = np.array(p["env"]["goal_state"])
+    agent.update_current_state(np.array(p["env"]["start"]))
+    x_curr = agent.current_state[:nx].reshape(nx)
+    H = u_ff.shape[0]
+    x_h = np.tile(x_curr, (1, ns))
+    X_traj = torch.empty((ns, nx, H + 1))
+    Ys = []
+    for H_idx in range(H):
+        agent.train_hallucinated_dynGP(1, use_model_without_derivatives=p["env"]["use_model_without_derivatives"])
+        agent.mpc_iteration(H_idx)
+        u_h = u_ff[H_idx].reshape(1, -1)
+        if p["agent"]["feedback"]["use"]:
+            bx = agent.get_batch_x_hat_u_diff(
+                x_h, -(x_equi - x_h.reshape(1, ns, -1)) @ K.T + np.tile(u_h[:, None, :], (ns, 1)))
+        else:
+            bx = agent.get_batch_x_hat(x_h, u_h)
+        gp_val, _, _ = quiet(agent.dyn_fg_jacobians, bx, 1)
+        Ys.append(agent.model_i_samples.clone())
+        X_traj[:, :, H_idx] = bx[:, 0, 0, :nx]
+        x_h = gp_val[:, :, 0, 0].reshape(1, -1)
+    X_traj[:, :, H_idx + 1] = torch.tensor(gp_val[:, :, 0, 0])
+    return X_traj.numpy(), torch.cat(Ys, dim=2).numpy()
+
+
 def main():
+    if "--real-gpytorch" in sys.argv:
+        sys.exit(real_gpytorch_pin())
+    if "--only" in sys.argv and sys.argv[sys.argv.index("--only") + 1] == "formats":
+        formats_fixture()
+        return
     install_gpytorch_stub()
     import src.agent as ref_agent                                                     # noqa
     from src.environments.pendulum1D import Pendulum as RefPendulum1D                 # noqa
@@ -188,33 +338,6 @@ def main():
                  min_dist_1=0.25)
 
     # ---------------- Agent end to end, GP algebra delegated to the oracle ----------------------------------
-    def fs_loop(agent, p, u_ff):
-        """reference benchmarking/simulate_forward_sampling_car.py:108-138, same calls in the same order."""
-        ns, nx = agent.ns, agent.nx
-        K = np.array(p["optimizer"]["terminal_tightening"]["K"])
-        x_equi = np.array(p["env"]["goal_state"])
-        agent.update_current_state(np.array(p["env"]["start"]))
-        x_curr = agent.current_state[:nx].reshape(nx)
-        H = u_ff.shape[0]
-        x_h = np.tile(x_curr, (1, ns))
-        X_traj = torch.empty((ns, nx, H + 1))
-        Ys = []
-        for H_idx in range(H):
-            agent.train_hallucinated_dynGP(1, use_model_without_derivatives=p["env"]["use_model_without_derivatives"])
-            agent.mpc_iteration(H_idx)
-            u_h = u_ff[H_idx].reshape(1, -1)
-            if p["agent"]["feedback"]["use"]:
-                bx = agent.get_batch_x_hat_u_diff(
-                    x_h, -(x_equi - x_h.reshape(1, ns, -1)) @ K.T + np.tile(u_h[:, None, :], (ns, 1)))
-            else:
-                bx = agent.get_batch_x_hat(x_h, u_h)
-            gp_val, _, _ = quiet(agent.dyn_fg_jacobians, bx, 1)
-            Ys.append(agent.model_i_samples.clone())
-            X_traj[:, :, H_idx] = bx[:, 0, 0, :nx]
-            x_h = gp_val[:, :, 0, 0].reshape(1, -1)
-        X_traj[:, :, H_idx + 1] = torch.tensor(gp_val[:, :, 0, 0])
-        return X_traj.numpy(), torch.cat(Ys, dim=2).numpy()
-
     cases = [
         # tag, class, yaml, Ns, H_traj, use_model_without_derivatives, feedback
         ("R_pendulum1D", RefPendulum1D, "params_pendulum1D_samples", 8, 10, False, True),
@@ -291,6 +414,7 @@ def main():
     np.savez(f"{HERE}/conditioning_gp.npz", X=ns_["X"], y=ns_["y"], Xtest=ns_["Xtest"], Xtest2=ns_["Xtest2"],
              random_weights=ns_["random_weights"], f_post=ns_["f_post"], f_post2=ns_["f_post2"],
              kernel_parameter=0.1, post_jitter=1e-6)
+    formats_fixture()
     print("goldens written to", HERE)
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):

@@ -200,3 +200,29 @@ def test_inline_asm_dpp_table_reads_have_no_valu_write_hazard():
     repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, os.path.join(repo, "tools", "check_dpp_hazard.py")], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout + r.stderr
+
+
+def test_on_disk_formats_are_read_by_the_reference_loaders(tmp_path):
+    """data.pkl, X_traj_list_<k>.pkl and data_X_traj_<idx>.pkl written by sampling_gpmpc_amd.io_formats: the fixture holds
+    what the REFERENCE's own loader lines produced from them (tests/golden/make_goldens.py --only formats executes
+    simulate_forward_sampling_car.py:91-98, extra/cdc_plt.py:169-176, generate_convex_hull.py:76-83 from the reference
+    sources); the files are rewritten here from the same inputs and read with the package's loaders."""
+    import torch
+    from sampling_gpmpc_amd import io_formats as io
+    d = np.load(os.path.join(GOLDEN, "formats_check.npz"))
+    X_traj, U = d["X_traj"], d["U"]
+    data = {k: [] for k in io.DATA_PKL_KEYS}
+    data["input_traj"] = [d["input_traj_0"], d["input_traj_1"]]
+    io.save_data_pkl(str(tmp_path), data)
+    back = io.load_data_pkl(os.path.join(str(tmp_path), "data.pkl"))
+    assert set(back) == set(io.DATA_PKL_KEYS)
+    np.testing.assert_array_equal(np.asarray(back["input_traj"][-1]), d["ref_input_traj_last"])
+    pth = io.save_x_traj_list(str(tmp_path), 3, X_traj, U, g_ny=1)
+    lst = io.load_x_traj_list(pth)
+    arr = np.array([np.asarray(t) for t in lst])
+    assert list(arr.shape) == d["ref_list_shape"].tolist() and lst[0].dtype == torch.float64
+    np.testing.assert_array_equal(arr[:, :, 0, 0, 0:2], d["ref_state_traj"])
+    np.testing.assert_array_equal(arr[:-1, 0, 0, 0, 2:], U)                       # applied input rides in the last columns
+    for idx in (1, 2):
+        io.save_x_traj(str(tmp_path), idx, X_traj + idx)
+    np.testing.assert_array_equal(io.merge_x_traj(str(tmp_path), (1, 2)), d["ref_merged"])

@@ -137,3 +137,20 @@ def test_value_only_algebra_against_reference_numpy_sampler():
         L = torch.linalg.cholesky(S)
         f = post.mean[0, 0] + L @ torch.tensor(d["random_weights"])
         np.testing.assert_allclose(f.numpy(), fp, rtol=1e-7, atol=1e-8)
+
+
+@pytest.mark.parametrize("tag,pname", [("R_pendulum1D", "params_pendulum1D_samples"), ("I_car", "params_car_residual_fs"),
+                                       ("R_car", "params_car_residual_fs")])
+def test_oracle_against_real_gpytorch_goldens_when_present(tag, pname):
+    """``tests/golden/make_goldens.py --real-gpytorch`` writes these on a machine that has gpytorch==1.13; until someone
+    runs it the GP algebra stays 'parity unpinned' and this test is skipped."""
+    path = os.path.join(GOLDEN, f"agent_e2e_{tag}_gpytorch.npz")
+    if not os.path.exists(path):
+        pytest.skip("no real-gpytorch golden (run tests/golden/make_goldens.py --real-gpytorch where gpytorch is installed)")
+    d = np.load(path)
+    p = fs_params(pname, int(d["Ns"]), int(d["H_traj"]), nograd=bool(d["nograd"]), feedback=bool(d["feedback"]),
+                  beta=float(d["beta"]))
+    agent = ao.OracleAgent(p, ao.make_oracle_env(p), torch.tensor(d["epistimic_random_vector"]))
+    X, Y = ao.forward_sampling_rollout(agent, d["u_ff"], return_samples=True)
+    np.testing.assert_allclose(X, d["X_traj"], rtol=1e-6, atol=1e-9)
+    np.testing.assert_allclose(Y, d["Y"], rtol=1e-5, atol=1e-8)
