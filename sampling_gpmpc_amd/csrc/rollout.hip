@@ -428,7 +428,7 @@ size_t gpmpc_rollout_workspace_bytes(const gpmpc_gp_desc_t* gp, int32_t mode, in
     RolloutPlan rp;
     if (plan_rollout(gp, GPMPC_MAX_NX, mode, hall_tasks, H, &rp) != GPMPC_OK) return 0;
     if (mode != GPMPC_MODE_RECONDITIONED) return 256;
-    return align_up((size_t)Ns * gp->g_ny * rp.chain_doubles * sizeof(double), 256) + 256;   // >= the tuned path's need
+    return align_up((size_t)Ns * gp->g_ny * rp.chain_doubles * sizeof(double), 256) + 2048;   // >= the tuned path's need (its zero page included)
 }
 
 int gpmpc_rollout(const gpmpc_gp_desc_t* gp, const gpmpc_env_desc_t* env, const void* plan, const double* X_r,

@@ -68,6 +68,7 @@ __host__ __device__ __forceinline__ long lhh_doubles(int nh_max, int rg) {
     slack = (slack < 0) ? 0 : ((slack + 1) & ~1);
     return lhh_rowofs(nh_max) + slack;
 }
+constexpr int kZeroPage = 128;         // doubles of zeros at the head of the HBM/L2 factor workspace (one row's worth of pairs)
 constexpr int kRingLds = 4;
 #ifndef GPMPC_FAST_RING_GLOBAL
 #define GPMPC_FAST_RING_GLOBAL 8
@@ -387,18 +388,20 @@ __global__ __launch_bounds__(GPMPC_FAST_MAXTHREADS, 1) void rollout_fast_kernel(
 
     // ---- LDS carve (all offsets even => 16-byte aligned) -----------------------------------------------------------
     double* Linv_all = smem;                                      // [G_NY][NR][NRS]  L_rr^-1 rows, shared by the workgroup
-    double* ybuf_all = Linv_all + G_NY * NR * NRS;                // [spw][2][G_NY] (+pad)
+    double* ybuf_all = Linv_all + (GRID ? 0 : G_NY * NR * NRS);   // [spw][2][G_NY] (+pad)
     double* wb = smem + a.lds_shared + (long)wave * a.lds_per_wave;
     double* kvs = wb;                                             // [T][NRP]  k_r, then (after phase B) v_r: one buffer
     double* Lhr1 = kvs + T * NRP;                                 // [nb1][NRS]
-    double* Lhh = LHH_LDS ? (Lhr1 + nb1 * NRS) : (a.ws + (s * G_NY + o) * a.ws_chain_stride);
+    double* Lhh = LHH_LDS ? (Lhr1 + nb1 * NRS) : (a.ws + kZeroPage + (s * G_NY + o) * a.ws_chain_stride);
     double* ybuf = ybuf_all + sw * 2 * G_NY;
     double* dgs = Lhr1 + nb1 * NRS;                               // [3][16] diagonal-segment scratch (global-factor variant only)
 
-    for (int e = threadIdx.x; e < G_NY * NR * NRS; e += blockDim.x) {
-        const int oo = e / (NR * NRS), rem = e - oo * NR * NRS;
-        const int i = rem / NRS, j = rem - i * NRS;
-        Linv_all[e] = (!GRID && j < NR) ? plan_LinvT(a.plan, gp, oo)[j * NR + i] : 0.0;
+    if constexpr (!GRID) {                                        // the grid root needs no L_rr^-1 (nor its LDS)
+        for (int e = threadIdx.x; e < G_NY * NR * NRS; e += blockDim.x) {
+            const int oo = e / (NR * NRS), rem = e - oo * NR * NRS;
+            const int i = rem / NRS, j = rem - i * NRS;
+            Linv_all[e] = (j < NR) ? plan_LinvT(a.plan, gp, oo)[j * NR + i] : 0.0;
+        }
     }
     if constexpr (G_NY > 1) {
         if (threadIdx.x < 4) s_info[threadIdx.x] = 0;
@@ -406,7 +409,13 @@ __global__ __launch_bounds__(GPMPC_FAST_MAXTHREADS, 1) void rollout_fast_kernel(
     __syncthreads();
     if (!valid) return;                                           // whole workgroups are valid when G_NY > 1 (spw == 1)
 
-    for (long e = lane; e < a.ws_chain_stride; e += kWave) Lhh[e] = 0.0;
+    // The LDS factor is zero-initialised (rows that do not exist yet read as zero).  The HBM/L2 factor is NOT (that was
+    // 56 KB per chain, 0.68 GB per launch at BASELINE configs[2]): a lane whose row does not exist yet reads the shared
+    // zero page at the head of the workspace instead (row0e / row1e below), existing rows only ever read entries left
+    // of their diagonal block, which were written when the row was appended.
+    if constexpr (LHH_LDS) {
+        for (long e = lane; e < a.ws_chain_stride; e += kWave) Lhh[e] = 0.0;
+    }
     for (int e = lane; e < nb1 * NRS; e += kWave) Lhr1[e] = 0.0;
 
     double il2[D];
@@ -459,6 +468,7 @@ __global__ __launch_bounds__(GPMPC_FAST_MAXTHREADS, 1) void rollout_fast_kernel(
     const double2_t* row1 = reinterpret_cast<const double2_t*>(Lhh + lhh_rowofs(min(lane + kWave, nh_max - 1)));
     const double2_t* lhr1row = reinterpret_cast<const double2_t*>(Lhr1 + (long)min(lane, max(nb1 - 1, 0)) * NRS);
     const double2_t* zero2 = reinterpret_cast<const double2_t*>(Lhh + lhh_rowofs(nh_max));    // first slack pair: never written
+    const double2_t* zpage = reinterpret_cast<const double2_t*>(a.ws);                         // kZeroPage zeros (HBM/L2 factor)
     const int a0t = lane - (lane / T) * T, a1t = (lane + kWave) - ((lane + kWave) / T) * T;   // task of this lane's rows
     const double cA0[2] = {(a0t == 1) ? il2[0] : 0.0, (a0t == 2) ? il2[1] : 0.0};              // [a == b > 0] / l_a^2
     const double cA1[2] = {(a1t == 1) ? il2[0] : 0.0, (a1t == 2) ? il2[1] : 0.0};
@@ -660,11 +670,13 @@ __global__ __launch_bounds__(GPMPC_FAST_MAXTHREADS, 1) void rollout_fast_kernel(
 
         if (n_h > 0) {
             double2_t lg0[8], lg1[8];                             // global-factor variant: own-row pairs of pivot block 0
+            const double2_t* row0e = (LHH_LDS || ex0) ? row0 : zpage;     // rows that do not exist yet: the zero page
+            const double2_t* row1e = (LHH_LDS || ex1) ? row1 : zpage;
             if constexpr (!LHH_LDS) {
 #pragma unroll
                 for (int q = 0; q < 8; ++q) lg0[q] = double2_t{0.0, 0.0}, lg1[q] = double2_t{0.0, 0.0};
-                if (n_h > 16) dpp_load_pairs(row0, 0, lg0);
-                if (two) dpp_load_pairs(row1, 0, lg1);
+                if (n_h > 16) dpp_load_pairs(row0e, 0, lg0);
+                if (two) dpp_load_pairs(row1e, 0, lg1);
             }
             // ---- rhs = k_h - L_hr v_r -----------------------------------------------------------------------------
 #ifndef GPMPC_ABLATE_RHS
@@ -707,14 +719,14 @@ __global__ __launch_bounds__(GPMPC_FAST_MAXTHREADS, 1) void rollout_fast_kernel(
 #pragma unroll
                 for (int q = 0; q < 8; ++q) la[q] = lg0[q], lb[q] = lg1[q];     // requested before the L_hr product
                 if (!two) {
-                    dppg_bank0_block<0, false>(row0, row1, n_h, bp_addr, dg0, la, lb, v0, v1);
+                    dppg_bank0_block<0, false>(row0e, row1e, n_h, bp_addr, dg0, la, lb, v0, v1);
                 } else {
-                    dppg_bank0_block<0, true>(row0, row1, n_h, bp_addr, dg0, la, lb, v0, v1);
+                    dppg_bank0_block<0, true>(row0e, row1e, n_h, bp_addr, dg0, la, lb, v0, v1);
                     double2_t lc[8];
 #pragma unroll
                     for (int q = 0; q < 8; ++q) lc[q] = la[q];
-                    if (kWave + 16 < n_h) dpp_load_pairs(row1, 4, lc);
-                    dppg_bank1_block<0>(row1, n_h, bp_addr, dg1, lc, v1);
+                    if (kWave + 16 < n_h) dpp_load_pairs(row1e, 4, lc);
+                    dppg_bank1_block<0>(row1e, n_h, bp_addr, dg1, lc, v1);
                 }
             }
             // v = rhs / L_pp (own rows; rows that do not exist yet are dropped); partial sums
@@ -1035,6 +1047,12 @@ bool rollout_fast_eligible(const gpmpc_gp_desc_t* gp, const gpmpc_env_desc_t* en
     return false;
 }
 
+static bool fast_grid_root(const gpmpc_gp_desc_t* gp) {
+    const char* eg = std::getenv("GPMPC_DISABLE_GRID_ROOT");
+    return !(eg && eg[0] == '1') && gp->grid_n1 == 9 && gp->grid_n0 * 9 == gp->N_r &&
+           plan_has_grid_root(gp->grid_n0, gp->grid_n1, gp->real_has_grad);
+}
+
 static void fast_plan(const gpmpc_gp_desc_t* gp, int nx, int H, bool force_global, FastPlan* fp) {
     const int NR = gp->N_r, T = 3, G = gp->g_ny;
     (void)nx;
@@ -1047,7 +1065,8 @@ static void fast_plan(const gpmpc_gp_desc_t* gp, int nx, int H, bool force_globa
     const long vec = (long)T * NRP + (long)nb1 * NRS;
     const size_t budget = 160 * 1024 - 64;
     const int max_spw = (G == 1) ? 4 : 1;
-    auto shared_doubles = [&](int spw) { return (G * NR * NRS + ((G > 1) ? spw * 2 * G : 0) + 1) & ~1; };
+    const bool grid = fast_grid_root(gp);                         // the grid root keeps no L_rr^-1 in LDS
+    auto shared_doubles = [&](int spw) { return ((grid ? 0 : G * NR * NRS) + ((G > 1) ? spw * 2 * G : 0) + 1) & ~1; };
     // L_hh stays in LDS only if that still leaves one wave on every SIMD (max_spw samples per workgroup): with fewer
     // resident samples the HBM/L2-workspace variant at full occupancy is faster (tools/horizon_sweep.py, Ns=4096:
     // H=31 1.07 vs 1.25 ms, H=43 1.9 vs 5.3 ms; at H<=30, where 4 samples fit, LDS wins 0.82 vs 0.95 ms)
@@ -1067,7 +1086,7 @@ static void fast_plan(const gpmpc_gp_desc_t* gp, int nx, int H, bool force_globa
 }
 
 size_t rollout_fast_workspace_bytes(const gpmpc_gp_desc_t* gp, int64_t Ns, int H) {
-    return (size_t)Ns * gp->g_ny * (size_t)lhh_doubles(3 * (H - 1), kRingGlobal) * sizeof(double);
+    return ((size_t)kZeroPage + (size_t)Ns * gp->g_ny * (size_t)lhh_doubles(3 * (H - 1), kRingGlobal)) * sizeof(double);
 }
 
 template <int NR, int G_NY, int ENV, bool GRID>
@@ -1101,11 +1120,10 @@ int rollout_fast_launch(const gpmpc_gp_desc_t* gp, const gpmpc_env_desc_t* env, 
     if (!fp.lhh_lds) {
         if (!ws || ws_bytes < rollout_fast_workspace_bytes(gp, args.Ns, args.H))
             return fail(GPMPC_E_WORKSPACE, "gpmpc_rollout: workspace too small");
+        GPMPC_HIP_CHECK(hipMemsetAsync(ws, 0, kZeroPage * sizeof(double), st));      // the zero page (1 KB); the factor itself is not cleared
     }
     // the grid root of the plan (separable real-data kernel row) when the real inputs are the reference's tensor grid
-    const char* eg = std::getenv("GPMPC_DISABLE_GRID_ROOT");
-    const bool grid = !(eg && eg[0] == '1') && gp->grid_n1 == 9 && gp->grid_n0 * 9 == gp->N_r &&
-                      plan_has_grid_root(gp->grid_n0, gp->grid_n1, gp->real_has_grad);
+    const bool grid = fast_grid_root(gp);
     if (env->env_id == GPMPC_ENV_PENDULUM1D)
         return grid ? launch_fast<36, 1, GPMPC_ENV_PENDULUM1D, true>(args, fp, st)
                     : launch_fast<36, 1, GPMPC_ENV_PENDULUM1D, false>(args, fp, st);
