@@ -51,6 +51,7 @@ extern "C" {
 #define GPMPC_INFO_NEG_1x1           0x0040 /* 1x1 covariance negative -> sqrt gives NaN (as gpytorch)      */
 #define GPMPC_INFO_ROOT_EIGH         0x0080 /* y was drawn with the eigendecomposition root (A.7 step 4)    */
 #define GPMPC_INFO_EIGH_NOCONV       0x0100 /* the Jacobi eigensolver hit its sweep limit (result still used) */
+#define GPMPC_INFO_STATE_FULL        0x0200 /* gpmpc_rollout_seeded: the factor state had no room for a new point  */
 
 /* root_mode of gpmpc_joint_sample */
 #define GPMPC_ROOT_AUTO      0   /* gpytorch: Cholesky with the jitter chain; if ANY chain of the batch fails all  */
@@ -159,6 +160,35 @@ int    gpmpc_rollout(const gpmpc_gp_desc_t* gp, const gpmpc_env_desc_t* env, con
                      const double* z, int64_t z_step_stride,
                      double* X_traj, double* Y, double* Xi, int32_t* info,
                      void* ws, size_t ws_bytes, void* stream);
+
+/*
+ * gpmpc_rollout_seeded - gpmpc_rollout whose chains START from given conditioning points and / or keep their factor.
+ * Replaces, in addition to gpmpc_rollout: the reference loop's behaviour that train_hallucinated_dynGP(1) never resets
+ * (a second rollout on the same Agent conditions on the points already there, benchmarking/
+ * simulate_forward_sampling_car.py:118), and the forward sampling of src/agent.py:362-415 (prepare_dynamics_set), which
+ * conditions on real + hallucinated + its own value-only draws.  SURVEY.md section 8b: the "final factor state" output.
+ *   X_h0  [dev] (Ns, g_ny, n_h0, D), Y_h0 [dev] (Ns, g_ny, n_h0, T)   seed points, all T tasks observed (no NaN), or NULL / 0:
+ *         every chain conditions on them (one append-row pass per point) before step 0
+ *   X_v0, Y_v0 (same shapes with n_v0 points) further seed points observed with hall_tasks tasks only (the value-only
+ *         forward-sampling points of src/agent.py:399-405); conditioned on after the full seeds
+ *   state [dev] gpmpc_rollout_state_bytes(gp, Ns, state_slots, state_points) or NULL: per sample the counts, the points and
+ *         per chain L_hr^T, L_hh (packed), w, 1/diag - written by the call (the last step's draw is appended too); with
+ *         resume = 1 the chains continue from it instead of from seeds (same hall_tasks, same state_slots / state_points)
+ *   limits: state_slots <= 256; without a state n_h0*T + hall_tasks*(n_v0 + H-1) <= 256 label slots per chain
+ *   info bit GPMPC_INFO_STATE_FULL: a resumed state had no room left for a new point (the draw itself is still valid)
+ * Runs the generic kernel (csrc/rollout.hip); the tuned kernels serve gpmpc_rollout.
+ */
+size_t gpmpc_rollout_state_bytes(const gpmpc_gp_desc_t* gp, int64_t Ns, int32_t state_slots, int32_t state_points);
+int    gpmpc_rollout_seeded(const gpmpc_gp_desc_t* gp, const gpmpc_env_desc_t* env, const void* plan,
+                            const double* X_r, int32_t mode, int32_t hall_tasks, double var_zero_thr, double beta,
+                            int64_t Ns, int32_t H,
+                            const double* x0, int32_t x0_per_sample, const double* u_ff,
+                            const double* z, int64_t z_step_stride,
+                            double* X_traj, double* Y, double* Xi, int32_t* info,
+                            void* ws, size_t ws_bytes, void* stream,
+                            const double* X_h0, const double* Y_h0, int32_t n_h0,
+                            const double* X_v0, const double* Y_v0, int32_t n_v0,
+                            void* state, int32_t state_slots, int32_t state_points, int32_t resume);
 
 /*
  * gpmpc_joint_sample - joint posterior draw at m test points per (sample, output), conditioning on the shared

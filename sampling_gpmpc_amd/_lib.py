@@ -27,6 +27,7 @@ INFO_VAR_CLAMPED = 0x0020
 INFO_NEG_1x1 = 0x0040
 INFO_ROOT_EIGH = 0x0080
 INFO_EIGH_NOCONV = 0x0100
+INFO_STATE_FULL = 0x0200
 
 ROOT_AUTO, ROOT_EIGH, ROOT_CHOLESKY = 0, 1, 2
 
@@ -56,6 +57,9 @@ SYMBOLS = {
     "gpmpc_rollout_workspace_bytes": (_SZ, [C.POINTER(GpDesc), _I32, _I32, _I64, _I32]),
     "gpmpc_rollout": (C.c_int, [C.POINTER(GpDesc), C.POINTER(EnvDesc), _P, _P, _I32, _I32, _D, _D, _I64, _I32,
                                 _P, _I32, _P, _P, _I64, _P, _P, _P, _P, _P, _SZ, _P]),
+    "gpmpc_rollout_state_bytes": (_SZ, [C.POINTER(GpDesc), _I64, _I32, _I32]),
+    "gpmpc_rollout_seeded": (C.c_int, [C.POINTER(GpDesc), C.POINTER(EnvDesc), _P, _P, _I32, _I32, _D, _D, _I64, _I32,
+                                       _P, _I32, _P, _P, _I64, _P, _P, _P, _P, _P, _SZ, _P, _P, _P, _I32, _P, _P, _I32, _P, _I32, _I32, _I32]),
     "gpmpc_joint_workspace_bytes": (_SZ, [C.POINTER(GpDesc), _I64, _I32, _I32]),
     "gpmpc_joint_sample": (C.c_int, [C.POINTER(GpDesc), _P, _P, _I64, _I32, _P, _P, _P, _I32, _I32, _P, _P,
                                      _D, _D, _I32, _P, _P, _P, _P, _P, _I32, _P, _P, _SZ, _P]),

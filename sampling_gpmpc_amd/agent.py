@@ -397,9 +397,16 @@ class Agent(object):
     # ---------------------------------------------------------------------------------------------------------
     # forward sampling with rejection (reference src/agent.py:331-443)
     # ---------------------------------------------------------------------------------------------------------
-    def prepare_dynamics_set(self, X_soln, U_soln, X_kp1, *, base_samples=None, rng=None):
+    def prepare_dynamics_set(self, X_soln, U_soln, X_kp1, *, base_samples=None, rng=None, fused=None):
         """Propagate every sampled dynamics along the shifted solution, reject the samples that leave the
-        ``ci_list`` tube, replace their hallucinated data by randomly chosen survivors'.
+        ``ci_list`` tube, replace their hallucinated data by randomly chosen survivors' (reference ``src/agent.py:331-443``).
+
+        The first propagation step draws from the model the SQP loop left behind (``self.model_i``, as the reference
+        does); the remaining ``H-2`` steps - each conditioning on real + hallucinated + the value-only draws so far,
+        ``train_forward_sampling_dynGP`` in the reference - run as ONE ``gpmpc_rollout_seeded`` launch when the
+        conditioning set fits the rollout kernel (``fused=None``: decide by size; the per-step path through
+        ``gpmpc_joint_sample`` otherwise, or with ``fused=False``).  The tube test and the survivor bookkeeping are
+        device tensor operations on the rollout's ``X_traj``.
 
         Keyword-only reproducibility hooks (the reference has neither): ``base_samples`` - one ``(Ns, g_ny, 1, T)``
         tensor per propagation step instead of the internal ``randn`` draw; ``rng`` - a ``numpy.random.RandomState``
@@ -421,7 +428,18 @@ class Agent(object):
         xu_hat = torch.tile(xu_init, dims=(n_sample, self.nx, 1, 1))
         rng = np.random if rng is None else rng
         self.rejection_trace = [samples_left.clone()]
-        for i in range(1, X_soln.shape[0] - 1):
+        n_last = X_soln.shape[0] - 2                                            # the loop runs i = 1 .. n_last
+        T = self.in_dim_y
+        n0 = int(self.Hallcinated_X_train.shape[2])
+        from .rollout import seeds_fit
+        can_fuse = (n_last >= 3 and T == 1 + self.in_dim_x and seeds_fit(self, n0, 1, n_last - 1, T, 1)
+                    and not bool(torch.isnan(self.Hallcinated_Y_train).any()))
+        if fused is None:
+            fused = can_fuse
+        elif fused and not can_fuse:
+            raise _lib.GpmpcError("prepare_dynamics_set: the conditioning set does not fit the fused rollout "
+                                  f"({n0} hallucinated points x {T} tasks + {n_last - 1} value-only draws > 256 label slots)")
+        for i in range(1, n_last + 1):
             g_xu_hat = self.env_model.get_g_xu_hat(xu_hat).contiguous()
             z = None if base_samples is None else base_samples[i - 1].to(dev)
             Y_sample = self.model_i(g_xu_hat).sample(z)
@@ -431,12 +449,15 @@ class Agent(object):
             diff = X_soln[i + 1, :, :] - x_next
             samples_left = samples_left * torch.prod(torch.abs(diff) - self.ci_list[i] < 0, dim=1)
             self.rejection_trace.append(samples_left.clone())
-            if i == X_soln.shape[0] - 2:
+            if i == n_last:
                 break
             self.FS_X_train_batch = torch.cat([self.FS_X_train_batch, g_xu_hat], dim=2)
             Y_sample = Y_sample.clone()
             Y_sample[:, :, :, 1:] = float("nan")
             self.FS_Y_train_batch = torch.cat([self.FS_Y_train_batch, Y_sample], dim=2)
+            if fused:
+                samples_left = self._propagate_fused(X_soln, U_soln, x_next, samples_left, base_samples, n_last, dev)
+                break
             self.train_forward_sampling_dynGP()
             xu_hat = torch.cat([torch.stack([x_next] * self.nx, dim=1)[:, :, None, :],
                                 torch.tile(U_soln[[i + 1]], dims=(n_sample, self.nx, 1, 1))], dim=-1)
@@ -452,3 +473,37 @@ class Agent(object):
             self.Hallcinated_Y_train[dead] = self.Hallcinated_Y_train[rng.choice(remaining, n_rep).tolist()]
         self.train_hallucinated_dynGP(sqp_iter=self.params["optimizer"]["SEMPC"]["max_sqp_iter"])
         return
+
+    def _propagate_fused(self, X_soln, U_soln, x_next1, samples_left, base_samples, n_last, dev):
+        """Propagation steps i = 2 .. n_last of ``prepare_dynamics_set`` in one ``gpmpc_rollout_seeded`` launch: the
+        chains condition on the hallucinated points (all tasks), on step 1's value-only draw, and append their own
+        value-only draws (``hall_tasks = 1``, reference ``src/agent.py:399-405``); inputs ``U_soln[i]`` without feedback
+        (``:409-415``), no clip (the reference calls ``.sample()`` directly)."""
+        from .rollout import rollout_device
+        Hf, T = n_last - 1, self.in_dim_y
+        if base_samples is None:
+            z = torch.randn(Hf, self.ns, self.g_ny, 1, T, dtype=F64, device=dev)
+        else:
+            z = torch.stack([base_samples[i - 1].to(dev) for i in range(2, n_last + 1)]).to(F64)
+        z = z.reshape(Hf, -1).contiguous()
+        seeds = (self.Hallcinated_X_train, self.Hallcinated_Y_train) if self.Hallcinated_X_train.shape[2] else None
+        vseeds = (self.FS_X_train_batch, torch.nan_to_num(self.FS_Y_train_batch, nan=0.0))
+        res = rollout_device(self, U_soln[2:2 + Hf].cpu().numpy(), z.reshape(-1), z.shape[1], H=Hf, mode=_lib.MODE_RECONDITIONED,
+                             use_model_without_derivatives=False, use_feedback=False, x0=x_next1, hall_tasks=1,
+                             var_zero_thr=-1.0, beta=float("inf"), seeds=seeds, value_seeds=vseeds)
+        bits = int(res.info.max().item()) if res.info.numel() else 0
+        if bits & _lib.INFO_TRAIN_CHOL_FAIL:
+            from .gp_model import NotPSDError
+            raise NotPSDError("Cholesky of the training covariance failed during forward sampling")
+        for t in range(Hf):
+            i = t + 2
+            diff = X_soln[i + 1, :, :] - res.X_traj[:, :, t + 1]
+            samples_left = samples_left * torch.prod(torch.abs(diff) - self.ci_list[i] < 0, dim=1)
+            self.rejection_trace.append(samples_left.clone())
+        if Hf > 1:                                                  # the draws of steps 2 .. n_last-1 are training points too
+            Xi = res.Xi[:, None, :Hf - 1, :].expand(-1, self.g_ny, -1, -1)
+            Yv = res.Y[:, :, :Hf - 1, :].clone()
+            Yv[..., 1:] = float("nan")
+            self.FS_X_train_batch = torch.cat([self.FS_X_train_batch, Xi], dim=2)
+            self.FS_Y_train_batch = torch.cat([self.FS_Y_train_batch, Yv], dim=2)
+        return samples_left

@@ -53,8 +53,8 @@ __global__ __launch_bounds__(64 * GPMPC_MAX_NY) void rollout_kernel(const Rollou
     const bool recond = (a.mode == GPMPC_MODE_RECONDITIONED);
 
     double* xbuf = smem;                          // [nx][H+1]
-    double* Xh = xbuf + nx * (H + 1);             // [H][D]   GP inputs of every step
-    double* ybuf = Xh + H * D;                    // [2][MAX_NY] value samples, double-buffered over t parity
+    double* Xh = xbuf + nx * (H + 1);             // [max_points][D]   GP inputs of the seed points, then of every step
+    double* ybuf = Xh + a.max_points * D;         // [2][MAX_NY] value samples, double-buffered over t parity
     double* wb = smem + a.lds_shared + (long)wave * a.lds_per_wave;
     double* kr = wb;                              // [T][n_r]
     double* vr = kr + T * n_r;                    // [T][n_r]
@@ -63,7 +63,10 @@ __global__ __launch_bounds__(64 * GPMPC_MAX_NY) void rollout_kernel(const Rollou
     double* yout = invd + nh_max;                 // [H][T]
     double* LinvT_s = yout + H * T;               // [n_r][n_r] staged copy of the plan's L_rr^-1 (transposed), if it fits
     double* w_r = LinvT_s + (a.linv_in_lds ? n_r * n_r : 0);   // [n_r]
-    double* fac = FAC_LDS ? (w_r + n_r) : (a.ws + (s * gp.g_ny + o) * a.ws_chain_stride);
+    // factor storage: LDS, the HBM workspace, or - when the caller keeps the factor state - the state buffer itself
+    double* st_s = a.state ? a.state + s * a.state_stride : nullptr;
+    double* st_c = a.state ? st_s + 4 + (long)a.state_points * D + (long)o * state_chain_doubles(n_r, nh_max) : nullptr;
+    double* fac = FAC_LDS ? (w_r + n_r) : (a.state ? st_c : a.ws + (s * gp.g_ny + o) * a.ws_chain_stride);
     double* LhrT = fac;                           // [n_r][nh_max]   LhrT[i*nh_max + slot] = L_hr[slot][i]
     double* Lhh = fac + (long)n_r * nh_max;       // packed lower, column-major: (slot,p) at col_ofs(p)+slot-p
 
@@ -85,17 +88,46 @@ __global__ __launch_bounds__(64 * GPMPC_MAX_NY) void rollout_kernel(const Rollou
     for (int d = 0; d < nx; ++d) x[d] = a.x0[(a.x0_per_sample ? s * nx : 0) + d];
     int info_acc = 0;
     int n_h = 0;
+    // Label slots are point-major: the n_seed seed points carry all T tasks, the appended points Th tasks each.
+    // (value-only seed points count as appended points: they carry Th tasks like the rollout's own draws)
+    int n_seed = a.resume ? 0 : a.n_h0, n_app = 0;                // seed points / appended points in the factor
+    if (a.resume) {                                               // continue from the exported factor state
+        n_seed = (int)st_s[0];
+        n_app = (int)st_s[1];
+        n_h = n_seed * T + n_app * Th;
+        for (int e = threadIdx.x; e < (n_seed + n_app) * D; e += blockDim.x) Xh[e] = st_s[4 + e];
+        const double* sw = st_c + (long)n_r * nh_max + ((long)nh_max * (nh_max + 1)) / 2;
+        for (int e = lane; e < n_h; e += kWave) {
+            wh[e] = sw[e];
+            invd[e] = sw[nh_max + e];
+        }
+    }
+    const int seed_slots = n_seed * T;
+    const int pt0 = n_seed + n_app + (a.resume ? 0 : a.n_v0);     // point index of rollout step 0
+    const int n_pre = a.resume ? 0 : a.n_h0 + a.n_v0;             // conditioning-only passes before step 0
     __syncthreads();
 
     long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     long long tph = __builtin_readcyclecounter();
-    for (int t = 0; t < H; ++t) {
+    for (int tt = -n_pre; tt < H; ++tt) {
+        const bool seeding = tt < 0;                              // uniform: condition on a given point, draw nothing
+        const int t = seeding ? 0 : tt;
+        const int pt = seeding ? tt + n_pre : pt0 + tt;           // this pass's point
+        const bool seed_full = seeding && pt < a.n_h0;            // seed with all T tasks (else: Th tasks)
         double u[GPMPC_MAX_NU], xi[D];
-        apply_feedback(env, x, a.u_ff + (long)t * nu, u);
-        gp_input(env, x, u, xi);
+        if (seeding) {
+            const double* xs = seed_full ? a.X_h0 + ((s * gp.g_ny + o) * (long)a.n_h0 + pt) * D
+                                         : a.X_v0 + ((s * gp.g_ny + o) * (long)a.n_v0 + (pt - a.n_h0)) * D;
+            for (int d = 0; d < D; ++d) xi[d] = xs[d];
+            for (int i = 0; i < nu; ++i) u[i] = 0.0;
+        } else {
+            apply_feedback(env, x, a.u_ff + (long)t * nu, u);
+            gp_input(env, x, u, xi);
+        }
         if (threadIdx.x == 0) {
-            for (int d = 0; d < nx; ++d) xbuf[d * (H + 1) + t] = x[d];
-            for (int d = 0; d < D; ++d) Xh[t * D + d] = xi[d];
+            if (!seeding)
+                for (int d = 0; d < nx; ++d) xbuf[d * (H + 1) + t] = x[d];
+            for (int d = 0; d < D; ++d) Xh[pt * D + d] = xi[d];
         }
 
         // ---- kernel row block against the real data ------------------------------------------------------
@@ -149,7 +181,16 @@ __global__ __launch_bounds__(64 * GPMPC_MAX_NY) void rollout_kernel(const Rollou
             for (int r = 0; r < RPL; ++r) {
                 const int slot = lane + kWave * r;
                 if (slot < n_h) {
-                    const int j = slot / Th, ah = slot - j * Th;
+                    int j, ah;                                    // point and task of the slot
+                    if (slot < seed_slots) {
+                        j = slot / T;
+                        ah = slot - j * T;
+                    } else {
+                        const int rel = slot - seed_slots;
+                        j = rel / Th;
+                        ah = rel - j * Th;
+                        j += n_seed;
+                    }
                     double q[D];
                     const double k = kern_scalar<D>(Xh + j * D, xi, il2, os, q);
                     double acc[T];
@@ -254,29 +295,43 @@ __global__ __launch_bounds__(64 * GPMPC_MAX_NY) void rollout_kernel(const Rollou
 
         GPMPC_PHASE(4);
         // ---- sample: y = mu + R z, post-processing of sample_gp -------------------------------------------
-        double R[T][T];
-        info_acc |= root_small<T>(S, gp.jitter, R);
-        const double* zt = a.z + (long)t * a.z_step_stride + (s * gp.g_ny + o) * T;
         double y[T];
+        if (seeding) {                                            // the given labels of the seed point
+            const double* ys = seed_full ? a.Y_h0 + ((s * gp.g_ny + o) * (long)a.n_h0 + pt) * T
+                                         : a.Y_v0 + ((s * gp.g_ny + o) * (long)a.n_v0 + (pt - a.n_h0)) * T;
 #pragma unroll
-        for (int b = 0; b < T; ++b) {
-            double acc = 0.0;
+            for (int b = 0; b < T; ++b) y[b] = ys[b];
+        } else {
+            double R[T][T];
+            info_acc |= root_small<T>(S, gp.jitter, R);
+            const double* zt = a.z + (long)t * a.z_step_stride + (s * gp.g_ny + o) * T;
 #pragma unroll
-            for (int c = 0; c <= b; ++c) acc += R[b][c] * zt[c];
-            double yb = acc + mu[b];
-            if (all_zero) yb = mu[b];
-            const double sd = a.beta * sqrt(var[b]);
-            yb = fmax(yb, mu[b] - sd);
-            yb = fmin(yb, mu[b] + sd);
-            y[b] = yb;
+            for (int b = 0; b < T; ++b) {
+                double acc = 0.0;
+#pragma unroll
+                for (int c = 0; c <= b; ++c) acc += R[b][c] * zt[c];
+                double yb = acc + mu[b];
+                if (all_zero) yb = mu[b];
+                const double sd = a.beta * sqrt(var[b]);
+                yb = fmax(yb, mu[b] - sd);
+                yb = fmin(yb, mu[b] + sd);
+                y[b] = yb;
+            }
         }
 
         GPMPC_PHASE(5);
         // ---- append the draw to the chain's own training set (A.9) ----------------------------------------
-        if (recond && t + 1 < H) {
+        // the last step's draw conditions nothing inside this rollout; it is appended only when the factor state is kept
+        const int Tc = seed_full ? T : Th;                        // tasks observed at this pass's point
+        bool do_append = recond && (seeding || t + 1 < H || a.state);
+        if (do_append && n_h + Tc > nh_max) {                     // a resumed state without room for this point
+            info_acc |= GPMPC_INFO_STATE_FULL;
+            do_append = false;
+        }
+        if (do_append) {
             double C[T][T], wn[T];
             bool ok = true;
-            if (Th == T) {
+            if (Tc == T) {
                 double Sn[T][T];
 #pragma unroll
                 for (int b = 0; b < T; ++b)
@@ -299,7 +354,7 @@ __global__ __launch_bounds__(64 * GPMPC_MAX_NY) void rollout_kernel(const Rollou
             if (!ok) info_acc |= GPMPC_INFO_TRAIN_CHOL_FAIL;
             const int base = n_h;
             for (int i = lane; i < n_r; i += kWave)
-                for (int c = 0; c < Th; ++c) LhrT[(long)i * nh_max + base + c] = vr[c * n_r + i];
+                for (int c = 0; c < Tc; ++c) LhrT[(long)i * nh_max + base + c] = vr[c * n_r + i];
 #pragma unroll
             for (int r = 0; r < RPL; ++r) {
                 const int slot = lane + kWave * r;
@@ -307,13 +362,13 @@ __global__ __launch_bounds__(64 * GPMPC_MAX_NY) void rollout_kernel(const Rollou
                     const long co = col_ofs(slot, nh_max) - slot;
 #pragma unroll
                     for (int c = 0; c < T; ++c)
-                        if (c < Th) Lhh[co + base + c] = rhs[r][c];
+                        if (c < Tc) Lhh[co + base + c] = rhs[r][c];
                 }
             }
             if (lane == 0) {
 #pragma unroll
                 for (int c = 0; c < T; ++c) {
-                    if (c < Th) {
+                    if (c < Tc) {
 #pragma unroll
                         for (int e = 0; e < T; ++e)
                             if (e <= c) Lhh[col_ofs(base + e, nh_max) + (c - e)] = C[c][e];
@@ -322,7 +377,12 @@ __global__ __launch_bounds__(64 * GPMPC_MAX_NY) void rollout_kernel(const Rollou
                     }
                 }
             }
-            n_h += Th;
+            n_h += Tc;
+            if (!seed_full) ++n_app;
+        }
+        if (seeding) {                                            // the appended rows are read by other lanes next pass
+            __syncthreads();
+            continue;
         }
 
         GPMPC_PHASE(6);
@@ -351,12 +411,26 @@ __global__ __launch_bounds__(64 * GPMPC_MAX_NY) void rollout_kernel(const Rollou
     if (a.Y)
         for (int e = lane; e < H * T; e += kWave) a.Y[(s * gp.g_ny + o) * H * T + e] = yout[e];
     if (a.Xi)
-        for (int e = threadIdx.x; e < H * D; e += blockDim.x) a.Xi[s * H * D + e] = Xh[e];
+        for (int e = threadIdx.x; e < H * D; e += blockDim.x) a.Xi[s * H * D + e] = Xh[pt0 * D + e];
+    if (a.state) {                                                // export: counts, points, w and 1/diag (the factor is already there)
+        if (threadIdx.x == 0) {
+            st_s[0] = n_seed;
+            st_s[1] = n_app;
+            st_s[2] = Th;
+            st_s[3] = nh_max;
+        }
+        for (int e = threadIdx.x; e < (n_seed + n_app) * D; e += blockDim.x) st_s[4 + e] = Xh[e];
+        double* sw = st_c + (long)n_r * nh_max + ((long)nh_max * (nh_max + 1)) / 2;
+        for (int e = lane; e < n_h; e += kWave) {
+            sw[e] = wh[e];
+            sw[nh_max + e] = invd[e];
+        }
+    }
     if (threadIdx.x == 0) a.info[s] = s_info;
 }
 
 struct RolloutPlan {
-    int nh_max, rpl, lds_shared, lds_per_wave, linv_in_lds;
+    int nh_max, rpl, lds_shared, lds_per_wave, linv_in_lds, max_points;
     long chain_doubles;
     bool fac_lds;
     size_t lds_bytes;
@@ -367,24 +441,28 @@ static bool force_global_factor() {
     return e && e[0] == '1';
 }
 
-static int plan_rollout(const gpmpc_gp_desc_t* gp, int nx, int mode, int hall_tasks, int H, RolloutPlan* rp) {
+static int plan_rollout(const gpmpc_gp_desc_t* gp, int nx, int mode, int hall_tasks, int H, RolloutPlan* rp,
+                        int n_h0 = 0, int n_v0 = 0, int state_slots = 0, int state_points = 0) {
     const int n_r = observed_real_slots(gp);
     const int T = gp->T;
-    int nh_max = (mode == GPMPC_MODE_RECONDITIONED) ? hall_tasks * (H - 1) : 0;
+    int nh_max = (mode == GPMPC_MODE_RECONDITIONED) ? n_h0 * T + hall_tasks * (n_v0 + H - 1) : 0;
+    if (state_slots > 0) nh_max = state_slots;                    // the exported factor's leading dimension
     if (nh_max < 1) nh_max = 1;
+    rp->max_points = (state_slots > 0) ? state_points : n_h0 + n_v0 + H;
     rp->nh_max = nh_max;
     rp->rpl = (nh_max + 63) / 64;
     if (rp->rpl > 4) return fail(GPMPC_E_UNSUPPORTED, "rollout: more than 256 hallucinated label slots per chain");
     if (rp->rpl == 3) rp->rpl = 4;
     rp->chain_doubles = (long)n_r * nh_max + ((long)nh_max * (nh_max + 1)) / 2;
-    rp->lds_shared = nx * (H + 1) + H * gp->D + 2 * GPMPC_MAX_NY;
+    rp->lds_shared = nx * (H + 1) + rp->max_points * gp->D + 2 * GPMPC_MAX_NY;
     rp->lds_shared = (rp->lds_shared + 1) & ~1;
     // stage L_rr^-1 per wave when it leaves room for the rest (n_r <= ~60); otherwise it is read through L2
     rp->linv_in_lds = ((size_t)gp->g_ny * n_r * n_r * sizeof(double) <= 64 * 1024) ? 1 : 0;
     const int vec = 2 * T * n_r + 2 * nh_max + H * T + (rp->linv_in_lds ? n_r * n_r : 0) + n_r;
     const long with_fac = vec + rp->chain_doubles;
     const size_t bytes_fac = ((size_t)rp->lds_shared + (size_t)gp->g_ny * ((with_fac + 1) & ~1L)) * sizeof(double);
-    rp->fac_lds = (mode == GPMPC_MODE_RECONDITIONED) && bytes_fac <= (size_t)(160 * 1024 - 256) && !force_global_factor();
+    rp->fac_lds = (mode == GPMPC_MODE_RECONDITIONED) && bytes_fac <= (size_t)(160 * 1024 - 256) && !force_global_factor() &&
+                  state_slots == 0;                               // a kept factor state lives in the caller's buffer
     rp->lds_per_wave = (int)(((rp->fac_lds ? with_fac : (long)vec) + 1) & ~1L);
     rp->lds_bytes = ((size_t)rp->lds_shared + (size_t)gp->g_ny * rp->lds_per_wave) * sizeof(double);
     if (rp->lds_bytes > (size_t)(160 * 1024 - 256)) return fail(GPMPC_E_UNSUPPORTED, "rollout: horizon too long for LDS vectors");
@@ -431,11 +509,13 @@ size_t gpmpc_rollout_workspace_bytes(const gpmpc_gp_desc_t* gp, int32_t mode, in
     return align_up((size_t)Ns * gp->g_ny * rp.chain_doubles * sizeof(double), 256) + 2048;   // >= the tuned path's need (its zero page included)
 }
 
-int gpmpc_rollout(const gpmpc_gp_desc_t* gp, const gpmpc_env_desc_t* env, const void* plan, const double* X_r,
-                  int32_t mode, int32_t hall_tasks, double var_zero_thr, double beta, int64_t Ns, int32_t H,
-                  const double* x0, int32_t x0_per_sample, const double* u_ff, const double* z,
-                  int64_t z_step_stride, double* X_traj, double* Y, double* Xi, int32_t* info, void* ws,
-                  size_t ws_bytes, void* stream) {
+static int rollout_impl(const gpmpc_gp_desc_t* gp, const gpmpc_env_desc_t* env, const void* plan, const double* X_r,
+                        int32_t mode, int32_t hall_tasks, double var_zero_thr, double beta, int64_t Ns, int32_t H,
+                        const double* x0, int32_t x0_per_sample, const double* u_ff, const double* z,
+                        int64_t z_step_stride, double* X_traj, double* Y, double* Xi, int32_t* info, void* ws,
+                        size_t ws_bytes, void* stream, const double* X_h0, const double* Y_h0, int32_t n_h0,
+                        const double* X_v0, const double* Y_v0, int32_t n_v0, void* state,
+                        int32_t state_slots, int32_t state_points, int32_t resume) {
     if (int rc = check_gp(gp)) return rc;
     if (int rc = check_env(gp, env)) return rc;
     if (!plan || !X_r || !x0 || !u_ff || !z || !X_traj || !info) return fail(GPMPC_E_ARG, "gpmpc_rollout: NULL pointer");
@@ -444,8 +524,18 @@ int gpmpc_rollout(const gpmpc_gp_desc_t* gp, const gpmpc_env_desc_t* env, const 
     if (mode == GPMPC_MODE_RECONDITIONED && !(hall_tasks == gp->T || hall_tasks == 1))
         return fail(GPMPC_E_ARG, "hall_tasks must be T or 1");
     if (mode == GPMPC_MODE_INDEPENDENT) hall_tasks = gp->T;
+    const bool seeded = (n_h0 > 0) || (n_v0 > 0) || state != nullptr;
+    if (n_h0 < 0 || (n_h0 > 0 && (!X_h0 || !Y_h0))) return fail(GPMPC_E_ARG, "gpmpc_rollout_seeded: seed points missing");
+    if (n_v0 < 0 || (n_v0 > 0 && (!X_v0 || !Y_v0))) return fail(GPMPC_E_ARG, "gpmpc_rollout_seeded: value-only seed points missing");
+    if (seeded && mode != GPMPC_MODE_RECONDITIONED) return fail(GPMPC_E_ARG, "seed points / factor state need GPMPC_MODE_RECONDITIONED");
+    if (resume && (!state || n_h0 > 0 || n_v0 > 0)) return fail(GPMPC_E_ARG, "resume needs the factor state and no seed points");
+    if (state) {
+        // capacity: the seeds, what the state may already hold (unknown here when resuming: the caller sized it), H new points
+        if (state_slots < n_h0 * gp->T + hall_tasks * (n_v0 + H) || state_points < n_h0 + n_v0 + H)
+            return fail(GPMPC_E_ARG, "gpmpc_rollout_seeded: factor state too small for the seeds plus H appended points");
+    }
     RolloutPlan rp;
-    if (int rc = plan_rollout(gp, env->nx, mode, hall_tasks, H, &rp)) return rc;
+    if (int rc = plan_rollout(gp, env->nx, mode, hall_tasks, H, &rp, n_h0, n_v0, state ? state_slots : 0, state_points)) return rc;
 
     RolloutArgs args;
     args.gp = make_gp_params(gp);
@@ -473,16 +563,27 @@ int gpmpc_rollout(const gpmpc_gp_desc_t* gp, const gpmpc_env_desc_t* env, const 
     args.lds_shared = rp.lds_shared;
     args.lds_per_wave = rp.lds_per_wave;
     args.linv_in_lds = rp.linv_in_lds;
-    if (mode == GPMPC_MODE_RECONDITIONED && !rp.fac_lds) {
+    args.X_h0 = X_h0;
+    args.Y_h0 = Y_h0;
+    args.n_h0 = n_h0;
+    args.X_v0 = X_v0;
+    args.Y_v0 = Y_v0;
+    args.n_v0 = n_v0;
+    args.state = (double*)state;
+    args.state_points = state_points;
+    args.state_stride = state ? state_sample_doubles(gp->g_ny, observed_real_slots(gp), state_slots, state_points, gp->D) : 0;
+    args.resume = resume;
+    args.max_points = rp.max_points;
+    if (mode == GPMPC_MODE_RECONDITIONED && !rp.fac_lds && !state) {
         const size_t need = (size_t)Ns * gp->g_ny * rp.chain_doubles * sizeof(double);
         if (!ws || ws_bytes < need) return fail(GPMPC_E_WORKSPACE, "gpmpc_rollout: workspace too small");
     }
     hipStream_t st = (hipStream_t)stream;
-    if (rollout_fast_eligible(gp, env, mode, hall_tasks, H)) {
+    if (!seeded && rollout_fast_eligible(gp, env, mode, hall_tasks, H)) {
         g_last_rollout_path = 1;
         return rollout_fast_launch(gp, env, args, ws, ws_bytes, st);
     }
-    if (rollout_indep_eligible(gp, env, mode)) {
+    if (!seeded && rollout_indep_eligible(gp, env, mode)) {
         g_last_rollout_path = 2;
         return rollout_indep_launch(gp, env, args, st);
     }
@@ -498,6 +599,34 @@ int gpmpc_rollout(const gpmpc_gp_desc_t* gp, const gpmpc_env_desc_t* env, const 
         return launch_rollout<3, 4>(args, rp, gp->g_ny, st);
     }
     return fail(GPMPC_E_UNSUPPORTED, "rollout: only T = 1 and T = 3 (D = 2) are instantiated");
+}
+
+int gpmpc_rollout(const gpmpc_gp_desc_t* gp, const gpmpc_env_desc_t* env, const void* plan, const double* X_r,
+                  int32_t mode, int32_t hall_tasks, double var_zero_thr, double beta, int64_t Ns, int32_t H,
+                  const double* x0, int32_t x0_per_sample, const double* u_ff, const double* z,
+                  int64_t z_step_stride, double* X_traj, double* Y, double* Xi, int32_t* info, void* ws,
+                  size_t ws_bytes, void* stream) {
+    return rollout_impl(gp, env, plan, X_r, mode, hall_tasks, var_zero_thr, beta, Ns, H, x0, x0_per_sample, u_ff, z,
+                        z_step_stride, X_traj, Y, Xi, info, ws, ws_bytes, stream, nullptr, nullptr, 0, nullptr, nullptr, 0,
+                        nullptr, 0, 0, 0);
+}
+
+size_t gpmpc_rollout_state_bytes(const gpmpc_gp_desc_t* gp, int64_t Ns, int32_t state_slots, int32_t state_points) {
+    if (check_gp(gp) != GPMPC_OK || state_slots < 1 || state_slots > 256 || state_points < 1) return 0;
+    return align_up((size_t)Ns * state_sample_doubles(gp->g_ny, observed_real_slots(gp), state_slots, state_points, gp->D) *
+                        sizeof(double), 256);
+}
+
+int gpmpc_rollout_seeded(const gpmpc_gp_desc_t* gp, const gpmpc_env_desc_t* env, const void* plan, const double* X_r,
+                         int32_t mode, int32_t hall_tasks, double var_zero_thr, double beta, int64_t Ns, int32_t H,
+                         const double* x0, int32_t x0_per_sample, const double* u_ff, const double* z,
+                         int64_t z_step_stride, double* X_traj, double* Y, double* Xi, int32_t* info, void* ws,
+                         size_t ws_bytes, void* stream, const double* X_h0, const double* Y_h0, int32_t n_h0,
+                         const double* X_v0, const double* Y_v0, int32_t n_v0, void* state,
+                         int32_t state_slots, int32_t state_points, int32_t resume) {
+    return rollout_impl(gp, env, plan, X_r, mode, hall_tasks, var_zero_thr, beta, Ns, H, x0, x0_per_sample, u_ff, z,
+                        z_step_stride, X_traj, Y, Xi, info, ws, ws_bytes, stream, X_h0, Y_h0, n_h0, X_v0, Y_v0, n_v0, state,
+                        state_slots, state_points, resume);
 }
 
 }  // extern "C"

@@ -28,7 +28,27 @@ struct RolloutArgs {
     int lds_shared;         // doubles of block-shared LDS
     int lds_per_wave;       // doubles of per-wave LDS
     int linv_in_lds;        // generic kernel: L_rr^-1 staged per wave in LDS (else read from the plan in HBM/L2)
+    // generic kernel only: conditioning points the chains start from, and the exported / resumed factor state
+    const double* X_h0;     // (Ns, g_ny, n_h0, D) seed points, all T tasks observed (NULL: none)
+    const double* Y_h0;     // (Ns, g_ny, n_h0, T)
+    int n_h0;
+    const double* X_v0;     // (Ns, g_ny, n_v0, D) further seed points observed with hall_tasks tasks (value-only when 1)
+    const double* Y_v0;     // (Ns, g_ny, n_v0, T): the first hall_tasks entries of a row are used
+    int n_v0;
+    double* state;          // per-sample factor state (gpmpc_rollout_state_bytes), NULL: not kept
+    long state_stride;      // doubles per sample
+    int state_points;       // point capacity of the state
+    int resume;             // 1: the chains continue from `state` (no seeds)
+    int max_points;         // capacity of the LDS point list (seed + resumed + H)
 };
+
+// factor state of one sample: [header 4 | points state_points x D | per chain: LhrT n_r x slots | L_hh packed | w | 1/diag]
+__host__ __device__ __forceinline__ long state_chain_doubles(int n_r, int slots) {
+    return (long)n_r * slots + ((long)slots * (slots + 1)) / 2 + 2L * slots;
+}
+__host__ __device__ __forceinline__ long state_sample_doubles(int g_ny, int n_r, int slots, int points, int D) {
+    return 4 + (long)points * D + (long)g_ny * state_chain_doubles(n_r, slots);
+}
 
 // packed lower-triangular, column-major: element (row, col) at col_ofs(col) + row - col, rows col..nh_max-1
 __host__ __device__ __forceinline__ long col_ofs(int p, int nh_max) { return (long)p * nh_max - ((long)p * (p - 1)) / 2; }

@@ -36,9 +36,16 @@ class RolloutResult:
 def rollout_device(agent: Agent, u_ff, z: torch.Tensor, z_step_stride: int, *, H: int, mode: int,
                    use_model_without_derivatives: bool, use_feedback: Optional[bool] = None,
                    x0=None, hall_tasks: Optional[int] = None, var_zero_thr: Optional[float] = None,
-                   beta: Optional[float] = None, want_samples: bool = True, sample_slice=None) -> RolloutResult:
+                   beta: Optional[float] = None, want_samples: bool = True, sample_slice=None,
+                   seeds=None, value_seeds=None, state: Optional["RolloutState"] = None,
+                   resume: bool = False) -> RolloutResult:
     """Launch ``gpmpc_rollout`` for the samples of ``agent`` (or a contiguous ``sample_slice`` of them) and return
-    device tensors.  ``z`` element (t, s, o, b) is read at ``z[t*z_step_stride + ((s*g_ny)+o)*T + b]``."""
+    device tensors.  ``z`` element (t, s, o, b) is read at ``z[t*z_step_stride + ((s*g_ny)+o)*T + b]``.
+
+    ``seeds = (X (Ns, g_ny, n, D), Y (Ns, g_ny, n, T))``: points every chain conditions on before step 0 (all tasks
+    observed); ``value_seeds``: the same with only the first ``hall_tasks`` label entries observed; ``state``: a
+    ``RolloutState`` that receives the chains' factor (and, with ``resume``, provides it) - these go through
+    ``gpmpc_rollout_seeded``."""
     lib = _lib.load()
     dev = _lib.require_hip_device(agent.torch_device)
     p = agent.params
@@ -73,13 +80,62 @@ def rollout_device(agent: Agent, u_ff, z: torch.Tensor, z_step_stride: int, *, H
         agent._ws_cache["rollout"] = ws
     assert z.is_cuda and z.dtype == F64
     z_ptr = z.data_ptr() + 8 * lo * g_ny * T
-    rc = lib.gpmpc_rollout(plan.desc, agent.env_desc(use_feedback), _lib.dptr(plan.buf), _lib.dptr(plan.X_r),
-                           mode, hall_tasks, float(var_zero_thr), float(beta), Ns, H,
-                           _lib.dptr(x0_d), per_sample, _lib.dptr(u_ff_d), z_ptr, int(z_step_stride),
-                           _lib.dptr(X_traj), _lib.dptr(Y), _lib.dptr(Xi), _lib.dptr(info),
-                           _lib.dptr(ws), ws.numel() * 8, _lib.current_stream_ptr())
-    _lib.check(rc, "gpmpc_rollout")
+    common = (plan.desc, agent.env_desc(use_feedback), _lib.dptr(plan.buf), _lib.dptr(plan.X_r),
+              mode, hall_tasks, float(var_zero_thr), float(beta), Ns, H,
+              _lib.dptr(x0_d), per_sample, _lib.dptr(u_ff_d), z_ptr, int(z_step_stride),
+              _lib.dptr(X_traj), _lib.dptr(Y), _lib.dptr(Xi), _lib.dptr(info),
+              _lib.dptr(ws), ws.numel() * 8, _lib.current_stream_ptr())
+    if seeds is None and value_seeds is None and state is None:
+        _lib.check(lib.gpmpc_rollout(*common), "gpmpc_rollout")
+        return RolloutResult(X_traj, Y, Xi, info)
+
+    def prep(pair, last):
+        if pair is None:
+            return None, None, 0
+        X_, Y_ = (t.to(device=dev, dtype=F64)[lo:hi].contiguous() for t in pair)
+        if X_.shape[:2] != (Ns, g_ny) or Y_.shape[:3] != X_.shape[:3] or X_.shape[3] != D or Y_.shape[3] != last:
+            raise ValueError("seed points must be (Ns, g_ny, n, D) / (Ns, g_ny, n, T)")
+        if bool(torch.isnan(Y_[..., :last if pair is seeds else hall_tasks]).any()):
+            raise ValueError("seed labels must be observed (no NaN): NaN-masked points need the joint kernel")
+        return X_, Y_, int(X_.shape[2])
+    Xs, Ys, n0 = prep(seeds, T)
+    Xv, Yv, nv = prep(value_seeds, T)
+    if sample_slice is not None and state is not None:
+        raise ValueError("a factor state covers all samples of the agent")
+    rc = lib.gpmpc_rollout_seeded(*common, _lib.dptr(Xs), _lib.dptr(Ys), n0, _lib.dptr(Xv), _lib.dptr(Yv), nv,
+                                  _lib.dptr(state.buf) if state is not None else None,
+                                  state.slots if state is not None else 0, state.points if state is not None else 0,
+                                  int(bool(resume)))
+    _lib.check(rc, "gpmpc_rollout_seeded")
     return RolloutResult(X_traj, Y, Xi, info)
+
+
+class RolloutState:
+    """The chains' factor after a rollout (``gpmpc_rollout_seeded``: per sample the point list and per chain
+    ``L_hr^T``, ``L_hh``, ``w``, ``1/diag``), so that a later rollout continues without re-factorising.
+    ``slots`` / ``points``: label-slot and point capacity per chain (slots <= 256)."""
+
+    def __init__(self, agent: Agent, slots: int, points: int, use_model_without_derivatives: bool = False):
+        lib = _lib.load()
+        dev = _lib.require_hip_device(agent.torch_device)
+        plan = agent._plan(use_grad=not use_model_without_derivatives)
+        self.slots, self.points, self.Ns = int(slots), int(points), agent.ns
+        nbytes = lib.gpmpc_rollout_state_bytes(plan.desc, agent.ns, self.slots, self.points)
+        if nbytes == 0:
+            raise _lib.GpmpcError("gpmpc_rollout_state_bytes: unsupported size (slots must be 1..256)")
+        self.buf = torch.zeros(nbytes // 8, dtype=F64, device=dev)
+        self._stride = (nbytes // 8) // agent.ns if agent.ns else 0
+
+    def counts(self):
+        """(seed points, appended points) per sample, read back from the device (uniform over samples)."""
+        return int(self.buf[0].item()), int(self.buf[1].item())
+
+
+MAX_ROLLOUT_SLOTS = 256          # generic kernel: label slots per chain (include/gpmpc_hip.h)
+
+
+def seeds_fit(agent: Agent, n_seed_points: int, n_value_points: int, H: int, T: int, hall_tasks: int) -> bool:
+    return n_seed_points * T + hall_tasks * (n_value_points + H - 1) <= MAX_ROLLOUT_SLOTS
 
 
 def fused_rollout_supported(agent: Agent) -> bool:
@@ -140,11 +196,16 @@ def forward_sampling_rollout(agent: Agent, u_ff, x0=None, return_samples: bool =
     if not fused_rollout_supported(agent):
         return forward_sampling_stepwise(agent, u_ff, x0=x0, return_samples=return_samples)
     nograd_ = bool(p["env"]["use_model_without_derivatives"])
+    seeds = None
     if agent.Hallcinated_X_train.shape[2] != 0 and not nograd_:
         # The reference loop's train_hallucinated_dynGP(1) never resets: a second call on the same agent (or a call after
-        # closed-loop iterations) conditions on the points already there.  The fused kernel starts every chain from the
-        # real data only, so such calls go through the per-step harness, which does condition on them.
-        return forward_sampling_stepwise(agent, u_ff, x0=x0, return_samples=return_samples)
+        # closed-loop iterations) conditions on the points already there.  They seed the chains' factor
+        # (gpmpc_rollout_seeded) when they fit and are fully observed; otherwise the per-step harness conditions on them.
+        n0 = agent.Hallcinated_X_train.shape[2]
+        if (not seeds_fit(agent, n0, 0, H, 1 + agent.in_dim_x, 1 + agent.in_dim_x)
+                or bool(torch.isnan(agent.Hallcinated_Y_train).any())):
+            return forward_sampling_stepwise(agent, u_ff, x0=x0, return_samples=return_samples)
+        seeds = (agent.Hallcinated_X_train, agent.Hallcinated_Y_train)
     if p["optimizer"]["H"] != 1 or erv.shape[0] < H or erv.shape[1] < 2:
         raise ValueError("forward sampling needs optimizer.H == 1, num_MPC_itrs >= H_traj and max_sqp_iter >= 2 "
                          "(reference simulate_forward_sampling_car.py indexes epistimic_random_vector[H_idx][1])")
@@ -156,7 +217,7 @@ def forward_sampling_rollout(agent: Agent, u_ff, x0=None, return_samples: bool =
     per_slab = agent.ns * agent.g_ny * 1 * T
     z = erv.reshape(-1)[per_slab:]                       # starts at [0][1]
     res = rollout_device(agent, u_ff, z, n_itrs * per_slab, H=H, mode=mode,
-                         use_model_without_derivatives=nograd, x0=x0)
+                         use_model_without_derivatives=nograd, x0=x0, seeds=seeds)
     if check:
         _raise_on_info(res.info)
     # dataset side effect of the reference loop (appended at every step, also in mode I where it is never used)

@@ -766,10 +766,13 @@ def test_forward_sampling_with_min_data_dist(sg, pname, min_dist):
     np.testing.assert_allclose(hy[~nan], hyo[~nano], rtol=1e-5, atol=1e-9)
 
 
-def test_prepare_dynamics_set_against_oracle(sg):
+@pytest.mark.parametrize("fused", [True, False])
+def test_prepare_dynamics_set_against_oracle(sg, fused):
     """Forward sampling with rejection (reference src/agent.py:331-443): the GP is re-trained on real + forward-sampled
     (value-only labels) + hallucinated data at every step, samples leaving the tube are rejected and their
-    hallucinated data replaced by survivors'.  Same base samples and the same RandomState on both sides."""
+    hallucinated data replaced by survivors'.  Same base samples and the same RandomState on both sides.
+    fused: steps 2.. in ONE gpmpc_rollout_seeded launch (hallucinated points as seeds, value-only draws appended);
+    otherwise one gpmpc_joint_sample per step."""
     Ns, H = 10, 6
     p = load_params("params_pendulum1D_samples")
     p["agent"]["num_dyn_samples"], p["optimizer"]["H"] = Ns, H
@@ -796,7 +799,7 @@ def test_prepare_dynamics_set_against_oracle(sg):
     for ag in (agent, oagent):
         ag.ci_list = [1e9] * (H + 1)
     # step 1: everything survives (huge tube); now tighten the tube of step 2 around the median sampled state
-    agent.prepare_dynamics_set(X_soln.clone(), U_soln, X_kp1, base_samples=z, rng=np.random.RandomState(5))
+    agent.prepare_dynamics_set(X_soln.clone(), U_soln, X_kp1, base_samples=z, rng=np.random.RandomState(5), fused=fused)
     oagent.prepare_dynamics_set(X_soln.clone(), U_soln, X_kp1, base_samples=z, rng=np.random.RandomState(5))
     np.testing.assert_allclose(agent.FS_X_train_batch.cpu().numpy(), oagent.FS_X_train_batch.numpy(), rtol=1e-8, atol=1e-10)
     fy, fyo = agent.FS_Y_train_batch.cpu().numpy(), oagent.FS_Y_train_batch.numpy()
@@ -817,7 +820,7 @@ def test_prepare_dynamics_set_against_oracle(sg):
         ag.ci_list[2] = torch.tensor([tol, 1e9], dtype=F64, device=dev)      # tube on theta only at that step
         ag.train_hallucinated_dynGP(1)
     hx_before = oagent.Hallcinated_X_train.clone()
-    agent.prepare_dynamics_set(X_soln2.clone(), U_soln, X_kp1, base_samples=z, rng=np.random.RandomState(7))
+    agent.prepare_dynamics_set(X_soln2.clone(), U_soln, X_kp1, base_samples=z, rng=np.random.RandomState(7), fused=fused)
     oagent.prepare_dynamics_set(X_soln2.clone(), U_soln, X_kp1, base_samples=z, rng=np.random.RandomState(7))
     left = oagent.rejection_trace[-1].numpy()
     assert 0 < left.sum() < Ns, f"the tube should split the samples, survivors: {left}"
@@ -893,3 +896,39 @@ def test_second_fused_rollout_conditions_on_existing_points(sg):
     assert relerr(X2, Xo2) < RTOL_TRAJ
     assert relerr(X2, X1) > 1e-6
     assert agent.Hallcinated_X_train.shape[2] == 12
+
+
+@pytest.mark.parametrize("pname", ["params_pendulum1D_samples", "params_car_residual_fs"])
+def test_rollout_factor_state_export_and_resume(sg, pname):
+    """SURVEY.md 8b "final factor state": a rollout keeps its chains' factor (gpmpc_rollout_seeded, state), a second call
+    resumes from it - the two tubes together equal ONE rollout over the whole horizon (oracle), nothing is re-factorised."""
+    from sampling_gpmpc_amd.rollout import RolloutState, rollout_device
+    Ns, H1, H2 = 5, 6, 4
+    H = H1 + H2
+    p = fs_params(pname, Ns, H, nograd=False, beta=(3.0 if "car" in pname else None))
+    agent, oagent = make_agents(sg, p)
+    u_ff = synthetic_u_ff(agent.nu, H)
+    Xo, Yo = ao.forward_sampling_rollout(oagent, u_ff, return_samples=True)
+    erv = agent.epistimic_random_vector.to(agent.torch_device).contiguous()
+    T = 3
+    per = Ns * agent.g_ny * T
+    z = erv.reshape(-1)[per:]
+    stride = erv.shape[1] * per
+    state = RolloutState(agent, slots=T * H, points=H)
+    r1 = rollout_device(agent, u_ff[:H1], z, stride, H=H1, mode=sg._lib.MODE_RECONDITIONED,
+                        use_model_without_derivatives=False, state=state)
+    assert state.counts() == (0, H1)                               # the last draw is in the factor too
+    x_mid = r1.X_traj[:, :, H1].contiguous()
+    r2 = rollout_device(agent, u_ff[H1:], z[H1 * stride:], stride, H=H2, mode=sg._lib.MODE_RECONDITIONED,
+                        use_model_without_derivatives=False, x0=x_mid, state=state, resume=True)
+    assert state.counts() == (0, H)
+    X = torch.cat([r1.X_traj, r2.X_traj[:, :, 1:]], dim=2).cpu().numpy()
+    Y = torch.cat([r1.Y, r2.Y], dim=2).cpu().numpy()
+    print(f"{pname}: resumed rollout vs one {H}-step rollout: rel err X {relerr(X, Xo):.2e}, Y {relerr(Y, Yo):.2e}")
+    assert relerr(X, Xo) < RTOL_TRAJ
+    np.testing.assert_allclose(Y, Yo, rtol=1e-4, atol=1e-8)
+    assert not int(r2.info.max().item()) & sg._lib.INFO_STATE_FULL
+    # a third call has no room left: the draw is still produced, the info bit says the factor was not extended
+    r3 = rollout_device(agent, u_ff[:1], z, stride, H=1, mode=sg._lib.MODE_RECONDITIONED,
+                        use_model_without_derivatives=False, x0=x_mid, state=state, resume=True)
+    assert int(r3.info.max().item()) & sg._lib.INFO_STATE_FULL and torch.isfinite(r3.X_traj).all()
