@@ -223,16 +223,17 @@ def test_rollout_sample_subset_invariance_full_size(sg):
 
 
 @pytest.mark.parametrize("pname,Ns,H,nograd", [("params_car_residual_fs", 262144, 40, True),     # BASELINE configs[3] as shipped
-                                               ("params_car_residual_fs", 4096, 40, False)])     # configs[2]
+                                               ("params_car_residual_fs", 4096, 40, False),      # configs[2]
+                                               ("params_car_residual_fs", 262144, 40, False)])   # configs[3] re-conditioned (T=3)
 def test_car_rollout_full_size_properties(sg, pname, Ns, H, nograd):
     """BASELINE full sizes of the car workloads (mode I, Ns=262144: the true-reachable-set launch of one GPU; mode R,
-    Ns=4096): finite, error-free info words, every sample independent of what else is in the launch (bit-exact on
+    Ns=4096; mode R at Ns=262144 - SURVEY cfg4's re-conditioned variant, 786432 chains, a 44 GB factor workspace): finite, error-free info words, every sample independent of what else is in the launch (bit-exact on
     re-launched subsets, incl. one that straddles workgroups and the ragged last one) and a 12-sample subset equal to
     the oracle."""
     from sampling_gpmpc_amd.rollout import rollout_device
     from sampling_gpmpc_amd import _lib
     p = fs_params(pname, Ns, H, nograd=nograd, beta=(None if nograd else 3.0))
-    p["agent"]["base_sample_generator"] = "vectorized"
+    p["agent"]["base_sample_generator"] = "vectorized" if Ns * (1 if nograd else 3) < 500000 else "counter"   # counter: on the device
     torch.manual_seed(11)
     pg = {**p, "common": {**p["common"], "use_cuda": True}}
     agent = sg.Agent(pg, sg.make_env(pg))
@@ -497,6 +498,29 @@ def test_sharded_rollout_single_rank_rccl(sg):
     dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
     try:
         tube = sharded_forward_sampling_rollout(agent, u_ff)
+        # the pipelined form bench.py runs for N > 1: rollout r+1 on the launch stream, the all-gather of r on a side
+        # stream, alternating buffers - five rollouts with different input sequences, every tube checked afterwards
+        from sampling_gpmpc_amd.distributed import OverlappedTubeGather
+        from sampling_gpmpc_amd.rollout import RolloutRunner
+        erv = agent.epistimic_random_vector.to(agent.torch_device).contiguous()
+        per = Ns * 3
+        runners = [RolloutRunner(agent, u_ff * (1.0 + 0.1 * r), erv.reshape(-1)[per:], erv.shape[1] * per, H,
+                                 sg._lib.MODE_RECONDITIONED, False) for r in range(5)]
+        pipe = OverlappedTubeGather(Ns, agent.nx, H)
+        tubes = []
+        for r, rn in enumerate(runners):
+            pipe.before_rollout(r)
+            rn.launch(out=pipe.buffer(r))
+            pipe.submit(r)
+            if r >= 1:                                           # consume tube r-1 while rollout r / gather r are in flight
+                pipe.wait(r - 1)
+                tubes.append(pipe.tube(r - 1).clone())
+        pipe.finish()
+        tubes.append(pipe.tube(len(runners) - 1).clone())
+        for r, rn in enumerate(runners):
+            ref = rn.launch().clone()
+            torch.cuda.synchronize()
+            assert torch.equal(tubes[r], ref), r
     finally:
         dist.destroy_process_group()
     X = forward_sampling_rollout(agent, u_ff)
