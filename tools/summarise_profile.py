@@ -9,7 +9,8 @@ import sys
 src, tag = sys.argv[1], sys.argv[2]
 dst = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles")
 os.makedirs(dst, exist_ok=True)
-lines = [f"# rocprofv3 summary `{tag}` (bench.py --steps 20 --warmup 3 --cpu-sample 0, MI355X gfx950)", ""]
+lines = [f"# rocprofv3 summary `{tag}` (kernel trace: `python bench.py --cpu-sample 0`; PMC passes: the headline workload "
+         f"only, `--steps 20 --warmup 3 --no-extra --reach-ns 0`; MI355X gfx950)", ""]
 ks = os.path.join(src, "trace", "trace_kernel_stats.csv")
 shutil.copy(ks, os.path.join(dst, f"{tag}_kernel_stats.csv"))
 lines += ["## kernel trace (--kernel-trace --stats)", "", "| kernel | calls | avg ns | min ns | max ns | % |", "|---|---|---|---|---|---|"]
