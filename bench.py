@@ -266,11 +266,19 @@ def main():
         raise SystemExit("bench.py needs a HIP device (no CPU fallback for the product path)")
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    # GPMPC_BENCH_FORCE_DIST=1: take the N > 1 code path (process group, per-shard base samples, pipelined all-gather) with a
+    # world of ONE rank - lets the multi-GPU path be exercised on a 1-GPU box (tests / smoke runs; not a scaling number)
+    force_dist = os.environ.get("GPMPC_BENCH_FORCE_DIST") == "1"
+    if world > 1 or force_dist:
         import torch.distributed as dist_
         dist = dist_
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29541")
+        if force_dist and world == 1:
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    multi = dist is not None
 
     import sampling_gpmpc_amd as sg
     from sampling_gpmpc_amd import _lib, workloads as wl
@@ -288,7 +296,7 @@ def main():
     per_slab = Ns * 3
     z = erv.reshape(-1)[per_slab:]
     runner = RolloutRunner(agent, u_ff, z, erv.shape[1] * per_slab, H, _lib.MODE_RECONDITIONED, False)
-    pipe = OverlappedTubeGather(Ns, agent.nx, H) if world > 1 else None
+    pipe = OverlappedTubeGather(Ns, agent.nx, H) if multi else None
 
     def run_steps(n, r0=0):
         """n steps; for N > 1: rollout r on the launch stream, its all-gather on the side stream (overlaps rollout r+1)"""
@@ -303,7 +311,7 @@ def main():
         pipe.finish()
 
     def fence():
-        if world > 1:
+        if multi:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -313,7 +321,7 @@ def main():
         run_steps(n)
         fence()
         wall = time.perf_counter() - t0
-        if world > 1:
+        if multi:
             t = torch.tensor([wall], dtype=torch.float64, device="cuda")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             wall = float(t.item())
@@ -333,9 +341,9 @@ def main():
     kern_ms_pairs, _ = time_launches(runner.launch, a.steps)
     # a launch cannot take longer than a step of the (un-instrumented) timed region it is part of: at N = 1 the region per
     # step is kernel + launch gap, and the event pairs of the second pass add a few microseconds of their own
-    kern_ms = min(kern_ms_pairs, wall / a.steps * 1e3) if world == 1 else kern_ms_pairs
+    kern_ms = min(kern_ms_pairs, wall / a.steps * 1e3) if not multi else kern_ms_pairs
     gather = None
-    if world > 1:
+    if multi:
         tube = pipe.tube(0)
         for _ in range(20):
             dist.all_gather_into_tensor(tube, pipe.buffer(0))
@@ -348,7 +356,8 @@ def main():
     bits = int(runner.info.max().item())
     assert torch.isfinite(X_last).all() and not (bits & (_lib.INFO_TRAIN_CHOL_FAIL | _lib.INFO_ROOT_FAIL)), bits
 
-    reach = reachable_set_leg(a, rank, world, dist, sg, _lib, RolloutRunner, wl)
+    reach = reachable_set_leg(a, rank, world if not (force_dist and world == 1) else 1, dist if world > 1 else None, sg, _lib,
+                              RolloutRunner, wl)
 
     if rank == 0:
         name, cus, _ = _lib.device_info(local_rank)
@@ -417,7 +426,7 @@ def main():
                     extra.append({"workload": fn.__name__, "error": repr(e)[:300]})
             out["extra"] = extra
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if multi:
         dist.barrier()
         dist.destroy_process_group()
 

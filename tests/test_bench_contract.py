@@ -1,0 +1,46 @@
+"""GPU: bench.py prints ONE JSON line with the driver's contract keys, the roofline and cpu_baseline objects; with
+GPMPC_BENCH_FORCE_DIST=1 the N > 1 code path (process group, per-shard base samples, pipelined all-gather) runs with a
+world of one rank."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+from tests.helpers import REPO
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(extra_env=None, args=()):
+    env = dict(os.environ)
+    env.update(extra_env or {})
+    out = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--steps", "5", "--warmup", "2", "--prewarm", "20",
+                          "--cpu-sample", "16", "--reach-ns", "512", *args], capture_output=True, text=True, env=env, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def test_bench_line_contract():
+    d = _run(args=("--no-extra",))
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline", "cold"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 5 and d["dtype"] == "f64" and d["scaling"] == "weak" and d["vs_baseline"] is None
+    assert "workload" in d["config"] and "model" not in d["config"]
+    r = d["roofline"]
+    assert r["bound"] == "fp64_valu" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12 and r["kernel_ms"] > 0
+    c = d["cpu_baseline"]
+    assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0
+    assert d["value"] > 1e6 and d["cold"]["ms_per_step"] > 0
+    assert d["reachable_set"]["finite"] and "roofline" in d["reachable_set"]
+
+
+def test_bench_multi_gpu_path_with_one_rank():
+    d = _run({"GPMPC_BENCH_FORCE_DIST": "1", "MASTER_PORT": "29547"}, args=("--no-extra", "--cpu-sample", "0"))
+    g = d["gather"]
+    assert g is not None and g["overlapped_with_next_rollout"] and g["standalone_ms"] > 0 and g["bytes_per_rank"] == 1024 * 2 * 31 * 8
+    assert d["value"] > 1e6
