@@ -205,3 +205,40 @@ def test_config5_shard_as_shipped(sg):
             osmall.Hallcinated_Y_train = small.Hallcinated_Y_train.cpu()
             mean_next = gp_val[:, :, :, 0].mean(axis=0).T
             x_h = np.tile(np.vstack([x0[None, :], mean_next[:-1]]), (1, Ns))
+
+
+def test_eigh_root_value_only_model_rank_one(sg):
+    """T = 1 (env.use_model_without_derivatives) joint draw whose test points all coincide - what iteration 0 of the closed
+    loop looks like: the posterior covariance has rank ONE, every Cholesky attempt fails at the second pivot, the eigh root
+    is a single column.  Exercises joint_eigh_kernel<1, *> and the smallest Jacobi (r = 1, padded to 2)."""
+    from tests.helpers import fs_params
+    Ns, H = 5, 20
+    p = fs_params("params_car_residual_fs", Ns, 1, nograd=True)
+    p["optimizer"]["H"] = H
+    p["common"]["num_MPC_itrs"], p["optimizer"]["SEMPC"]["max_sqp_iter"] = 1, 1
+    p["agent"]["Dyn_gp_jitter"] = 1e-20
+    agent, oagent = make_agents(sg, p)
+    agent.debug_keep_root = True
+    x_h = np.tile(np.array(p["env"]["start"], dtype=np.float64), (H, Ns))
+    u_h = np.zeros((H, 2))
+    for a in (agent, oagent):
+        a.train_hallucinated_dynGP(0, use_model_without_derivatives=True)
+    # whether the second pivot of the rank-one matrix comes out as +-1 ulp is a round-off coin flip (LAPACK: eigh branch;
+    # the kernel's Cholesky may pass its first retry): the eigh root is requested explicitly on the HIP side
+    post = agent.model_i(agent.env_model.get_g_xu_hat(agent.get_batch_x_hat(x_h, u_h)).contiguous())
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        y, _ = post._run(agent.epistimic_random_vector[0][0], clip=True, beta=p["agent"]["Dyn_gp_beta"],
+                         want_root=True, root_mode=sg._lib.ROOT_EIGH)
+    yo = oagent.sample_gp(oagent.env_model.get_g_xu_hat(oagent.get_batch_x_hat(x_h, u_h)),
+                          base_samples=oagent.epistimic_random_vector[0][0])
+    opost = oagent.model_i_call
+    assert opost.root_info.used_eigh and (post.last_info.cpu().numpy() & sg._lib.INFO_ROOT_EIGH).all()
+    R = post.root.cpu()
+    rank = int((R.abs().amax(dim=-2) > 0).sum(dim=-1).max())
+    ysa, Ro = _sign_aligned_oracle_sample(opost, R, oagent.epistimic_random_vector[0][0], p["agent"]["Dyn_gp_beta"])
+    err = float((y.cpu() - ysa).abs().max())
+    print(f"value-only rank-one joint draw: rank {rank}, sample err {err:.2e} (max|y| {float(ysa.abs().max()):.2e})")
+    assert rank <= 2
+    np.testing.assert_allclose(post.mean.cpu().numpy(), opost.mean.numpy(), rtol=1e-6, atol=1e-10)
+    assert err < 1e-6 * float(ysa.abs().max()) + 1e-9
