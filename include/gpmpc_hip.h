@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define GPMPC_ABI_VERSION 3
+#define GPMPC_ABI_VERSION 4
 
 #define GPMPC_MAX_NY 4   /* GP outputs            (reference agent.g_dim.ny : 1 pendulum1D, 3 car)          */
 #define GPMPC_MAX_D  4   /* GP input dimension    (g_nx + g_nu : 2 in all shipped configs)                 */
@@ -211,8 +211,17 @@ int    gpmpc_rollout_seeded(const gpmpc_gp_desc_t* gp, const gpmpc_env_desc_t* e
  *                                      ascending eigenvalue like torch.linalg.eigh; column signs are solver specific)
  *   root_mode  GPMPC_ROOT_*
  *   info    [dev] (Ns, g_ny) int32
- *   limits: m*T <= 256 and n_ho + 1 + m*T <= 1024 label rows per chain (GPMPC_E_UNSUPPORTED beyond)
+ *   factor_cache [dev] gpmpc_joint_cache_bytes(gp, Ns, cache_rows) or NULL: per chain the hallucinated rows of the
+ *           factor (L_hr, L_hh) and 1/diag.  The reference re-factorises K_oo from scratch on every call
+ *           (src/agent.py:241-250, 640); in the SQP loop the hallucinated set only GROWS between two resets
+ *           (src/agent.py:164-202, 261-272), so the rows of the slots that were already there are unchanged: with
+ *           n_cached > 0 (a multiple of 16, <= n_ho) the first n_cached rows are taken from the cache - the CALLER vouches
+ *           that h_slots[:n_cached] and their points X_h are the ones of the call that filled it (labels may differ:
+ *           the factor does not depend on them) - and every call writes the rows it computed (n_ho <= cache_rows).
+ *           Results are bit-identical with and without the cache.
+ *   limits: m*T <= 256 and n_ho + 1 + m*T <= 2048 label rows per chain (GPMPC_E_UNSUPPORTED beyond)
  */
+size_t gpmpc_joint_cache_bytes(const gpmpc_gp_desc_t* gp, int64_t Ns, int32_t cache_rows);
 size_t gpmpc_joint_workspace_bytes(const gpmpc_gp_desc_t* gp, int64_t Ns, int32_t n_ho, int32_t m);
 int    gpmpc_joint_sample(const gpmpc_gp_desc_t* gp, const void* plan, const double* X_r,
                           int64_t Ns, int32_t n_h, const double* X_h, const double* Y_h,
@@ -221,7 +230,8 @@ int    gpmpc_joint_sample(const gpmpc_gp_desc_t* gp, const void* plan, const dou
                           double var_zero_thr, double beta, int32_t apply_clip,
                           double* mean, double* var, double* y, double* covar, double* root,
                           int32_t root_mode, int32_t* info,
-                          void* ws, size_t ws_bytes, void* stream);
+                          void* ws, size_t ws_bytes, void* stream,
+                          void* factor_cache, int32_t cache_rows, int32_t n_cached);
 
 /*
  * gpmpc_assemble_jacobians - full-state value and Jacobians from the GP sample.

@@ -50,6 +50,14 @@ struct JointArgs {
     int ld;                 // rows of M (padded)
     double* Sall;           // [chains][mT*mT] posterior covariance, column-major, lower part valid
     int* any_fail;          // set when a chain's jitter chain failed (read by joint_eigh_kernel)
+    // factor cache (caller-owned, persists between calls): per chain the hallucinated rows of the factor, row-major
+    // [rows_cap][fc_cs] (columns: real slots, then hallucinated slots; the diagonal blocks as block_factor left them) and
+    // 1/diag [rows_cap].  The first n_c rows (a multiple of NB) are valid on entry and are not recomputed.
+    double* fcache;
+    long fc_stride;         // doubles per chain
+    int fc_cs;              // row stride = n_r + rows_cap
+    int fc_cap;             // rows_cap
+    int n_c;
 };
 
 // Blocked left-looking step shared by the three phases.  For the column block whose pivot rows are
@@ -282,6 +290,11 @@ __global__ __launch_bounds__(NT, WPE) void joint_kernel(const JointArgs a) {
 
     for (long chain = blockIdx.x; chain < nchains; chain += gridDim.x) {
         double* Sm = a.Sall + chain * (long)mT * mT;             // [mT][mT]    column-major, lower part valid
+        double* fc = a.fcache ? a.fcache + chain * a.fc_stride : nullptr;      // cached factor rows of this chain
+        double* fdinv = fc ? fc + (long)a.fc_cap * a.fc_cs : nullptr;
+        const int n_c = fc ? a.n_c : 0, CS = a.fc_cs;             // rows < n_c: valid in the cache, not recomputed
+        const int rb = n_c;                                       // thread 0 owns row rb: the workgroup spans the rows that are computed
+        const bool fill = fc && n_ho <= a.fc_cap;                 // this call's hallucinated rows go into the cache
         const long s = chain / gp.g_ny;
         const int o = (int)(chain - s * gp.g_ny);
         const double* LinvT = plan_LinvT(a.plan, gp, o);
@@ -321,7 +334,7 @@ __global__ __launch_bounds__(NT, WPE) void joint_kernel(const JointArgs a) {
         int rowt[RPT];
 #pragma unroll
         for (int rs = 0; rs < RPT; ++rs) {
-            const int row = tid + rs * nt;
+            const int row = rb + tid + rs * nt;
             rowt[rs] = 0;
 #pragma unroll
             for (int d = 0; d < D; ++d) rowx[rs][d] = 0.0;
@@ -356,11 +369,11 @@ __global__ __launch_bounds__(NT, WPE) void joint_kernel(const JointArgs a) {
                 double acc[RPT][NB];
 #pragma unroll
                 for (int rs = 0; rs < RPT; ++rs) {
-                    const int row = tid + rs * nt;
+                    const int row = rb + tid + rs * nt;
 #pragma unroll
                     for (int q = 0; q < NB; ++q) {
                         acc[rs][q] = 0.0;
-                        if (q < nb && row < nrow && row != wrow) {
+                        if (q < nb && row >= n_c && row < nrow && row != wrow) {
                             double qq[D];
                             const double k = kern_scalar<D>(colx[q], rowx[rs], il2, os, qq);    // r = x_real - x_row
                             acc[rs][q] = kern_entry<D>(qq, k, il2, colt[q], rowt[rs]);
@@ -368,16 +381,21 @@ __global__ __launch_bounds__(NT, WPE) void joint_kernel(const JointArgs a) {
                         if ((q & 3) == 3) asm volatile("" ::: "memory");
                     }
                 }
-                block_update<NB, RPT, KC, NT>(M, ld, cb, Lrr + (long)cb * n_r, n_r, 1, nb, 0, nrow, acc, piv);
+                block_update<NB, RPT, KC, NT>(M + rb, ld, cb, Lrr + (long)cb * n_r, n_r, 1, nb, 0, nrow - rb, acc, piv);
 #pragma unroll
                 for (int rs = 0; rs < RPT; ++rs) {
-                    const int row = tid + rs * nt;
-                    if (row < nrow) {
+                    const int row = rb + tid + rs * nt;
+                    if (row >= n_c && row < nrow) {
                         double x[NB];
                         block_solve<NB>(acc[rs], x, blk, dinv_s, nb, NB);
 #pragma unroll
                         for (int q = 0; q < NB; ++q)
                             if (q < nb) M[(long)(cb + q) * ld + row] = (row == wrow) ? coly[q] : x[q];
+                        if (fill && row < n_ho) {
+#pragma unroll
+                            for (int q = 0; q < NB; ++q)
+                                if (q < nb) fc[(long)row * CS + cb + q] = x[q];
+                        }
                     }
                 }
                 __syncthreads();
@@ -408,10 +426,10 @@ __global__ __launch_bounds__(NT, WPE) void joint_kernel(const JointArgs a) {
             double acc[RPT][NB];
 #pragma unroll
             for (int rs = 0; rs < RPT; ++rs) {
-                const int row = tid + rs * nt;
+                const int row = rb + tid + rs * nt;
 #pragma unroll
                 for (int q = 0; q < NB; ++q) acc[rs][q] = 0.0;
-                if (row >= c0 && row < nrow) {
+                if (row >= max(c0, n_c) && row < nrow) {
                     if (row == wrow) {
 #pragma unroll
                         for (int q = 0; q < NB; ++q)
@@ -433,32 +451,55 @@ __global__ __launch_bounds__(NT, WPE) void joint_kernel(const JointArgs a) {
                 }
             }
             JPH(1);
-            block_update<NB, RPT, KC, NT>(M, ld, n_r + c0, M + c0, 1, ld, nb, c0, nrow, acc, piv);
+            const bool cached = c0 < n_c;                     // uniform: the block's pivot rows and its factorised diagonal block are in the cache
+            block_update<NB, RPT, KC, NT>(M + rb, ld, n_r + c0, cached ? fc + (long)c0 * CS : M + c0, cached ? CS : 1,
+                                          cached ? 1 : ld, nb, cached ? 0 : c0 - rb, nrow - rb, acc, piv);
             __syncthreads();
             JPH(2);
-#pragma unroll
-            for (int rs = 0; rs < RPT; ++rs) {
-                const int row = tid + rs * nt;
-                if (row >= c0 && row < c0 + nb) {
-#pragma unroll
-                    for (int q = 0; q < NB; ++q)
-                        if (q <= row - c0) blk[row - c0][q] = acc[rs][q];
+            if (cached) {
+                for (int e = tid; e < NB * NB; e += nt) {
+                    const int q = e / NB, c = e - q * NB;
+                    if (c <= q) blk[q][c] = fc[(long)(c0 + q) * CS + n_r + c0 + c];
                 }
+                if (tid < NB) dinv_s[tid] = fdinv[c0 + tid];
+                if (tid == 0) s_flag = 0;
+            } else {
+#pragma unroll
+                for (int rs = 0; rs < RPT; ++rs) {
+                    const int row = rb + tid + rs * nt;
+                    if (row >= c0 && row < c0 + nb) {
+#pragma unroll
+                        for (int q = 0; q < NB; ++q)
+                            if (q <= row - c0) blk[row - c0][q] = acc[rs][q];
+                    }
+                }
+                __syncthreads();
+                if (tid < 64) block_factor<NB>(blk, dinv_s, nb, &s_flag);
             }
-            __syncthreads();
-            if (tid < 64) block_factor<NB>(blk, dinv_s, nb, &s_flag);
             __syncthreads();
             JPH(3);
             if (s_flag) info_acc |= GPMPC_INFO_TRAIN_CHOL_FAIL;
+            if (fill && !cached) {                            // the diagonal block as block_factor left it, and 1/diag
+                for (int e = tid; e < NB * NB; e += nt) {
+                    const int q = e / NB, c = e - q * NB;
+                    if (c <= q && q < nb) fc[(long)(c0 + q) * CS + n_r + c0 + c] = blk[q][c];
+                }
+                if (tid < nb) fdinv[c0 + tid] = dinv_s[tid];
+            }
 #pragma unroll
             for (int rs = 0; rs < RPT; ++rs) {
-                const int row = tid + rs * nt;
-                if (row >= c0 && row < nrow) {
+                const int row = rb + tid + rs * nt;
+                if (row >= max(c0, n_c) && row < nrow) {
                     double x[NB];
                     block_solve<NB>(acc[rs], x, blk, dinv_s, nb, (row < n_ho) ? row - c0 : NB);
 #pragma unroll
                     for (int q = 0; q < NB; ++q)
                         if (q < nb) M[(long)(n_r + c0 + q) * ld + row] = x[q];
+                    if (fill && row >= c0 + nb && row < n_ho) {   // rows below the block (its own rows: written above)
+#pragma unroll
+                        for (int q = 0; q < NB; ++q)
+                            if (q < nb) fc[(long)row * CS + n_r + c0 + q] = x[q];
+                    }
                 }
             }
             __syncthreads();
@@ -730,6 +771,13 @@ int gpmpc_debug_eigh_occupancy(int mT, size_t extra_lds) {
     return nb;
 }
 
+// bytes of the caller-owned factor cache of gpmpc_joint_sample for up to cache_rows hallucinated label rows per chain
+size_t gpmpc_joint_cache_bytes(const gpmpc_gp_desc_t* gp, int64_t Ns, int32_t cache_rows) {
+    if (check_gp(gp) != GPMPC_OK || cache_rows < 16 || Ns < 1) return 0;
+    const size_t cs = (size_t)observed_real_slots(gp) + cache_rows;
+    return align_up((size_t)Ns * gp->g_ny * cache_rows * (cs + 1) * sizeof(double), 256);
+}
+
 size_t gpmpc_joint_workspace_bytes(const gpmpc_gp_desc_t* gp, int64_t Ns, int32_t n_ho, int32_t m) {
     if (check_gp(gp) != GPMPC_OK) return 0;
     const JointWs w = joint_ws_layout(observed_real_slots(gp), n_ho, m, gp->T, Ns * gp->g_ny);
@@ -740,7 +788,8 @@ int gpmpc_joint_sample(const gpmpc_gp_desc_t* gp, const void* plan, const double
                        const double* X_h, const double* Y_h, const int32_t* h_slots, int32_t n_ho, int32_t m,
                        const double* X_s, const double* z, double var_zero_thr, double beta, int32_t apply_clip,
                        double* mean, double* var, double* y, double* covar, double* root, int32_t root_mode,
-                       int32_t* info, void* ws, size_t ws_bytes, void* stream) {
+                       int32_t* info, void* ws, size_t ws_bytes, void* stream, void* factor_cache, int32_t cache_rows,
+                       int32_t n_cached) {
     if (int rc = check_gp(gp)) return rc;
     if (!plan || !X_r || !X_s || !z || !mean || !var || !y || !info || !ws)
         return fail(GPMPC_E_ARG, "gpmpc_joint_sample: NULL pointer");
@@ -783,9 +832,22 @@ int gpmpc_joint_sample(const gpmpc_gp_desc_t* gp, const void* plan, const double
         return fail(GPMPC_E_WORKSPACE, "gpmpc_joint_sample: workspace too small");
     a.Sall = (double*)ws + w.s_off;
     a.any_fail = (int*)((double*)ws + w.f_off);
+    if (factor_cache) {
+        if (cache_rows < 16 || n_cached < 0 || n_cached > n_ho || n_cached > cache_rows || (n_cached & 15))
+            return fail(GPMPC_E_ARG, "gpmpc_joint_sample: factor cache: rows >= 16, 0 <= n_cached <= min(n_ho, rows), n_cached % 16 == 0");
+        a.fcache = (double*)factor_cache;
+        a.fc_cap = cache_rows;
+        a.fc_cs = a.gp.n_r + cache_rows;
+        a.fc_stride = (long)cache_rows * (a.fc_cs + 1);
+        a.n_c = n_cached;
+    } else {
+        a.fcache = nullptr;
+        a.fc_cap = a.fc_cs = a.n_c = 0;
+        a.fc_stride = 0;
+    }
     hipStream_t st = (hipStream_t)stream;
     GPMPC_HIP_CHECK(hipMemsetAsync(a.any_fail, 0, sizeof(int), st));
-    const int nrow = n_ho + 1 + mT;
+    const int nrow = n_ho + 1 + mT - a.n_c;            // rows that are computed (the cached ones have no thread)
     // one label row per thread and a workgroup just wide enough for the rows (more chains per CU when they are short:
     // iteration 0 of config 5 has 121 rows; iteration 0 of every later MPC step conditions on the previous step's
     // whole hallucinated set - the reference's reset-after-build quirk - i.e. 601 rows at config 5: 1024 threads)

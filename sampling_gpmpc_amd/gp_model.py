@@ -113,6 +113,76 @@ def _detect_tensor_grid(X: torch.Tensor):
     return (n0, n1) if ok else (0, 0)
 
 
+class JointFactorCache:
+    """Caller-owned factor cache of ``gpmpc_joint_sample`` (include/gpmpc_hip.h): per chain the hallucinated rows of the
+    train-side factor.  The reference re-factorises the whole conditioning set on every ``model_i(x)`` call; between two
+    resets the hallucinated set only grows (``src/agent.py:164-202, 261-272``), so the rows of the slots that were there
+    at the previous call are reused.  The façade vouches for validity by comparing the current slot list and the points of
+    the cached rows with a snapshot taken when they were written (the factor does not depend on the labels)."""
+
+    MAX_BYTES = 24 << 30          # do not cache beyond this (the per-GPU shard of BASELINE configs[4] needs ~7 GB)
+
+    def __init__(self):
+        self.buf = None
+        self.rows = 0                 # capacity (label rows per chain)
+        self.key = None               # (Ns, g_ny, n_r, T, plan id)
+        self.slots = None             # int32 device tensor: the slots whose rows are valid
+        self.X = None                 # (Ns, g_ny, n_pts, D) snapshot of the points behind them
+        self.enabled = True
+
+    def invalidate(self):
+        self.slots = self.X = None
+
+    def prepare(self, mdl: "HipGPModel", Ns: int, n_ho: int):
+        """-> (buffer or None, capacity, n_cached) for a call with ``n_ho`` observed hallucinated slots."""
+        if not self.enabled or n_ho < 16:
+            return None, 0, 0
+        lib = _lib.load()
+        hy = mdl.hyper
+        key = (Ns, hy.g_ny, mdl.plan.n_r, hy.T, id(mdl.plan))
+        if self.buf is None or key != self.key or n_ho > self.rows:
+            # the set grows by the same number of slots every SQP iteration: room for four of them where that fits
+            for mult in (4.0, 2.0, 1.25):
+                rows = min(MAX_JOINT_ROWS, max(256, -(-int(mult * n_ho) // 128) * 128))
+                nbytes = lib.gpmpc_joint_cache_bytes(mdl.plan.desc, Ns, rows)
+                if 0 < nbytes <= self.MAX_BYTES:
+                    break
+            if nbytes == 0 or nbytes > self.MAX_BYTES:
+                self.buf, self.rows, self.key = None, 0, None
+                self.invalidate()
+                return None, 0, 0
+            self.buf = None                                                    # release the old one first
+            self.buf = torch.empty(nbytes // 8, dtype=F64, device=mdl.plan.X_r.device)
+            self.rows, self.key = rows, key
+            self.invalidate()
+        n_c = 0
+        if self.slots is not None:
+            n_old, n_pts = int(self.slots.numel()), int(self.X.shape[2])
+            # append-only growth: the old slot list is a prefix of the new one and the points it was built on are unchanged
+            if n_old <= n_ho and n_pts <= mdl.n_h and bool(torch.equal(mdl.h_slots[:n_old], self.slots)) \
+                    and bool(torch.equal(mdl.hall_X[:, :, :n_pts], self.X)):
+                n_c = n_old & ~15
+        return self.buf, self.rows, n_c
+
+    def rewind(self, n_slots: int):
+        """Forget the rows beyond the first ``n_slots`` (benchmarks: put the cache back into the state it had before a
+        draw, so that repeated timed draws do the work of the first one)."""
+        if self.slots is not None:
+            self.slots = self.slots[:max(0, min(int(n_slots), int(self.slots.numel())))]
+
+    @property
+    def n_valid(self) -> int:
+        return 0 if self.slots is None else int(self.slots.numel())
+
+    def commit(self, mdl: "HipGPModel", n_ho: int, ok: bool):
+        """After a call that filled the cache for all ``n_ho`` slots (``ok``: no factorisation failure)."""
+        if self.buf is None or not ok or n_ho > self.rows:
+            self.invalidate()
+            return
+        self.slots = mdl.h_slots[:n_ho].clone()
+        self.X = mdl.hall_X.clone()
+
+
 class HipPosterior:
     """What ``model_i(x)`` returns: a lazily evaluated joint posterior at the ``m`` test points of every chain."""
 
@@ -152,14 +222,17 @@ class HipPosterior:
                 f"reset (the reference's max_sqp_iter of 150 is not reachable: its cost grows with the cube of the rows).")
         ws_bytes = lib.gpmpc_joint_workspace_bytes(mdl.plan.desc, Ns, n_ho, m)
         ws = mdl._workspace(ws_bytes)
+        fcache = mdl._ws_cache.setdefault("joint_factor_cache", JointFactorCache())
+        fbuf, frows, n_c = fcache.prepare(mdl, Ns, n_ho)
         rc = lib.gpmpc_joint_sample(
             mdl.plan.desc, _lib.dptr(mdl.plan.buf), _lib.dptr(mdl.plan.X_r), Ns, mdl.n_h,
             _lib.dptr(mdl.hall_X) if mdl.n_h else None, _lib.dptr(mdl.hall_Y) if mdl.n_h else None,
             _lib.dptr(mdl.h_slots) if n_ho else None, n_ho, m, _lib.dptr(self._x), _lib.dptr(z),
             float(var_zero_thr), float(beta), int(bool(clip)), _lib.dptr(mean), _lib.dptr(var), _lib.dptr(y),
             _lib.dptr(covar), _lib.dptr(root), int(root_mode), _lib.dptr(info), _lib.dptr(ws), ws.numel() * 8,
-            _lib.current_stream_ptr())
+            _lib.current_stream_ptr(), _lib.dptr(fbuf), int(frows), int(n_c))
         _lib.check(rc, "gpmpc_joint_sample")
+        self.n_cached_rows = n_c
         self._mean, self._var = mean, var
         if want_covar:
             self._covar = covar
@@ -168,6 +241,8 @@ class HipPosterior:
         bits = _or_reduce(info)
         self.last_info = info
         self.used_eigh = bool(bits & _lib.INFO_ROOT_EIGH)
+        if fbuf is not None:
+            fcache.commit(mdl, n_ho, ok=not (bits & _lib.INFO_TRAIN_CHOL_FAIL))
         if bits & _lib.INFO_TRAIN_CHOL_FAIL:
             raise NotPSDError("Cholesky of the training covariance (real + hallucinated data) failed")
         if bits & _lib.INFO_VAR_CLAMPED:

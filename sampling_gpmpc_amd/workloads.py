@@ -76,6 +76,12 @@ def flop_mode_j(g_ny, T, n_real_obs, H, k) -> float:
     return g_ny * (n ** 3 / 3 + 2 * n * n + m * n * n + m * m * n + m ** 3 / 3 + 2 * m * m + 2 * m * n)
 
 
+def flop_mode_j_cached_rows(g_ny, n_real_obs, n_cached) -> float:
+    """FLOP of `flop_mode_j` that a call with `n_cached` factor rows in the caller's cache does not execute: the
+    factorisation of those rows (columns up to each row's own)."""
+    return g_ny * ((n_real_obs + n_cached) ** 3 - n_real_obs ** 3) / 3
+
+
 def flop_mode_i(g_ny, N_r) -> float:
     return g_ny * (14 * N_r + N_r * N_r + 2 * N_r + 10)
 

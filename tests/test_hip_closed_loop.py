@@ -69,3 +69,54 @@ def test_closed_loop_as_shipped_car_runs_the_eigh_root(sg):
     assert np.isfinite(loop.solver.p_lin).all() and np.isfinite(loop.recorder.state_traj[0]).all()
     assert agent.model_i.n_h == 3 * 40                              # three iterations' points behind the fourth draw
     print("as shipped car closed loop: GP side per SQP iteration (ms):", [round(t, 2) for t in loop.solver.gp_ms])
+
+
+@pytest.mark.parametrize("pname,Ns,H", [("params_pendulum1D_samples", 5, 30), ("params_car_residual", 4, 40)])
+def test_joint_factor_cache_is_bit_exact_and_used(sg, pname, Ns, H):
+    """The factor cache of gpmpc_joint_sample: between two resets the hallucinated set only grows, so the rows of the slots
+    that were already there are reused (the reference re-factorises everything on every call).  Two MPC steps x four SQP
+    iterations with and without the cache: bit-identical Jacobians; the cache is hit at k >= 1 and at k = 0 of the second
+    MPC step (the reset-after-build quirk conditions on the previous step's whole set), and dropped when the points change."""
+    from sampling_gpmpc_amd.gp_model import JointFactorCache
+    iters = 4
+    p = closed_loop_params(pname, Ns, H, 2, iters)
+    agent, _ = make_agents(sg, p)
+    plain, _ = make_agents(sg, p, erv=agent.epistimic_random_vector.cpu())
+    off = JointFactorCache()
+    off.enabled = False
+    plain._ws_cache["joint_factor_cache"] = off
+    x0 = np.array(p["env"]["start"], dtype=np.float64)[: agent.nx]
+    u_h = np.zeros((H, agent.nu))
+    hits = []
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for step in range(2):
+            x_h = np.tile(x0 + 0.01 * step, (H, Ns))
+            for k in range(iters):
+                outs = []
+                for a in (agent, plain):
+                    a.mpc_iteration(step)
+                    a.train_hallucinated_dynGP(k)
+                    outs.append(a.dyn_fg_jacobians(a.get_batch_x_hat(x_h, u_h), k))
+                for u, v in zip(*outs):
+                    np.testing.assert_array_equal(u, v)
+                hits.append(agent.model_i_call.n_cached_rows)
+                assert plain.model_i_call.n_cached_rows == 0
+                mean_next = outs[0][0][:, :, :, 0].mean(axis=0).T
+                x_h = np.tile(np.vstack([x0[None, :], mean_next[:-1]]), (1, Ns))
+        T = 3
+        print(f"{pname}: cached rows per call {hits}")
+        assert hits[0] == 0 and hits[1] == 0                         # k = 0: empty set; k = 1: its rows are new
+        assert hits[2] == (H * T) & ~15 and hits[3] == (2 * H * T) & ~15
+        assert hits[4] == (3 * H * T) & ~15                          # next MPC step, k = 0: the pre-reset set
+        assert hits[5] == 0                                          # after the reset: other points
+        # changing a cached point (survivor replacement does that) invalidates the cache
+        agent.Hallcinated_X_train[0, :, 0, :] += 1e-3
+        plain.Hallcinated_X_train[0, :, 0, :] += 1e-3
+        outs = []
+        for a in (agent, plain):
+            a.train_hallucinated_dynGP(iters)
+            outs.append(a.dyn_fg_jacobians(a.get_batch_x_hat(x_h, u_h), iters - 1))
+        assert agent.model_i_call.n_cached_rows == 0
+        for u, v in zip(*outs):
+            np.testing.assert_array_equal(u, v)
