@@ -272,6 +272,7 @@ __global__ __launch_bounds__(NT, WPE) void joint_kernel(const JointArgs a) {
     __shared__ int s_info;
     __shared__ __attribute__((aligned(16))) double colx[NB][D];   // input point / task / label of the block's NB pivot slots
     __shared__ int colt[NB];
+    __shared__ int colsame[NB];                                   // the slot's input point is the previous slot's (one exp for both)
     __shared__ double coly[NB];
     const GpParams& gp = a.gp;
     const int tid = threadIdx.x;
@@ -370,12 +371,12 @@ __global__ __launch_bounds__(NT, WPE) void joint_kernel(const JointArgs a) {
 #pragma unroll
                 for (int rs = 0; rs < RPT; ++rs) {
                     const int row = rb + tid + rs * nt;
+                    double qq[D] = {0.0, 0.0}, k = 0.0;                 // one exponential per real input point (its Tr task slots are adjacent)
 #pragma unroll
                     for (int q = 0; q < NB; ++q) {
                         acc[rs][q] = 0.0;
                         if (q < nb && row >= n_c && row < nrow && row != wrow) {
-                            double qq[D];
-                            const double k = kern_scalar<D>(colx[q], rowx[rs], il2, os, qq);    // r = x_real - x_row
+                            if (q == 0 || colt[q] == 0) k = kern_scalar<D>(colx[q], rowx[rs], il2, os, qq);    // r = x_real - x_row
                             acc[rs][q] = kern_entry<D>(qq, k, il2, colt[q], rowt[rs]);
                         }
                         if ((q & 3) == 3) asm volatile("" ::: "memory");
@@ -408,7 +409,7 @@ __global__ __launch_bounds__(NT, WPE) void joint_kernel(const JointArgs a) {
         for (int c0 = 0; c0 < n_ho; c0 += NB) {
             const int nb = min(NB, n_ho - c0);
             if (tid < NB) {                                   // descriptors of the block's pivot slots, shared by all rows
-                int tc = 0;
+                int tc = 0, same = 0;
                 double x0 = 0.0, x1 = 0.0, yl = 0.0;
                 if (tid < nb) {
                     const double* xc;
@@ -416,10 +417,12 @@ __global__ __launch_bounds__(NT, WPE) void joint_kernel(const JointArgs a) {
                     x0 = xc[0];
                     x1 = xc[1];
                     yl = Yh[a.h_slots[c0 + tid]];
+                    same = (tid > 0 && a.h_slots[c0 + tid] / T == a.h_slots[c0 + tid - 1] / T) ? 1 : 0;
                 }
                 colx[tid][0] = x0;
                 colx[tid][1] = x1;
                 colt[tid] = tc;
+                colsame[tid] = same;
                 coly[tid] = yl;
             }
             __syncthreads();
@@ -435,12 +438,13 @@ __global__ __launch_bounds__(NT, WPE) void joint_kernel(const JointArgs a) {
                         for (int q = 0; q < NB; ++q)
                             if (q < nb) acc[rs][q] = coly[q];
                     } else {
+                        // the T task slots of one input point share the exponential: it is evaluated when the point changes
+                        double qq[D] = {0.0, 0.0}, k = 0.0;
 #pragma unroll
                         for (int q = 0; q < NB; ++q) {
                             if (q < nb) {
                                 const int tc = colt[q];
-                                double qq[D];
-                                const double k = kern_scalar<D>(rowx[rs], colx[q], il2, os, qq);   // r = x_row - x_c
+                                if (q == 0 || !colsame[q]) k = kern_scalar<D>(rowx[rs], colx[q], il2, os, qq);   // r = x_row - x_c
                                 double kv = kern_entry<D>(qq, k, il2, rowt[rs], tc);
                                 if (row == c0 + q) kv += gp.noise[tc];
                                 acc[rs][q] = kv;
@@ -531,12 +535,12 @@ __global__ __launch_bounds__(NT, WPE) void joint_kernel(const JointArgs a) {
                 const int t1 = tid + rs * nt;
                 if (t1 >= c0 && t1 < mT) {
                     const int j1 = t1 / T, b1 = t1 - j1 * T;
+                    double qq[D] = {0.0, 0.0}, k = 0.0;
 #pragma unroll
                     for (int q = 0; q < NB; ++q) {
                         if (q < nb) {
                             const int t2 = c0 + q, j2 = t2 / T, b2 = t2 - j2 * T;
-                            double qq[D];
-                            const double k = kern_scalar<D>(Xs + (long)j1 * D, Xs + (long)j2 * D, il2, os, qq);
+                            if (q == 0 || b2 == 0) k = kern_scalar<D>(Xs + (long)j1 * D, Xs + (long)j2 * D, il2, os, qq);
                             acc[rs][q] = kern_entry<D>(qq, k, il2, b1, b2);
                         }
                         if ((q & 3) == 3) asm volatile("" ::: "memory");
