@@ -77,6 +77,19 @@ __device__ long long g_joint_phase[16];
 #define JPH(idx)
 #endif
 
+// pivot columns staged per chunk (0: 8 for the 128-thread workgroups, 16 beyond) and the row ring: GPMPC_JOINT_RD batches of
+// GPMPC_JOINT_KU columns (0: the chunk in GPMPC_JOINT_RD batches).  tools/joint_sweep.sh, round 2 with the factor cache
+// (car k=0 / k=2 / k=3, pendulum k=1; ms): 8,4,2: 2.47 / 7.03 / 11.69, 0.84 - 16,8,2: 2.63 / 6.87 / 10.97, 0.83 -
+// 16,4,4: 2.70 / 6.94 / 11.12, 0.84 - 12,4,3: 2.99 / 8.44 / 13.13, 1.03
+#ifndef GPMPC_JOINT_KC
+#define GPMPC_JOINT_KC 0
+#endif
+#ifndef GPMPC_JOINT_KU
+#define GPMPC_JOINT_KU 0
+#endif
+#ifndef GPMPC_JOINT_RD
+#define GPMPC_JOINT_RD 2
+#endif
 #ifndef GPMPC_JOINT_LDS_BCAST
 #define GPMPC_JOINT_LDS_BCAST 0          // 1: the broadcast-ds_read_b128 update (comparison builds, tools/joint_sweep.sh)
 #endif
@@ -118,9 +131,9 @@ __device__ __forceinline__ void block_update(const double* __restrict__ W, int l
     //   * the thread's own row entries: KU columns per batch, the next batch is in flight while this one is consumed;
     //   * the pivot rows of the NEXT KC-column chunk are fetched into registers while this chunk is consumed.
     const int tid = threadIdx.x;
-    constexpr int KU = (RPT >= 4) ? 2 : 4;                       // columns per row batch
+    constexpr int KU = (RPT >= 4) ? 2 : (GPMPC_JOINT_KU ? GPMPC_JOINT_KU : KC / GPMPC_JOINT_RD);   // columns per row batch
     constexpr int PV = (NB * KC + NT - 1) / NT;
-    constexpr int RD = 2;                                        // row batches in the ring
+    constexpr int RD = GPMPC_JOINT_RD;                           // row batches in the ring
     static_assert(KC % (RD * KU) == 0, "the batch ring must turn a whole number of times per pivot chunk");
     bool own[RPT];
     const double* wr[RPT];
@@ -264,7 +277,7 @@ __device__ __forceinline__ void block_solve(const double (&acc)[NB], double (&x)
 template <int T, int NB, int RPT, int NT, int WPE>
 __global__ __launch_bounds__(NT, WPE) void joint_kernel(const JointArgs a) {
     constexpr int D = 2;
-    constexpr int KC = 8;                                        // pivot columns staged per chunk: small chunks (few prefetch registers, early start) measured best
+    constexpr int KC = GPMPC_JOINT_KC ? GPMPC_JOINT_KC : ((NT <= 128 || RPT > 1) ? 8 : 16);   // pivot columns staged per chunk
     __shared__ __attribute__((aligned(16))) double piv[KC][NB];
     __shared__ double blk[NB][NB + 1];
     __shared__ double dinv_s[NB];
