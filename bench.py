@@ -49,7 +49,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--ns", type=int, default=1024, help="samples per GPU (BASELINE configs[1]: 1024)")
     ap.add_argument("--horizon", type=int, default=30)
-    ap.add_argument("--cpu-sample", type=int, default=256, help="samples of the CPU-oracle baseline (0 = skip)")
+    ap.add_argument("--cpu-sample", type=int, default=1024, help="samples of the CPU-oracle baseline (0 = skip)")
     ap.add_argument("--prewarm", type=int, default=2000,
                     help="untimed steps before the second warmup that bring the GPU to its sustained clocks (the cold "
                          "region is measured before them and reported as well); 0 = off")
