@@ -324,33 +324,28 @@ class Agent(object):
         return y
 
     def get_batch_gp_sensitivities(self, xu_hat, sqp_iter):
-        """GP value+gradient sample at the linearisation points (reference ``src/agent.py:566-627``)."""
-        ag = self.params["agent"]
-        H = self.params["optimizer"]["H"]
-        g_xu_hat = self.env_model.get_g_xu_hat(xu_hat).contiguous()
-        update = True
-        if (ag["true_dyn_as_sample"] or ag["mean_as_dyn_sample"]) and self.ns == 1:
-            y = torch.zeros((1, self.g_ny, H, self.in_dim_y), dtype=F64, device=self.torch_device)
-            update = False
-        elif (ag["true_dyn_as_sample"] and ag["mean_as_dyn_sample"]) and self.ns == 2:
-            y = torch.zeros((2, self.g_ny, H, self.in_dim_y), dtype=F64, device=self.torch_device)
-            update = False
+        """GP value+gradient sample at the linearisation points (reference ``src/agent.py:566-627``): a joint draw for
+        every dynamics sample, except that the leading samples can be pinned - first to the true dynamics
+        (``true_dyn_as_sample``), then to the posterior mean (``mean_as_dyn_sample``).  When the pinned samples are ALL the
+        samples nothing is drawn and the hallucinated set is left alone."""
+        cfg = self.params["agent"]
+        g_in = self.env_model.get_g_xu_hat(xu_hat).contiguous()
+        pinned = [kind for kind, on in (("true_dyn", cfg["true_dyn_as_sample"]), ("mean", cfg["mean_as_dyn_sample"])) if on]
+        nothing_drawn = (len(pinned) >= 1 and self.ns == 1) or (len(pinned) == 2 and self.ns == 2)
+        if nothing_drawn:
+            y = torch.zeros((self.ns, self.g_ny, self.params["optimizer"]["H"], self.in_dim_y), dtype=F64,
+                            device=self.torch_device)
+            self.model_i_call = self.model_i(g_in)
         else:
-            y = self.sample_gp(g_xu_hat, base_samples=self.epistimic_random_vector[self.mpc_iter][sqp_iter])
-        if not update:
-            self.model_i_call = self.model_i(g_xu_hat)
-        idx = 0
-        if ag["true_dyn_as_sample"]:
-            t = self.env_model.get_prior_data(g_xu_hat[idx, 0, :, :])
-            if self.in_dim_y == 1:
-                t = t[:, :, [0]]
-            y[idx, :, :, :] = t
-            idx += 1
-        if ag["mean_as_dyn_sample"]:
-            y[[idx], :, :, :] = self.model_i_call.mean[[idx], :, :, :]
-            idx += 1
-        if update:
-            self.update_hallucinated_Dyn_dataset(g_xu_hat, y)
+            y = self.sample_gp(g_in, base_samples=self.epistimic_random_vector[self.mpc_iter][sqp_iter])
+        for slot, kind in enumerate(pinned):
+            if kind == "true_dyn":
+                truth = self.env_model.get_prior_data(g_in[slot, 0, :, :])
+                y[slot, :, :, :] = truth[:, :, [0]] if self.in_dim_y == 1 else truth
+            else:
+                y[[slot], :, :, :] = self.model_i_call.mean[[slot], :, :, :]
+        if not nothing_drawn:
+            self.update_hallucinated_Dyn_dataset(g_in, y)
         return y
 
     def dyn_fg_jacobians(self, xu_hat, sqp_iter):
@@ -412,67 +407,74 @@ class Agent(object):
         tensor per propagation step instead of the internal ``randn`` draw; ``rng`` - a ``numpy.random.RandomState``
         for the survivor choice instead of the global ``np.random``.  ``self.rejection_trace`` keeps the survivor mask
         after every step."""
-        n_sample = self.ns
-        tight = self.params["agent"]["tight"]
-        B_d_norm = np.sqrt(self.params["optimizer"]["terminal_tightening"]["P"][1][1])
-        var_eps = (tight["dyn_eps"] + tight["w_bound"]) * B_d_norm
+        Ns, nx = self.ns, self.nx
         dev = _lib.require_hip_device(self.torch_device)
-        self.FS_X_train_batch = torch.empty(n_sample, self.g_ny, 0, self.in_dim_x, dtype=F64, device=dev)
-        self.FS_Y_train_batch = torch.empty(n_sample, self.g_ny, 0, self.in_dim_y, dtype=F64, device=dev)
-        X_soln = torch.as_tensor(X_soln, dtype=F64).reshape(X_soln.shape[0], n_sample, self.nx).to(dev)
-        X_kp1 = torch.as_tensor(X_kp1, dtype=F64).transpose(0, 1).to(dev)
-        U_soln = torch.as_tensor(U_soln, dtype=F64).to(dev)
-        diff = X_soln[1, :, :] - X_kp1
-        samples_left = torch.prod(torch.abs(diff) - var_eps < 0, dim=1)
-        xu_init = torch.cat([X_kp1, U_soln[[1]]], dim=-1)
-        xu_hat = torch.tile(xu_init, dims=(n_sample, self.nx, 1, 1))
+        cfg_t = self.params["agent"]["tight"]
+        first_bound = (cfg_t["dyn_eps"] + cfg_t["w_bound"]) * np.sqrt(self.params["optimizer"]["terminal_tightening"]["P"][1][1])
         rng = np.random if rng is None else rng
-        self.rejection_trace = [samples_left.clone()]
-        n_last = X_soln.shape[0] - 2                                            # the loop runs i = 1 .. n_last
         T = self.in_dim_y
-        n0 = int(self.Hallcinated_X_train.shape[2])
+
+        def inside(err, bound):                      # 1 where every state component is strictly inside the tube, else 0
+            return (torch.abs(err) - bound < 0).all(dim=1).to(torch.int64)
+
+        def gp_input_batch(states, u_row):           # (Ns or 1, nx) states + one input row -> (Ns, nx, 1, nx + nu)
+            xu = torch.cat([states.expand(Ns, nx), u_row.reshape(1, -1).expand(Ns, -1)], dim=-1)
+            return xu[:, None, None, :].expand(Ns, nx, 1, nx + self.nu).contiguous()
+
+        plan_x = torch.as_tensor(X_soln, dtype=F64).reshape(X_soln.shape[0], Ns, nx).to(dev)     # the solver's trajectories
+        plan_u = torch.as_tensor(U_soln, dtype=F64).to(dev)
+        x_real = torch.as_tensor(X_kp1, dtype=F64).transpose(0, 1).to(dev)                          # (1, nx): the state reached
+        steps = plan_x.shape[0] - 2                                                                # propagation steps 1 .. steps
+        self.FS_X_train_batch = torch.empty(Ns, self.g_ny, 0, self.in_dim_x, dtype=F64, device=dev)
+        self.FS_Y_train_batch = torch.empty(Ns, self.g_ny, 0, T, dtype=F64, device=dev)
+
+        alive = inside(plan_x[1] - x_real, first_bound)
+        self.rejection_trace = [alive.clone()]
+
+        n_hall = int(self.Hallcinated_X_train.shape[2])
         from .rollout import seeds_fit
-        can_fuse = (n_last >= 3 and T == 1 + self.in_dim_x and seeds_fit(self, n0, 1, n_last - 1, T, 1)
-                    and not bool(torch.isnan(self.Hallcinated_Y_train).any()))
+        fusable = (steps >= 3 and T == 1 + self.in_dim_x and seeds_fit(self, n_hall, 1, steps - 1, T, 1)
+                   and not bool(torch.isnan(self.Hallcinated_Y_train).any()))
         if fused is None:
-            fused = can_fuse
-        elif fused and not can_fuse:
+            fused = fusable
+        elif fused and not fusable:
             raise _lib.GpmpcError("prepare_dynamics_set: the conditioning set does not fit the fused rollout "
-                                  f"({n0} hallucinated points x {T} tasks + {n_last - 1} value-only draws > 256 label slots)")
-        for i in range(1, n_last + 1):
-            g_xu_hat = self.env_model.get_g_xu_hat(xu_hat).contiguous()
-            z = None if base_samples is None else base_samples[i - 1].to(dev)
-            Y_sample = self.model_i(g_xu_hat).sample(z)
-            g_val = Y_sample[:, :, :].squeeze()[:, : self.g_ny]
-            f_val = self.env_model.known_dyn(xu_hat).squeeze()
-            x_next = f_val + torch.matmul(self.env_model.B_d, g_val.t()).t()
-            diff = X_soln[i + 1, :, :] - x_next
-            samples_left = samples_left * torch.prod(torch.abs(diff) - self.ci_list[i] < 0, dim=1)
-            self.rejection_trace.append(samples_left.clone())
-            if i == n_last:
+                                  f"({n_hall} hallucinated points x {T} tasks + {steps - 1} value-only draws > 256 label slots)")
+
+        states = x_real
+        for step in range(1, steps + 1):
+            xu = gp_input_batch(states, plan_u[step])
+            g_in = self.env_model.get_g_xu_hat(xu).contiguous()
+            draw = self.model_i(g_in).sample(None if base_samples is None else base_samples[step - 1].to(dev))
+            residual = draw[:, :, 0, 0]                                                   # value component of every output
+            states = self.env_model.known_dyn(xu).reshape(Ns, nx) + residual @ self.env_model.B_d.t()
+            alive = alive * inside(plan_x[step + 1] - states, self.ci_list[step])
+            self.rejection_trace.append(alive.clone())
+            if step == steps:
                 break
-            self.FS_X_train_batch = torch.cat([self.FS_X_train_batch, g_xu_hat], dim=2)
-            Y_sample = Y_sample.clone()
-            Y_sample[:, :, :, 1:] = float("nan")
-            self.FS_Y_train_batch = torch.cat([self.FS_Y_train_batch, Y_sample], dim=2)
+            # the draw becomes a value-only training point of the forward-sampling GP (gradient labels unobserved)
+            label = draw.clone()
+            label[:, :, :, 1:] = float("nan")
+            self.FS_X_train_batch = torch.cat([self.FS_X_train_batch, g_in], dim=2)
+            self.FS_Y_train_batch = torch.cat([self.FS_Y_train_batch, label], dim=2)
             if fused:
-                samples_left = self._propagate_fused(X_soln, U_soln, x_next, samples_left, base_samples, n_last, dev)
+                alive = self._propagate_fused(plan_x, plan_u, states, alive, base_samples, steps, dev)
                 break
             self.train_forward_sampling_dynGP()
-            xu_hat = torch.cat([torch.stack([x_next] * self.nx, dim=1)[:, :, None, :],
-                                torch.tile(U_soln[[i + 1]], dims=(n_sample, self.nx, 1, 1))], dim=-1)
+
+        # rejected samples inherit the hallucinated data of randomly chosen survivors (X and Y drawn separately, as the
+        # reference does: two calls of the generator)
         if self.dist_group is not None:                                            # samples sharded over ranks
             from .distributed import replace_rejected_samples
             self.Hallcinated_X_train, self.Hallcinated_Y_train = replace_rejected_samples(
-                self.Hallcinated_X_train, self.Hallcinated_Y_train, samples_left, self.ns_global, rng, self.dist_group)
-        elif torch.sum(samples_left) > 0:
-            n_rep = int(torch.sum(samples_left == 0).item())
-            remaining = torch.arange(n_sample)[(samples_left > 0).cpu()].numpy()
-            dead = samples_left == 0
-            self.Hallcinated_X_train[dead] = self.Hallcinated_X_train[rng.choice(remaining, n_rep).tolist()]
-            self.Hallcinated_Y_train[dead] = self.Hallcinated_Y_train[rng.choice(remaining, n_rep).tolist()]
+                self.Hallcinated_X_train, self.Hallcinated_Y_train, alive, self.ns_global, rng, self.dist_group)
+        elif int(alive.sum().item()) > 0:
+            rejected = alive == 0
+            n_rejected = int(rejected.sum().item())
+            survivors = torch.nonzero(alive > 0).reshape(-1).cpu().numpy()
+            self.Hallcinated_X_train[rejected] = self.Hallcinated_X_train[rng.choice(survivors, n_rejected).tolist()]
+            self.Hallcinated_Y_train[rejected] = self.Hallcinated_Y_train[rng.choice(survivors, n_rejected).tolist()]
         self.train_hallucinated_dynGP(sqp_iter=self.params["optimizer"]["SEMPC"]["max_sqp_iter"])
-        return
 
     def _propagate_fused(self, X_soln, U_soln, x_next1, samples_left, base_samples, n_last, dev):
         """Propagation steps i = 2 .. n_last of ``prepare_dynamics_set`` in one ``gpmpc_rollout_seeded`` launch: the
