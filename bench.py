@@ -49,7 +49,8 @@ def parse():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--ns", type=int, default=1024, help="samples per GPU (BASELINE configs[1]: 1024)")
     ap.add_argument("--horizon", type=int, default=30)
-    ap.add_argument("--cpu-sample", type=int, default=1024, help="samples of the CPU-oracle baseline (0 = skip)")
+    ap.add_argument("--cpu-sample", type=int, default=256, help="samples per CPU-oracle baseline rollout (0 = skip)")
+    ap.add_argument("--cpu-repeats", type=int, default=6, help="rollouts of the CPU-oracle baseline (~10 s of CPU work in all)")
     ap.add_argument("--prewarm", type=int, default=2000,
                     help="untimed steps before the second warmup that bring the GPU to its sustained clocks (the cold "
                          "region is measured before them and reported as well); 0 = off")
@@ -71,7 +72,7 @@ def roofline(flop_per_launch, kernel_ms, kernel, hbm_bytes_algorithmic, note=Non
     return r
 
 
-def cpu_baseline(Ns_cpu, H, u_ff):
+def cpu_baseline(Ns_cpu, H, u_ff, repeats=1):
     """Time the oracle (reference-faithful: Ns-tiled real data, dense kernel rebuild, from-scratch Cholesky per step) at
     the best of several torch thread counts (probed on a quarter-size sample), on the bounded sample."""
     from oracle import agent_oracle as ao
@@ -96,7 +97,8 @@ def cpu_baseline(Ns_cpu, H, u_ff):
     for th in sorted({t for t in (8, 16, 32, 64, 128) if t <= ncpu}):
         probe[th] = run(max(Ns_cpu // 4, 16), th)[0]
     best = max(probe, key=probe.get)
-    v, dt = run(Ns_cpu, best)
+    dt = sum(run(Ns_cpu, best)[1] for _ in range(max(repeats, 1)))
+    v = max(repeats, 1) * Ns_cpu * H / dt
     torch.set_num_threads(default_threads)
     return v, dt, best, {str(k): round(x, 1) for k, x in probe.items()}
 
@@ -437,11 +439,12 @@ def main():
             "gather": gather,
         }
         if world == 1 and a.cpu_sample > 0:
-            v, dt, th, probe = cpu_baseline(a.cpu_sample, H, u_ff)
+            v, dt, th, probe = cpu_baseline(a.cpu_sample, H, u_ff, a.cpu_repeats)
             out["cpu_baseline"] = {"value": v, "unit": "trajectory-steps/s", "cores": th, "kind": "port",
-                                   "sample": "same workload, Ns=%d of %d samples, full H=%d horizon, %.1f s of CPU work "
-                                             "(oracle: reference-faithful from-scratch batched Cholesky per step, torch "
-                                             "CPU FP64; gpytorch itself is not installable on the box)" % (a.cpu_sample, Ns, H, dt),
+                                   "sample": "same workload, %d rollouts of Ns=%d of %d samples, full H=%d horizon, %.1f s "
+                                             "of CPU work at the best of the probed thread counts (oracle: reference-faithful "
+                                             "from-scratch batched Cholesky per step, torch CPU FP64; gpytorch itself is not "
+                                             "installable on the box)" % (max(a.cpu_repeats, 1), a.cpu_sample, Ns, H, dt),
                                    "thread_probe_steps_per_s": probe, "host_cpus": os.cpu_count()}
         else:
             out["cpu_baseline"] = None
