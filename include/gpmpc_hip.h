@@ -215,7 +215,7 @@ int    gpmpc_rollout_seeded(const gpmpc_gp_desc_t* gp, const gpmpc_env_desc_t* e
  *           factor (L_hr, L_hh) and 1/diag.  The reference re-factorises K_oo from scratch on every call
  *           (src/agent.py:241-250, 640); in the SQP loop the hallucinated set only GROWS between two resets
  *           (src/agent.py:164-202, 261-272), so the rows of the slots that were already there are unchanged: with
- *           n_cached > 0 (a multiple of 16, <= n_ho) the first n_cached rows are taken from the cache - the CALLER vouches
+ *           n_cached > 0 (<= n_ho) the first n_cached rows are taken from the cache - the CALLER vouches
  *           that h_slots[:n_cached] and their points X_h are the ones of the call that filled it (labels may differ:
  *           the factor does not depend on them) - and every call writes the rows it computed (n_ho <= cache_rows).
  *           Results are bit-identical with and without the cache.

@@ -419,8 +419,11 @@ __global__ __launch_bounds__(NT, WPE) void joint_kernel(const JointArgs a) {
         JPH(0);
 
         // ---- hallucinated columns, NB at a time -------------------------------------------------------------------
-        for (int c0 = 0; c0 < n_ho; c0 += NB) {
-            const int nb = min(NB, n_ho - c0);
+        // (the blocks are NB wide from slot 0 and again from slot n_c: a block never straddles the cached / new boundary,
+        // so n_c needs no alignment - the cache holds plain factor entries, any partition can read them)
+        for (int c0 = 0, nb = 0; c0 < n_ho; c0 += nb) {
+            const bool cached = c0 < n_c;                     // uniform: the block's pivot rows and its factorised diagonal block are in the cache
+            nb = min(NB, (cached ? n_c : n_ho) - c0);
             if (tid < NB) {                                   // descriptors of the block's pivot slots, shared by all rows
                 int tc = 0, same = 0;
                 double x0 = 0.0, x1 = 0.0, yl = 0.0;
@@ -468,7 +471,6 @@ __global__ __launch_bounds__(NT, WPE) void joint_kernel(const JointArgs a) {
                 }
             }
             JPH(1);
-            const bool cached = c0 < n_c;                     // uniform: the block's pivot rows and its factorised diagonal block are in the cache
             block_update<NB, RPT, KC, NT>(M + rb, ld, n_r + c0, cached ? fc + (long)c0 * CS : M + c0, cached ? CS : 1,
                                           cached ? 1 : ld, nb, cached ? 0 : c0 - rb, nrow - rb, acc, piv);
             __syncthreads();
@@ -476,9 +478,9 @@ __global__ __launch_bounds__(NT, WPE) void joint_kernel(const JointArgs a) {
             if (cached) {
                 for (int e = tid; e < NB * NB; e += nt) {
                     const int q = e / NB, c = e - q * NB;
-                    if (c <= q) blk[q][c] = fc[(long)(c0 + q) * CS + n_r + c0 + c];
+                    if (c <= q) blk[q][c] = (q < nb) ? fc[(long)(c0 + q) * CS + n_r + c0 + c] : 0.0;
                 }
-                if (tid < NB) dinv_s[tid] = fdinv[c0 + tid];
+                if (tid < NB) dinv_s[tid] = (tid < nb) ? fdinv[c0 + tid] : 0.0;
                 if (tid == 0) s_flag = 0;
             } else {
 #pragma unroll
@@ -850,8 +852,8 @@ int gpmpc_joint_sample(const gpmpc_gp_desc_t* gp, const void* plan, const double
     a.Sall = (double*)ws + w.s_off;
     a.any_fail = (int*)((double*)ws + w.f_off);
     if (factor_cache) {
-        if (cache_rows < 16 || n_cached < 0 || n_cached > n_ho || n_cached > cache_rows || (n_cached & 15))
-            return fail(GPMPC_E_ARG, "gpmpc_joint_sample: factor cache: rows >= 16, 0 <= n_cached <= min(n_ho, rows), n_cached % 16 == 0");
+        if (cache_rows < 16 || n_cached < 0 || n_cached > n_ho || n_cached > cache_rows)
+            return fail(GPMPC_E_ARG, "gpmpc_joint_sample: factor cache: rows >= 16, 0 <= n_cached <= min(n_ho, rows)");
         a.fcache = (double*)factor_cache;
         a.fc_cap = cache_rows;
         a.fc_cs = a.gp.n_r + cache_rows;

@@ -161,7 +161,7 @@ class JointFactorCache:
             # append-only growth: the old slot list is a prefix of the new one and the points it was built on are unchanged
             if n_old <= n_ho and n_pts <= mdl.n_h and bool(torch.equal(mdl.h_slots[:n_old], self.slots)) \
                     and bool(torch.equal(mdl.hall_X[:, :, :n_pts], self.X)):
-                n_c = n_old & ~15
+                n_c = n_old
         return self.buf, self.rows, n_c
 
     def rewind(self, n_slots: int):

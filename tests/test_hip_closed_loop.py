@@ -107,8 +107,8 @@ def test_joint_factor_cache_is_bit_exact_and_used(sg, pname, Ns, H):
         T = 3
         print(f"{pname}: cached rows per call {hits}")
         assert hits[0] == 0 and hits[1] == 0                         # k = 0: empty set; k = 1: its rows are new
-        assert hits[2] == (H * T) & ~15 and hits[3] == (2 * H * T) & ~15
-        assert hits[4] == (3 * H * T) & ~15                          # next MPC step, k = 0: the pre-reset set
+        assert hits[2] == H * T and hits[3] == 2 * H * T
+        assert hits[4] == 3 * H * T                                  # next MPC step, k = 0: the pre-reset set
         assert hits[5] == 0                                          # after the reset: other points
         # changing a cached point (survivor replacement does that) invalidates the cache
         agent.Hallcinated_X_train[0, :, 0, :] += 1e-3
