@@ -226,3 +226,59 @@ def test_on_disk_formats_are_read_by_the_reference_loaders(tmp_path):
     for idx in (1, 2):
         io.save_x_traj(str(tmp_path), idx, X_traj + idx)
     np.testing.assert_array_equal(io.merge_x_traj(str(tmp_path), (1, 2)), d["ref_merged"])
+
+
+def test_joint_factor_cache_bookkeeping():
+    """Host logic of gp_model.JointFactorCache (no GPU): which rows it vouches for.  Append-only growth of the slot list
+    keeps the old rows, a changed point / a shorter or different slot list / a failed factorisation drops them, the
+    buffer grows with the set."""
+    from types import SimpleNamespace
+    from sampling_gpmpc_amd import _lib
+    from sampling_gpmpc_amd.gp_model import JointFactorCache
+    _lib.load()
+    Ns, g_ny, T, D, n_r = 4, 3, 3, 2, 45
+    desc = _lib.make_gp_desc(g_ny, D, T, n_r, False, [[2.0, 1.1]] * 3, [0.05] * 3, [2e-7] * 3, 1e-20)
+    g = torch.Generator().manual_seed(0)
+    X = torch.randn(Ns, g_ny, 40, D, generator=g, dtype=torch.float64)
+
+    def model(n_pts):
+        return SimpleNamespace(hyper=SimpleNamespace(g_ny=g_ny, T=T), n_h=n_pts, hall_X=X[:, :, :n_pts].clone(),
+                               plan=SimpleNamespace(n_r=n_r, desc=desc, X_r=torch.zeros(1)),
+                               h_slots=torch.arange(n_pts * T, dtype=torch.int32))
+
+    plan = model(0).plan
+
+    def mk(n_pts):
+        m = model(n_pts)
+        m.plan = plan                                   # the cache is keyed by the plan object
+        return m
+
+    c = JointFactorCache()
+    assert c.prepare(mk(2), Ns, 6)[0] is None           # fewer than 16 slots: not worth a cache
+    buf, rows, n_c = c.prepare(mk(10), Ns, 30)
+    assert buf is not None and rows >= 4 * 30 and n_c == 0 and buf.numel() * 8 == _lib.load().gpmpc_joint_cache_bytes(desc, Ns, rows)
+    c.commit(mk(10), 30, ok=True)
+    assert c.n_valid == 30
+    assert c.prepare(mk(20), Ns, 60)[2] == 30           # grown: the old slots' rows are kept
+    assert c.prepare(mk(10), Ns, 30)[2] == 30           # the same set again: everything cached
+    m = mk(20)
+    m.hall_X[1, 2, 3, 0] += 1e-9
+    assert c.prepare(m, Ns, 60)[2] == 0                 # a cached point moved
+    m = mk(20)
+    m.h_slots = torch.cat([m.h_slots[:5], m.h_slots[6:]])
+    assert c.prepare(m, Ns, 59)[2] == 0                 # a slot disappeared from the prefix (NaN-masked label)
+    assert c.prepare(mk(5), Ns, 15)[2] == 0             # reset: fewer slots than cached
+    c.rewind(12)
+    assert c.n_valid == 12 and c.prepare(mk(20), Ns, 60)[2] == 12
+    c.commit(mk(20), 60, ok=False)
+    assert c.n_valid == 0 and c.prepare(mk(20), Ns, 60)[2] == 0      # a failed factorisation is not kept
+    c.commit(mk(20), 60, ok=True)
+    old_rows = c.rows
+    big = SimpleNamespace(**vars(mk(20)))
+    big.h_slots = torch.arange(old_rows + 16, dtype=torch.int32)
+    big.n_h = (old_rows + 16 + T - 1) // T
+    big.hall_X = torch.zeros(Ns, g_ny, big.n_h, D, dtype=torch.float64)
+    buf2, rows2, n_c2 = c.prepare(big, Ns, old_rows + 16)
+    assert rows2 > old_rows and n_c2 == 0               # a set beyond the capacity: new buffer, nothing carried over
+    c.enabled = False
+    assert c.prepare(mk(20), Ns, 60) == (None, 0, 0)
