@@ -151,7 +151,10 @@ class JointFactorCache:
                 self.buf, self.rows, self.key = None, 0, None
                 self.invalidate()
                 return None, 0, 0
-            self.buf = None                                                    # release the old one first
+            had = self.buf is not None
+            self.buf = None                                                    # release the old one first, back to the driver
+            if had and mdl.plan.X_r.is_cuda:
+                torch.cuda.empty_cache()
             self.buf = torch.empty(nbytes // 8, dtype=F64, device=mdl.plan.X_r.device)
             self.rows, self.key = rows, key
             self.invalidate()
@@ -368,7 +371,14 @@ class HipGPModel:
     def _workspace(self, nbytes: int) -> torch.Tensor:
         buf = self._ws_cache.get("joint")
         if buf is None or buf.numel() * 8 < nbytes:
-            buf = torch.empty((nbytes + 7) // 8, dtype=F64, device=self.plan.X_r.device)
+            # grow-only, with headroom (the conditioning set grows every SQP iteration); the outgrown buffer goes back to
+            # the driver instead of staying in torch's cache, where nothing of that size would ever reuse it
+            had = buf is not None
+            buf = None
+            self._ws_cache.pop("joint", None)
+            if had and self.plan.X_r.is_cuda:
+                torch.cuda.empty_cache()
+            buf = torch.empty(((nbytes + nbytes // 4) + 7) // 8, dtype=F64, device=self.plan.X_r.device)
             self._ws_cache["joint"] = buf
         return buf
 
