@@ -871,10 +871,12 @@ int gpmpc_joint_sample(const gpmpc_gp_desc_t* gp, const void* plan, const double
     // iteration 0 of config 5 has 121 rows; iteration 0 of every later MPC step conditions on the previous step's
     // whole hallucinated set - the reference's reset-after-build quirk - i.e. 601 rows at config 5: 1024 threads)
     const dim3 g((unsigned)grid);
+    static const char* penv = getenv("GPMPC_JOINT_LDS_PAD");           // experiment knob: dynamic LDS bytes per workgroup (caps the chains per CU)
+    const size_t lds_pad = penv ? (size_t)atol(penv) : 0;
 #define GPMPC_JOINT_LAUNCH(TT)                                                                              \
     do {                                                                                                    \
-        if (nrow <= 128) hipLaunchKernelGGL((joint_kernel<TT, 16, 1, 128, GPMPC_JOINT_WPE>), g, dim3(128), 0, st, a);      \
-        else if (nrow <= 256) hipLaunchKernelGGL((joint_kernel<TT, 16, 1, 256, GPMPC_JOINT_WPE>), g, dim3(256), 0, st, a); \
+        if (nrow <= 128) hipLaunchKernelGGL((joint_kernel<TT, 16, 1, 128, GPMPC_JOINT_WPE>), g, dim3(128), lds_pad, st, a);      \
+        else if (nrow <= 256) hipLaunchKernelGGL((joint_kernel<TT, 16, 1, 256, GPMPC_JOINT_WPE>), g, dim3(256), lds_pad, st, a); \
         else if (nrow <= 512) hipLaunchKernelGGL((joint_kernel<TT, 16, 1, 512, GPMPC_JOINT_WPE>), g, dim3(512), 0, st, a); \
         else if (nrow <= 1024) hipLaunchKernelGGL((joint_kernel<TT, 16, 1, 1024, 4>), g, dim3(1024), 0, st, a);            \
         else hipLaunchKernelGGL((joint_kernel<TT, 16, 2, 1024, 4>), g, dim3(1024), 0, st, a);               \
