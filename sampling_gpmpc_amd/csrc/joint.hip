@@ -90,6 +90,9 @@ __device__ long long g_joint_phase[16];
 #ifndef GPMPC_JOINT_RD
 #define GPMPC_JOINT_RD 2
 #endif
+#ifndef GPMPC_JOINT_NB
+#define GPMPC_JOINT_NB 16          // pivot columns per block of the launches of <= 256 rows (experiment knob: 32)
+#endif
 #ifndef GPMPC_JOINT_LDS_BCAST
 #define GPMPC_JOINT_LDS_BCAST 0          // 1: the broadcast-ds_read_b128 update (comparison builds, tools/joint_sweep.sh)
 #endif
@@ -197,6 +200,15 @@ __device__ __forceinline__ void block_update(const double* __restrict__ W, int l
                                 const double pk = piv[kb + j][tid & 15];
 #pragma unroll
                                 for (int rs = 0; rs < RPT; ++rs) fmac16_dpp(acc[rs], pk, ring[r][j][rs]);
+                            }
+                        } else if constexpr (NB == 32 && !GPMPC_JOINT_LDS_BCAST) {
+                            if (kb + j < kc) {
+                                const double pk0 = piv[kb + j][tid & 15], pk1 = piv[kb + j][16 + (tid & 15)];
+#pragma unroll
+                                for (int rs = 0; rs < RPT; ++rs) {
+                                    fmac16_dpp(*reinterpret_cast<double(*)[16]>(&acc[rs][0]), pk0, ring[r][j][rs]);
+                                    fmac16_dpp(*reinterpret_cast<double(*)[16]>(&acc[rs][16]), pk1, ring[r][j][rs]);
+                                }
                             }
                         } else
                         if (kb + j < kc) {
@@ -873,10 +885,16 @@ int gpmpc_joint_sample(const gpmpc_gp_desc_t* gp, const void* plan, const double
     const dim3 g((unsigned)grid);
     static const char* penv = getenv("GPMPC_JOINT_LDS_PAD");           // experiment knob: dynamic LDS bytes per workgroup (caps the chains per CU)
     const size_t lds_pad = penv ? (size_t)atol(penv) : 0;
+    // long conditioning sets on the 256-thread workgroups: 32-column blocks at two waves per SIMD (256 VGPRs) - half the
+    // workspace re-reads; the draw is stream-bound and loses little with fewer chains per CU, but the wider blocks cost more
+    // serial work per block, so only from ~300 hallucinated slots on (k=3 scattered points 9.8 against 10.8 ms; k=2 7.2 / 7.0)
+    static const char* wenv = getenv("GPMPC_JOINT_WIDE_FROM");        // experiment knob: hallucinated slots from which it is used
+    const bool wide = n_ho >= (wenv ? atoi(wenv) : 300);
 #define GPMPC_JOINT_LAUNCH(TT)                                                                              \
     do {                                                                                                    \
-        if (nrow <= 128) hipLaunchKernelGGL((joint_kernel<TT, 16, 1, 128, GPMPC_JOINT_WPE>), g, dim3(128), lds_pad, st, a);      \
-        else if (nrow <= 256) hipLaunchKernelGGL((joint_kernel<TT, 16, 1, 256, GPMPC_JOINT_WPE>), g, dim3(256), lds_pad, st, a); \
+        if (nrow <= 128) hipLaunchKernelGGL((joint_kernel<TT, GPMPC_JOINT_NB, 1, 128, GPMPC_JOINT_WPE>), g, dim3(128), lds_pad, st, a);      \
+        else if (nrow <= 256 && wide) hipLaunchKernelGGL((joint_kernel<TT, 32, 1, 256, 2>), g, dim3(256), lds_pad, st, a);           \
+        else if (nrow <= 256) hipLaunchKernelGGL((joint_kernel<TT, GPMPC_JOINT_NB, 1, 256, GPMPC_JOINT_WPE>), g, dim3(256), lds_pad, st, a); \
         else if (nrow <= 512) hipLaunchKernelGGL((joint_kernel<TT, 16, 1, 512, GPMPC_JOINT_WPE>), g, dim3(512), 0, st, a); \
         else if (nrow <= 1024) hipLaunchKernelGGL((joint_kernel<TT, 16, 1, 1024, 4>), g, dim3(1024), 0, st, a);            \
         else hipLaunchKernelGGL((joint_kernel<TT, 16, 2, 1024, 4>), g, dim3(1024), 0, st, a);               \
