@@ -90,6 +90,9 @@ __device__ long long g_joint_phase[16];
 #ifndef GPMPC_JOINT_RD
 #define GPMPC_JOINT_RD 2
 #endif
+#ifndef GPMPC_JOINT_WIDE_NB
+#define GPMPC_JOINT_WIDE_NB 32     // pivot columns per block of the two-waves-per-SIMD variant for long conditioning sets
+#endif
 #ifndef GPMPC_JOINT_NB
 #define GPMPC_JOINT_NB 16          // pivot columns per block of the launches of <= 256 rows (experiment knob: 32)
 #endif
@@ -201,13 +204,14 @@ __device__ __forceinline__ void block_update(const double* __restrict__ W, int l
 #pragma unroll
                                 for (int rs = 0; rs < RPT; ++rs) fmac16_dpp(acc[rs], pk, ring[r][j][rs]);
                             }
-                        } else if constexpr (NB == 32 && !GPMPC_JOINT_LDS_BCAST) {
+                        } else if constexpr ((NB == 32 || NB == 48) && !GPMPC_JOINT_LDS_BCAST) {
                             if (kb + j < kc) {
-                                const double pk0 = piv[kb + j][tid & 15], pk1 = piv[kb + j][16 + (tid & 15)];
 #pragma unroll
-                                for (int rs = 0; rs < RPT; ++rs) {
-                                    fmac16_dpp(*reinterpret_cast<double(*)[16]>(&acc[rs][0]), pk0, ring[r][j][rs]);
-                                    fmac16_dpp(*reinterpret_cast<double(*)[16]>(&acc[rs][16]), pk1, ring[r][j][rs]);
+                                for (int h = 0; h < NB / 16; ++h) {
+                                    const double pkh = piv[kb + j][16 * h + (tid & 15)];
+#pragma unroll
+                                    for (int rs = 0; rs < RPT; ++rs)
+                                        fmac16_dpp(*reinterpret_cast<double(*)[16]>(&acc[rs][16 * h]), pkh, ring[r][j][rs]);
                                 }
                             }
                         } else
@@ -893,7 +897,7 @@ int gpmpc_joint_sample(const gpmpc_gp_desc_t* gp, const void* plan, const double
 #define GPMPC_JOINT_LAUNCH(TT)                                                                              \
     do {                                                                                                    \
         if (nrow <= 128) hipLaunchKernelGGL((joint_kernel<TT, GPMPC_JOINT_NB, 1, 128, GPMPC_JOINT_WPE>), g, dim3(128), lds_pad, st, a);      \
-        else if (nrow <= 256 && wide) hipLaunchKernelGGL((joint_kernel<TT, 32, 1, 256, 2>), g, dim3(256), lds_pad, st, a);           \
+        else if (nrow <= 256 && wide) hipLaunchKernelGGL((joint_kernel<TT, GPMPC_JOINT_WIDE_NB, 1, 256, 2>), g, dim3(256), lds_pad, st, a); \
         else if (nrow <= 256) hipLaunchKernelGGL((joint_kernel<TT, GPMPC_JOINT_NB, 1, 256, GPMPC_JOINT_WPE>), g, dim3(256), lds_pad, st, a); \
         else if (nrow <= 512) hipLaunchKernelGGL((joint_kernel<TT, 16, 1, 512, GPMPC_JOINT_WPE>), g, dim3(512), 0, st, a); \
         else if (nrow <= 1024) hipLaunchKernelGGL((joint_kernel<TT, 16, 1, 1024, 4>), g, dim3(1024), 0, st, a);            \
