@@ -94,7 +94,8 @@ __device__ long long g_joint_phase[16];
 #define GPMPC_JOINT_WIDE_NB 32     // pivot columns per block of the two-waves-per-SIMD variant for long conditioning sets
 #endif
 #ifndef GPMPC_JOINT_NB
-#define GPMPC_JOINT_NB 16          // pivot columns per block of the launches of <= 256 rows (experiment knob: 32)
+#define GPMPC_JOINT_NB 16          // pivot columns per block of the launches of <= 256 rows (experiment knob; 24 at three waves per
+                                   // SIMD measured: car k=0 / k=2 2.47 / 6.85 ms against 2.47 / 6.97, pendulum k=1 1.12 against 0.83)
 #endif
 #ifndef GPMPC_JOINT_LDS_BCAST
 #define GPMPC_JOINT_LDS_BCAST 0          // 1: the broadcast-ds_read_b128 update (comparison builds, tools/joint_sweep.sh)
@@ -123,6 +124,21 @@ __device__ __forceinline__ void fmac16_dpp(double (&acc)[16], double p, double w
         "v_fmac_f64_dpp %15, %16, -%17 row_newbcast:15 row_mask:0xf bank_mask:0xf"
         : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]), "+v"(acc[4]), "+v"(acc[5]), "+v"(acc[6]), "+v"(acc[7]),
           "+v"(acc[8]), "+v"(acc[9]), "+v"(acc[10]), "+v"(acc[11]), "+v"(acc[12]), "+v"(acc[13]), "+v"(acc[14]), "+v"(acc[15])
+        : "v"(p), "v"(w));
+}
+
+// the same for 8 pivot-row entries (lanes 0..7 of every DPP row hold them): the tail of a 24-column block
+__device__ __forceinline__ void fmac8_dpp(double (&acc)[8], double p, double w) {
+    asm("s_nop 1\n\t"
+        "v_fmac_f64_dpp %0, %8, -%9 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f64_dpp %1, %8, -%9 row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f64_dpp %2, %8, -%9 row_newbcast:2 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f64_dpp %3, %8, -%9 row_newbcast:3 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f64_dpp %4, %8, -%9 row_newbcast:4 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f64_dpp %5, %8, -%9 row_newbcast:5 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f64_dpp %6, %8, -%9 row_newbcast:6 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f64_dpp %7, %8, -%9 row_newbcast:7 row_mask:0xf bank_mask:0xf"
+        : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]), "+v"(acc[4]), "+v"(acc[5]), "+v"(acc[6]), "+v"(acc[7])
         : "v"(p), "v"(w));
 }
 
@@ -204,7 +220,7 @@ __device__ __forceinline__ void block_update(const double* __restrict__ W, int l
 #pragma unroll
                                 for (int rs = 0; rs < RPT; ++rs) fmac16_dpp(acc[rs], pk, ring[r][j][rs]);
                             }
-                        } else if constexpr ((NB == 32 || NB == 48) && !GPMPC_JOINT_LDS_BCAST) {
+                        } else if constexpr ((NB == 24 || NB == 32 || NB == 48) && !GPMPC_JOINT_LDS_BCAST) {
                             if (kb + j < kc) {
 #pragma unroll
                                 for (int h = 0; h < NB / 16; ++h) {
@@ -212,6 +228,12 @@ __device__ __forceinline__ void block_update(const double* __restrict__ W, int l
 #pragma unroll
                                     for (int rs = 0; rs < RPT; ++rs)
                                         fmac16_dpp(*reinterpret_cast<double(*)[16]>(&acc[rs][16 * h]), pkh, ring[r][j][rs]);
+                                }
+                                if constexpr (NB % 16 == 8) {
+                                    const double pkt = piv[kb + j][(NB & ~15) + (tid & 7)];
+#pragma unroll
+                                    for (int rs = 0; rs < RPT; ++rs)
+                                        fmac8_dpp(*reinterpret_cast<double(*)[8]>(&acc[rs][NB & ~15]), pkt, ring[r][j][rs]);
                                 }
                             }
                         } else
