@@ -1,4 +1,6 @@
-import os, sys, time, warnings
+import os, sys, time, warnings, gc
+if os.environ.get("NOGC") == "1":
+    gc.disable()
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 import numpy as np, torch
 import sampling_gpmpc_amd as sg
