@@ -27,7 +27,10 @@ if os.environ.get("GPMPC_PHASE_TIMERS") == "1":      # debug build: per-phase s_
 
 # Per-file code-generation flags.  rollout_fast.hip runs at one wave per SIMD: machine-LICM hoists ~100 registers of
 # constants/addresses out of the time-step loop, which starves the scheduler of VGPRs and serialises the LDS loads.
-EXTRA_FLAGS = {"rollout_fast.hip": os.environ.get("GPMPC_FAST_FLAGS", "-mllvm -disable-machine-licm").split()}
+# joint.hip sits at the 128-VGPR cliff: without machine-LICM its kernels spill 0-50 registers instead of 55-77 (2-9 % per
+# joint draw, tools/bench_joint.py / bench.py extras, round 2).
+EXTRA_FLAGS = {"rollout_fast.hip": os.environ.get("GPMPC_FAST_FLAGS", "-mllvm -disable-machine-licm").split(),
+               "joint.hip": os.environ.get("GPMPC_JOINT_FLAGS", "-mllvm -disable-machine-licm").split()}
 
 
 STAMP = os.path.join(OBJDIR, "flags.stamp")
