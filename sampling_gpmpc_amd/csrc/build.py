@@ -30,7 +30,11 @@ if os.environ.get("GPMPC_PHASE_TIMERS") == "1":      # debug build: per-phase s_
 # joint.hip sits at the 128-VGPR cliff: without machine-LICM its kernels spill 0-50 registers instead of 55-77 (2-9 % per
 # joint draw, tools/bench_joint.py / bench.py extras, round 2).
 EXTRA_FLAGS = {"rollout_fast.hip": os.environ.get("GPMPC_FAST_FLAGS", "-mllvm -disable-machine-licm").split(),
-               "joint.hip": os.environ.get("GPMPC_JOINT_FLAGS", "-mllvm -disable-machine-licm").split()}
+               "joint.hip": os.environ.get("GPMPC_JOINT_FLAGS", "-mllvm -disable-machine-licm").split(),
+               # the generic rollout kernel: 119-152 VGPRs instead of 131-174 (car Ns=4096 H=40: 22.3 -> 13.2 ms; pendulum 1.14 ms
+               # either way); the sample-per-lane kernels of rollout_indep.hip measure 0.093 / 0.543 ms with it off, 0.097 / 0.547 on
+               "rollout.hip": os.environ.get("GPMPC_ROLLOUT_FLAGS", "-mllvm -disable-machine-licm").split(),
+               "rollout_indep.hip": os.environ.get("GPMPC_INDEP_FLAGS", "").split()}
 
 
 STAMP = os.path.join(OBJDIR, "flags.stamp")
