@@ -5,6 +5,10 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
+Both forms work for N > 1: started WITHOUT a launcher (WORLD_SIZE unset), this process - before it has touched HIP -
+starts the N ranks as fresh child processes through torch.distributed.run (one per GPU), forwards rank 0's JSON line and
+exits with the children's status (`self_launch`; the reference scales out with a job array, benchmarking/euler_job.sh:5-11).
+
 A "step" is one pass of the hot path over one batch: the full H-step re-conditioned rollout of the rank's Ns sampled
 dynamics functions (one gpmpc_rollout launch) plus, for N > 1, the RCCL all-gather that assembles the reachable tube
 X_traj (N*Ns, nx, H+1) on every rank.  Workload at every N: BASELINE.json configs[1] per GPU - pendulum1D
@@ -25,7 +29,10 @@ duration measured with HIP events on the launch stream (one event pair per launc
 after the timed region).  `cpu_baseline` times the CPU oracle (the reference-faithful from-scratch algorithm, torch CPU
 FP64) on rank 0 at N = 1 on a bounded sample of the same workload, at the best of several thread counts.  `extra`
 (N = 1) carries BASELINE configs[2] (car, mode R) and configs[4]'s per-GPU shard (car closed loop AS SHIPPED, mode J,
-SQP iterations k = 0..3), each with its own roofline object.
+SQP iterations k = 0..3) and configs[1]'s mode-J points (pendulum, k = 0 / 1), each with its own roofline object;
+`end_to_end_ms` (N = 1) is host z -> HBM, rollout, X_traj -> host.  For N > 1 `extra` carries the SHARDED closed loop of
+configs[4] (per-rank Agents over 1024 samples each, per SQP iteration: joint draw + Jacobians on the device, ONE gather
+of the packed Jacobians to rank 0, one D2H copy; max over ranks).
 """
 import argparse
 import json
@@ -56,8 +63,38 @@ def parse():
                          "region is measured before them and reported as well); 0 = off")
     ap.add_argument("--reach-ns", type=int, default=32768,
                     help="samples per GPU of the informational reachable-set leg (configs[3], mode I; 0 = skip)")
-    ap.add_argument("--no-extra", action="store_true", help="skip the configs[2] / configs[4] legs (N = 1 only)")
+    ap.add_argument("--no-extra", action="store_true", help="skip the configs[2] / configs[4] legs")
+    ap.add_argument("--cl-ns", type=int, default=1024, help="samples per GPU of the sharded closed-loop leg (N > 1)")
     return ap.parse_args()
+
+
+def self_launch(a):
+    """`python bench.py --gpus N` with no launcher around it: start the N ranks as fresh processes (one per GPU, RCCL) and
+    forward what they print.  Runs BEFORE anything touches HIP in this process (no torch.cuda.is_available(), no library
+    load): a process that has initialised the GPU must never fork / exec the ranks."""
+    import socket
+    import subprocess
+    dry = os.environ.get("GPMPC_BENCH_DRY_LAUNCH") == "1"
+    if not dry and torch.cuda.device_count() < a.gpus:          # device_count() does not initialise the GPU on this image
+        sys.stderr.write("bench.py: --gpus %d but %d HIP device(s) visible\n" % (a.gpus, torch.cuda.device_count()))
+        sys.exit(2)
+    sk = socket.socket()
+    sk.bind(("127.0.0.1", 0))
+    port = sk.getsockname()[1]
+    sk.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % a.gpus,
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")           # dmabuf IPC only on this pool (RCCL needs it)
+    env["GPMPC_BENCH_PARENT"] = str(os.getpid())
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    for line in proc.stdout:                                     # rank 0's JSON line (and the dry-launch markers)
+        sys.stdout.write(line)
+        sys.stdout.flush()
+    rc = proc.wait()
+    sys.stderr.write(json.dumps({"launcher": {"pid": os.getpid(), "ranks": a.gpus, "port": port, "rc": rc,
+                                              "hip_initialised_in_parent": bool(torch.cuda.is_initialized())}}) + "\n")
+    sys.exit(rc if rc == 0 or 0 < rc < 256 else 1)
 
 
 def roofline(flop_per_launch, kernel_ms, kernel, hbm_bytes_algorithmic, note=None, **more):
@@ -138,17 +175,20 @@ def extra_car_rollout(sg, _lib, RolloutRunner, wl):
                                  wl.min_hbm_bytes(4, 3, 3) * Ns * H)}
 
 
-def extra_closed_loop(sg, _lib, wl):
-    """BASELINE configs[4] on its per-GPU shard, AS SHIPPED (params_car_residual.yaml incl. Dyn_gp_jitter 1e-20 -> the
-    eigendecomposition root): Ns = 8192 / 8 = 1024, H = 40, joint draw per SQP iteration k = 0..3 (reference
-    src/solver.py:84-94); linearisation points from the deterministic surrogate of SURVEY.md 8d (sample mean of the
-    previous iteration's prediction)."""
+def extra_closed_loop(sg, _lib, wl, name="params_car_residual", Ns=1024, H=40, iters=4, next_step=True, label=None):
+    """Joint draws of the closed loop (mode J), per SQP iteration k (reference src/solver.py:84-94); linearisation points
+    from the deterministic surrogate of SURVEY.md 8d (sample mean of the previous iteration's prediction).
+    Default: BASELINE configs[4] on its per-GPU shard, AS SHIPPED (params_car_residual.yaml incl. Dyn_gp_jitter 1e-20 -> the
+    eigendecomposition root): Ns = 8192 / 8 = 1024, H = 40, k = 0..3 and k = 0 of the next MPC step.  Also used for
+    configs[1]'s mode-J points (pendulum, Ns = 1024, H = 30, k = 0 and k = 1; Cholesky root, jitter 1e-6).
+    `ms_per_draw`: HIP events around the draw (min of 4); `wall_ms_per_iteration`: wall clock of the real SQP iteration of
+    the facade (train -> x_hat -> draw + Jacobians + D2H of the three arrays), synchronised at both ends."""
     import warnings
-    Ns, H, iters = 1024, 40, 4
-    p = wl.closed_loop_params("params_car_residual", Ns, H, 2, iters)
+    p = wl.closed_loop_params(name, Ns, H, 2, iters)
     p["common"]["use_cuda"] = True
     p["agent"]["base_sample_generator"] = "counter"
     agent = sg.Agent(p, sg.make_env(p))
+    g_ny, T = agent.g_ny, agent.in_dim_y
     x0 = np.asarray(p["env"]["start"], dtype=np.float64)[: agent.nx]
     u_h = wl.synthetic_u_ff(agent.nu, H)
     x_h = np.tile(x0, (H, Ns))
@@ -178,23 +218,30 @@ def extra_closed_loop(sg, _lib, wl):
         torch.cuda.synchronize()
         ms, ms_min = time_launches(draw, 4)
         rewind()
-        gp_val, _, _ = agent.dyn_fg_jacobians(bx, k)            # the real call: appends the draw to the hallucinated set
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        agent.train_hallucinated_dynGP(k)                       # the real iteration of the facade, wall clock
+        gp_val, _, _ = agent.dyn_fg_jacobians(agent.get_batch_x_hat(x_h, u_h), k)   # appends the draw to the hallucinated set
+        torch.cuda.synchronize()
+        wall_ms = (time.perf_counter() - t0) * 1e3
         info = agent.model_i_call.last_info
         n_ho = int(agent.model_i.h_slots.numel())
         n_c = int(agent.model_i_call.n_cached_rows)
-        flop_ref = wl.flop_mode_j(3, 3, 45, H, n_ho // (3 * H)) * Ns           # what the reference's call computes
-        flop = flop_ref - wl.flop_mode_j_cached_rows(3, 45, n_c) * Ns          # what this call executes
-        out.append({"mpc_step": step, "k": k, "n_o": int(agent.model_i.plan.n_r + n_ho),
+        n_r = int(agent.model_i.plan.n_r)
+        flop_ref = wl.flop_mode_j(g_ny, T, n_r, H, n_ho // (T * H)) * Ns       # what the reference's call computes
+        flop = flop_ref - wl.flop_mode_j_cached_rows(g_ny, n_r, n_c) * Ns      # what this call executes
+        eigh = bool((info & _lib.INFO_ROOT_EIGH).all().item())
+        out.append({"mpc_step": step, "k": k, "n_o": int(n_r + n_ho),
                     "cached_rows": n_c, "executed_flop_frac": flop / flop_ref, "ms_per_draw": ms_min,
+                    "wall_ms_per_iteration": wall_ms,
                     "trajectory_steps_per_s": Ns * H / (ms_min * 1e-3),
-                    "eigh_root": bool((info & _lib.INFO_ROOT_EIGH).all().item()),
-                    "finite": bool(np.isfinite(gp_val).all()),
-                    "roofline": roofline(flop, ms_min, "joint_kernel<3,16,1,NT,4> + joint_eigh_kernel<3,2>",
-                                         8 * (2 * 4 + 2 * 3 * 3) * Ns * H,
+                    "eigh_root": eigh, "finite": bool(np.isfinite(gp_val).all()),
+                    "roofline": roofline(flop, ms_min, "joint_kernel<3,NB,1,NT,W>" + (" + joint_eigh_kernel<3,2>" if eigh else ""),
+                                         8 * (2 * agent.nx + 2 * g_ny * T) * Ns * H,
                                          note="joint draw incl. the facade's info reduction; FLOP = SURVEY 8d mode-J "
                                               "formula minus the factor rows served from the cache (`cached_rows`; "
-                                              "`executed_flop_frac` of what the reference's call computes); the "
-                                              "eigendecomposition is extra, uncounted work")})
+                                              "`executed_flop_frac` of what the reference's call computes)"
+                                              + ("; the eigendecomposition is extra, uncounted work" if eigh else ""))})
         mean_next = gp_val[:, :, :, 0].mean(axis=0).T
         return np.tile(np.vstack([x0[None, :], mean_next[:-1]]), (1, Ns))
 
@@ -203,12 +250,121 @@ def extra_closed_loop(sg, _lib, wl):
         agent.mpc_iteration(0)
         for k in range(iters):
             x_h = iteration(0, k, x_h)
-        # iteration 0 of the NEXT MPC step: the reference resets the hallucinated set only after the model has been
-        # built (src/agent.py:261-272), so this draw conditions on all four iterations' points of the previous step
-        agent.mpc_iteration(1)
-        iteration(1, 0, x_h)
-    return {"workload": "BASELINE configs[4] per-GPU shard as shipped: params_car_residual (Dyn_gp_jitter 1e-20), mode J, "
-                        "Ns=1024 (8192 / 8 GPUs), H=40, SQP iterations k=0..3 of MPC step 0 and k=0 of MPC step 1", "iterations": out}
+        if next_step:
+            # iteration 0 of the NEXT MPC step: the reference resets the hallucinated set only after the model has been
+            # built (src/agent.py:261-272), so this draw conditions on all the iterations' points of the previous step
+            agent.mpc_iteration(1)
+            iteration(1, 0, x_h)
+    return {"workload": label or ("BASELINE configs[4] per-GPU shard as shipped: params_car_residual (Dyn_gp_jitter 1e-20), "
+                                  "mode J, Ns=1024 (8192 / 8 GPUs), H=40, SQP iterations k=0..3 of MPC step 0 and k=0 of MPC "
+                                  "step 1"), "iterations": out}
+
+
+def extra_pendulum_joint(sg, _lib, wl):
+    """SURVEY 8d cfg2, mode J: params_pendulum1D_samples as shipped (jitter 1e-6: Cholesky root), Ns=1024, H=30, k=0 and k=1."""
+    return extra_closed_loop(sg, _lib, wl, "params_pendulum1D_samples", 1024, 30, 2, next_step=False,
+                             label="BASELINE configs[1] in mode J (SURVEY 8d cfg2): params_pendulum1D_samples, Ns=1024, H=30, "
+                                   "joint draw at SQP iterations k=0 and k=1")
+
+
+def sharded_closed_loop_leg(rank, world, dist, sg, _lib, wl, ns_per_gpu=1024, H=40, iters=4):
+    """BASELINE configs[4] sharded over the ranks (N > 1): params_car_residual as shipped, `ns_per_gpu` samples per GPU
+    (8192 / 8 = 1024), H = 40, per-SQP-iteration GP re-conditioning (reference src/solver.py:84-131).  Every rank owns an
+    Agent over its shard (distributed.make_sharded_agent: base samples keyed by global sample id); per iteration k:
+    train_hallucinated_dynGP -> x_hat -> joint draw + Jacobian assembly on the device (`draw_ms`, HIP events) ->
+    distributed.gather_jacobians: ONE gather of the packed (ns, nx, H, 1+nx+nu) blocks to rank 0 + one D2H copy
+    (`gather_ms`, wall clock between two synchronisations) -> rank 0 plays the solver (surrogate of SURVEY 8d: next
+    linearisation point = sample mean over ALL ranks' samples) and broadcasts the iterate.  MPC step 0 pays for the
+    grow-only buffers (workspace, factor cache); MPC step 1 is the steady state, its k = 0 conditions on the 480 slots the
+    reference's reset-after-build quirk leaves.  Every number is the max over ranks."""
+    import warnings
+    from sampling_gpmpc_amd.distributed import gather_jacobians, make_sharded_agent
+    Ns = ns_per_gpu * world
+    p = wl.closed_loop_params("params_car_residual", Ns, H, 2, iters)
+    p["common"]["use_cuda"] = True
+    p["agent"]["base_sample_generator"] = "counter"
+    agent = make_sharded_agent(sg.Agent, p, sg.make_env(p))
+    nx = agent.nx
+    x0 = np.asarray(p["env"]["start"], dtype=np.float64)[:nx]
+    u_h = wl.synthetic_u_ff(agent.nu, H)
+    row = torch.as_tensor(np.tile(x0, (H, 1)), device="cuda")     # (H, nx): the iterate, identical for every sample
+    out = []
+
+    def rank_max(vals):
+        t = torch.tensor(vals, dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return [float(v) for v in t.tolist()]
+
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for step in range(2):
+            agent.mpc_iteration(step)
+            for k in range(iters):
+                x_h = np.tile(row.cpu().numpy(), (1, agent.ns))
+                dist.barrier()
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                agent.train_hallucinated_dynGP(k)
+                bx = agent.get_batch_x_hat(x_h, u_h)
+                e0.record()
+                jac = agent.dyn_fg_jacobians_device(bx, k)
+                e1.record()
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                full = gather_jacobians(jac, Ns, dst=0)
+                torch.cuda.synchronize()
+                t2 = time.perf_counter()
+                if rank == 0:                                     # the solver's side: next iterate from ALL samples
+                    mean_next = full[0][:, :, :, 0].mean(axis=0).T
+                    row.copy_(torch.as_tensor(np.vstack([x0[None, :], mean_next[:-1]])))
+                    finite = bool(np.isfinite(full[0]).all() and np.isfinite(full[1]).all() and np.isfinite(full[2]).all())
+                dist.broadcast(row, src=0)
+                torch.cuda.synchronize()
+                t3 = time.perf_counter()
+                draw_ms, gather_ms, wall_ms = rank_max([e0.elapsed_time(e1), (t2 - t1) * 1e3, (t3 - t0) * 1e3])
+                if rank == 0:
+                    out.append({"mpc_step": step, "k": k, "n_o": int(agent.model_i.plan.n_r + agent.model_i.h_slots.numel()),
+                                "cached_rows": int(agent.model_i_call.n_cached_rows), "draw_ms": draw_ms,
+                                "gather_ms": gather_ms, "wall_ms_per_iteration": wall_ms, "finite": finite,
+                                "gathered_bytes": int(sum(a.nbytes for a in full)),
+                                "trajectory_steps_per_s": Ns * H / (wall_ms * 1e-3)})
+    return {"workload": "BASELINE configs[4] sharded over %d GPU(s): params_car_residual as shipped (Dyn_gp_jitter 1e-20), mode J, "
+                        "Ns=%d (%d per GPU), H=%d, SQP iterations k=0..%d of MPC steps 0 (cold: buffers grow) and 1 (steady)"
+                        % (world, Ns, ns_per_gpu, H, iters - 1),
+            "collective": "gather of the packed Jacobians (ns, nx, H, 1+nx+nu) f64 to rank 0 (RCCL) + one D2H copy",
+            "iterations": out}
+
+
+def reach_roofline(wl, Ns, kms):
+    """Mode I roofline by the algorithm the kernel executes (grid root: 1.66e3 FLOP per trajectory-step, workloads.
+    flop_mode_i_grid_root) AND by bytes (112 B per trajectory-step): the leg is closer to the HBM roof."""
+    units = Ns * 40
+    r = roofline(wl.flop_mode_i_grid_root(3, 5, 9) * units, kms, "rollout_indep_grid_kernel<car,5,9,3>",
+                 wl.min_hbm_bytes(4, 3, 1) * units,
+                 note="FLOP = the grid-root algorithm the kernel executes (3 x 554 per trajectory-step); SURVEY 8d's count "
+                      "of the triangular algorithm it replaces is 8.3e3 (`survey_flop_equiv_tflops`, not a roofline fraction)")
+    r["hbm_frac"] = r["algorithmic_hbm_gbps"] / 8000.0
+    r["survey_flop_equiv_tflops"] = wl.flop_mode_i(3, 45) * units / (kms * 1e-3) / 1e12
+    r["bound"] = "hbm" if r["hbm_frac"] > r["frac"] else "fp64_valu"
+    return r
+
+
+def end_to_end_ms(runner, agent, reps=20):
+    """SURVEY 8d "end-to-end": pinned host z -> HBM, one rollout launch, X_traj -> pinned host; wall clock, median."""
+    erv = agent.epistimic_random_vector
+    z_host = erv.cpu().pin_memory()
+    x_host = torch.empty(runner.X_traj.shape, dtype=runner.X_traj.dtype).pin_memory()
+    ts = []
+    for _ in range(reps + 3):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        erv.copy_(z_host, non_blocking=True)
+        runner.launch()
+        x_host.copy_(runner.X_traj, non_blocking=True)
+        torch.cuda.synchronize()
+        ts.append((time.perf_counter() - t0) * 1e3)
+    return float(np.median(ts[3:])), int(z_host.numel() * 8), int(x_host.numel() * 8)
 
 
 def reachable_set_leg(a, rank, world, dist, sg, _lib, RolloutRunner, wl):
@@ -277,11 +433,7 @@ def reachable_set_leg(a, rank, world, dist, sg, _lib, RolloutRunner, wl):
     res.update({"Ns_per_gpu": a.reach_ns, "Ns_total": world * a.reach_ns, "H": 40, "n_gpus": world, "reps": reps,
                 "wallclock_ms": wall / reps * 1e3, "trajectory_steps_per_s": world * a.reach_ns * 40 * reps / wall,
                 "finite": finite,
-                "roofline": roofline(wl.flop_mode_i(3, 45) * a.reach_ns * 40, kms, "rollout_indep_grid_kernel<car,5,9,3>",
-                                     wl.min_hbm_bytes(4, 3, 1) * a.reach_ns * 40,
-                                     note="FLOP = SURVEY 8d count of the triangular algorithm (8.3e3 per trajectory-step); the "
-                                          "grid-root kernel executes ~1.5e3, so frac can exceed what the pipe could do on "
-                                          "the counted algorithm")})
+                "roofline": reach_roofline(wl, a.reach_ns, kms)})
     return res
 
 
@@ -290,9 +442,19 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if "WORLD_SIZE" not in os.environ and a.gpus > 1:
+        self_launch(a)                                           # never returns
+    if os.environ.get("GPMPC_BENCH_DRY_LAUNCH") == "1" and world > 1:
+        # launch-path check (tests, CPU): every rank joins the group, reports, leaves - nothing else runs
+        import torch.distributed as dist_
+        dist_.init_process_group(backend="gloo")
+        print(json.dumps({"dry_launch": True, "rank": rank, "world": world, "pid": os.getpid(),
+                          "parent": os.environ.get("GPMPC_BENCH_PARENT")}), flush=True)
+        dist_.barrier()
+        dist_.destroy_process_group()
+        sys.exit(3 if os.environ.get("GPMPC_BENCH_DRY_FAIL_RANK") == str(rank) else 0)
     if a.gpus != world:
-        if world == 1 and a.gpus > 1:
-            raise SystemExit("launch N > 1 with torch.distributed.run (one process per GPU)")
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (a.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (no CPU fallback for the product path)")
     torch.cuda.set_device(local_rank)
@@ -389,6 +551,18 @@ def main():
 
     reach = reachable_set_leg(a, rank, world if not (force_dist and world == 1) else 1, dist if world > 1 else None, sg, _lib,
                               RolloutRunner, wl)
+    e2e = end_to_end_ms(runner, agent) if (rank == 0 and not multi) else None
+    sharded_cl = None
+    if multi and not a.no_extra:                                  # every rank takes part (collectives inside)
+        ok = 1
+        try:
+            sharded_cl = sharded_closed_loop_leg(rank, world, dist, sg, _lib, wl, ns_per_gpu=a.cl_ns)
+        except Exception as e:                                    # noqa: BLE001 - never fatal for the bench line
+            ok, sharded_cl = 0, {"workload": "sharded_closed_loop_leg", "error": repr(e)[:300]}
+        flag = torch.tensor([ok], dtype=torch.int32, device="cuda")
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if not int(flag.item()) and ok:
+            sharded_cl = {"workload": "sharded_closed_loop_leg", "error": "another rank failed"}
 
     if rank == 0:
         name, cus, _ = _lib.device_info(local_rank)
@@ -449,9 +623,16 @@ def main():
         else:
             out["cpu_baseline"] = None
         out["reachable_set"] = reach
-        if world == 1 and not a.no_extra:
+        if e2e is not None:
+            out["end_to_end_ms"] = {"ms": e2e[0], "h2d_bytes": e2e[1], "d2h_bytes": e2e[2], "value": units / (e2e[0] * 1e-3),
+                                    "note": "pinned host z -> HBM + one rollout + X_traj -> pinned host, wall clock, median of 20 "
+                                            "(SURVEY 8d end-to-end; never `value`)"}
+        if sharded_cl is not None:
+            out["extra"] = [sharded_cl]
+        if not multi and not a.no_extra:
             extra = []
-            for fn, args in ((extra_car_rollout, (sg, _lib, RolloutRunner, wl)), (extra_closed_loop, (sg, _lib, wl))):
+            for fn, args in ((extra_car_rollout, (sg, _lib, RolloutRunner, wl)), (extra_closed_loop, (sg, _lib, wl)),
+                             (extra_pendulum_joint, (sg, _lib, wl))):
                 try:
                     extra.append(fn(*args))
                 except Exception as e:                            # noqa: BLE001 - never fatal for the bench line

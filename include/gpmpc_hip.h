@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define GPMPC_ABI_VERSION 4
+#define GPMPC_ABI_VERSION 5
 
 #define GPMPC_MAX_NY 4   /* GP outputs            (reference agent.g_dim.ny : 1 pendulum1D, 3 car)          */
 #define GPMPC_MAX_D  4   /* GP input dimension    (g_nx + g_nu : 2 in all shipped configs)                 */
@@ -175,10 +175,15 @@ int    gpmpc_rollout(const gpmpc_gp_desc_t* gp, const gpmpc_env_desc_t* env, con
  *         per chain L_hr^T, L_hh (packed), w, 1/diag - written by the call (the last step's draw is appended too); with
  *         resume = 1 the chains continue from it instead of from seeds (same hall_tasks, same state_slots / state_points)
  *   limits: state_slots <= 256; without a state n_h0*T + hall_tasks*(n_v0 + H-1) <= 256 label slots per chain
- *   info bit GPMPC_INFO_STATE_FULL: a resumed state had no room left for a new point (the draw itself is still valid)
+ *   info bit GPMPC_INFO_STATE_FULL: a resumed state had no room left (label slots or points) for a new point: the point
+ *         is not appended, the draw itself and X_traj / Y / Xi are still valid
  * Runs the generic kernel (csrc/rollout.hip); the tuned kernels serve gpmpc_rollout.
  */
 size_t gpmpc_rollout_state_bytes(const gpmpc_gp_desc_t* gp, int64_t Ns, int32_t state_slots, int32_t state_points);
+/* workspace of a seeded call WITHOUT a state: the chains' factor covers n_h0*T + hall_tasks*(n_v0 + H-1) label slots and
+ * leaves LDS sooner than gpmpc_rollout's (>= gpmpc_rollout_workspace_bytes for the same Ns, H) */
+size_t gpmpc_rollout_seeded_workspace_bytes(const gpmpc_gp_desc_t* gp, int32_t mode, int32_t hall_tasks,
+                                            int64_t Ns, int32_t H, int32_t n_h0, int32_t n_v0);
 int    gpmpc_rollout_seeded(const gpmpc_gp_desc_t* gp, const gpmpc_env_desc_t* env, const void* plan,
                             const double* X_r, int32_t mode, int32_t hall_tasks, double var_zero_thr, double beta,
                             int64_t Ns, int32_t H,

@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libgpmpc_hip.so")
 
 MAX_NY, MAX_D, MAX_T, MAX_NX, MAX_NU = 4, 4, 5, 8, 4
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 ENV_PENDULUM1D, ENV_CAR_RESIDUAL = 0, 1
 MODE_INDEPENDENT, MODE_RECONDITIONED = 0, 1
@@ -58,6 +58,7 @@ SYMBOLS = {
     "gpmpc_rollout": (C.c_int, [C.POINTER(GpDesc), C.POINTER(EnvDesc), _P, _P, _I32, _I32, _D, _D, _I64, _I32,
                                 _P, _I32, _P, _P, _I64, _P, _P, _P, _P, _P, _SZ, _P]),
     "gpmpc_rollout_state_bytes": (_SZ, [C.POINTER(GpDesc), _I64, _I32, _I32]),
+    "gpmpc_rollout_seeded_workspace_bytes": (_SZ, [C.POINTER(GpDesc), _I32, _I32, _I64, _I32, _I32, _I32]),
     "gpmpc_rollout_seeded": (C.c_int, [C.POINTER(GpDesc), C.POINTER(EnvDesc), _P, _P, _I32, _I32, _D, _D, _I64, _I32,
                                        _P, _I32, _P, _P, _I64, _P, _P, _P, _P, _P, _SZ, _P, _P, _P, _I32, _P, _P, _I32, _P, _I32, _I32, _I32]),
     "gpmpc_joint_workspace_bytes": (_SZ, [C.POINTER(GpDesc), _I64, _I32, _I32]),

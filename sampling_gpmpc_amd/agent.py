@@ -348,9 +348,9 @@ class Agent(object):
             self.update_hallucinated_Dyn_dataset(g_in, y)
         return y
 
-    def dyn_fg_jacobians(self, xu_hat, sqp_iter):
-        """Full-state value and Jacobians ``f + B_d g`` at the linearisation points (reference ``src/agent.py:532-564``).
-        Returns numpy float64 ``gp_val (Ns,nx,H,1)``, ``y_grad (Ns,nx,H,nx)``, ``u_grad (Ns,nx,H,nu)``."""
+    def dyn_fg_jacobians_device(self, xu_hat, sqp_iter):
+        """``dyn_fg_jacobians`` without the device-to-host copies: the three float64 DEVICE tensors ``gp_val (Ns,nx,H,1)``,
+        ``y_grad (Ns,nx,H,nx)``, ``u_grad (Ns,nx,H,nu)`` (what ``pack_p_lin`` and ``distributed.gather_jacobians`` consume)."""
         lib = _lib.load()
         xu_hat = xu_hat.to(device=self.torch_device, dtype=F64).contiguous()
         ns, nH = xu_hat.shape[0], xu_hat.shape[2]
@@ -364,6 +364,12 @@ class Agent(object):
                                                 _lib.dptr(gp_val), _lib.dptr(y_grad), _lib.dptr(u_grad),
                                                 _lib.current_stream_ptr()), "gpmpc_assemble_jacobians")
         self._last_device_jacobians = (gp_val, y_grad, u_grad)
+        return self._last_device_jacobians
+
+    def dyn_fg_jacobians(self, xu_hat, sqp_iter):
+        """Full-state value and Jacobians ``f + B_d g`` at the linearisation points (reference ``src/agent.py:532-564``).
+        Returns numpy float64 ``gp_val (Ns,nx,H,1)``, ``y_grad (Ns,nx,H,nx)``, ``u_grad (Ns,nx,H,nu)``."""
+        gp_val, y_grad, u_grad = self.dyn_fg_jacobians_device(xu_hat, sqp_iter)
         out = (gp_val.cpu().numpy(), y_grad.cpu().numpy(), u_grad.cpu().numpy())
         if not (np.isfinite(out[0]).all() and np.isfinite(out[1]).all() and np.isfinite(out[2]).all()):
             print("Nan/inf in y_sample")
@@ -433,8 +439,12 @@ class Agent(object):
 
         n_hall = int(self.Hallcinated_X_train.shape[2])
         from .rollout import seeds_fit
+        has_nan = torch.isnan(self.Hallcinated_Y_train).any().to(torch.int32).reshape(1)
+        if self.dist_group is not None:            # every rank must take the same path (the per-step one has collectives)
+            import torch.distributed as dist
+            dist.all_reduce(has_nan, op=dist.ReduceOp.MAX, group=self.dist_group)
         fusable = (steps >= 3 and T == 1 + self.in_dim_x and seeds_fit(self, n_hall, 1, steps - 1, T, 1)
-                   and not bool(torch.isnan(self.Hallcinated_Y_train).any()))
+                   and not bool(has_nan.item()))
         if fused is None:
             fused = fusable
         elif fused and not fusable:
@@ -458,8 +468,13 @@ class Agent(object):
             self.FS_X_train_batch = torch.cat([self.FS_X_train_batch, g_in], dim=2)
             self.FS_Y_train_batch = torch.cat([self.FS_Y_train_batch, label], dim=2)
             if fused:
-                alive = self._propagate_fused(plan_x, plan_u, states, alive, base_samples, steps, dev)
-                break
+                done = self._propagate_fused(plan_x, plan_u, states, alive, base_samples, steps, dev)
+                if done is not None:
+                    alive = done
+                    break
+                # a chain's T x T posterior root failed every jitter retry: the fused kernel has no eigendecomposition
+                # root (the failing chains carry NaN), the per-step path (gpmpc_joint_sample) does - finish there
+                fused = False
             self.train_forward_sampling_dynGP()
 
         # rejected samples inherit the hallucinated data of randomly chosen survivors (X and Y drawn separately, as the
@@ -493,10 +508,12 @@ class Agent(object):
         res = rollout_device(self, U_soln[2:2 + Hf].cpu().numpy(), z.reshape(-1), z.shape[1], H=Hf, mode=_lib.MODE_RECONDITIONED,
                              use_model_without_derivatives=False, use_feedback=False, x0=x_next1, hall_tasks=1,
                              var_zero_thr=-1.0, beta=float("inf"), seeds=seeds, value_seeds=vseeds)
-        bits = int(res.info.max().item()) if res.info.numel() else 0
+        from .gp_model import NotPSDError, _or_reduce
+        bits = _or_reduce(res.info, self.dist_group)                # OR over samples (and ranks): not the max of the words
         if bits & _lib.INFO_TRAIN_CHOL_FAIL:
-            from .gp_model import NotPSDError
             raise NotPSDError("Cholesky of the training covariance failed during forward sampling")
+        if bits & (_lib.INFO_ROOT_FAIL | _lib.INFO_NEG_1x1):
+            return None                                             # the caller continues on the per-step path
         for t in range(Hf):
             i = t + 2
             diff = X_soln[i + 1, :, :] - res.X_traj[:, :, t + 1]

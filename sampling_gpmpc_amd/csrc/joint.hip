@@ -52,7 +52,8 @@ struct JointArgs {
     int* any_fail;          // set when a chain's jitter chain failed (read by joint_eigh_kernel)
     // factor cache (caller-owned, persists between calls): per chain the hallucinated rows of the factor, row-major
     // [rows_cap][fc_cs] (columns: real slots, then hallucinated slots; the diagonal blocks as block_factor left them) and
-    // 1/diag [rows_cap].  The first n_c rows (a multiple of NB) are valid on entry and are not recomputed.
+    // 1/diag [rows_cap].  The first n_c rows (any count: the column blocks restart at slot n_c) are valid on entry and are
+    // not recomputed.
     double* fcache;
     long fc_stride;         // doubles per chain
     int fc_cs;              // row stride = n_r + rows_cap

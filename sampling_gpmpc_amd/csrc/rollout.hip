@@ -324,7 +324,8 @@ __global__ __launch_bounds__(64 * GPMPC_MAX_NY) void rollout_kernel(const Rollou
         // the last step's draw conditions nothing inside this rollout; it is appended only when the factor state is kept
         const int Tc = seed_full ? T : Th;                        // tasks observed at this pass's point
         bool do_append = recond && (seeding || t + 1 < H || a.state);
-        if (do_append && n_h + Tc > nh_max) {                     // a resumed state without room for this point
+        // a resumed state without room for this point: label slots, or (kept state) its point list
+        if (do_append && (n_h + Tc > nh_max || (a.state && n_seed + n_app + (seed_full ? 0 : 1) > a.state_points))) {
             info_acc |= GPMPC_INFO_STATE_FULL;
             do_append = false;
         }
@@ -419,7 +420,7 @@ __global__ __launch_bounds__(64 * GPMPC_MAX_NY) void rollout_kernel(const Rollou
             st_s[2] = Th;
             st_s[3] = nh_max;
         }
-        for (int e = threadIdx.x; e < (n_seed + n_app) * D; e += blockDim.x) st_s[4 + e] = Xh[e];
+        for (int e = threadIdx.x; e < min(n_seed + n_app, a.state_points) * D; e += blockDim.x) st_s[4 + e] = Xh[e];
         double* sw = st_c + (long)n_r * nh_max + ((long)nh_max * (nh_max + 1)) / 2;
         for (int e = lane; e < n_h; e += kWave) {
             sw[e] = wh[e];
@@ -448,7 +449,9 @@ static int plan_rollout(const gpmpc_gp_desc_t* gp, int nx, int mode, int hall_ta
     int nh_max = (mode == GPMPC_MODE_RECONDITIONED) ? n_h0 * T + hall_tasks * (n_v0 + H - 1) : 0;
     if (state_slots > 0) nh_max = state_slots;                    // the exported factor's leading dimension
     if (nh_max < 1) nh_max = 1;
-    rp->max_points = (state_slots > 0) ? state_points : n_h0 + n_v0 + H;
+    // LDS point list: with a kept / resumed state the points already in it are unknown on the host (up to state_points),
+    // and every step of this call records its GP input whether or not the factor still has room for it
+    rp->max_points = (state_slots > 0) ? state_points + H : n_h0 + n_v0 + H;
     rp->nh_max = nh_max;
     rp->rpl = (nh_max + 63) / 64;
     if (rp->rpl > 4) return fail(GPMPC_E_UNSUPPORTED, "rollout: more than 256 hallucinated label slots per chain");
@@ -507,6 +510,17 @@ size_t gpmpc_rollout_workspace_bytes(const gpmpc_gp_desc_t* gp, int32_t mode, in
     if (plan_rollout(gp, GPMPC_MAX_NX, mode, hall_tasks, H, &rp) != GPMPC_OK) return 0;
     if (mode != GPMPC_MODE_RECONDITIONED) return 256;
     return align_up((size_t)Ns * gp->g_ny * rp.chain_doubles * sizeof(double), 256) + 2048;   // >= the tuned path's need (its zero page included)
+}
+
+size_t gpmpc_rollout_seeded_workspace_bytes(const gpmpc_gp_desc_t* gp, int32_t mode, int32_t hall_tasks, int64_t Ns,
+                                            int32_t H, int32_t n_h0, int32_t n_v0) {
+    if (check_gp(gp) != GPMPC_OK || n_h0 < 0 || n_v0 < 0) return 0;
+    if (mode != GPMPC_MODE_RECONDITIONED) return 256;
+    RolloutPlan rp;
+    if (plan_rollout(gp, GPMPC_MAX_NX, mode, hall_tasks, H, &rp, n_h0, n_v0) != GPMPC_OK) return 0;
+    const size_t seeded = align_up((size_t)Ns * gp->g_ny * rp.chain_doubles * sizeof(double), 256) + 2048;
+    const size_t plain = gpmpc_rollout_workspace_bytes(gp, mode, hall_tasks, Ns, H);
+    return seeded > plain ? seeded : plain;
 }
 
 static int rollout_impl(const gpmpc_gp_desc_t* gp, const gpmpc_env_desc_t* env, const void* plan, const double* X_r,

@@ -15,6 +15,7 @@ is materialised only if somebody reads ``train_inputs``), nothing is autograd-ca
 """
 from __future__ import annotations
 
+import itertools
 import warnings
 from dataclasses import dataclass
 from typing import Optional
@@ -64,8 +65,11 @@ class GPHyperParams:
 class RealDataPlan:
     """The shared real-data block, factorised once on the device (``gpmpc_plan_build``)."""
 
+    _versions = itertools.count(1)
+
     def __init__(self, X_r: torch.Tensor, Y_r: torch.Tensor, hyper: GPHyperParams):
         dev = _lib.require_hip_device(X_r.device)
+        self.version = next(RealDataPlan._versions)               # identifies the plan for caches (id() can be reused)
         lib = _lib.load()
         self.hyper = hyper
         self.X_r = X_r.to(dtype=F64).contiguous()                 # (N_r, D)
@@ -125,13 +129,19 @@ class JointFactorCache:
     def __init__(self):
         self.buf = None
         self.rows = 0                 # capacity (label rows per chain)
-        self.key = None               # (Ns, g_ny, n_r, T, plan id)
+        self.key = None               # (Ns, g_ny, n_r, T, plan version)
         self.slots = None             # int32 device tensor: the slots whose rows are valid
-        self.X = None                 # (Ns, g_ny, n_pts, D) snapshot of the points behind them
+        self.Xbuf = None              # (Ns, g_ny, rows, D) snapshot buffer of the points behind them, n_pts of it in use
+        self.n_pts = 0
         self.enabled = True
 
     def invalidate(self):
-        self.slots = self.X = None
+        self.slots = None
+        self.n_pts = 0
+
+    @property
+    def X(self):
+        return None if self.slots is None else self.Xbuf[:, :, :self.n_pts]
 
     def prepare(self, mdl: "HipGPModel", Ns: int, n_ho: int):
         """-> (buffer or None, capacity, n_cached) for a call with ``n_ho`` observed hallucinated slots."""
@@ -139,7 +149,7 @@ class JointFactorCache:
             return None, 0, 0
         lib = _lib.load()
         hy = mdl.hyper
-        key = (Ns, hy.g_ny, mdl.plan.n_r, hy.T, id(mdl.plan))
+        key = (Ns, hy.g_ny, mdl.plan.n_r, hy.T, mdl.plan.version)
         if self.buf is None or key != self.key or n_ho > self.rows:
             # the set grows by the same number of slots every SQP iteration: room for four of them where that fits
             for mult in (4.0, 2.0, 1.25):
@@ -156,11 +166,12 @@ class JointFactorCache:
             if had and mdl.plan.X_r.is_cuda:
                 torch.cuda.empty_cache()
             self.buf = torch.empty(nbytes // 8, dtype=F64, device=mdl.plan.X_r.device)
+            self.Xbuf = torch.empty(Ns, hy.g_ny, rows, hy.D, dtype=F64, device=mdl.plan.X_r.device)
             self.rows, self.key = rows, key
             self.invalidate()
         n_c = 0
         if self.slots is not None:
-            n_old, n_pts = int(self.slots.numel()), int(self.X.shape[2])
+            n_old, n_pts = int(self.slots.numel()), self.n_pts
             # append-only growth: the old slot list is a prefix of the new one and the points it was built on are unchanged
             if n_old <= n_ho and n_pts <= mdl.n_h and bool(torch.equal(mdl.h_slots[:n_old], self.slots)) \
                     and bool(torch.equal(mdl.hall_X[:, :, :n_pts], self.X)):
@@ -177,13 +188,18 @@ class JointFactorCache:
     def n_valid(self) -> int:
         return 0 if self.slots is None else int(self.slots.numel())
 
-    def commit(self, mdl: "HipGPModel", n_ho: int, ok: bool):
+    def commit(self, mdl: "HipGPModel", n_ho: int, ok: bool, n_cached: int = 0):
         """After a call that filled the cache for all ``n_ho`` slots (``ok``: no factorisation failure)."""
-        if self.buf is None or not ok or n_ho > self.rows:
+        if self.buf is None or not ok or n_ho > self.rows or mdl.n_h > self.rows:
             self.invalidate()
             return
+        if n_cached == n_ho and self.slots is not None and self.n_pts == mdl.n_h:
+            return                                                 # nothing new was written (mean- / covariance-only repeats)
+        # `prepare` has just verified the first n_pts points against the snapshot: only the appended ones are copied
+        keep = self.n_pts if (self.slots is not None and n_cached > 0) else 0
+        self.Xbuf[:, :, keep:mdl.n_h] = mdl.hall_X[:, :, keep:]
+        self.n_pts = mdl.n_h
         self.slots = mdl.h_slots[:n_ho].clone()
-        self.X = mdl.hall_X.clone()
 
 
 class HipPosterior:
@@ -199,7 +215,8 @@ class HipPosterior:
 
     # -- one kernel launch ----------------------------------------------------------------------------------
     def _run(self, z: Optional[torch.Tensor], clip: bool, beta: float = 0.0, var_zero_thr: float = -1.0,
-             want_covar: bool = False, want_root: bool = False, root_mode: int = _lib.ROOT_AUTO):
+             want_covar: bool = False, want_root: bool = False, root_mode: int = _lib.ROOT_AUTO,
+             raise_chol_fail: bool = True):
         mdl = self._model
         lib = _lib.load()
         hy = mdl.hyper
@@ -245,8 +262,8 @@ class HipPosterior:
         self.last_info = info
         self.used_eigh = bool(bits & _lib.INFO_ROOT_EIGH)
         if fbuf is not None:
-            fcache.commit(mdl, n_ho, ok=not (bits & _lib.INFO_TRAIN_CHOL_FAIL))
-        if bits & _lib.INFO_TRAIN_CHOL_FAIL:
+            fcache.commit(mdl, n_ho, ok=not (bits & _lib.INFO_TRAIN_CHOL_FAIL), n_cached=n_c)
+        if (bits & _lib.INFO_TRAIN_CHOL_FAIL) and raise_chol_fail:
             raise NotPSDError("Cholesky of the training covariance (real + hallucinated data) failed")
         if bits & _lib.INFO_VAR_CLAMPED:
             warnings.warn("Negative variance values detected; rounding them up to 1e-10.", NumericalWarning)
@@ -300,17 +317,25 @@ class HipPosterior:
         T = self._model.hyper.T
         if base_samples is None:
             base_samples = torch.randn(Ns, g_ny, m, T, dtype=F64, device=self._x.device)
-        y, bits = self._run(base_samples, clip, beta, var_zero_thr, want_root=want_root)
         group = self._model.dist_group
-        if group is not None and m * T > 1:
-            # the eigh fallback is a property of the WHOLE batch (all ranks' chains): a rank none of whose chains failed
-            # redraws with the eigendecomposition root when a chain on another rank did
-            import torch.distributed as dist
-            flag = torch.tensor([1 if self.used_eigh else 0], dtype=torch.int32, device=self._x.device)
-            dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=group)
-            if int(flag.item()) and not self.used_eigh:
-                y, bits = self._run(base_samples, clip, beta, var_zero_thr, want_root=want_root,
-                                    root_mode=_lib.ROOT_EIGH)
+        if group is None:
+            y, bits = self._run(base_samples, clip, beta, var_zero_thr, want_root=want_root)
+            return y
+        # Samples sharded over ranks: two properties of the draw belong to the WHOLE batch (all ranks' chains) - a failed
+        # training factorisation raises on every rank (a rank raising alone would leave the others in the collective), and
+        # the eigh fallback: a rank none of whose chains failed redraws with the eigendecomposition root when a chain on
+        # another rank did.  One all-reduce of both flags; every rank takes the same branch.
+        import torch.distributed as dist
+        y, bits = self._run(base_samples, clip, beta, var_zero_thr, want_root=want_root, raise_chol_fail=False)
+        flags = torch.tensor([1 if (bits & _lib.INFO_TRAIN_CHOL_FAIL) else 0, 1 if self.used_eigh else 0],
+                             dtype=torch.int32, device=self._x.device)
+        dist.all_reduce(flags, op=dist.ReduceOp.MAX, group=group)
+        chol_fail, any_eigh = (int(v) for v in flags.tolist())
+        if chol_fail:
+            raise NotPSDError("Cholesky of the training covariance (real + hallucinated data) failed"
+                              + ("" if bits & _lib.INFO_TRAIN_CHOL_FAIL else " on another rank's samples"))
+        if any_eigh and not self.used_eigh and m * T > 1:
+            y, bits = self._run(base_samples, clip, beta, var_zero_thr, want_root=want_root, root_mode=_lib.ROOT_EIGH)
         return y
 
     @property
@@ -319,13 +344,22 @@ class HipPosterior:
         return self._root
 
 
-def _or_reduce(info: torch.Tensor) -> int:
-    """bitwise OR over an int32 tensor (tiny; one device->host sync)."""
-    if info.numel() == 0:
+_INFO_BITS = (0x1, 0x2, 0x4, 0x8, 0x10, 0x20, 0x40, 0x80, 0x100, 0x200)
+
+
+def _or_reduce(info: torch.Tensor, group=None) -> int:
+    """bitwise OR over an int32 tensor (tiny; one device->host sync) and, with ``group``, over its ranks."""
+    if info.numel() == 0 and group is None:
         return 0
     v = info.flatten()
     # OR == max per bit: one small reduction per flag bit, a single transfer
-    packed = torch.stack([(v & b).max() for b in (0x1, 0x2, 0x4, 0x8, 0x10, 0x20, 0x40, 0x80, 0x100)])
+    if v.numel():
+        packed = torch.stack([(v & b).max() for b in _INFO_BITS])
+    else:
+        packed = torch.zeros(len(_INFO_BITS), dtype=info.dtype, device=info.device)
+    if group is not None:
+        import torch.distributed as dist
+        dist.all_reduce(packed, op=dist.ReduceOp.MAX, group=group)
     bits = 0
     for x in packed.tolist():
         bits |= int(x)

@@ -73,7 +73,15 @@ def rollout_device(agent: Agent, u_ff, z: torch.Tensor, z_step_stride: int, *, H
     Y = torch.empty(Ns, g_ny, H, T, dtype=F64, device=dev) if want_samples else None
     Xi = torch.empty(Ns, H, D, dtype=F64, device=dev) if want_samples else None
     info = torch.zeros(Ns, dtype=torch.int32, device=dev)
-    ws_bytes = lib.gpmpc_rollout_workspace_bytes(plan.desc, mode, hall_tasks, Ns, H)
+    # seed points lengthen the chains' factor: n_h0*T + hall_tasks*(n_v0 + H-1) label slots, which leaves LDS sooner
+    n_seed_pts = int(seeds[0].shape[2]) if seeds is not None else 0
+    n_vseed_pts = int(value_seeds[0].shape[2]) if value_seeds is not None else 0
+    if state is None and (n_seed_pts or n_vseed_pts):
+        ws_bytes = lib.gpmpc_rollout_seeded_workspace_bytes(plan.desc, mode, hall_tasks, Ns, H, n_seed_pts, n_vseed_pts)
+    else:
+        ws_bytes = lib.gpmpc_rollout_workspace_bytes(plan.desc, mode, hall_tasks, Ns, H)
+    if ws_bytes == 0:
+        _lib.check(-4, "gpmpc_rollout_workspace_bytes")
     ws = agent._ws_cache.get("rollout")
     if ws is None or ws.numel() * 8 < ws_bytes:
         ws = torch.empty((ws_bytes + 7) // 8, dtype=F64, device=dev)

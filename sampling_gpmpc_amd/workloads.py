@@ -86,6 +86,16 @@ def flop_mode_i(g_ny, N_r) -> float:
     return g_ny * (14 * N_r + N_r * N_r + 2 * N_r + 10)
 
 
+def flop_mode_i_grid_root(g_ny, n0, n1) -> float:
+    """FP64 FLOP per trajectory-step of the mode-I algorithm the grid-root kernel EXECUTES (csrc/rollout_indep.hip; DESIGN
+    4.2), per output: the separable products  A = Qa^T ea (n0^2 FMA), B = Qb^T eb (n1^2), mu = sum_c B_c sum_a m1_ac A_a
+    and k^T (K+s2 I)^-1 k = sum_c B_c^2 sum_a m2_ac A_a^2 (2 n0 n1 + 2 n1 FMA) = 2 FLOP each; the kernel factors by the
+    equispaced-axis recurrence: 4 exponentials (22 FLOP each: Cody-Waite + degree-11 polynomial) and 2 (n0 + n1)
+    multiplications; ~10 for variance floor, root, sample and clip.  Car (5 x 9): 3 x 554 = 1.66e3 (SURVEY 8d counts the
+    triangular algorithm it replaces: 8.3e3)."""
+    return g_ny * (2.0 * (n0 * n0 + n1 * n1 + 2 * n0 * n1 + 2 * n1) + 4 * 22 + 2 * (n0 + n1) + 10)
+
+
 def min_hbm_bytes(nx, g_ny, T) -> int:
     """Unavoidable HBM bytes per trajectory-step with the factor on chip: state in/out, z in, y out."""
     return 8 * (2 * nx + 2 * g_ny * T)

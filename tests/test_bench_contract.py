@@ -36,7 +36,10 @@ def test_bench_line_contract():
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0
     assert d["value"] > 1e6 and d["cold"]["ms_per_step"] > 0
-    assert d["reachable_set"]["finite"] and "roofline" in d["reachable_set"]
+    rs = d["reachable_set"]
+    assert rs["finite"] and rs["roofline"]["frac"] <= 1.0 and 0.0 < rs["roofline"]["hbm_frac"] <= 1.0
+    e = d["end_to_end_ms"]
+    assert e["ms"] >= d["ms_per_step"] and e["h2d_bytes"] == 30 * 2 * 1024 * 3 * 8 and e["d2h_bytes"] == 1024 * 2 * 31 * 8
 
 
 def test_bench_multi_gpu_path_with_one_rank():
@@ -44,3 +47,16 @@ def test_bench_multi_gpu_path_with_one_rank():
     g = d["gather"]
     assert g is not None and g["overlapped_with_next_rollout"] and g["standalone_ms"] > 0 and g["bytes_per_rank"] == 1024 * 2 * 31 * 8
     assert d["value"] > 1e6
+
+
+def test_bench_sharded_closed_loop_leg_with_one_rank():
+    """The N > 1 leg of configs[4]: per-rank Agent over its shard, per SQP iteration draw + device gather of the packed
+    Jacobians + one D2H copy on rank 0 (here a world of one rank, 32 samples)."""
+    d = _run({"GPMPC_BENCH_FORCE_DIST": "1", "MASTER_PORT": "29549"}, args=("--cpu-sample", "0", "--cl-ns", "32"))
+    legs = d["extra"]
+    assert len(legs) == 1 and "error" not in legs[0], legs
+    its = legs[0]["iterations"]
+    assert [(i["mpc_step"], i["k"]) for i in its] == [(s, k) for s in range(2) for k in range(4)]
+    assert all(i["finite"] and i["draw_ms"] > 0 and i["gather_ms"] > 0 and i["wall_ms_per_iteration"] >= i["draw_ms"] for i in its)
+    assert its[0]["n_o"] == 45 and its[3]["n_o"] == 45 + 3 * 120 and its[4]["n_o"] == 45 + 4 * 120    # the reset-after-build quirk
+    assert its[0]["gathered_bytes"] == 32 * 4 * 40 * 7 * 8

@@ -125,7 +125,9 @@ def test_cross_sample_couplings_sharded_equal_single_process(Ns):
     Y = torch.randn(Ns, g_ny, n, T, generator=gen, dtype=torch.float64)
     left = (torch.rand(Ns, generator=gen) < 0.5).to(torch.int64)
     left[0], left[-1] = 1, 0                                      # at least one survivor, one rejected sample
-    jac = [np.arange(Ns * 2 * 3, dtype=np.float64).reshape(Ns, 2, 3, 1), np.random.RandomState(1).randn(Ns, 2, 3, 2)]
+    # the three arrays of dyn_fg_jacobians (gp_val, y_grad, u_grad): packed, ONE gather collective, split on rank 0
+    jac = [np.arange(Ns * 2 * 3, dtype=np.float64).reshape(Ns, 2, 3, 1), np.random.RandomState(1).randn(Ns, 2, 3, 2),
+           np.random.RandomState(2).randn(Ns, 2, 3, 1)]
     params = copy.deepcopy(load_params("params_pendulum1D_samples"))
     params["common"]["use_cuda"] = False
     params["agent"]["num_dyn_samples"] = Ns

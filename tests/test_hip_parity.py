@@ -922,6 +922,32 @@ def test_second_fused_rollout_conditions_on_existing_points(sg):
     assert agent.Hallcinated_X_train.shape[2] == 12
 
 
+def test_seeded_rollout_with_more_than_200_seed_slots(sg):
+    """a seeded rollout's factor covers the seed slots too (here 70 points x 3 tasks = 210 + 3 x 11 appended:
+    far beyond what stays in LDS), so its workspace comes from gpmpc_rollout_seeded_workspace_bytes - the un-seeded query
+    (3 x 11 slots) would be too small and the call would fail with GPMPC_E_WORKSPACE."""
+    from sampling_gpmpc_amd.rollout import forward_sampling_rollout, seeds_fit
+    H1, H2 = 70, 12
+    p = fs_params("params_pendulum1D_samples", 4, H1, nograd=False)
+    agent, oagent = make_agents(sg, p)
+    X1 = forward_sampling_rollout(agent, synthetic_u_ff(1, H1))
+    Xo1 = ao.forward_sampling_rollout(oagent, synthetic_u_ff(1, H1))
+    assert relerr(X1, Xo1) < RTOL_TRAJ and agent.Hallcinated_X_train.shape[2] == H1
+    assert seeds_fit(agent, H1, 0, H2, 3, 3)
+    lib = sg._lib.load()
+    plan = agent._plan(use_grad=True)
+    small = lib.gpmpc_rollout_workspace_bytes(plan.desc, sg._lib.MODE_RECONDITIONED, 3, 4, H2)
+    need = lib.gpmpc_rollout_seeded_workspace_bytes(plan.desc, sg._lib.MODE_RECONDITIONED, 3, 4, H2, H1, 0)
+    assert need > small
+    agent._ws_cache.pop("rollout", None)                          # force a fresh, exactly sized workspace
+    u2 = synthetic_u_ff(1, H2)
+    X2 = forward_sampling_rollout(agent, u2)                      # seeded: conditions on the 70 points of the first rollout
+    assert lib.gpmpc_debug_last_rollout_path() == 0
+    Xo2 = ao.forward_sampling_rollout(oagent, u2)
+    print(f"seeded rollout on 210 seed slots: rel err {relerr(X2, Xo2):.2e}")
+    assert relerr(X2, Xo2) < RTOL_TRAJ and agent.Hallcinated_X_train.shape[2] == H1 + H2
+
+
 @pytest.mark.parametrize("pname", ["params_pendulum1D_samples", "params_car_residual_fs"])
 def test_rollout_factor_state_export_and_resume(sg, pname):
     """SURVEY.md 8b "final factor state": a rollout keeps its chains' factor (gpmpc_rollout_seeded, state), a second call

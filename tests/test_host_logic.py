@@ -242,15 +242,15 @@ def test_joint_factor_cache_bookkeeping():
     X = torch.randn(Ns, g_ny, 40, D, generator=g, dtype=torch.float64)
 
     def model(n_pts):
-        return SimpleNamespace(hyper=SimpleNamespace(g_ny=g_ny, T=T), n_h=n_pts, hall_X=X[:, :, :n_pts].clone(),
-                               plan=SimpleNamespace(n_r=n_r, desc=desc, X_r=torch.zeros(1)),
+        return SimpleNamespace(hyper=SimpleNamespace(g_ny=g_ny, T=T, D=D), n_h=n_pts, hall_X=X[:, :, :n_pts].clone(),
+                               plan=SimpleNamespace(n_r=n_r, desc=desc, X_r=torch.zeros(1), version=1),
                                h_slots=torch.arange(n_pts * T, dtype=torch.int32))
 
     plan = model(0).plan
 
     def mk(n_pts):
         m = model(n_pts)
-        m.plan = plan                                   # the cache is keyed by the plan object
+        m.plan = plan                                   # the cache is keyed by the plan's version
         return m
 
     c = JointFactorCache()
@@ -280,5 +280,22 @@ def test_joint_factor_cache_bookkeeping():
     big.hall_X = torch.zeros(Ns, g_ny, big.n_h, D, dtype=torch.float64)
     buf2, rows2, n_c2 = c.prepare(big, Ns, old_rows + 16)
     assert rows2 > old_rows and n_c2 == 0               # a set beyond the capacity: new buffer, nothing carried over
+    # a rebuilt plan (new version) never inherits the rows, even if CPython reuses the old object's id
+    c.commit(big, old_rows + 16, ok=True)
+    assert c.prepare(big, Ns, old_rows + 16)[2] == old_rows + 16
+    big.plan = SimpleNamespace(**vars(plan))
+    big.plan.version = 2
+    assert c.prepare(big, Ns, old_rows + 16)[2] == 0
+    # commit copies only the appended points and skips calls that computed nothing new
+    c2 = JointFactorCache()
+    c2.prepare(mk(10), Ns, 30)
+    c2.commit(mk(10), 30, ok=True)
+    snap = c2.X.clone()
+    assert c2.prepare(mk(10), Ns, 30)[2] == 30
+    c2.commit(mk(10), 30, ok=True, n_cached=30)          # mean-only repeat: nothing to copy
+    assert torch.equal(c2.X, snap)
+    assert c2.prepare(mk(20), Ns, 60)[2] == 30
+    c2.commit(mk(20), 60, ok=True, n_cached=30)
+    assert c2.n_valid == 60 and torch.equal(c2.X, X[:, :, :20])
     c.enabled = False
     assert c.prepare(mk(20), Ns, 60) == (None, 0, 0)
