@@ -12,7 +12,7 @@ from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 REPO = os.path.dirname(os.path.dirname(HERE))
-SOURCES = ["capi.hip", "rollout.hip", "rollout_fast.hip", "rollout_indep.hip", "joint.hip", "assemble.hip"]
+SOURCES = ["capi.hip", "rollout.hip", "rollout_fast.hip", "rollout_tiles.hip", "rollout_indep.hip", "joint.hip", "assemble.hip"]
 HEADERS = ["gpmpc_device.hpp", "gpmpc_host.hpp", "rollout_args.hpp", "joint_eigh.hpp",
            os.path.join(REPO, "include", "gpmpc_hip.h")]
 OUT = os.path.join(os.path.dirname(HERE), "libgpmpc_hip.so")
@@ -34,6 +34,7 @@ EXTRA_FLAGS = {"rollout_fast.hip": os.environ.get("GPMPC_FAST_FLAGS", "-mllvm -d
                # the generic rollout kernel: 119-152 VGPRs instead of 131-174 (car Ns=4096 H=40: 22.3 -> 13.2 ms; pendulum 1.14 ms
                # either way); the sample-per-lane kernels of rollout_indep.hip measure 0.093 / 0.543 ms with it off, 0.097 / 0.547 on
                "rollout.hip": os.environ.get("GPMPC_ROLLOUT_FLAGS", "-mllvm -disable-machine-licm").split(),
+               "rollout_tiles.hip": os.environ.get("GPMPC_TILES_FLAGS", "").split(),
                "rollout_indep.hip": os.environ.get("GPMPC_INDEP_FLAGS", "").split()}
 
 

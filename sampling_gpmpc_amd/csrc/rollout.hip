@@ -495,7 +495,7 @@ using namespace gpmpc;
 extern "C" {
 
 // debug helpers, deliberately not declared in include/gpmpc_hip.h
-static int g_last_rollout_path = -1;     // 0 generic, 1 tuned re-conditioned (rollout_fast), 2 thread-per-sample (rollout_indep)
+static int g_last_rollout_path = -1;     // 0 generic, 1 tuned re-conditioned (rollout_fast), 2 thread-per-sample (rollout_indep), 3 tiled (rollout_tiles)
 int gpmpc_debug_last_rollout_path(void) { return g_last_rollout_path; }
 
 int gpmpc_debug_read_phases(long long* out /*[host] 16*/) {
@@ -509,7 +509,14 @@ size_t gpmpc_rollout_workspace_bytes(const gpmpc_gp_desc_t* gp, int32_t mode, in
     RolloutPlan rp;
     if (plan_rollout(gp, GPMPC_MAX_NX, mode, hall_tasks, H, &rp) != GPMPC_OK) return 0;
     if (mode != GPMPC_MODE_RECONDITIONED) return 256;
-    return align_up((size_t)Ns * gp->g_ny * rp.chain_doubles * sizeof(double), 256) + 2048;   // >= the tuned path's need (its zero page included)
+    size_t need = align_up((size_t)Ns * gp->g_ny * rp.chain_doubles * sizeof(double), 256) + 2048;   // >= the tuned path's need (its zero page included)
+    // the tiled throughput kernel keeps the whole tile matrix of a wave's four chains in the workspace (whichever env /
+    // size it ends up serving: the query does not know the env, so the larger of the two layouts is reported)
+    if (gp->T == 3 && hall_tasks == 3 && 3 * (H - 1) <= 128 && H >= 2) {
+        const size_t tl = rollout_tiles_workspace_bytes(gp, Ns, H) + 256;
+        need = tl > need ? tl : need;
+    }
+    return need;
 }
 
 size_t gpmpc_rollout_seeded_workspace_bytes(const gpmpc_gp_desc_t* gp, int32_t mode, int32_t hall_tasks, int64_t Ns,
@@ -593,6 +600,10 @@ static int rollout_impl(const gpmpc_gp_desc_t* gp, const gpmpc_env_desc_t* env, 
         if (!ws || ws_bytes < need) return fail(GPMPC_E_WORKSPACE, "gpmpc_rollout: workspace too small");
     }
     hipStream_t st = (hipStream_t)stream;
+    if (!seeded && rollout_tiles_eligible(gp, env, mode, hall_tasks, H, Ns)) {
+        g_last_rollout_path = 3;
+        return rollout_tiles_launch(gp, env, args, ws, ws_bytes, st);
+    }
     if (!seeded && rollout_fast_eligible(gp, env, mode, hall_tasks, H)) {
         g_last_rollout_path = 1;
         return rollout_fast_launch(gp, env, args, ws, ws_bytes, st);

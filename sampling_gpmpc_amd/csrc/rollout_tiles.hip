@@ -1,0 +1,810 @@
+// rollout_tiles_kernel: the THROUGHPUT form of the re-conditioned rollout (mode R, T = 3 label slots per point, value-only
+// real labels on a tensor grid).  gfx950, wave64, one wave per workgroup, one workgroup per SIMD (512 registers).
+//
+// The tuned kernel of rollout_fast.hip gives a chain (sample, output) a whole wave: at BASELINE configs[1] that is what
+// fills the chip, but beyond Ns = 1024 chains it costs Ns / 1024 rounds, 18 % of its lanes do algorithmic work and the car
+// streams 60-97x its algorithmic traffic.  Here a wave carries FOUR chains (pendulum: four samples; car: the three outputs
+// of one sample, the fourth is a copy of the third) and the forward substitution runs on the matrix pipe:
+//
+//   * v_mfma_f64_4x4x4_4b_f64 multiplies four independent 4x4 blocks, block b = lanes {16 k + 4 b + x} (the b-th quad of
+//     every DPP row).  Lane maps (tools/ubench/mfma64_layout.hip, measured): A[i][k] at lane 16 k + 4 b + i, B[k][j] at
+//     16 k + 4 b + j, D[i][j] at 16 i + 4 b + j.  With block == chain, a 4-row TILE of a chain's right-hand sides
+//     (rows x {3 right-hand sides + one spare column}) is one FP64 register, the chain's factor is a lower-triangular
+//     matrix of 4x4 tiles (one register per tile), and  acc_r -= L_rp V_p  is ONE instruction for all four chains, at
+//     17 cycles, 15 of the SIMD's 16 FP64 FMA per clock (a lone wave issues v_fma_f64 every 6.8 cycles: 9.5 per clock).
+//     A register holding a matrix X in the "natural" layout (X[r][c] at lane 16 r + 4 b + c = the B / D map) acts as X^T
+//     when used as the A operand:  mfma(X, Y) = X^T Y.  Factor tiles are therefore kept as (-L_rp)^T in natural layout;
+//     the diagonal tiles as (L_rr^-1)^T, so that the whole solve is a left-looking sequence of MFMAs
+//         acc = R_r + sum_{p<r} (-L_rp) V_p ;  V_r = L_rr^-1 acc,
+//     two accumulators alternating (a dependent FP64 MFMA needs 4 software wait states = an MFMA in between).
+//   * the spare column carries the whitened labels: R[:, y] = y_h - mu_real(x_h), hence V[:, y] = w_h, and ONE more MFMA
+//     per tile, S' += V_r^T V_r, yields v^T v (the posterior covariance's subtrahend) and v^T w (the mean) together.  The
+//     real-data block enters the same way: 12 pseudo-tiles of phi_e = dsc_e A_a B_c (the grid root, gpmpc_device.hpp) and
+//     w_E.  No cross-lane reduction ladder anywhere.
+//   * the first NRA tile rows of the factor live in AGPRs (MFMA reads its A operand from there at no cost; VALU cannot
+//     address them), the rest streams from an HBM/L2 workspace, one coalesced 512-byte load per tile and wave, a tile row
+//     ahead.  New rows are V itself: in step t the right-hand side of task c is put in column (n_h + c) mod 4, so the lane
+//     that holds v_p[c] IS the lane of the new row's entry in the A operand - appending is one masked store per tile.
+//   * everything that is not a triangular solve runs on the VALU with chain == DPP row and lane == conditioning POINT
+//     (16 points per pass): kernel entries, and the real-data correction  L_hr v_r  in the grid root's Kronecker form
+//     (a point keeps Qa^T{ea, ea q0} and Qb^T{eb, eb q1}: 28 doubles in LDS instead of three 45-vectors), per-chain
+//     operands broadcast with v_fmac_f64_dpp row_newbcast.  A 1.5 KB LDS scratch converts between the two lane maps.
+#include "gpmpc_host.hpp"
+#include "rollout_args.hpp"
+
+#include <type_traits>
+#include <utility>
+
+namespace gpmpc {
+
+typedef double double2_v __attribute__((ext_vector_type(2)));
+typedef unsigned u32x2_v __attribute__((ext_vector_type(2)));
+
+// GPMPC_TILES_DEBUG (build.py: GPMPC_EXTRA_DEFS=-DGPMPC_TILES_DEBUG): wave 0 dumps its solved tiles and the tiles it appends
+// at step GPMPC_TILES_DEBUG_STEP into g_tiles_dbg (tools/debug/tiles_dbg.py compares them with a dense numpy factor)
+__device__ double g_tiles_dbg[64 * 64];
+#ifndef GPMPC_TILES_DEBUG_STEP
+#define GPMPC_TILES_DEBUG_STEP 2
+#endif
+#ifdef GPMPC_TILES_DEBUG
+#define TDBG(slot, val) do { if (blockIdx.x == 0 && t == GPMPC_TILES_DEBUG_STEP) g_tiles_dbg[(slot) * 64 + lane] = (val); } while (0)
+#else
+#define TDBG(slot, val)
+#endif
+
+constexpr int kTileNRA = 14;                                   // tile rows of the factor kept in AGPRs (105 tiles = 210 registers)
+__host__ __device__ constexpr int tri(int r) { return r * (r + 1) / 2; }
+
+__device__ __forceinline__ void tiles_sync_lds() {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// FP64 MFMA, issued from inline asm so that the operand register classes are ours (A from an AGPR where the factor is
+// resident).  hipcc pads nothing inside or around asm, and on gfx950 (tools/ubench/mfma64_hazard2.hip, mfma64_chain.hip)
+//   MFMA D -> MFMA SrcC: 4 wait states; MFMA D -> MFMA SrcA/B or ANY VALU reader (also a spill of the result): 6;
+//   VALU write -> MFMA source: 2; overwriting an MFMA's source right behind it: safe.
+// Hence: chains of MFMAs are ONE statement each (rollout_tiles_mfma.inc, generated), every statement opens with s_nop 1
+// and closes with s_nop 5.
+// ---------------------------------------------------------------------------------------------------------------
+#include "rollout_tiles_mfma.inc"
+// D = A B (C = 0)
+__device__ __forceinline__ double mfma_zero_v(double a, double b) {
+    double d;
+    asm volatile("s_nop 1\n\tv_mfma_f64_4x4x4_4b_f64 %0, %1, %2, 0\n\ts_nop 5" : "=&v"(d) : "v"(a), "v"(b));
+    return d;
+}
+__device__ __forceinline__ double mfma_zero_a(double a, double b) {
+    double d;
+    asm volatile("s_nop 1\n\tv_mfma_f64_4x4x4_4b_f64 %0, %1, %2, 0\n\ts_nop 5" : "=&v"(d) : "a"(a), "v"(b));
+    return d;
+}
+// acc[p & 3] += A[p] B[p], p = 0 .. N-1, in statements of at most 12 MFMAs (12 = 0 mod 4: the round robin continues)
+template <int N, bool AGPR, int P0 = 0>
+__device__ __forceinline__ void mfma_rowsum(double (&acc)[4], const double* A, const double* B) {
+    if constexpr (P0 < N) {
+        constexpr int K = (N - P0 < 12) ? N - P0 : 12;
+        if constexpr (AGPR) mfma_chain_a<K>(acc[0], acc[1], acc[2], acc[3], A + P0, B + P0);
+        else mfma_chain_v<K>(acc[0], acc[1], acc[2], acc[3], A + P0, B + P0);
+        mfma_rowsum<N, AGPR, P0 + K>(acc, A, B);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// DPP-row broadcasts (chain == DPP row on the VALU side).  The broadcast sources are written long before they are read
+// through DPP (the two wait states of the VALU-write -> DPP-read hazard): the grid factors' blocks carry their own s_nop.
+// ---------------------------------------------------------------------------------------------------------------
+template <int LN>
+__device__ __forceinline__ void tl_fmac2_bcast(double& acc0, double& acc1, double r0, double r1, double l) {
+    asm("s_nop 1\n\t"
+        "v_fmac_f64_dpp %0, %3, %2 row_newbcast:%5 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f64_dpp %1, %4, %2 row_newbcast:%5 row_mask:0xf bank_mask:0xf"
+        : "+v"(acc0), "+v"(acc1)
+        : "v"(l), "v"(r0), "v"(r1), "n"(LN));
+}
+// s00 += E0@LN y0, s01 += E1@LN y0, s10 += E0@LN y1, s11 += E1@LN y1
+template <int LN>
+__device__ __forceinline__ void tl_fmac4_bcast(double& s00, double& s01, double& s10, double& s11, double e0, double e1, double y0,
+                                               double y1) {
+    asm("s_nop 1\n\t"
+        "v_fmac_f64_dpp %0, %4, %6 row_newbcast:%8 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f64_dpp %1, %5, %6 row_newbcast:%8 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f64_dpp %2, %4, %7 row_newbcast:%8 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f64_dpp %3, %5, %7 row_newbcast:%8 row_mask:0xf bank_mask:0xf"
+        : "+v"(s00), "+v"(s01), "+v"(s10), "+v"(s11)
+        : "v"(e0), "v"(e1), "v"(y0), "v"(y1), "n"(LN));
+}
+// o0 += P0@LN xa, o1 += P1@LN xa, o2 += P0@LN xb
+template <int LN>
+__device__ __forceinline__ void tl_fmac3_bcast(double& o0, double& o1, double& o2, double p0, double p1, double xa, double xb) {
+    asm("s_nop 1\n\t"
+        "v_fmac_f64_dpp %0, %3, %5 row_newbcast:%7 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f64_dpp %1, %4, %5 row_newbcast:%7 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f64_dpp %2, %3, %6 row_newbcast:%7 row_mask:0xf bank_mask:0xf"
+        : "+v"(o0), "+v"(o1), "+v"(o2)
+        : "v"(p0), "v"(p1), "v"(xa), "v"(xb), "n"(LN));
+}
+
+template <int N, int J = 0>
+__device__ __forceinline__ void tl_axis_product(double& P0, double& P1, double k0, double k1, const double (&cf)[N]) {
+    if constexpr (J < N) {
+        tl_fmac2_bcast<J>(P0, P1, k0, k1, cf[J]);
+        tl_axis_product<N, J + 1>(P0, P1, k0, k1, cf);
+    }
+}
+// the four D-weighted inner products of a point: s[y][m][a] = sum_c E_m[a][c] Y_y[c]; entry (a, c) of E sits in register
+// (a N1 + c) / 16 at lane (a N1 + c) % 16 of the chain's DPP row
+template <int N0, int N1, int NE, int A = 0, int C = 0>
+__device__ __forceinline__ void tl_inner(double (&s00)[N0], double (&s01)[N0], double (&s10)[N0], double (&s11)[N0],
+                                         const double (&E0)[NE], const double (&E1)[NE], const double (&Y0)[N1], const double (&Y1)[N1]) {
+    if constexpr (A < N0) {
+        constexpr int e = A * N1 + C;
+        tl_fmac4_bcast<e % 16>(s00[A], s01[A], s10[A], s11[A], E0[e / 16], E1[e / 16], Y0[C], Y1[C]);
+        if constexpr (C + 1 < N1) tl_inner<N0, N1, NE, A, C + 1>(s00, s01, s10, s11, E0, E1, Y0, Y1);
+        else tl_inner<N0, N1, NE, A + 1, 0>(s00, s01, s10, s11, E0, E1, Y0, Y1);
+    }
+}
+template <int N0, int A = 0>
+__device__ __forceinline__ void tl_outer(double& o0, double& o1, double& o2, double P0, double P1, const double (&xa)[N0],
+                                         const double (&xb)[N0]) {
+    if constexpr (A < N0) {
+        tl_fmac3_bcast<A>(o0, o1, o2, P0, P1, xa[A], xb[A]);
+        tl_outer<N0, A + 1>(o0, o1, o2, P0, P1, xa, xb);
+    }
+}
+
+// compile-time loop with an integral_constant index (register arrays need static indices)
+template <int B, int E, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (B < E) {
+        f(std::integral_constant<int, B>{});
+        static_for<B + 1, E>(f);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// LDS map of a workgroup (= one wave), doubles.  GL chains are stored (car: 3, the fourth chain aliases the third).
+// ---------------------------------------------------------------------------------------------------------------
+template <int N0, int N1>
+struct TilesLds {
+    static constexpr int XH = (N0 + 1) & ~1;                      // padded length of PA0 / PA1
+    static constexpr int YH = (N1 + 1) & ~1;
+    static constexpr int XS = (2 * XH) % 4 == 0 ? 2 * XH + 2 : 2 * XH;   // record stride of XF: an odd number of 16-byte slots
+    static constexpr int YS = 2 * YH;
+    static constexpr int SXN = 96;                                // per chain: new-point record (2 XH + 2 YH <= 32), S' exchange (32), scalars (16)
+    static constexpr int SCRN = 192;                              // per chain: 48 rows x 4 columns
+    __host__ __device__ static constexpr int per_chain(int npt) { return npt * (XS + YS + 4) + SCRN + SXN; }
+};
+
+template <int N0, int N1, int ENV, int NT>
+__global__ __launch_bounds__(64, 1) void rollout_tiles_kernel(const RolloutArgs a) {
+    constexpr int D = 2, T = 3;
+    constexpr int G_NY = (ENV == GPMPC_ENV_PENDULUM1D) ? 1 : 3;
+    constexpr int NX = (ENV == GPMPC_ENV_PENDULUM1D) ? 2 : 4;
+    constexpr int NU = (ENV == GPMPC_ENV_PENDULUM1D) ? 1 : 2;
+    constexpr int GL = (G_NY == 1) ? 4 : 3;                       // chains with their own LDS / results
+    constexpr int NE = (N0 * N1 + 15) / 16;                       // registers holding one value per grid entry (a, c)
+    constexpr int NRT = (N0 * N1 + 3) / 4;                        // pseudo-tiles of the real block
+    constexpr int NPS = (NT * 4 / 3 + 15) / 16;                   // passes of 16 conditioning points
+    constexpr int NRA = kTileNRA;
+    using L = TilesLds<N0, N1>;
+    static_assert(N0 + N1 <= 16 && NE <= 3 && NT % 4 == 0, "grid / tile limits");
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+
+    const GpParams& gp = a.gp;
+    const int lane = threadIdx.x;
+    const int cv = lane >> 4, l = lane & 15;                      // VALU side: chain = DPP row, lane l of the row
+    const int kq = lane >> 4, bm = (lane >> 2) & 3, jq = lane & 3;    // MFMA side: chain = quad bm; row (A: column) kq, column (A: row) jq
+    const int H = a.H, npt_cap = max(H - 1, 1);
+    const long blk = blockIdx.x;
+    // chain -> (sample, output)
+    auto chain_sample = [&](int c) -> long { return (G_NY == 1) ? min(4 * blk + c, a.Ns - 1) : blk; };
+    auto chain_live = [&](int c) -> bool { return (G_NY == 1) ? (4 * blk + c < a.Ns) : (c < 3); };
+    const long s = chain_sample(cv);
+    const int o = (G_NY == 1) ? 0 : min(cv, 2);
+    const bool live = chain_live(cv);
+    const int lc = min(cv, GL - 1), lcm = min(bm, GL - 1);       // LDS chain slots of the two lane maps
+
+    const int pc = L::per_chain(npt_cap);
+    double* XF = smem + lc * pc;                                  // [npt][XS]   PA0 | PA1
+    double* YF = XF + npt_cap * L::XS;                            // [npt][YS]   PB0 | PB1
+    double* YT = YF + npt_cap * L::YS;                            // [npt][4]    whitened-label residual y - mu_real of the point's rows
+    double* SCR = YT + npt_cap * 4;                               // [48][4]     lane-map converter
+    double* SX = SCR + L::SCRN;                                   // new-point record | S' exchange | chain scalars
+    double* SCRm = smem + lcm * pc + npt_cap * (L::XS + L::YS + 4);
+    double* SXm = SCRm + L::SCRN;
+
+    // ---- per-chain / per-lane constants (VALU side) ----------------------------------------------------------------
+    const double il0 = gp.inv_l2[o][0], il1 = gp.inv_l2[o][1], os = gp.os[o];
+    // axis lanes: lane l < N0 carries axis-0 point l, lane N0 + j axis-1 point j
+    const bool ax0 = l < N0, ax1 = (l >= N0) && (l < N0 + N1);
+    const double g_x = ax0 ? a.X_r[(l * N1) * D] : (ax1 ? a.X_r[(l - N0) * D + 1] : 0.0);
+    const double g_il = ax0 ? il0 : (ax1 ? il1 : 0.0);
+    // grid entry e = 16 q + l = a N1 + c (three registers cover the N0 N1 entries); the plan's constants per entry and the
+    // columns of Qa / Qb are re-read every step (L1 / L2 resident) instead of occupying ~50 registers through the step
+    int ea_[NE], ec_[NE], ee_[NE];
+    bool ev_[NE];
+#pragma unroll
+    for (int q = 0; q < NE; ++q) {
+        const int e = 16 * q + l;
+        ev_[q] = e < N0 * N1;
+        ee_[q] = ev_[q] ? e : 0;
+        ea_[q] = ee_[q] / N1;
+        ec_[q] = ee_[q] - ea_[q] * N1;
+    }
+    const double* Qa_p = plan_grid_Qa(a.plan, gp, o) + (ax0 ? l : 0);
+    const double* Qb_p = plan_grid_Qb(a.plan, gp, o) + (ax1 ? l - N0 : 0);
+    const double* m2_p = plan_grid_m2(a.plan, gp, o);
+    const double* dsc_p = plan_grid_dsc(a.plan, gp, o);
+    const double* wE_p = plan_grid_w(a.plan, gp, o);
+    // MFMA side constants: the identity in natural layout, and this lane's slot in the wave's factor workspace
+    const double Inat = (kq == jq) ? 1.0 : 0.0;
+    // tile e of the wave: 512 bytes at wsu + 512 e, this lane's double at + 8 lane.  Accessed through a buffer descriptor
+    // (uniform base, scalar tile offset, 32-bit lane offset): with per-lane 64-bit addresses hipcc hoists the address
+    // arithmetic of all 528 tiles out of the step loop and spills it.
+    char* wsu = reinterpret_cast<char*>(a.ws + blk * a.ws_chain_stride);
+    const unsigned lane8 = (unsigned)lane * 8u;
+    const __amdgpu_buffer_rsrc_t wsr = __builtin_amdgcn_make_buffer_rsrc(wsu, 0, (int)(a.ws_chain_stride * 8), 0x00020000);
+    auto tile_load = [&](unsigned voff, int e) -> double {
+        // sc1 (aux bit 4): served by L2.  A tile row is re-read after this wave has stored into it (rows arrive three at a
+        // time, the diagonal tile is rewritten); the CU's L1 keeps the line it fetched BEFORE the store (measured: stale
+        // tiles at the third step), and streaming 4x the L1's size per step gains nothing from L1 anyway
+        return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(wsr, voff, e * 512, 16));
+    };
+    auto tile_store = [&](unsigned voff, int e, double v) {
+        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2_v, v), wsr, voff, e * 512, 0);
+    };
+
+    double x[NX];
+#pragma unroll
+    for (int d = 0; d < NX; ++d) x[d] = a.x0[(a.x0_per_sample ? s * NX : 0) + d];
+
+    double xpt[NPS][D];                                           // GP input of the point this lane owns in pass q
+#pragma unroll
+    for (int q = 0; q < NPS; ++q) xpt[q][0] = xpt[q][1] = 0.0;
+    // AGPR-resident tile rows 0 .. NRA-1 (natural layout, see header).  Every element is DEFINED by an asm load with an
+    // "=a" output and only ever read through "a" operands, so the values are of the AGPR class from birth (a C++ array
+    // that merely feeds "a" operands is allocated to VGPRs and spilled).  Row r is loaded when it completes and not read
+    // before (rows >= rs stream), hence no initialisation.
+    double At[tri(NRA)];
+    double Ucur = Inat, dcur = (kq == jq) ? 1.0 : 0.0;           // the incomplete diagonal tile: L^T and 1/diag (natural layout)
+    int info_acc = 0;
+    int n_pts = 0;                                                // appended points; n_h = 3 n_pts label rows
+
+#pragma unroll 1
+    for (int t = 0; t < H; ++t) {
+        const int n_h = 3 * n_pts, i0 = n_h & 3, nt = (n_h + 3) >> 2, nfull = n_h >> 2;
+        const int ycol = (i0 + 3) & 3;
+        // ---- input, GP input ---------------------------------------------------------------------------------------
+        double u[NU], xi[D];
+#pragma unroll
+        for (int i = 0; i < NU; ++i) {
+            const double uf = a.u_ff[t * NU + i];
+            if (a.env.use_feedback) {
+                double acc = 0.0;
+#pragma unroll
+                for (int j = 0; j < NX; ++j) acc += (a.env.x_goal[j] - x[j]) * a.env.K[i][j];
+                u[i] = -acc + uf;
+            } else {
+                u[i] = uf;
+            }
+        }
+        xi[0] = (ENV == GPMPC_ENV_PENDULUM1D) ? x[0] : x[2];
+        xi[1] = u[0];
+        double zt[T];                                             // base samples of this step (used after the solve)
+#pragma unroll
+        for (int c = 0; c < T; ++c) zt[c] = a.z[(long)t * a.z_step_stride + (s * G_NY + o) * T + c];
+        if (l == 0 && live && o == 0) {
+#pragma unroll
+            for (int d = 0; d < NX; ++d) a.X_traj[(s * NX + d) * (H + 1) + t] = x[d];
+            if (a.Xi) {
+#pragma unroll
+                for (int d = 0; d < D; ++d) a.Xi[(s * H + t) * D + d] = xi[d];
+            }
+        }
+
+        // ---- phase A: the real block at the test point (grid root) ---------------------------------------------------
+        double P0 = 0.0, P1 = 0.0;                                // lanes < N0: PA0', PA1'; lanes N0 .. N0+N1-1: PB0', PB1'
+        double E0[NE], E1[NE];
+        double Sr;                                                // S' of the real block (natural layout)
+        {
+            double cf[N0 + N1];                                   // column l of Qa (lanes < N0) / column l - N0 of Qb
+#pragma unroll
+            for (int j = 0; j < N0; ++j) cf[j] = ax0 ? Qa_p[j * N0] : 0.0;
+#pragma unroll
+            for (int j = 0; j < N1; ++j) cf[N0 + j] = ax1 ? Qb_p[j * N1] : 0.0;
+            double m2e[NE], dsce[NE], wEe[NE];
+#pragma unroll
+            for (int q = 0; q < NE; ++q) {
+                m2e[q] = ev_[q] ? m2_p[ee_[q]] : 0.0;
+                dsce[q] = ev_[q] ? dsc_p[ee_[q]] : 0.0;
+                wEe[q] = ev_[q] ? wE_p[ee_[q]] : 0.0;
+            }
+            const double gr = g_x - (ax0 ? xi[0] : xi[1]);
+            const double gq = gr * g_il;
+            const double ea = exp(-0.5 * gr * gq);
+            const double k0 = ea, k1 = ea * gq;
+            tl_axis_product<N0 + N1>(P0, P1, k0, k1, cf);
+            // the new point's record (also what is appended): PA0 | PA1 | PB0 | PB1
+            if (ax0) {
+                SX[l] = P0;
+                SX[L::XH + l] = P1;
+            } else if (ax1) {
+                SX[2 * L::XH + (l - N0)] = P0;
+                SX[2 * L::XH + L::YH + (l - N0)] = P1;
+            }
+            tiles_sync_lds();
+#pragma unroll
+            for (int q = 0; q < NE; ++q) {
+                const double pa0 = SX[ea_[q]], pa1 = SX[L::XH + ea_[q]];
+                const double pb0 = SX[2 * L::XH + ec_[q]], pb1 = SX[2 * L::XH + L::YH + ec_[q]];
+                E0[q] = m2e[q] * pb0;
+                E1[q] = m2e[q] * pb1;
+                const double d0 = dsce[q] * pb0;
+                double* dst = SCR + (16 * q + l) * 4;             // column of task b: (i0 + b) & 3 (dynamic, uniform)
+                dst[i0] = d0 * pa0;                               // (PA0, PB0): value
+                dst[(i0 + 1) & 3] = d0 * pa1;                     // (PA1, PB0): d/dx0
+                dst[(i0 + 2) & 3] = dsce[q] * pb1 * pa0;          // (PA0, PB1): d/dx1
+                dst[ycol] = wEe[q];
+            }
+            tiles_sync_lds();
+            double Sq[4] = {0.0, 0.0, 0.0, 0.0};
+            double rt[NRT];
+#pragma unroll
+            for (int q = 0; q < NRT; ++q) rt[q] = SCRm[(4 * q + kq) * 4 + jq];
+            mfma_rowsum<NRT, false>(Sq, rt, rt);
+            const double Sa = Sq[0] + Sq[1], Sb = Sq[2] + Sq[3];
+            Sr = Sa + Sb;
+            tiles_sync_lds();                                     // SCR is reused by phase B
+        }
+
+        // ---- phase B: right-hand sides of the hallucinated rows, 16 points per pass; phase C: into tile registers ------
+        double V[NT];
+#pragma unroll
+        for (int r = 0; r < NT; ++r) V[r] = 0.0;
+        static_for<0, NPS>([&](auto qc) {
+            constexpr int q = decltype(qc)::value;
+            if (16 * q < n_pts) {                                 // uniform
+                const int jp = 16 * q + l;
+                const bool ex = jp < n_pts;
+                const int jr = min(jp, npt_cap - 1);
+                // kernel entries against the test point: cov(task a of the point, task b of the test point)
+                const double d0 = xpt[q][0] - xi[0], d1 = xpt[q][1] - xi[1];
+                const double q0 = d0 * il0, q1 = d1 * il1;
+                const double kk = ex ? os * exp(-0.5 * (d0 * q0 + d1 * q1)) : 0.0;
+                double out[T][T];
+                {
+                    const double Aa[T] = {1.0, -q0, -q1}, Bb[T] = {1.0, q0, q1}, cd[T] = {0.0, il0, il1};
+#pragma unroll
+                    for (int aa = 0; aa < T; ++aa)
+#pragma unroll
+                        for (int b = 0; b < T; ++b) out[aa][b] = kk * fma(Aa[aa], Bb[b], (aa == b) ? cd[aa] : 0.0);
+                }
+                // minus the real-data correction  v_r(point, task a) . v_r(test point, task b)  in Kronecker form
+                {
+                    double PAj[2][N0], PBj[2][N1];
+                    const double* xr = XF + jr * L::XS;
+                    const double* yr = YF + jr * L::YS;
+#pragma unroll
+                    for (int i = 0; i < L::XH / 2; ++i) {
+                        const double2_v u0 = *reinterpret_cast<const double2_v*>(xr + 2 * i);
+                        const double2_v u1 = *reinterpret_cast<const double2_v*>(xr + L::XH + 2 * i);
+                        if (2 * i < N0) PAj[0][2 * i] = u0.x, PAj[1][2 * i] = u1.x;
+                        if (2 * i + 1 < N0) PAj[0][2 * i + 1] = u0.y, PAj[1][2 * i + 1] = u1.y;
+                    }
+#pragma unroll
+                    for (int i = 0; i < L::YH / 2; ++i) {
+                        const double2_v u0 = *reinterpret_cast<const double2_v*>(yr + 2 * i);
+                        const double2_v u1 = *reinterpret_cast<const double2_v*>(yr + L::YH + 2 * i);
+                        if (2 * i < N1) PBj[0][2 * i] = u0.x, PBj[1][2 * i] = u1.x;
+                        if (2 * i + 1 < N1) PBj[0][2 * i + 1] = u0.y, PBj[1][2 * i + 1] = u1.y;
+                    }
+                    double s00[N0], s01[N0], s10[N0], s11[N0];    // s[y][m]: Y = PB_y of the point, E_m of the test point
+#pragma unroll
+                    for (int i = 0; i < N0; ++i) s00[i] = s01[i] = s10[i] = s11[i] = 0.0;
+                    tl_inner<N0, N1, NE>(s00, s01, s10, s11, E0, E1, PBj[0], PBj[1]);
+                    // rows a: (X, y) = (PA0, 0), (PA1, 0), (PA0, 1); right-hand sides b: (P', m) = (P0, 0), (P1, 0), (P0, 1)
+                    double xa[N0], xb[N0], c0, c1, c2;
+#pragma unroll
+                    for (int i = 0; i < N0; ++i) xa[i] = PAj[0][i] * s00[i], xb[i] = PAj[0][i] * s01[i];
+                    c0 = c1 = c2 = 0.0;
+                    tl_outer<N0>(c0, c1, c2, P0, P1, xa, xb);
+                    out[0][0] -= c0, out[0][1] -= c1, out[0][2] -= c2;
+#pragma unroll
+                    for (int i = 0; i < N0; ++i) xa[i] = PAj[1][i] * s00[i], xb[i] = PAj[1][i] * s01[i];
+                    c0 = c1 = c2 = 0.0;
+                    tl_outer<N0>(c0, c1, c2, P0, P1, xa, xb);
+                    out[1][0] -= c0, out[1][1] -= c1, out[1][2] -= c2;
+#pragma unroll
+                    for (int i = 0; i < N0; ++i) xa[i] = PAj[0][i] * s10[i], xb[i] = PAj[0][i] * s11[i];
+                    c0 = c1 = c2 = 0.0;
+                    tl_outer<N0>(c0, c1, c2, P0, P1, xa, xb);
+                    out[2][0] -= c0, out[2][1] -= c1, out[2][2] -= c2;
+                }
+                const double2_v y01 = *reinterpret_cast<const double2_v*>(YT + jr * 4);
+                const double y2 = YT[jr * 4 + 2];
+                const double yt[T] = {y01.x, y01.y, y2};
+#pragma unroll
+                for (int aa = 0; aa < T; ++aa) {
+                    double* dst = SCR + (3 * l + aa) * 4;
+                    dst[i0] = ex ? out[aa][0] : 0.0;
+                    dst[(i0 + 1) & 3] = ex ? out[aa][1] : 0.0;
+                    dst[(i0 + 2) & 3] = ex ? out[aa][2] : 0.0;
+                    dst[ycol] = ex ? yt[aa] : 0.0;
+                }
+                tiles_sync_lds();
+                static_for<0, 12>([&](auto wc) {
+                    constexpr int w = decltype(wc)::value, tg = 12 * q + w;
+                    if constexpr (tg < NT) {
+                        if (tg < nt) V[tg] = SCRm[(4 * w + kq) * 4 + jq];
+                    }
+                });
+                tiles_sync_lds();
+            }
+        });
+
+        TDBG(0, V[0]);
+        TDBG(1, V[1]);
+        TDBG(2, V[2]);
+        TDBG(3, V[3]);
+        // ---- phase D: forward substitution, left-looking over tile rows; phase E: S' += V_r^T V_r -----------------------
+        // Tile rows below `rs` are complete and AGPR-resident; rows rs .. nt-1 stream from the workspace, each row's tiles
+        // requested while the previous row's MFMAs run (two register buffers; sched_barrier keeps hipcc from hoisting all
+        // the loads to the top, which spills hundreds of registers).
+        double Sh[4] = {0.0, 0.0, 0.0, 0.0};
+        if (nt > 0) {
+            const bool part = (n_h & 3) != 0;                     // the last tile row is incomplete: rows >= n_h are masked
+            const bool rowex = (4 * nfull + jq) < n_h;            // A operand of the incomplete tile row: its row index is jq
+#ifdef GPMPC_TILES_NO_AGPR
+            const int rs = 0;                                     // debug: every tile row streams from the workspace
+#else
+            const int rs = min(NRA, nfull);
+#endif
+            double bufA[NT], bufB[NT];
+            auto fetch_row = [&](auto rc, double (&buf)[NT]) {
+                constexpr int r = decltype(rc)::value;
+#pragma unroll
+                for (int p = 0; p <= r; ++p) buf[p] = tile_load(lane8, tri(r) + p);
+            };
+            if (rs == 0) fetch_row(std::integral_constant<int, 0>{}, bufA);
+            __builtin_amdgcn_sched_barrier(0);
+            static_for<0, NT>([&](auto rc) {
+                constexpr int r = decltype(rc)::value;
+                if (r < nt) {                                     // uniform
+                    if constexpr (r + 1 < NT) {
+                        if (r + 1 < nt && r + 1 >= rs) fetch_row(std::integral_constant<int, r + 1>{}, ((r + 1) & 1) ? bufB : bufA);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    double ac[4] = {V[r], 0.0, 0.0, 0.0};
+                    bool streamed = true;
+                    if constexpr (r < NRA) {
+                        if (r < rs) {                             // complete and resident
+                            streamed = false;
+                            mfma_rowsum<r, true>(ac, At + tri(r), V);
+                            const double acc = (ac[0] + ac[1]) + (ac[2] + ac[3]);
+                            V[r] = mfma_zero_a(At[tri(r) + r], acc);
+                        }
+                    }
+                    if (streamed) {
+                        double (&cur)[NT] = (r & 1) ? bufB : bufA;
+                        if (part && r == nt - 1) {
+#pragma unroll
+                            for (int p = 0; p < r; ++p) cur[p] = rowex ? cur[p] : 0.0;
+                        }
+                        mfma_rowsum<r, false>(ac, cur, V);
+                        const double acc = (ac[0] + ac[1]) + (ac[2] + ac[3]);
+                        if constexpr (r < 3) {
+                            TDBG(8 + 4 * r, acc);
+                            TDBG(9 + 4 * r, cur[r]);
+                            TDBG(10 + 4 * r, cur[0]);
+                        }
+                        V[r] = mfma_zero_v(cur[r], acc);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            });
+            // S' += V_r^T V_r, eight tiles per statement (tiles >= nt are zero)
+            static_for<0, NT / 8>([&](auto gc) {
+                constexpr int g = decltype(gc)::value;
+                if (8 * g < nt) mfma_rowsum<8, false>(Sh, V + 8 * g, V + 8 * g);
+            });
+        }
+        TDBG(4, V[0]);
+        TDBG(5, V[1]);
+        TDBG(6, V[2]);
+        TDBG(7, V[3]);
+        // ---- phase F: S' to the chains' VALU lanes ---------------------------------------------------------------------
+        const double Stot = Sr + ((Sh[0] + Sh[1]) + (Sh[2] + Sh[3]));
+        TDBG(20, Stot);
+        TDBG(21, Sr);
+        SXm[32 + kq * 4 + jq] = Stot;
+        SXm[48 + kq * 4 + jq] = Sr;
+        tiles_sync_lds();
+        double mu[T], mur[T], S[T][T];
+        {
+            const int cb[T] = {i0, (i0 + 1) & 3, (i0 + 2) & 3};
+            const double il2[D] = {il0, il1};
+#pragma unroll
+            for (int b = 0; b < T; ++b) {
+                mu[b] = SX[32 + cb[b] * 4 + ycol];
+                mur[b] = SX[48 + cb[b] * 4 + ycol];
+#pragma unroll
+                for (int c = 0; c <= b; ++c) {
+                    const double kss = (b == c) ? ((b == 0) ? os : os * il2[b - 1]) : 0.0;
+                    const double val = kss - SX[32 + cb[b] * 4 + cb[c]];
+                    S[b][c] = val;
+                    S[c][b] = val;
+                }
+            }
+        }
+        // ---- phase G: variance floor, roots, sample (as sample_gp, src/agent.py:629-708) ----------------------------------
+        double var[T];
+        bool all_zero = (a.var_zero_thr >= 0.0);
+#pragma unroll
+        for (int b = 0; b < T; ++b) {
+            var[b] = S[b][b];
+            if (var[b] < gp.var_floor) {
+                var[b] = gp.var_floor;
+                info_acc |= GPMPC_INFO_VAR_CLAMPED;
+            }
+            all_zero = all_zero && (var[b] <= a.var_zero_thr);
+        }
+        double R[T][T], C[T][T], cinv[T];
+        bool c_ok;
+        {
+            double Sn[T][T], rinv[T];
+#pragma unroll
+            for (int b = 0; b < T; ++b)
+#pragma unroll
+                for (int c = 0; c < T; ++c) Sn[b][c] = S[b][c] + ((b == c) ? gp.noise[b] : 0.0);
+            bool r_ok;
+            chol3_pair_fast(Sn, S, C, R, cinv, rinv, c_ok, r_ok);
+            if (!r_ok) info_acc |= root_small_fast_retry<T>(S, gp.jitter, R);
+        }
+        double y[T];
+#pragma unroll
+        for (int b = 0; b < T; ++b) {
+            double acc = 0.0;
+#pragma unroll
+            for (int c = 0; c <= b; ++c) acc = fma(R[b][c], zt[c], acc);
+            double yb = acc + mu[b];
+            if (all_zero) yb = mu[b];
+            const double dlt = yb - mu[b];
+            if (dlt * dlt > a.beta * a.beta * var[b]) {
+                const double sd = a.beta * sqrt(var[b]);
+                yb = fmin(fmax(yb, mu[b] - sd), mu[b] + sd);
+            }
+            y[b] = yb;
+        }
+        if (l == 0 && live && a.Y) {
+#pragma unroll
+            for (int b = 0; b < T; ++b) a.Y[((s * G_NY + o) * H + t) * T + b] = y[b];
+        }
+
+        // ---- phase H: append the point (A.9): three rows of the factor, the point's record, its label residuals -------------
+        if (t + 1 < H) {
+            if (!c_ok) info_acc |= GPMPC_INFO_TRAIN_CHOL_FAIL;
+            const int jn = n_pts, tn = n_h >> 2;
+            // VALU side: the record, the residuals y - mu_real, the point itself, and the chain's scalars for the MFMA side
+            if (ax0) {
+                XF[jn * L::XS + l] = P0;
+                XF[jn * L::XS + L::XH + l] = P1;
+            } else if (ax1) {
+                YF[jn * L::YS + (l - N0)] = P0;
+                YF[jn * L::YS + L::YH + (l - N0)] = P1;
+            }
+            if (l < T) YT[jn * 4 + l] = ((l == 0) ? y[0] : ((l == 1) ? y[1] : y[2])) - ((l == 0) ? mur[0] : ((l == 1) ? mur[1] : mur[2]));
+            static_for<0, NPS>([&](auto qc) {
+                constexpr int q = decltype(qc)::value;
+                const bool mine = (16 * q + l) == jn;
+                xpt[q][0] = mine ? xi[0] : xpt[q][0];
+                xpt[q][1] = mine ? xi[1] : xpt[q][1];
+            });
+            if (l == 0) {                                         // C (lower, row-major 3x3) and 1/diag
+#pragma unroll
+                for (int b = 0; b < T; ++b) {
+#pragma unroll
+                    for (int c = 0; c < T; ++c) SX[64 + 3 * b + c] = (c <= b) ? C[b][c] : 0.0;
+                    SX[73 + b] = cinv[b];
+                }
+            }
+            tiles_sync_lds();
+            // MFMA side.  Lane (kq, jq) of tile pair (Rt, Pt) is the entry row gi = 4 Rt + jq, column gk = 4 Pt + kq of L.
+            // New rows are n_h .. n_h+2; their entry against an OLD column is v of that column = V[Pt] in this very lane.
+            const int base = n_h;
+            auto entry = [&](int Rt, int Pt, double vown, double old) -> double {
+                const int gi = 4 * Rt + jq, gk = 4 * Pt + kq;
+                const int ci = min(max(gi - base, 0), 2), ck = min(max(gk - base, 0), 2);
+                const double cval = SXm[64 + 3 * ci + ck];
+                double val = (gk <= gi) ? cval : 0.0;             // both new
+                val = (gk < base) ? vown : val;                   // new row, old column
+                val = (gi >= base + 3) ? ((gi == gk) ? 1.0 : 0.0) : val;   // rows that do not exist yet: identity
+                val = (gi < base) ? old : val;                    // old rows keep what they had
+                return val;
+            };
+            // which tile row does this lane's new row belong to (columns i0.. stay in tile tn, the wrapped ones open tn+1)
+            const bool isnew = jq != ycol;                        // column jq carries the new row (n_h + c), c = (jq - i0) & 3 <= 2
+            const int myrow = (jq >= i0) ? tn : tn + 1;
+            const unsigned rowoff = (unsigned)tri(myrow) * 512u + lane8;   // per-lane: the two target tile rows differ
+            // off-diagonal tiles against complete old tile rows p < tn: -v
+            static_for<0, NT>([&](auto pcn) {
+                constexpr int p = decltype(pcn)::value;
+                if (p < tn) {
+                    if (isnew) tile_store(rowoff, p, -V[p]);
+                }
+            });
+            // the tile pairs that involve tile tn itself (old rows of the incomplete tile) and the new tile tn+1
+            double Vtn = 0.0;
+            static_for<0, NT>([&](auto pcn) {
+                constexpr int p = decltype(pcn)::value;
+                if (p == tn) Vtn = V[p];
+            });
+            const bool wraps = i0 >= 2;                           // rows n_h .. n_h+2 reach into tile tn+1
+            // diagonal tile tn: U = L^T (natural), its row / column scalings
+            auto diag_scal = [&](int Rt, double oldv, bool rowwise) -> double {
+                const int g = 4 * Rt + (rowwise ? kq : jq);
+                const int c = min(max(g - base, 0), 2);
+                const double cv_ = SXm[73 + c];
+                double v = (g >= base + 3) ? 1.0 : cv_;
+                v = (g < base) ? oldv : v;
+                return v;
+            };
+            auto inverse_tile = [&](double U, double drow, double dcol) -> double {
+                // U = Dg (I - M), M strictly upper:  U^-1 = (I + M)(I + M^2) Dg^-1   (M^4 = 0)
+                const double M = Inat - drow * U;
+                const double Mt = mfma_zero_v(M, Inat);           // M^T
+                const double M2 = mfma_zero_v(Mt, M);             // M M
+                const double Pq = mfma_zero_v(Inat + Mt, Inat + M2);   // (I + M)(I + M^2)
+                return Pq * dcol;
+            };
+            {
+                // old 1/diag of the incomplete tile, row-wise and column-wise copies travel in dcur through LDS-free
+                // lookups: dcur holds 1/d on the diagonal lanes only; rebuild both scalings from it with two MFMAs
+                const double ones = 1.0;
+                const double drow_old = mfma_zero_v(dcur, ones);  // [k][i] = 1 / d_k
+                const double dcol_old = mfma_zero_v(ones, dcur);  // [k][i] = 1 / d_i
+                const double U = entry(tn, tn, Vtn, Ucur);
+                const double drow = diag_scal(tn, drow_old, true), dcol = diag_scal(tn, dcol_old, false);
+                const double Gt = inverse_tile(U, drow, dcol);
+                TDBG(26, U);
+                TDBG(27, drow);
+                TDBG(28, dcol);
+                TDBG(29, Gt);
+                tile_store(lane8, tri(tn) + tn, Gt);
+                double Unext = U, dnext = (kq == jq) ? drow : 0.0;
+                if (wraps) {
+                    const double X = entry(tn + 1, tn, Vtn, 0.0);
+                    const bool newrow1 = jq <= i0 - 2;            // rows of tile tn+1 that exist now
+                    if (newrow1) tile_store(lane8, tri(tn + 1) + tn, -X);
+                    const double U1 = entry(tn + 1, tn + 1, 0.0, 0.0);
+                    const double drow1 = diag_scal(tn + 1, 1.0, true), dcol1 = diag_scal(tn + 1, 1.0, false);
+                    const double G1 = inverse_tile(U1, drow1, dcol1);
+                    TDBG(30, U1);
+                    TDBG(31, drow1);
+                    TDBG(32, dcol1);
+                    TDBG(33, G1);
+                    TDBG(34, X);
+                    tile_store(lane8, tri(tn + 1) + tn + 1, G1);
+                    Unext = U1;
+                    dnext = (kq == jq) ? drow1 : 0.0;
+                }
+                // the incomplete tile after this step: tn while i0 == 0 (rows 0..2 of a fresh tile), else tn + 1 (fresh
+                // when nothing wrapped: identity)
+                if (i0 == 1) {                                    // tile tn is complete now, the next tile is untouched
+                    Unext = Inat;
+                    dnext = (kq == jq) ? 1.0 : 0.0;
+                }
+                Ucur = Unext;
+                dcur = dnext;
+            }
+            // a tile row that became complete moves into its AGPRs
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the row's stores (this lane re-reads only its own slots)
+            if (i0 >= 1) {
+                static_for<0, NRA>([&](auto rc) {
+                    constexpr int r = decltype(rc)::value;
+                    if (r == tn) load_row_agpr<r + 1>(wsr, lane8, tri(r) * 512, At + tri(r));   // loads + their wait: one statement
+                });
+            }
+            n_pts += 1;
+        }
+
+        // ---- state hand-over ---------------------------------------------------------------------------------------------
+        if (ENV == GPMPC_ENV_PENDULUM1D) {
+            const double x0n = x[0] + x[1] * a.env.dt;
+            x[1] = x[1] + y[0];
+            x[0] = x0n;
+        } else {
+            // value samples of the three outputs: lane 0 of DPP rows 0, 1, 2
+            const double g0 = readlane_f64(y[0], 0), g1 = readlane_f64(y[0], 16), g2 = readlane_f64(y[0], 32);
+            const double vv = x[3];
+            x[0] = x[0] + vv * g0;
+            x[1] = x[1] + vv * g1;
+            x[2] = x[2] + vv * g2;
+            x[3] = x[3] + u[NU - 1] * a.env.dt;
+        }
+    }
+
+    if (l == 0 && live && o == 0) {
+#pragma unroll
+        for (int d = 0; d < NX; ++d) a.X_traj[(s * NX + d) * (H + 1) + H] = x[d];
+    }
+    if (G_NY == 1) {
+        if (l == 0 && live) a.info[s] = info_acc;
+    } else {
+        const int i1 = __builtin_amdgcn_readlane(info_acc, 16), i2 = __builtin_amdgcn_readlane(info_acc, 32);
+        if (lane == 0) a.info[s] = info_acc | i1 | i2;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int kTilesNT = 32;                                     // 128 label rows per chain: H <= 43
+
+static int tiles_mode() {                                        // 0 auto, 1 forced, -1 disabled
+    const char* e = std::getenv("GPMPC_ROLLOUT_TILES");
+    if (!e) return 0;
+    return (e[0] == '1') ? 1 : ((e[0] == '0') ? -1 : 0);
+}
+
+template <int N0, int N1>
+static size_t tiles_lds_bytes(int g_ny, int H) {
+    const int gl = (g_ny == 1) ? 4 : 3;
+    return (size_t)gl * TilesLds<N0, N1>::per_chain(H - 1 > 1 ? H - 1 : 1) * sizeof(double);
+}
+
+bool rollout_tiles_eligible(const gpmpc_gp_desc_t* gp, const gpmpc_env_desc_t* env, int mode, int hall_tasks, int H, int64_t Ns) {
+    const int md = tiles_mode();
+    if (md < 0) return false;
+    const char* e = std::getenv("GPMPC_DISABLE_FAST_ROLLOUT");
+    if (e && e[0] == '1') return false;
+    const char* eg = std::getenv("GPMPC_DISABLE_GRID_ROOT");
+    if (eg && eg[0] == '1') return false;
+    if (mode != GPMPC_MODE_RECONDITIONED || gp->T != 3 || gp->D != 2 || hall_tasks != 3 || gp->real_has_grad) return false;
+    if (!plan_has_grid_root(gp->grid_n0, gp->grid_n1, gp->real_has_grad)) return false;
+    if (H < 2 || 3 * (H - 1) > 4 * kTilesNT) return false;
+    size_t lds = 0;
+    if (env->env_id == GPMPC_ENV_PENDULUM1D && gp->g_ny == 1 && gp->grid_n0 == 4 && gp->grid_n1 == 9) lds = tiles_lds_bytes<4, 9>(1, H);
+    else if (env->env_id == GPMPC_ENV_CAR_RESIDUAL && gp->g_ny == 3 && gp->grid_n0 == 5 && gp->grid_n1 == 9) lds = tiles_lds_bytes<5, 9>(3, H);
+    else return false;
+    if (lds > 160 * 1024 - 64) return false;
+    if (md > 0) return true;
+    // a wave carries four chains: worth it once the one-chain-per-wave kernels need more than one round of the chip
+    const int64_t chains = Ns * gp->g_ny;
+    return chains >= 2048;
+}
+
+size_t rollout_tiles_workspace_bytes(const gpmpc_gp_desc_t* gp, int64_t Ns, int H) {
+    (void)H;
+    const int64_t waves = (gp->g_ny == 1) ? (Ns + 3) / 4 : Ns;
+    return (size_t)waves * tri(kTilesNT) * 64 * sizeof(double);
+}
+
+template <int N0, int N1, int ENV>
+static int launch_tiles(RolloutArgs& args, int g_ny, hipStream_t st) {
+    const size_t lds = tiles_lds_bytes<N0, N1>(g_ny, args.H);
+    const long nblk = (g_ny == 1) ? (args.Ns + 3) / 4 : args.Ns;
+    auto k = rollout_tiles_kernel<N0, N1, ENV, kTilesNT>;
+    GPMPC_HIP_CHECK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(k, dim3((unsigned)nblk), dim3(64), lds, st, args);
+    GPMPC_HIP_CHECK(hipGetLastError());
+    return GPMPC_OK;
+}
+
+int rollout_tiles_launch(const gpmpc_gp_desc_t* gp, const gpmpc_env_desc_t* env, RolloutArgs& args, void* ws, size_t ws_bytes,
+                         hipStream_t st) {
+    if (!ws || ws_bytes < rollout_tiles_workspace_bytes(gp, args.Ns, args.H))
+        return fail(GPMPC_E_WORKSPACE, "gpmpc_rollout: workspace too small");
+    args.ws = (double*)ws;
+    args.ws_chain_stride = (long)tri(kTilesNT) * 64;             // doubles per wave
+    if (env->env_id == GPMPC_ENV_PENDULUM1D) return launch_tiles<4, 9, GPMPC_ENV_PENDULUM1D>(args, 1, st);
+    return launch_tiles<5, 9, GPMPC_ENV_CAR_RESIDUAL>(args, 3, st);
+}
+
+}  // namespace gpmpc
+
+extern "C" int gpmpc_debug_read_tiles(double* out /*[host] 4096*/) {
+    GPMPC_HIP_CHECK(hipMemcpyFromSymbol(out, HIP_SYMBOL(gpmpc::g_tiles_dbg), 64 * 64 * sizeof(double)));
+    return GPMPC_OK;
+}

@@ -191,6 +191,33 @@ def test_rollout_against_oracle(sg, pname, Ns, H, nograd, force_global, monkeypa
     np.testing.assert_allclose(Y, Yo, rtol=1e-4, atol=1e-8)
 
 
+@pytest.mark.parametrize("pname,Ns,H,feedback", [
+    ("params_pendulum1D_samples", 6, 3, None),        # two appended points: one incomplete tile row
+    ("params_pendulum1D_samples", 7, 12, None),       # ragged last wave (7 = 4 + 3 chains), 33 rows: every tile phase (n_h mod 4)
+    ("params_pendulum1D_samples", 9, 30, None),       # configs[1] horizon: 87 rows = 22 tile rows, 14 resident + 8 streamed
+    ("params_car_residual_fs", 3, 10, None),          # one sample = one wave (three outputs + the copy)
+    ("params_car_residual_fs", 5, 40, None),          # configs[2] horizon: 117 rows = 30 tile rows
+    ("params_car_residual_fs", 4, 43, False),         # the longest horizon the 32-tile kernel takes (126 rows), no feedback
+])
+def test_tiled_rollout_against_oracle(sg, pname, Ns, H, feedback, monkeypatch):
+    """rollout_tiles.hip (four chains per wave, forward substitution on the FP64 matrix pipe) is selected by size; forced
+    here at small Ns against the oracle.  Same tolerances as the other rollout kernels."""
+    from sampling_gpmpc_amd.rollout import forward_sampling_rollout
+    monkeypatch.setenv("GPMPC_ROLLOUT_TILES", "1")
+    p = fs_params(pname, Ns, H, nograd=False, feedback=feedback, beta=(3.0 if "car" in pname else None))
+    agent, oagent = make_agents(sg, p)
+    u_ff = synthetic_u_ff(agent.nu, H)
+    X, Y = forward_sampling_rollout(agent, u_ff, return_samples=True)
+    assert sg._lib.load().gpmpc_debug_last_rollout_path() == 3, "the tiled kernel was not selected"
+    Xo, Yo = ao.forward_sampling_rollout(oagent, u_ff, return_samples=True)
+    ex, ey = relerr(X, Xo), relerr(Y, Yo)
+    print(f"tiled {pname} Ns={Ns} H={H}: rel err X_traj {ex:.2e}, Y {ey:.2e}")
+    assert np.isfinite(X).all()
+    assert ex < RTOL_TRAJ and ex < RTOL_NORTH_STAR
+    np.testing.assert_allclose(Y, Yo, rtol=1e-4, atol=1e-8)
+    np.testing.assert_allclose(agent.Hallcinated_X_train[:, 0].cpu().numpy(), oagent.Hallcinated_X_train[:, 0].numpy(), rtol=1e-6, atol=1e-9)
+
+
 def test_rollout_sample_subset_invariance_full_size(sg):
     """BASELINE config 2 (Ns=1024, H=30): every sample's trajectory is independent of what else is in the launch
     (bit-exact on a re-launched subset), values are finite, and a 16-sample subset matches the oracle."""
