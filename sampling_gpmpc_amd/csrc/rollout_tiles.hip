@@ -52,8 +52,28 @@ __device__ double g_tiles_dbg[64 * 64];
 #define TDBG(slot, val)
 #endif
 
-constexpr int kTileNRA = 14;                                   // tile rows of the factor kept in AGPRs (105 tiles = 210 registers)
+// GPMPC_TILES_PHASES: per-phase s_memtime totals of wave 0 (lane 0) in g_tiles_dbg[63 * 64 + phase] (tools/debug/tiles_phases.py)
+#ifdef GPMPC_TILES_PHASES
+#define TPH_DECL long long tph_[8] = {0, 0, 0, 0, 0, 0, 0, 0}; long long tpht_ = __builtin_readcyclecounter()
+#define TPH(i) do { const long long n_ = __builtin_readcyclecounter(); tph_[i] += n_ - tpht_; tpht_ = n_; } while (0)
+#define TPH_STORE do { if (blockIdx.x == 0 && threadIdx.x == 0) for (int i_ = 0; i_ < 8; ++i_) g_tiles_dbg[63 * 64 + i_] = (double)tph_[i_]; } while (0)
+#else
+#define TPH_DECL
+#define TPH(i)
+#define TPH_STORE
+#endif
+
+constexpr int kTileNRA = 10;                                   // tile rows of the factor kept in AGPRs (55 tiles = 110 registers)
 __host__ __device__ constexpr int tri(int r) { return r * (r + 1) / 2; }
+// the last tile row q >= r such that rows r .. q together (sum of j + 1) fit the 64-slot ring of streamed tiles
+__host__ __device__ constexpr int ring_hi(int r) {
+    int q = r, n = r + 1;
+    while (n + (q + 2) <= 64) {
+        ++q;
+        n += q + 1;
+    }
+    return q;
+}
 
 __device__ __forceinline__ void tiles_sync_lds() {
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -154,6 +174,24 @@ __device__ __forceinline__ void tl_outer(double& o0, double& o1, double& o2, dou
     }
 }
 
+// A double kept in two AGPRs between its uses.  A lone wave has 256 VALU-addressable registers; the solve phase needs 64
+// (V) + 128 (the ring of streamed tiles) of them, so everything that merely has to SURVIVE the solve (state, test point,
+// the chain's constants, the incomplete diagonal tile ...) is parked by hand: left to hipcc, it is the freshly loaded
+// ring entries that get spilled - to scratch, one s_waitcnt vmcnt(0) each.
+struct Parked {
+    int lo, hi;
+    __device__ __forceinline__ void put(double v) {
+        asm volatile("v_accvgpr_write_b32 %0, %2\n\tv_accvgpr_write_b32 %1, %3"
+                     : "=a"(lo), "=a"(hi)
+                     : "v"(__double2loint(v)), "v"(__double2hiint(v)));
+    }
+    __device__ __forceinline__ double get() const {
+        int vlo, vhi;
+        asm volatile("v_accvgpr_read_b32 %0, %2\n\tv_accvgpr_read_b32 %1, %3" : "=v"(vlo), "=v"(vhi) : "a"(lo), "a"(hi));
+        return __hiloint2double(vhi, vlo);
+    }
+};
+
 // compile-time loop with an integral_constant index (register arrays need static indices)
 template <int B, int E, class F>
 __device__ __forceinline__ void static_for(F&& f) {
@@ -216,28 +254,51 @@ __global__ __launch_bounds__(64, 1) void rollout_tiles_kernel(const RolloutArgs 
     double* SXm = SCRm + L::SCRN;
 
     // ---- per-chain / per-lane constants (VALU side) ----------------------------------------------------------------
-    const double il0 = gp.inv_l2[o][0], il1 = gp.inv_l2[o][1], os = gp.os[o];
     // axis lanes: lane l < N0 carries axis-0 point l, lane N0 + j axis-1 point j
     const bool ax0 = l < N0, ax1 = (l >= N0) && (l < N0 + N1);
-    const double g_x = ax0 ? a.X_r[(l * N1) * D] : (ax1 ? a.X_r[(l - N0) * D + 1] : 0.0);
-    const double g_il = ax0 ? il0 : (ax1 ? il1 : 0.0);
-    // grid entry e = 16 q + l = a N1 + c (three registers cover the N0 N1 entries); the plan's constants per entry and the
-    // columns of Qa / Qb are re-read every step (L1 / L2 resident) instead of occupying ~50 registers through the step
-    int ea_[NE], ec_[NE], ee_[NE];
-    bool ev_[NE];
-#pragma unroll
-    for (int q = 0; q < NE; ++q) {
-        const int e = 16 * q + l;
-        ev_[q] = e < N0 * N1;
-        ee_[q] = ev_[q] ? e : 0;
-        ea_[q] = ee_[q] / N1;
-        ec_[q] = ee_[q] - ea_[q] * N1;
+    Parked c_il0, c_il1, c_os, c_gx, c_gil;
+    {
+        const double il0 = gp.inv_l2[o][0], il1 = gp.inv_l2[o][1];
+        c_il0.put(il0);
+        c_il1.put(il1);
+        c_os.put(gp.os[o]);
+        c_gx.put(ax0 ? a.X_r[(l * N1) * D] : (ax1 ? a.X_r[(l - N0) * D + 1] : 0.0));
+        c_gil.put(ax0 ? il0 : (ax1 ? il1 : 0.0));
     }
-    const double* Qa_p = plan_grid_Qa(a.plan, gp, o) + (ax0 ? l : 0);
-    const double* Qb_p = plan_grid_Qb(a.plan, gp, o) + (ax1 ? l - N0 : 0);
-    const double* m2_p = plan_grid_m2(a.plan, gp, o);
-    const double* dsc_p = plan_grid_dsc(a.plan, gp, o);
-    const double* wE_p = plan_grid_w(a.plan, gp, o);
+    // grid entry e = 16 q + l = a N1 + c (three registers cover the N0 N1 entries); the plan's constants per entry and the
+    // columns of Qa / Qb live ...
+    // ... in AGPRs: 46 registers the VALU cannot address but v_accvgpr_read fetches in one instruction each, where a
+    // global load of the plan (L2) costs its latency at the head of every step
+    int cfA[2 * (N0 + N1)], geA[6 * NE];
+    {
+        const double* Qa = plan_grid_Qa(a.plan, gp, o);
+        const double* Qb = plan_grid_Qb(a.plan, gp, o);
+        auto park = [](int& dst, int v) { asm volatile("v_accvgpr_write_b32 %0, %1" : "=a"(dst) : "v"(v)); };
+#pragma unroll
+        for (int j = 0; j < N0 + N1; ++j) {
+            const double c = (j < N0) ? (ax0 ? Qa[j * N0 + l] : 0.0) : (ax1 ? Qb[(j - N0) * N1 + (l - N0)] : 0.0);
+            park(cfA[2 * j], __double2loint(c));
+            park(cfA[2 * j + 1], __double2hiint(c));
+        }
+#pragma unroll
+        for (int q = 0; q < NE; ++q) {
+            const int e = 16 * q + l;
+            const bool ev = e < N0 * N1;
+            const int ee = ev ? e : 0;
+            const double v3[3] = {ev ? plan_grid_m2(a.plan, gp, o)[ee] : 0.0, ev ? plan_grid_dsc(a.plan, gp, o)[ee] : 0.0,
+                                  ev ? plan_grid_w(a.plan, gp, o)[ee] : 0.0};
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                park(geA[6 * q + 2 * k], __double2loint(v3[k]));
+                park(geA[6 * q + 2 * k + 1], __double2hiint(v3[k]));
+            }
+        }
+    }
+    auto unpark = [](int lo, int hi) -> double {
+        int vlo, vhi;
+        asm volatile("v_accvgpr_read_b32 %0, %2\n\tv_accvgpr_read_b32 %1, %3" : "=v"(vlo), "=v"(vhi) : "a"(lo), "a"(hi));
+        return __hiloint2double(vhi, vlo);
+    };
     // MFMA side constants: the identity in natural layout, and this lane's slot in the wave's factor workspace
     const double Inat = (kq == jq) ? 1.0 : 0.0;
     // tile e of the wave: 512 bytes at wsu + 512 e, this lane's double at + 8 lane.  Accessed through a buffer descriptor
@@ -256,51 +317,56 @@ __global__ __launch_bounds__(64, 1) void rollout_tiles_kernel(const RolloutArgs 
         __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2_v, v), wsr, voff, e * 512, 0);
     };
 
-    double x[NX];
+    Parked xP[NX], xiP[D], uP, pP[2], xptP[NPS][D], ucP, dcP;     // state; test point; last input; P0 / P1; the lane's points; U, 1/diag
 #pragma unroll
-    for (int d = 0; d < NX; ++d) x[d] = a.x0[(a.x0_per_sample ? s * NX : 0) + d];
-
-    double xpt[NPS][D];                                           // GP input of the point this lane owns in pass q
+    for (int d = 0; d < NX; ++d) xP[d].put(a.x0[(a.x0_per_sample ? s * NX : 0) + d]);
 #pragma unroll
-    for (int q = 0; q < NPS; ++q) xpt[q][0] = xpt[q][1] = 0.0;
+    for (int q = 0; q < NPS; ++q) xptP[q][0].put(0.0), xptP[q][1].put(0.0);
+    ucP.put((kq == jq) ? 1.0 : 0.0);                             // the incomplete diagonal tile: L^T and 1/diag (natural layout)
+    dcP.put((kq == jq) ? 1.0 : 0.0);
     // AGPR-resident tile rows 0 .. NRA-1 (natural layout, see header).  Every element is DEFINED by an asm load with an
     // "=a" output and only ever read through "a" operands, so the values are of the AGPR class from birth (a C++ array
     // that merely feeds "a" operands is allocated to VGPRs and spilled).  Row r is loaded when it completes and not read
     // before (rows >= rs stream), hence no initialisation.
     double At[tri(NRA)];
-    double Ucur = Inat, dcur = (kq == jq) ? 1.0 : 0.0;           // the incomplete diagonal tile: L^T and 1/diag (natural layout)
     int info_acc = 0;
     int n_pts = 0;                                                // appended points; n_h = 3 n_pts label rows
 
+    TPH_DECL;
 #pragma unroll 1
     for (int t = 0; t < H; ++t) {
         const int n_h = 3 * n_pts, i0 = n_h & 3, nt = (n_h + 3) >> 2, nfull = n_h >> 2;
         const int ycol = (i0 + 3) & 3;
         // ---- input, GP input ---------------------------------------------------------------------------------------
-        double u[NU], xi[D];
+        double xi[D];
+        {
+            double x[NX], u[NU];
 #pragma unroll
-        for (int i = 0; i < NU; ++i) {
-            const double uf = a.u_ff[t * NU + i];
-            if (a.env.use_feedback) {
-                double acc = 0.0;
+            for (int d = 0; d < NX; ++d) x[d] = xP[d].get();
 #pragma unroll
-                for (int j = 0; j < NX; ++j) acc += (a.env.x_goal[j] - x[j]) * a.env.K[i][j];
-                u[i] = -acc + uf;
-            } else {
-                u[i] = uf;
+            for (int i = 0; i < NU; ++i) {
+                const double uf = a.u_ff[t * NU + i];
+                if (a.env.use_feedback) {
+                    double acc = 0.0;
+#pragma unroll
+                    for (int j = 0; j < NX; ++j) acc += (a.env.x_goal[j] - x[j]) * a.env.K[i][j];
+                    u[i] = -acc + uf;
+                } else {
+                    u[i] = uf;
+                }
             }
-        }
-        xi[0] = (ENV == GPMPC_ENV_PENDULUM1D) ? x[0] : x[2];
-        xi[1] = u[0];
-        double zt[T];                                             // base samples of this step (used after the solve)
+            xi[0] = x[(ENV == GPMPC_ENV_PENDULUM1D) ? 0 : (NX > 2 ? 2 : 0)];
+            xi[1] = u[0];
+            xiP[0].put(xi[0]);
+            xiP[1].put(xi[1]);
+            uP.put(u[NU - 1]);
+            if (l == 0 && live && o == 0) {
 #pragma unroll
-        for (int c = 0; c < T; ++c) zt[c] = a.z[(long)t * a.z_step_stride + (s * G_NY + o) * T + c];
-        if (l == 0 && live && o == 0) {
+                for (int d = 0; d < NX; ++d) a.X_traj[(s * NX + d) * (H + 1) + t] = x[d];
+                if (a.Xi) {
 #pragma unroll
-            for (int d = 0; d < NX; ++d) a.X_traj[(s * NX + d) * (H + 1) + t] = x[d];
-            if (a.Xi) {
-#pragma unroll
-                for (int d = 0; d < D; ++d) a.Xi[(s * H + t) * D + d] = xi[d];
+                    for (int d = 0; d < D; ++d) a.Xi[(s * H + t) * D + d] = xi[d];
+                }
             }
         }
 
@@ -311,16 +377,22 @@ __global__ __launch_bounds__(64, 1) void rollout_tiles_kernel(const RolloutArgs 
         {
             double cf[N0 + N1];                                   // column l of Qa (lanes < N0) / column l - N0 of Qb
 #pragma unroll
-            for (int j = 0; j < N0; ++j) cf[j] = ax0 ? Qa_p[j * N0] : 0.0;
-#pragma unroll
-            for (int j = 0; j < N1; ++j) cf[N0 + j] = ax1 ? Qb_p[j * N1] : 0.0;
+            for (int j = 0; j < N0 + N1; ++j) cf[j] = unpark(cfA[2 * j], cfA[2 * j + 1]);
             double m2e[NE], dsce[NE], wEe[NE];
 #pragma unroll
             for (int q = 0; q < NE; ++q) {
-                m2e[q] = ev_[q] ? m2_p[ee_[q]] : 0.0;
-                dsce[q] = ev_[q] ? dsc_p[ee_[q]] : 0.0;
-                wEe[q] = ev_[q] ? wE_p[ee_[q]] : 0.0;
+                m2e[q] = unpark(geA[6 * q], geA[6 * q + 1]);
+                dsce[q] = unpark(geA[6 * q + 2], geA[6 * q + 3]);
+                wEe[q] = unpark(geA[6 * q + 4], geA[6 * q + 5]);
             }
+            int ea_[NE], ec_[NE];
+#pragma unroll
+            for (int q = 0; q < NE; ++q) {
+                const int e = 16 * q + l, ee = (e < N0 * N1) ? e : 0;
+                ea_[q] = ee / N1;
+                ec_[q] = ee - ea_[q] * N1;
+            }
+            const double g_x = c_gx.get(), g_il = c_gil.get();
             const double gr = g_x - (ax0 ? xi[0] : xi[1]);
             const double gq = gr * g_il;
             const double ea = exp(-0.5 * gr * gq);
@@ -359,6 +431,7 @@ __global__ __launch_bounds__(64, 1) void rollout_tiles_kernel(const RolloutArgs 
             tiles_sync_lds();                                     // SCR is reused by phase B
         }
 
+        TPH(0);
         // ---- phase B: right-hand sides of the hallucinated rows, 16 points per pass; phase C: into tile registers ------
         double V[NT];
 #pragma unroll
@@ -366,11 +439,13 @@ __global__ __launch_bounds__(64, 1) void rollout_tiles_kernel(const RolloutArgs 
         static_for<0, NPS>([&](auto qc) {
             constexpr int q = decltype(qc)::value;
             if (16 * q < n_pts) {                                 // uniform
+                const double il0 = c_il0.get(), il1 = c_il1.get(), os = c_os.get();
+                const double xpt0 = xptP[q][0].get(), xpt1 = xptP[q][1].get();
                 const int jp = 16 * q + l;
                 const bool ex = jp < n_pts;
                 const int jr = min(jp, npt_cap - 1);
                 // kernel entries against the test point: cov(task a of the point, task b of the test point)
-                const double d0 = xpt[q][0] - xi[0], d1 = xpt[q][1] - xi[1];
+                const double d0 = xpt0 - xi[0], d1 = xpt1 - xi[1];
                 const double q0 = d0 * il0, q1 = d1 * il1;
                 const double kk = ex ? os * exp(-0.5 * (d0 * q0 + d1 * q1)) : 0.0;
                 double out[T][T];
@@ -444,66 +519,102 @@ __global__ __launch_bounds__(64, 1) void rollout_tiles_kernel(const RolloutArgs 
             }
         });
 
+        pP[0].put(P0);
+        pP[1].put(P1);
+        TPH(1);
         TDBG(0, V[0]);
         TDBG(1, V[1]);
         TDBG(2, V[2]);
         TDBG(3, V[3]);
         // ---- phase D: forward substitution, left-looking over tile rows; phase E: S' += V_r^T V_r -----------------------
-        // Tile rows below `rs` are complete and AGPR-resident; rows rs .. nt-1 stream from the workspace, each row's tiles
-        // requested while the previous row's MFMAs run (two register buffers; sched_barrier keeps hipcc from hoisting all
-        // the loads to the top, which spills hundreds of registers).
+        // Tile rows below `rs` are complete and AGPR-resident; rows rs .. nt-1 stream from the workspace through a ring of
+        // 64 registers (sched_barrier keeps hipcc from hoisting all the loads to the top, which spills hundreds of registers).
         double Sh[4] = {0.0, 0.0, 0.0, 0.0};
         if (nt > 0) {
             const bool part = (n_h & 3) != 0;                     // the last tile row is incomplete: rows >= n_h are masked
             const bool rowex = (4 * nfull + jq) < n_h;            // A operand of the incomplete tile row: its row index is jq
-#ifdef GPMPC_TILES_NO_AGPR
-            const int rs = 0;                                     // debug: every tile row streams from the workspace
-#else
-            const int rs = min(NRA, nfull);
-#endif
-            double bufA[NT], bufB[NT];
-            auto fetch_row = [&](auto rc, double (&buf)[NT]) {
-                constexpr int r = decltype(rc)::value;
+            // 64 register slots hold the streamed tiles in flight, tile (r, p) in slot (tri(r) + p) mod 64: at row r every row
+            // up to ring_hi(r) has been requested (as many whole rows as fit behind row r: two or three rows ~ 1000 cycles of
+            // MFMAs ahead while the rows are short, one row once they are 25+ tiles long).
+            // hipcc's s_waitcnt insertion counts loads exactly only along straight-line code: a load under an `if` that
+            // rejoins makes every later wait a vmcnt(0), which waits for the prefetch just issued.  Hence two regimes:
+            //   (i)  fewer than NRA complete tile rows: few rows, everything streams, waits as hipcc places them;
+            //   (ii) rows 0 .. NRA-1 resident (straight line), rows NRA .. stream with UNCONDITIONAL requests - up to two
+            //        rows beyond nt are requested and never used (inside the wave's workspace) - and early exits only.
+            double ring[64];
+            auto fetch_row = [&](auto qc) {
+                constexpr int q = decltype(qc)::value;
 #pragma unroll
-                for (int p = 0; p <= r; ++p) buf[p] = tile_load(lane8, tri(r) + p);
+                for (int p = 0; p <= q; ++p) ring[(tri(q) + p) & 63] = tile_load(lane8, tri(q) + p);
             };
-            if (rs == 0) fetch_row(std::integral_constant<int, 0>{}, bufA);
-            __builtin_amdgcn_sched_barrier(0);
-            static_for<0, NT>([&](auto rc) {
+            auto streamed_row = [&](auto rc) {
                 constexpr int r = decltype(rc)::value;
-                if (r < nt) {                                     // uniform
-                    if constexpr (r + 1 < NT) {
-                        if (r + 1 < nt && r + 1 >= rs) fetch_row(std::integral_constant<int, r + 1>{}, ((r + 1) & 1) ? bufB : bufA);
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
-                    double ac[4] = {V[r], 0.0, 0.0, 0.0};
-                    bool streamed = true;
-                    if constexpr (r < NRA) {
-                        if (r < rs) {                             // complete and resident
-                            streamed = false;
-                            mfma_rowsum<r, true>(ac, At + tri(r), V);
-                            const double acc = (ac[0] + ac[1]) + (ac[2] + ac[3]);
-                            V[r] = mfma_zero_a(At[tri(r) + r], acc);
-                        }
-                    }
-                    if (streamed) {
-                        double (&cur)[NT] = (r & 1) ? bufB : bufA;
-                        if (part && r == nt - 1) {
+                double ac[4] = {V[r], 0.0, 0.0, 0.0};
+                if (part && r == nt - 1) {                        // in place: a masked COPY of the row would need its own registers
 #pragma unroll
-                            for (int p = 0; p < r; ++p) cur[p] = rowex ? cur[p] : 0.0;
-                        }
-                        mfma_rowsum<r, false>(ac, cur, V);
-                        const double acc = (ac[0] + ac[1]) + (ac[2] + ac[3]);
-                        if constexpr (r < 3) {
-                            TDBG(8 + 4 * r, acc);
-                            TDBG(9 + 4 * r, cur[r]);
-                            TDBG(10 + 4 * r, cur[0]);
-                        }
-                        V[r] = mfma_zero_v(cur[r], acc);
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
+                    for (int p = 0; p < r; ++p) ring[(tri(r) + p) & 63] = rowex ? ring[(tri(r) + p) & 63] : 0.0;
                 }
-            });
+                double cur[r + 1];
+#pragma unroll
+                for (int p = 0; p <= r; ++p) cur[p] = ring[(tri(r) + p) & 63];
+                mfma_rowsum<r, false>(ac, cur, V);
+                const double acc = (ac[0] + ac[1]) + (ac[2] + ac[3]);
+                if constexpr (r < 3) {
+                    TDBG(8 + 4 * r, acc);
+                    TDBG(9 + 4 * r, cur[r]);
+                    TDBG(10 + 4 * r, cur[0]);
+                }
+                V[r] = mfma_zero_v(cur[r], acc);
+            };
+#ifdef GPMPC_TILES_NO_AGPR
+            const bool resident = false;
+#else
+            const bool resident = nfull >= NRA;
+#endif
+            if (!resident) {                                      // regime (i)
+                static_for<0, (NRA + 1 < NT ? NRA + 1 : NT)>([&](auto rc) {
+                    constexpr int r = decltype(rc)::value;
+                    if (r < nt) {
+                        fetch_row(rc);
+                        streamed_row(rc);
+                    }
+                });
+#ifdef GPMPC_TILES_NO_AGPR
+                static_for<NRA + 1, NT>([&](auto rc) {
+                    constexpr int r = decltype(rc)::value;
+                    if (r < nt) {
+                        fetch_row(rc);
+                        streamed_row(rc);
+                    }
+                });
+#endif
+            } else {                                              // regime (ii)
+                static_for<NRA, ring_hi(NRA) + 1>(fetch_row);     // in flight behind the resident rows
+                __builtin_amdgcn_sched_barrier(0);
+                static_for<0, NRA>([&](auto rc) {
+                    constexpr int r = decltype(rc)::value;
+                    double ac[4] = {V[r], 0.0, 0.0, 0.0};
+                    mfma_rowsum<r, true>(ac, At + tri(r), V);
+                    const double acc = (ac[0] + ac[1]) + (ac[2] + ac[3]);
+                    V[r] = mfma_zero_a(At[tri(r) + r], acc);
+                });
+                __builtin_amdgcn_sched_barrier(0);
+                auto rest = [&](auto self, auto rc) -> void {
+                    constexpr int r = decltype(rc)::value;
+                    if constexpr (r < NT) {
+                        if (r < nt) {                             // uniform; the only way out is the end of the phase
+                            constexpr int q0 = ring_hi(r - 1) + 1, q1 = (ring_hi(r) < NT - 1) ? ring_hi(r) : NT - 1;
+                            if constexpr (r > NRA) static_for<q0, q1 + 1>(fetch_row);
+                            __builtin_amdgcn_sched_barrier(0);
+                            streamed_row(rc);
+                            __builtin_amdgcn_sched_barrier(0);
+                            self(self, std::integral_constant<int, r + 1>{});
+                        }
+                    }
+                };
+                rest(rest, std::integral_constant<int, NRA>{});
+            }
+            TPH(2);
             // S' += V_r^T V_r, eight tiles per statement (tiles >= nt are zero)
             static_for<0, NT / 8>([&](auto gc) {
                 constexpr int g = decltype(gc)::value;
@@ -514,6 +625,9 @@ __global__ __launch_bounds__(64, 1) void rollout_tiles_kernel(const RolloutArgs 
         TDBG(5, V[1]);
         TDBG(6, V[2]);
         TDBG(7, V[3]);
+        double zt[T];                                             // base samples of this step: requested here, used after phase F
+#pragma unroll
+        for (int c = 0; c < T; ++c) zt[c] = a.z[(long)t * a.z_step_stride + (s * G_NY + o) * T + c];
         // ---- phase F: S' to the chains' VALU lanes ---------------------------------------------------------------------
         const double Stot = Sr + ((Sh[0] + Sh[1]) + (Sh[2] + Sh[3]));
         TDBG(20, Stot);
@@ -524,7 +638,7 @@ __global__ __launch_bounds__(64, 1) void rollout_tiles_kernel(const RolloutArgs 
         double mu[T], mur[T], S[T][T];
         {
             const int cb[T] = {i0, (i0 + 1) & 3, (i0 + 2) & 3};
-            const double il2[D] = {il0, il1};
+            const double il2[D] = {c_il0.get(), c_il1.get()}, os = c_os.get();
 #pragma unroll
             for (int b = 0; b < T; ++b) {
                 mu[b] = SX[32 + cb[b] * 4 + ycol];
@@ -538,6 +652,7 @@ __global__ __launch_bounds__(64, 1) void rollout_tiles_kernel(const RolloutArgs 
                 }
             }
         }
+        TPH(3);
         // ---- phase G: variance floor, roots, sample (as sample_gp, src/agent.py:629-708) ----------------------------------
         double var[T];
         bool all_zero = (a.var_zero_thr >= 0.0);
@@ -582,11 +697,13 @@ __global__ __launch_bounds__(64, 1) void rollout_tiles_kernel(const RolloutArgs 
             for (int b = 0; b < T; ++b) a.Y[((s * G_NY + o) * H + t) * T + b] = y[b];
         }
 
+        TPH(4);
         // ---- phase H: append the point (A.9): three rows of the factor, the point's record, its label residuals -------------
         if (t + 1 < H) {
             if (!c_ok) info_acc |= GPMPC_INFO_TRAIN_CHOL_FAIL;
             const int jn = n_pts, tn = n_h >> 2;
             // VALU side: the record, the residuals y - mu_real, the point itself, and the chain's scalars for the MFMA side
+            const double P0 = pP[0].get(), P1 = pP[1].get();
             if (ax0) {
                 XF[jn * L::XS + l] = P0;
                 XF[jn * L::XS + L::XH + l] = P1;
@@ -597,9 +714,12 @@ __global__ __launch_bounds__(64, 1) void rollout_tiles_kernel(const RolloutArgs 
             if (l < T) YT[jn * 4 + l] = ((l == 0) ? y[0] : ((l == 1) ? y[1] : y[2])) - ((l == 0) ? mur[0] : ((l == 1) ? mur[1] : mur[2]));
             static_for<0, NPS>([&](auto qc) {
                 constexpr int q = decltype(qc)::value;
-                const bool mine = (16 * q + l) == jn;
-                xpt[q][0] = mine ? xi[0] : xpt[q][0];
-                xpt[q][1] = mine ? xi[1] : xpt[q][1];
+                if ((jn >> 4) == q) {                             // uniform: the pass the new point belongs to
+                    const bool mine = (16 * q + l) == jn;
+                    const double o0 = xptP[q][0].get(), o1 = xptP[q][1].get();
+                    xptP[q][0].put(mine ? xiP[0].get() : o0);
+                    xptP[q][1].put(mine ? xiP[1].get() : o1);
+                }
             });
             if (l == 0) {                                         // C (lower, row-major 3x3) and 1/diag
 #pragma unroll
@@ -662,9 +782,10 @@ __global__ __launch_bounds__(64, 1) void rollout_tiles_kernel(const RolloutArgs 
                 // old 1/diag of the incomplete tile, row-wise and column-wise copies travel in dcur through LDS-free
                 // lookups: dcur holds 1/d on the diagonal lanes only; rebuild both scalings from it with two MFMAs
                 const double ones = 1.0;
+                const double dcur = dcP.get();
                 const double drow_old = mfma_zero_v(dcur, ones);  // [k][i] = 1 / d_k
                 const double dcol_old = mfma_zero_v(ones, dcur);  // [k][i] = 1 / d_i
-                const double U = entry(tn, tn, Vtn, Ucur);
+                const double U = entry(tn, tn, Vtn, ucP.get());
                 const double drow = diag_scal(tn, drow_old, true), dcol = diag_scal(tn, dcol_old, false);
                 const double Gt = inverse_tile(U, drow, dcol);
                 TDBG(26, U);
@@ -695,8 +816,8 @@ __global__ __launch_bounds__(64, 1) void rollout_tiles_kernel(const RolloutArgs 
                     Unext = Inat;
                     dnext = (kq == jq) ? 1.0 : 0.0;
                 }
-                Ucur = Unext;
-                dcur = dnext;
+                ucP.put(Unext);
+                dcP.put(dnext);
             }
             // a tile row that became complete moves into its AGPRs
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the row's stores (this lane re-reads only its own slots)
@@ -709,25 +830,35 @@ __global__ __launch_bounds__(64, 1) void rollout_tiles_kernel(const RolloutArgs 
             n_pts += 1;
         }
 
+        TPH(5);
         // ---- state hand-over ---------------------------------------------------------------------------------------------
-        if (ENV == GPMPC_ENV_PENDULUM1D) {
-            const double x0n = x[0] + x[1] * a.env.dt;
-            x[1] = x[1] + y[0];
-            x[0] = x0n;
-        } else {
-            // value samples of the three outputs: lane 0 of DPP rows 0, 1, 2
-            const double g0 = readlane_f64(y[0], 0), g1 = readlane_f64(y[0], 16), g2 = readlane_f64(y[0], 32);
-            const double vv = x[3];
-            x[0] = x[0] + vv * g0;
-            x[1] = x[1] + vv * g1;
-            x[2] = x[2] + vv * g2;
-            x[3] = x[3] + u[NU - 1] * a.env.dt;
+        {
+            double x[NX];
+#pragma unroll
+            for (int d = 0; d < NX; ++d) x[d] = xP[d].get();
+            if (ENV == GPMPC_ENV_PENDULUM1D) {
+                const double x0n = x[0] + x[1] * a.env.dt;
+                x[1] = x[1] + y[0];
+                x[0] = x0n;
+            } else {
+                // value samples of the three outputs: lane 0 of DPP rows 0, 1, 2
+                const double g0 = readlane_f64(y[0], 0), g1 = readlane_f64(y[0], 16), g2 = readlane_f64(y[0], 32);
+                constexpr int I2 = (NX > 2) ? 2 : 0, I3 = (NX > 3) ? 3 : 0;
+                const double vv = x[I3];
+                x[0] = x[0] + vv * g0;
+                x[1] = x[1] + vv * g1;
+                x[I2] = x[I2] + vv * g2;
+                x[I3] = x[I3] + uP.get() * a.env.dt;
+            }
+#pragma unroll
+            for (int d = 0; d < NX; ++d) xP[d].put(x[d]);
         }
     }
 
+    TPH_STORE;
     if (l == 0 && live && o == 0) {
 #pragma unroll
-        for (int d = 0; d < NX; ++d) a.X_traj[(s * NX + d) * (H + 1) + H] = x[d];
+        for (int d = 0; d < NX; ++d) a.X_traj[(s * NX + d) * (H + 1) + H] = xP[d].get();
     }
     if (G_NY == 1) {
         if (l == 0 && live) a.info[s] = info_acc;
