@@ -63,7 +63,7 @@ __device__ double g_tiles_dbg[64 * 64];
 #define TPH_STORE
 #endif
 
-constexpr int kTileNRA = 10;                                   // tile rows of the factor kept in AGPRs (55 tiles = 110 registers)
+constexpr int kTileNRA = 11;                                   // tile rows of the factor kept in AGPRs (66 tiles = 132 registers)
 __host__ __device__ constexpr int tri(int r) { return r * (r + 1) / 2; }
 // the last tile row q >= r such that rows r .. q together (sum of j + 1) fit the 64-slot ring of streamed tiles
 __host__ __device__ constexpr int ring_hi(int r) {
@@ -100,20 +100,21 @@ __device__ __forceinline__ double mfma_zero_a(double a, double b) {
     asm volatile("s_nop 1\n\tv_mfma_f64_4x4x4_4b_f64 %0, %1, %2, 0\n\ts_nop 5" : "=&v"(d) : "a"(a), "v"(b));
     return d;
 }
-// acc[p & 3] += A[p] B[p], p = 0 .. N-1, in statements of at most 12 MFMAs (12 = 0 mod 4: the round robin continues)
+// acc[p & 1] += A[p] B[p], p = 0 .. N-1, in statements of at most 12 MFMAs
 template <int N, bool AGPR, int P0 = 0>
-__device__ __forceinline__ void mfma_rowsum(double (&acc)[4], const double* A, const double* B) {
+__device__ __forceinline__ void mfma_rowsum(double (&acc)[2], const double* A, const double* B) {
     if constexpr (P0 < N) {
         constexpr int K = (N - P0 < 12) ? N - P0 : 12;
-        if constexpr (AGPR) mfma_chain_a<K>(acc[0], acc[1], acc[2], acc[3], A + P0, B + P0);
-        else mfma_chain_v<K>(acc[0], acc[1], acc[2], acc[3], A + P0, B + P0);
+        if constexpr (AGPR) mfma_chain_a<K>(acc[0], acc[1], A + P0, B + P0);
+        else mfma_chain_v<K>(acc[0], acc[1], A + P0, B + P0);
         mfma_rowsum<N, AGPR, P0 + K>(acc, A, B);
     }
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// DPP-row broadcasts (chain == DPP row on the VALU side).  The broadcast sources are written long before they are read
-// through DPP (the two wait states of the VALU-write -> DPP-read hazard): the grid factors' blocks carry their own s_nop.
+// DPP-row broadcasts (chain == DPP row on the VALU side).  A VGPR written by the VALU may be read through DPP two wait
+// states later: the grid factors (written right before) carry an s_nop; E0 / E1 / P0 / P1 are written a phase before they
+// are broadcast, and tools/check_dpp_hazard.py (a CPU test) scans the ISA for a copy or reload hipcc might put in front.
 // ---------------------------------------------------------------------------------------------------------------
 template <int LN>
 __device__ __forceinline__ void tl_fmac2_bcast(double& acc0, double& acc1, double r0, double r1, double l) {
@@ -127,8 +128,7 @@ __device__ __forceinline__ void tl_fmac2_bcast(double& acc0, double& acc1, doubl
 template <int LN>
 __device__ __forceinline__ void tl_fmac4_bcast(double& s00, double& s01, double& s10, double& s11, double e0, double e1, double y0,
                                                double y1) {
-    asm("s_nop 1\n\t"
-        "v_fmac_f64_dpp %0, %4, %6 row_newbcast:%8 row_mask:0xf bank_mask:0xf\n\t"
+    asm("v_fmac_f64_dpp %0, %4, %6 row_newbcast:%8 row_mask:0xf bank_mask:0xf\n\t"
         "v_fmac_f64_dpp %1, %5, %6 row_newbcast:%8 row_mask:0xf bank_mask:0xf\n\t"
         "v_fmac_f64_dpp %2, %4, %7 row_newbcast:%8 row_mask:0xf bank_mask:0xf\n\t"
         "v_fmac_f64_dpp %3, %5, %7 row_newbcast:%8 row_mask:0xf bank_mask:0xf"
@@ -138,8 +138,7 @@ __device__ __forceinline__ void tl_fmac4_bcast(double& s00, double& s01, double&
 // o0 += P0@LN xa, o1 += P1@LN xa, o2 += P0@LN xb
 template <int LN>
 __device__ __forceinline__ void tl_fmac3_bcast(double& o0, double& o1, double& o2, double p0, double p1, double xa, double xb) {
-    asm("s_nop 1\n\t"
-        "v_fmac_f64_dpp %0, %3, %5 row_newbcast:%7 row_mask:0xf bank_mask:0xf\n\t"
+    asm("v_fmac_f64_dpp %0, %3, %5 row_newbcast:%7 row_mask:0xf bank_mask:0xf\n\t"
         "v_fmac_f64_dpp %1, %4, %5 row_newbcast:%7 row_mask:0xf bank_mask:0xf\n\t"
         "v_fmac_f64_dpp %2, %3, %6 row_newbcast:%7 row_mask:0xf bank_mask:0xf"
         : "+v"(o0), "+v"(o1), "+v"(o2)
@@ -208,7 +207,9 @@ template <int N0, int N1>
 struct TilesLds {
     static constexpr int XH = (N0 + 1) & ~1;                      // padded length of PA0 / PA1
     static constexpr int YH = (N1 + 1) & ~1;
-    static constexpr int XS = (2 * XH) % 4 == 0 ? 2 * XH + 2 : 2 * XH;   // record stride of XF: an odd number of 16-byte slots
+    // record stride of XF in doubles: six consecutive points (a 16-lane group reads six) must start in six different 16-byte
+    // slots mod 16, as must their PA1 halves: 12 doubles (6 slots: 0 6 12 2 8 14 | +3) do, 8 doubles (4 slots) do not -> 10
+    static constexpr int XS = (XH == 4) ? 10 : 2 * XH;
     static constexpr int YS = 2 * YH;
     static constexpr int SXN = 96;                                // per chain: new-point record (2 XH + 2 YH <= 32), S' exchange (32), scalars (16)
     static constexpr int SCRN = 192;                              // per chain: 48 rows x 4 columns
@@ -305,7 +306,10 @@ __global__ __launch_bounds__(64, 1) void rollout_tiles_kernel(const RolloutArgs 
     // (uniform base, scalar tile offset, 32-bit lane offset): with per-lane 64-bit addresses hipcc hoists the address
     // arithmetic of all 528 tiles out of the step loop and spills it.
     char* wsu = reinterpret_cast<char*>(a.ws + blk * a.ws_chain_stride);
-    const unsigned lane8 = (unsigned)lane * 8u;
+    // lanes of a chain that carries no sample (the car's fourth quad, the tail of the last pendulum wave) address past the
+    // descriptor's end: their loads return zero and their stores are dropped without memory traffic
+    const bool live_m = (G_NY == 1) ? (4 * blk + bm < a.Ns) : (bm < 3);
+    const unsigned lane8 = live_m ? (unsigned)lane * 8u : 0x7ffff000u;
     const __amdgpu_buffer_rsrc_t wsr = __builtin_amdgcn_make_buffer_rsrc(wsu, 0, (int)(a.ws_chain_stride * 8), 0x00020000);
     auto tile_load = [&](unsigned voff, int e) -> double {
         // sc1 (aux bit 4): served by L2.  A tile row is re-read after this wave has stored into it (rows arrive three at a
@@ -421,12 +425,12 @@ __global__ __launch_bounds__(64, 1) void rollout_tiles_kernel(const RolloutArgs 
                 dst[ycol] = wEe[q];
             }
             tiles_sync_lds();
-            double Sq[4] = {0.0, 0.0, 0.0, 0.0};
+            double Sq[2] = {0.0, 0.0};
             double rt[NRT];
 #pragma unroll
             for (int q = 0; q < NRT; ++q) rt[q] = SCRm[(4 * q + kq) * 4 + jq];
             mfma_rowsum<NRT, false>(Sq, rt, rt);
-            const double Sa = Sq[0] + Sq[1], Sb = Sq[2] + Sq[3];
+            const double Sa = Sq[0], Sb = Sq[1];
             Sr = Sa + Sb;
             tiles_sync_lds();                                     // SCR is reused by phase B
         }
@@ -529,8 +533,11 @@ __global__ __launch_bounds__(64, 1) void rollout_tiles_kernel(const RolloutArgs 
         // ---- phase D: forward substitution, left-looking over tile rows; phase E: S' += V_r^T V_r -----------------------
         // Tile rows below `rs` are complete and AGPR-resident; rows rs .. nt-1 stream from the workspace through a ring of
         // 64 registers (sched_barrier keeps hipcc from hoisting all the loads to the top, which spills hundreds of registers).
-        double Sh[4] = {0.0, 0.0, 0.0, 0.0};
+        double Sh[2] = {0.0, 0.0};
         if (nt > 0) {
+            // the previous step's tile stores precede this step's tile loads (same lane, same addresses); they were
+            // issued thousands of cycles ago, the wait is a formality
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             const bool part = (n_h & 3) != 0;                     // the last tile row is incomplete: rows >= n_h are masked
             const bool rowex = (4 * nfull + jq) < n_h;            // A operand of the incomplete tile row: its row index is jq
             // 64 register slots hold the streamed tiles in flight, tile (r, p) in slot (tri(r) + p) mod 64: at row r every row
@@ -549,7 +556,7 @@ __global__ __launch_bounds__(64, 1) void rollout_tiles_kernel(const RolloutArgs 
             };
             auto streamed_row = [&](auto rc) {
                 constexpr int r = decltype(rc)::value;
-                double ac[4] = {V[r], 0.0, 0.0, 0.0};
+                double ac[2] = {V[r], 0.0};
                 if (part && r == nt - 1) {                        // in place: a masked COPY of the row would need its own registers
 #pragma unroll
                     for (int p = 0; p < r; ++p) ring[(tri(r) + p) & 63] = rowex ? ring[(tri(r) + p) & 63] : 0.0;
@@ -558,7 +565,7 @@ __global__ __launch_bounds__(64, 1) void rollout_tiles_kernel(const RolloutArgs 
 #pragma unroll
                 for (int p = 0; p <= r; ++p) cur[p] = ring[(tri(r) + p) & 63];
                 mfma_rowsum<r, false>(ac, cur, V);
-                const double acc = (ac[0] + ac[1]) + (ac[2] + ac[3]);
+                const double acc = ac[0] + ac[1];
                 if constexpr (r < 3) {
                     TDBG(8 + 4 * r, acc);
                     TDBG(9 + 4 * r, cur[r]);
@@ -593,9 +600,9 @@ __global__ __launch_bounds__(64, 1) void rollout_tiles_kernel(const RolloutArgs 
                 __builtin_amdgcn_sched_barrier(0);
                 static_for<0, NRA>([&](auto rc) {
                     constexpr int r = decltype(rc)::value;
-                    double ac[4] = {V[r], 0.0, 0.0, 0.0};
+                    double ac[2] = {V[r], 0.0};
                     mfma_rowsum<r, true>(ac, At + tri(r), V);
-                    const double acc = (ac[0] + ac[1]) + (ac[2] + ac[3]);
+                    const double acc = ac[0] + ac[1];
                     V[r] = mfma_zero_a(At[tri(r) + r], acc);
                 });
                 __builtin_amdgcn_sched_barrier(0);
@@ -629,11 +636,13 @@ __global__ __launch_bounds__(64, 1) void rollout_tiles_kernel(const RolloutArgs 
 #pragma unroll
         for (int c = 0; c < T; ++c) zt[c] = a.z[(long)t * a.z_step_stride + (s * G_NY + o) * T + c];
         // ---- phase F: S' to the chains' VALU lanes ---------------------------------------------------------------------
-        const double Stot = Sr + ((Sh[0] + Sh[1]) + (Sh[2] + Sh[3]));
+        const double Stot = Sr + (Sh[0] + Sh[1]);
         TDBG(20, Stot);
         TDBG(21, Sr);
-        SXm[32 + kq * 4 + jq] = Stot;
-        SXm[48 + kq * 4 + jq] = Sr;
+        if (live_m) {                                             // a chain without a sample shares its LDS slot with the last live one
+            SXm[32 + kq * 4 + jq] = Stot;
+            SXm[48 + kq * 4 + jq] = Sr;
+        }
         tiles_sync_lds();
         double mu[T], mur[T], S[T][T];
         {
@@ -820,8 +829,8 @@ __global__ __launch_bounds__(64, 1) void rollout_tiles_kernel(const RolloutArgs 
                 dcP.put(dnext);
             }
             // a tile row that became complete moves into its AGPRs
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the row's stores (this lane re-reads only its own slots)
-            if (i0 >= 1) {
+            if (i0 >= 1 && tn < NRA) {                            // (uniform) a resident row completed: its stores first -
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this lane re-reads only its own slots
                 static_for<0, NRA>([&](auto rc) {
                     constexpr int r = decltype(rc)::value;
                     if (r == tn) load_row_agpr<r + 1>(wsr, lane8, tri(r) * 512, At + tri(r));   // loads + their wait: one statement
@@ -901,9 +910,10 @@ bool rollout_tiles_eligible(const gpmpc_gp_desc_t* gp, const gpmpc_env_desc_t* e
     else return false;
     if (lds > 160 * 1024 - 64) return false;
     if (md > 0) return true;
-    // a wave carries four chains: worth it once the one-chain-per-wave kernels need more than one round of the chip
+    // a wave carries four chains and takes ~2x as long as the one-chain-per-wave kernels do for a round of the chip
+    // (tools/bench_tiles.py: pendulum Ns = 1024: 0.20 vs 0.11 ms, Ns = 4096: 0.28 vs 0.43 ms; car Ns = 1024: 0.57 vs 0.85 ms)
     const int64_t chains = Ns * gp->g_ny;
-    return chains >= 2048;
+    return chains >= 3072;
 }
 
 size_t rollout_tiles_workspace_bytes(const gpmpc_gp_desc_t* gp, int64_t Ns, int H) {

@@ -1,15 +1,22 @@
 #!/usr/bin/env python3
-"""Scan the gfx950 ISA of rollout_indep.hip for the DPP read-after-VALU-write hazard of its inline-asm table FMAs.
+"""Scan the gfx950 ISA of the kernels that issue v_fmac_f64_dpp / v_mfma_f64 from inline asm for the hazards hipcc does
+not pad there (it neither sees into an asm statement nor pads its boundary beyond one wait state).
 
-rollout_indep_grid_kernel reads its register-resident tables as the DPP source of inline-asm `v_fmac_f64_dpp`.  A VGPR
-written by a VALU instruction may be read through DPP only two wait states later; the compiler inserts the wait states
-for DPP instructions it generates itself, but it cannot see into inline asm.  The table registers are never written in
-the step loop, so the hazard can only arise if the register allocator inserts a copy of a table register right in
-front of an asm statement.  This script compiles the file to ISA (or takes a .s file) and checks that none of the two
-instructions in front of every asm `v_fmac_f64_dpp` writes its DPP source register pair (an `s_nop N` counts N + 1
-wait states).  Exit code 0 = clean.
+Rules (measured on MI355X: tools/ubench/mfma64_hazard2.hip, mfma64_chain.hip, mfma64_war.hip; an `s_nop N` is N + 1 wait
+states, every other instruction one - an MFMA in between counts as ONE, whatever time it takes):
 
-    python tools/check_dpp_hazard.py [file.s]
+  D1  VALU write of a VGPR -> the same VGPR read through DPP (row_newbcast source)            2 wait states
+  M1  VALU write of a VGPR -> MFMA reading it as SrcA / SrcB / SrcC                           2
+  M2  MFMA D -> MFMA reading it as SrcC                                                        4
+  M3  MFMA D -> MFMA reading it as SrcA / SrcB                                                 6
+  M4  MFMA D -> ANY other instruction reading it (VALU, v_accvgpr_write, a store's data)       6
+
+rollout_indep.hip keeps its tables in registers that the step loop never writes, rollout_tiles.hip's broadcast sources
+are written a phase earlier: D1 can only arise if the register allocator puts a copy or a reload right in front of an
+asm statement - which is exactly what this script looks for in the ISA hipcc produced.  M1-M4 guard the MFMA chains of
+rollout_tiles.hip (statements open with s_nop 1 and close with s_nop 5; a regression in the generator shows up here).
+
+    python tools/check_dpp_hazard.py [file.s ...]          exit code 0 = clean
 """
 import os
 import re
@@ -19,28 +26,34 @@ import tempfile
 
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(REPO, "sampling_gpmpc_amd", "csrc")
+SOURCES = ["rollout_indep.hip", "rollout_tiles.hip"]
 
 
-def compile_to_isa():
-    out = os.path.join(tempfile.mkdtemp(prefix="gpmpc_isa_"), "rollout_indep.s")
+def compile_to_isa(src):
+    out = os.path.join(tempfile.mkdtemp(prefix="gpmpc_isa_"), src.replace(".hip", ".s"))
     cmd = [os.environ.get("HIPCC", "/opt/rocm/bin/hipcc"), "-x", "hip", "-S", "--cuda-device-only",
-           os.path.join(CSRC, "rollout_indep.hip"), "-o", out, "--offload-arch=gfx950", "-O3", "-std=c++17",
+           os.path.join(CSRC, src), "-o", out, "--offload-arch=gfx950", "-O3", "-std=c++17",
            "-fno-gpu-rdc", "-ffp-contract=on", "-I", os.path.join(REPO, "include"), "-I", CSRC]
     subprocess.run(cmd, check=True, capture_output=True)
     return out
 
 
-def vregs(tok):
-    m = re.fullmatch(r"-?v\[(\d+):(\d+)\]", tok)
+def regs(tok):
+    """register file and numbers of an operand token: ('v', {..}) / ('a', {..}) / (None, set())"""
+    m = re.fullmatch(r"-?([va])\[(\d+):(\d+)\]", tok)
     if m:
-        return set(range(int(m.group(1)), int(m.group(2)) + 1))
-    m = re.fullmatch(r"-?v(\d+)", tok)
-    return {int(m.group(1))} if m else set()
+        return m.group(1), set(range(int(m.group(2)), int(m.group(3)) + 1))
+    m = re.fullmatch(r"-?([va])(\d+)", tok)
+    return (m.group(1), {int(m.group(2))}) if m else (None, set())
+
+
+TOK = r"-?[va]\[\d+:\d+\]|-?[va]\d+"
 
 
 def check(path):
-    n_dpp, problems, kernel = 0, [], None
-    window = []                                   # (wait states it provides, VGPRs it writes) of the preceding instructions
+    counts = {"dpp": 0, "mfma": 0}
+    problems, kernel = [], None
+    window = []          # preceding instructions, newest last: (wait states, kind, set of ('v'|'a', n) written)
     for ln, raw in enumerate(open(path), 1):
         t = raw.strip()
         if re.match(r"^_Z\w+:", t):
@@ -52,33 +65,56 @@ def check(path):
         if not code:
             continue
         op = code.split()[0]
-        toks = re.findall(r"-?v\[\d+:\d+\]|-?v\d+", code)
-        if op == "v_fmac_f64_dpp" and "row_newbcast" in code:
-            n_dpp += 1
-            src = vregs(toks[1]) if len(toks) > 1 else set()
+        toks = re.findall(TOK, code)
+        ops = [regs(x) for x in toks]
+        tagged = [{(f, n) for n in ns} for f, ns in ops]
+
+        def scan(read, rule, need, kinds):
             ws = 0
-            for states, written in reversed(window):
-                if ws >= 2:
-                    break
-                if written & src:
-                    problems.append((kernel, ln, code, sorted(written & src)))
-                    break
+            for states, kind, written in reversed(window):
+                if ws >= need:
+                    return
+                if kind in kinds and (written & read):
+                    problems.append((kernel, ln, code, rule, sorted(written & read)))
+                    return
                 ws += states
+
+        is_mfma = op.startswith("v_mfma")
+        if op == "v_fmac_f64_dpp" and "row_newbcast" in code:
+            counts["dpp"] += 1
+            if len(tagged) > 1:
+                scan(tagged[1], "D1", 2, ("valu",))
+        if is_mfma:
+            counts["mfma"] += 1
+            srcs = tagged[1:]
+            for i, rd in enumerate(srcs):
+                scan(rd, "M1", 2, ("valu",))
+                scan(rd, "M2" if i == 2 else "M3", 4 if i == 2 else 6, ("mfma",))
+        else:
+            reads = set().union(*tagged[(1 if (op.startswith("v_") or op.startswith("ds_read") or op.startswith("buffer_load")
+                                               or op.startswith("global_load") or op.startswith("scratch_load")) else 0):]) if tagged else set()
+            if reads:
+                scan(reads, "M4", 6, ("mfma",))
         if op == "s_nop":
             m = re.search(r"s_nop\s+(\d+)", code)
-            window.append((int(m.group(1)) + 1 if m else 1, set()))
-        elif op.startswith("v_") and toks:
-            window.append((1, vregs(toks[0])))        # VALU: destination is the first operand
+            window.append((int(m.group(1)) + 1 if m else 1, "nop", set()))
+        elif is_mfma:
+            window.append((1, "mfma", tagged[0] if tagged else set()))
+        elif op.startswith("v_") and tagged:
+            window.append((1, "valu", tagged[0]))         # VALU: the destination is the first operand
         else:
-            window.append((1, set()))
-        window = window[-4:]
-    return n_dpp, problems
+            window.append((1, "other", set()))
+        window = window[-12:]
+    return counts, problems
 
 
 if __name__ == "__main__":
-    src = sys.argv[1] if len(sys.argv) > 1 else compile_to_isa()
-    n, probs = check(src)
-    print(f"{src}: {n} DPP table reads checked, {len(probs)} hazard(s)")
-    for k, ln, code, regs in probs[:20]:
-        print(f"  {k} line {ln}: `{code}` reads v{regs} written less than two wait states earlier")
-    sys.exit(1 if probs or n == 0 else 0)
+    paths = sys.argv[1:] or [compile_to_isa(s) for s in SOURCES]
+    bad = 0
+    for src in paths:
+        c, probs = check(src)
+        print(f"{src}: {c['dpp']} DPP broadcast reads and {c['mfma']} MFMAs checked, {len(probs)} hazard(s)")
+        for k, ln, code, rule, rg in probs[:20]:
+            print(f"  [{rule}] {k} line {ln}: `{code}` <- {rg}")
+        bad += len(probs) + (0 if (c["dpp"] or c["mfma"]) else 1)
+    sys.exit(1 if bad else 0)
