@@ -171,7 +171,9 @@ def extra_car_rollout(sg, _lib, RolloutRunner, wl):
     flop = wl.flop_mode_r(3, 3, 45, 45, H) * Ns * H
     return {"workload": "BASELINE configs[2]: params_car_residual, mode R (T=3), Ns=4096, H=40, 1 GPU",
             "value": Ns * H / (ms * 1e-3), "unit": "trajectory-steps/s", "ms_per_rollout": ms, "finite": ok,
-            "roofline": roofline(flop, ms, "rollout_fast_kernel<3,45,3,car_residual,grid root>",
+            "kernel_path": int(_lib.load().gpmpc_debug_last_rollout_path()),
+            "roofline": roofline(flop, ms, "rollout_tiles_kernel<5,9,car_residual,32> (four chains per wave, FP64 4x4x4 MFMA solve)"
+                                 if _lib.load().gpmpc_debug_last_rollout_path() == 3 else "rollout_fast_kernel<3,45,3,car_residual,grid root>",
                                  wl.min_hbm_bytes(4, 3, 3) * Ns * H)}
 
 

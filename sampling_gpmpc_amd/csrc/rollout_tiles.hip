@@ -63,7 +63,7 @@ __device__ double g_tiles_dbg[64 * 64];
 #define TPH_STORE
 #endif
 
-constexpr int kTileNRA = 11;                                   // tile rows of the factor kept in AGPRs (66 tiles = 132 registers)
+constexpr int kTileNRA = 12;                                   // tile rows of the factor kept in AGPRs (78 tiles = 156 registers)
 __host__ __device__ constexpr int tri(int r) { return r * (r + 1) / 2; }
 // the last tile row q >= r such that rows r .. q together (sum of j + 1) fit the 64-slot ring of streamed tiles
 __host__ __device__ constexpr int ring_hi(int r) {
@@ -309,7 +309,9 @@ __global__ __launch_bounds__(64, 1) void rollout_tiles_kernel(const RolloutArgs 
     // lanes of a chain that carries no sample (the car's fourth quad, the tail of the last pendulum wave) address past the
     // descriptor's end: their loads return zero and their stores are dropped without memory traffic
     const bool live_m = (G_NY == 1) ? (4 * blk + bm < a.Ns) : (bm < 3);
-    const unsigned lane8 = live_m ? (unsigned)lane * 8u : 0x7ffff000u;
+    // inside a tile the 64 doubles are ordered chain-major (chain bm owns one 128-byte line): the line of a chain without a
+    // sample is never fetched - in lane order every line would carry 32 dead bytes and all four would move
+    const unsigned lane8 = live_m ? (unsigned)(bm * 16 + kq * 4 + jq) * 8u : 0x7ffff000u;
     const __amdgpu_buffer_rsrc_t wsr = __builtin_amdgcn_make_buffer_rsrc(wsu, 0, (int)(a.ws_chain_stride * 8), 0x00020000);
     auto tile_load = [&](unsigned voff, int e) -> double {
         // sc1 (aux bit 4): served by L2.  A tile row is re-read after this wave has stored into it (rows arrive three at a
@@ -545,7 +547,7 @@ __global__ __launch_bounds__(64, 1) void rollout_tiles_kernel(const RolloutArgs 
             // MFMAs ahead while the rows are short, one row once they are 25+ tiles long).
             // hipcc's s_waitcnt insertion counts loads exactly only along straight-line code: a load under an `if` that
             // rejoins makes every later wait a vmcnt(0), which waits for the prefetch just issued.  Hence two regimes:
-            //   (i)  fewer than NRA complete tile rows: few rows, everything streams, waits as hipcc places them;
+            //   (i)  fewer than NRA complete tile rows: all of them resident, only the incomplete row streams;
             //   (ii) rows 0 .. NRA-1 resident (straight line), rows NRA .. stream with UNCONDITIONAL requests - up to two
             //        rows beyond nt are requested and never used (inside the wave's workspace) - and early exits only.
             double ring[64];
@@ -579,33 +581,60 @@ __global__ __launch_bounds__(64, 1) void rollout_tiles_kernel(const RolloutArgs 
             const bool resident = nfull >= NRA;
 #endif
             if (!resident) {                                      // regime (i)
-                static_for<0, (NRA + 1 < NT ? NRA + 1 : NT)>([&](auto rc) {
+#ifdef GPMPC_TILES_NO_AGPR
+                static_for<0, NT>([&](auto rc) {
                     constexpr int r = decltype(rc)::value;
                     if (r < nt) {
                         fetch_row(rc);
                         streamed_row(rc);
                     }
                 });
-#ifdef GPMPC_TILES_NO_AGPR
-                static_for<NRA + 1, NT>([&](auto rc) {
+#else
+                // the complete rows 0 .. nfull-1 are resident (each was loaded when it completed); only the incomplete row
+                // nfull streams (its own registers, requested when its turn comes: one exposed L2 latency per step while the
+                // factor is this small - requesting it ahead through the ring costs more in spills than it hides)
+                static_for<0, NRA + 1>([&](auto rc) {
                     constexpr int r = decltype(rc)::value;
-                    if (r < nt) {
-                        fetch_row(rc);
-                        streamed_row(rc);
+                    if constexpr (r < NRA) {
+                        if (r < nfull) {
+                            double ac[2] = {V[r], 0.0};
+                            mfma_rowsum<r, true>(ac, At + tri(r), V);
+                            const double acc = ac[0] + ac[1];
+                            V[r] = mfma_zero_a(At[tri(r) + r], acc);
+                        }
+                    }
+                    if (part && r == nfull) {
+                        double cur[r + 1];
+#pragma unroll
+                        for (int p = 0; p <= r; ++p) cur[p] = tile_load(lane8, tri(r) + p);
+#pragma unroll
+                        for (int p = 0; p < r; ++p) cur[p] = rowex ? cur[p] : 0.0;
+                        double ac[2] = {V[r], 0.0};
+                        mfma_rowsum<r, false>(ac, cur, V);
+                        const double acc = ac[0] + ac[1];
+                        V[r] = mfma_zero_v(cur[r], acc);
                     }
                 });
 #endif
             } else {                                              // regime (ii)
-                static_for<NRA, ring_hi(NRA) + 1>(fetch_row);     // in flight behind the resident rows
-                __builtin_amdgcn_sched_barrier(0);
+                // the first streamed rows (NRA .. ring_hi(NRA)) are requested behind the resident rows, a few tiles in
+                // front of each row's MFMAs: 50+ loads issued in one burst by the CU's four waves keep the vector-memory
+                // issue port busy for thousands of cycles before the first MFMA
+                constexpr int E0 = tri(NRA), E1 = tri(ring_hi(NRA) + 1), PER = (E1 - E0 + NRA - 1) / NRA;
                 static_for<0, NRA>([&](auto rc) {
                     constexpr int r = decltype(rc)::value;
+                    constexpr int e0 = E0 + r * PER, e1 = (e0 + PER < E1) ? e0 + PER : E1;
+#pragma unroll
+                    for (int e = e0; e < e1; ++e) ring[e & 63] = tile_load(lane8, e);
+                    __builtin_amdgcn_sched_barrier(0);
                     double ac[2] = {V[r], 0.0};
                     mfma_rowsum<r, true>(ac, At + tri(r), V);
                     const double acc = ac[0] + ac[1];
                     V[r] = mfma_zero_a(At[tri(r) + r], acc);
+                    __builtin_amdgcn_sched_barrier(0);
                 });
                 __builtin_amdgcn_sched_barrier(0);
+                TPH(6);
                 auto rest = [&](auto self, auto rc) -> void {
                     constexpr int r = decltype(rc)::value;
                     if constexpr (r < NT) {

@@ -13,7 +13,7 @@ raw = C.CDLL(sg._lib.LIB_PATH)
 buf = (C.c_double * 4096)()
 raw.gpmpc_debug_read_tiles(buf)
 ph = np.array(buf)[63 * 64: 63 * 64 + 8]
-names = ["input + A (real block)", "B + C (rhs of hall. rows)", "D (solve)", "E + F (gram, exchange)", "G (roots, sample)", "H (append)", "env step", "-"]
+names = ["input + A (real block)", "B + C (rhs of hall. rows)", "D (solve; streamed rows in ii)", "E + F (gram, exchange)", "G (roots, sample)", "H (append)", "D: resident rows (regime ii)", "-"]
 tot = ph.sum()
 for n, v in zip(names, ph):
     print(f"  {n:28s} {v / H:10.0f} cycles/step  {100 * v / max(tot, 1):5.1f} %")
