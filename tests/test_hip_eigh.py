@@ -242,3 +242,37 @@ def test_eigh_root_value_only_model_rank_one(sg):
     assert rank <= 2
     np.testing.assert_allclose(post.mean.cpu().numpy(), opost.mean.numpy(), rtol=1e-6, atol=1e-10)
     assert err < 1e-6 * float(ysa.abs().max()) + 1e-9
+
+
+def test_eigh_root_against_50_digit_eigensolver(sg):
+    """the kernel's eigendecomposition root against 50-digit arithmetic on a <= 8-slot singular covariance.
+    Two stages of the car horizon at the SAME linearisation point give a 6 x 6 posterior covariance of rank 3; the kernel's
+    own Sigma (covariance_matrix) is decomposed with mpmath's symmetric eigensolver at 50 digits, and the root the kernel
+    drew with must satisfy R R^T == max(Sigma, 0) to FP64 round-off of Sigma's scale (no LAPACK in the comparison)."""
+    from tests.test_oracle_independent import _psd_part_mp
+    Ns, H = 3, 2
+    p = _car(Ns, H, 1)
+    agent, _ = make_agents(sg, p)
+    agent.debug_keep_root = True
+    x_h = np.tile(np.array(p["env"]["start"], dtype=np.float64)[:4], (H, Ns))
+    u_h = np.array([[0.03, 0.0], [0.03, 0.0]])
+    agent.train_hallucinated_dynGP(0)
+    g_in = agent.env_model.get_g_xu_hat(agent.get_batch_x_hat(x_h, u_h)).contiguous()
+    post = agent.model_i(g_in)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        post._run(agent.epistimic_random_vector[0][0], clip=True, beta=p["agent"]["Dyn_gp_beta"], want_root=True,
+                  want_covar=True, root_mode=sg._lib.ROOT_EIGH)
+    S_all, R_all = post.covariance_matrix.cpu().numpy(), post.root.cpu().numpy()
+    worst = 0.0
+    for s in range(Ns):
+        for o in range(3):
+            S = 0.5 * (S_all[s, o] + S_all[s, o].T)
+            P, lam = _psd_part_mp(S)
+            R = R_all[s, o]
+            scale = np.abs(S).max()
+            err = np.abs(R @ R.T - P).max() / scale
+            worst = max(worst, err)
+            assert int((lam > 1e-12 * lam.max()).sum()) <= 3          # rank 3: the second stage repeats the first
+    print(f"kernel eigh root vs 50-digit max(Sigma, 0) on 6 x 6 rank-3 covariances: max |R R^T - P| / max|Sigma| = {worst:.2e}")
+    assert worst < 1e-12
