@@ -453,8 +453,9 @@ def main():
         # launch-path check (tests, CPU): every rank joins the group, reports, leaves - nothing else runs
         import torch.distributed as dist_
         dist_.init_process_group(backend="gloo")
-        print(json.dumps({"dry_launch": True, "rank": rank, "world": world, "pid": os.getpid(),
-                          "parent": os.environ.get("GPMPC_BENCH_PARENT")}), flush=True)
+        # one write per record: the ranks share the launcher's pipe, print() would emit the newline separately
+        os.write(1, (json.dumps({"dry_launch": True, "rank": rank, "world": world, "pid": os.getpid(),
+                                 "parent": os.environ.get("GPMPC_BENCH_PARENT")}) + "\n").encode())
         dist_.barrier()
         dist_.destroy_process_group()
         sys.exit(3 if os.environ.get("GPMPC_BENCH_DRY_FAIL_RANK") == str(rank) else 0)

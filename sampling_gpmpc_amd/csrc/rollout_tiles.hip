@@ -63,18 +63,15 @@ __device__ double g_tiles_dbg[64 * 64];
 #define TPH_STORE
 #endif
 
-constexpr int kTileNRA = 12;                                   // tile rows of the factor kept in AGPRs (78 tiles = 156 registers)
-__host__ __device__ constexpr int tri(int r) { return r * (r + 1) / 2; }
-// the last tile row q >= r such that rows r .. q together (sum of j + 1) fit the 64-slot ring of streamed tiles
-__host__ __device__ constexpr int ring_hi(int r) {
-    int q = r, n = r + 1;
-    while (n + (q + 2) <= 64) {
-        ++q;
-        n += q + 1;
-    }
-    return q;
+// Tile rows of the factor kept in AGPRs: 12 (78 tiles = 156 registers) where the parked state and constants leave room,
+// else 11 (66 tiles).  The wave's other AGPRs: the parked doubles (state, test point, input, P0 / P1, U, 1/diag, five chain
+// constants, the lane's point of each pass), the columns of Qa / Qb and three constants per grid-entry register.
+__host__ __device__ constexpr int tiles_nra(int n0, int n1, int nx, int nt) {
+    const int nps = (nt * 4 / 3 + 15) / 16, ne = (n0 * n1 + 15) / 16;
+    const int other = 2 * (nx + 12 + 2 * nps) + 2 * (n0 + n1) + 6 * ne;
+    return (156 + other <= 246) ? 12 : 11;                        // hipcc starts spilling AGPRs a few registers short of 256
 }
-
+__host__ __device__ constexpr int tri(int r) { return r * (r + 1) / 2; }
 __device__ __forceinline__ void tiles_sync_lds() {
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -212,7 +209,8 @@ struct TilesLds {
     static constexpr int XS = (XH == 4) ? 10 : 2 * XH;
     static constexpr int YS = 2 * YH;
     static constexpr int SXN = 96;                                // per chain: new-point record (2 XH + 2 YH <= 32), S' exchange (32), scalars (16)
-    static constexpr int SCRN = 192;                              // per chain: 48 rows x 4 columns
+    // per chain: rows x 4 columns of the lane-map converter: 48 rows (16 points x 3 tasks) or the padded grid (16 per register)
+    static constexpr int SCRN = 4 * ((16 * ((N0 * N1 + 15) / 16) > 48) ? 16 * ((N0 * N1 + 15) / 16) : 48);
     __host__ __device__ static constexpr int per_chain(int npt) { return npt * (XS + YS + 4) + SCRN + SXN; }
 };
 
@@ -226,9 +224,23 @@ __global__ __launch_bounds__(64, 1) void rollout_tiles_kernel(const RolloutArgs 
     constexpr int NE = (N0 * N1 + 15) / 16;                       // registers holding one value per grid entry (a, c)
     constexpr int NRT = (N0 * N1 + 3) / 4;                        // pseudo-tiles of the real block
     constexpr int NPS = (NT * 4 / 3 + 15) / 16;                   // passes of 16 conditioning points
-    constexpr int NRA = kTileNRA;
+    constexpr int NRA = tiles_nra(N0, N1, NX, NT);
+#ifdef GPMPC_TILES_NRV_EXTRA                                      // experiment knob (tools/tiles_try.sh)
+    constexpr int NRV = NRA + GPMPC_TILES_NRV_EXTRA;
+#else
+    constexpr int NRV = NRA;                                      // + tile rows kept in VGPRs: 2 rows cost 60-90 spilled registers in phases A-C
+#endif
+    constexpr int NBT = tri(NRV) - tri(NRA);
+#ifdef GPMPC_TILES_RC                                             // experiment knob (tools/tiles_try.sh)
+    constexpr int RC = GPMPC_TILES_RC;
+#else
+    // register slots of the streamed-tile ring.  A DEEPER ring is slower (car Ns = 4096, H = 40: 1.75 ms at 24, 1.77 at 32,
+    // 1.81 at 48, 1.88 at 60; tools/ubench/stream_tiles.hip shows the same for bare loads): a CU's four waves keep ~200
+    // 128-byte lines in flight at 16 tiles each, beyond that requests only queue
+    constexpr int RC = (NT <= 32) ? 24 : 32;
+#endif
     using L = TilesLds<N0, N1>;
-    static_assert(N0 + N1 <= 16 && NE <= 3 && NT % 4 == 0, "grid / tile limits");
+    static_assert(N0 + N1 <= 16 && NE <= 4 && NT % 8 == 0 && NT > NRA, "grid / tile limits");
     extern __shared__ __attribute__((aligned(16))) double smem[];
 
     const GpParams& gp = a.gp;
@@ -335,6 +347,9 @@ __global__ __launch_bounds__(64, 1) void rollout_tiles_kernel(const RolloutArgs 
     // that merely feeds "a" operands is allocated to VGPRs and spilled).  Row r is loaded when it completes and not read
     // before (rows >= rs stream), hence no initialisation.
     double At[tri(NRA)];
+    double Bt[NBT > 0 ? NBT : 1];                                 // tile rows NRA .. NRV-1: ordinary registers, loaded when the row completes
+#pragma unroll
+    for (int i = 0; i < (NBT > 0 ? NBT : 1); ++i) Bt[i] = 0.0;
     int info_acc = 0;
     int n_pts = 0;                                                // appended points; n_h = 3 n_pts label rows
 
@@ -536,64 +551,76 @@ __global__ __launch_bounds__(64, 1) void rollout_tiles_kernel(const RolloutArgs 
         // Tile rows below `rs` are complete and AGPR-resident; rows rs .. nt-1 stream from the workspace through a ring of
         // 64 registers (sched_barrier keeps hipcc from hoisting all the loads to the top, which spills hundreds of registers).
         double Sh[2] = {0.0, 0.0};
+        double Vlast = 0.0;                                      // V of the last tile row solved (phase H wants the incomplete one)
         if (nt > 0) {
             // the previous step's tile stores precede this step's tile loads (same lane, same addresses); they were
             // issued thousands of cycles ago, the wait is a formality
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             const bool part = (n_h & 3) != 0;                     // the last tile row is incomplete: rows >= n_h are masked
-            const bool rowex = (4 * nfull + jq) < n_h;            // A operand of the incomplete tile row: its row index is jq
-            // 64 register slots hold the streamed tiles in flight, tile (r, p) in slot (tri(r) + p) mod 64: at row r every row
-            // up to ring_hi(r) has been requested (as many whole rows as fit behind row r: two or three rows ~ 1000 cycles of
-            // MFMAs ahead while the rows are short, one row once they are 25+ tiles long).
+            // The incomplete tile row: its rows >= n_h do not exist yet and their entries in the workspace are whatever the
+            // last launch left there.  Row i of a product (-L_rp) V_p depends on row i of L_rp alone, so nothing has to be
+            // masked but the accumulated row block itself (D layout: row index kq), once.
+            const bool accex = !part || (4 * nfull + kq) < n_h;
+            // RC register slots hold the streamed tiles in flight, tile e = tri(r) + p in slot e mod RC.  Tiles are requested
+            // in the order they are consumed, always RC tiles ahead: in front of every statement of <= 12 MFMAs the slots the
+            // previous statements emptied are re-requested (a lead of RC x ~21 cycles of MFMAs ~ 1300 cycles, above the L2
+            // latency under load, whatever the row length).
             // hipcc's s_waitcnt insertion counts loads exactly only along straight-line code: a load under an `if` that
             // rejoins makes every later wait a vmcnt(0), which waits for the prefetch just issued.  Hence two regimes:
             //   (i)  fewer than NRA complete tile rows: all of them resident, only the incomplete row streams;
-            //   (ii) rows 0 .. NRA-1 resident (straight line), rows NRA .. stream with UNCONDITIONAL requests - up to two
-            //        rows beyond nt are requested and never used (inside the wave's workspace) - and early exits only.
-            double ring[64];
-            auto fetch_row = [&](auto qc) {
-                constexpr int q = decltype(qc)::value;
+            //   (ii) rows 0 .. NRA-1 resident (straight line), rows NRA .. stream with UNCONDITIONAL requests - up to RC
+            //        tiles beyond row nt-1 are requested and never used (inside the wave's workspace) - and early exits only.
+            constexpr int TOT = tri(NT), E0 = tri(NRV);
+            double ring[RC];
+            auto request = [&](auto loc, auto hic) {              // tiles [lo, hi) of the triangle, clamped to the workspace
+                constexpr int lo = decltype(loc)::value, hi = decltype(hic)::value;
 #pragma unroll
-                for (int p = 0; p <= q; ++p) ring[(tri(q) + p) & 63] = tile_load(lane8, tri(q) + p);
+                for (int e = lo; e < (hi < TOT ? hi : TOT); ++e) ring[e % RC] = tile_load(lane8, e);
             };
             auto streamed_row = [&](auto rc) {
-                constexpr int r = decltype(rc)::value;
+                constexpr int r = decltype(rc)::value, base = tri(r), NCH = (r + 11) / 12;
                 double ac[2] = {V[r], 0.0};
-                if (part && r == nt - 1) {                        // in place: a masked COPY of the row would need its own registers
+                static_for<0, NCH>([&](auto cc) {
+                    constexpr int c = decltype(cc)::value, p0 = 12 * c, K = (r - p0 < 12) ? r - p0 : 12, e0 = base + p0;
+                    // what the previous statement (of this row, of the row above, or the resident rows) left requested
+                    constexpr int prev = (c > 0) ? e0 - 12 : ((r == NRV) ? E0 : tri(r - 1) + 12 * ((r - 1 + 11) / 12 - 1));
+                    request(std::integral_constant<int, prev + RC>{}, std::integral_constant<int, e0 + RC>{});
+                    __builtin_amdgcn_sched_barrier(0);
+                    double cur[K];
 #pragma unroll
-                    for (int p = 0; p < r; ++p) ring[(tri(r) + p) & 63] = rowex ? ring[(tri(r) + p) & 63] : 0.0;
-                }
-                double cur[r + 1];
-#pragma unroll
-                for (int p = 0; p <= r; ++p) cur[p] = ring[(tri(r) + p) & 63];
-                mfma_rowsum<r, false>(ac, cur, V);
-                const double acc = ac[0] + ac[1];
-                if constexpr (r < 3) {
-                    TDBG(8 + 4 * r, acc);
-                    TDBG(9 + 4 * r, cur[r]);
-                    TDBG(10 + 4 * r, cur[0]);
-                }
-                V[r] = mfma_zero_v(cur[r], acc);
+                    for (int k = 0; k < K; ++k) cur[k] = ring[(e0 + k) % RC];
+                    mfma_chain_v<K>(ac[0], ac[1], cur, V + p0);
+                    __builtin_amdgcn_sched_barrier(0);
+                });
+                const double acc = (r < nt - 1 || accex) ? ac[0] + ac[1] : 0.0;
+                V[r] = mfma_zero_v(ring[(base + r) % RC], acc);
+                Vlast = V[r];
             };
 #ifdef GPMPC_TILES_NO_AGPR
             const bool resident = false;
 #else
-            const bool resident = nfull >= NRA;
+            const bool resident = nfull >= NRV;
 #endif
             if (!resident) {                                      // regime (i)
 #ifdef GPMPC_TILES_NO_AGPR
-                static_for<0, NT>([&](auto rc) {
+                static_for<0, NT>([&](auto rc) {                  // debug build: every row from the workspace, no prefetch
                     constexpr int r = decltype(rc)::value;
                     if (r < nt) {
-                        fetch_row(rc);
-                        streamed_row(rc);
+                        double cur[r + 1];
+#pragma unroll
+                        for (int p = 0; p <= r; ++p) cur[p] = tile_load(lane8, tri(r) + p);
+                        double ac[2] = {V[r], 0.0};
+                        mfma_rowsum<r, false>(ac, cur, V);
+                        const double acc = (r < nt - 1 || accex) ? ac[0] + ac[1] : 0.0;
+                        V[r] = mfma_zero_v(cur[r], acc);
+                        Vlast = V[r];
                     }
                 });
 #else
                 // the complete rows 0 .. nfull-1 are resident (each was loaded when it completed); only the incomplete row
                 // nfull streams (its own registers, requested when its turn comes: one exposed L2 latency per step while the
                 // factor is this small - requesting it ahead through the ring costs more in spills than it hides)
-                static_for<0, NRA + 1>([&](auto rc) {
+                static_for<0, NRV + 1>([&](auto rc) {
                     constexpr int r = decltype(rc)::value;
                     if constexpr (r < NRA) {
                         if (r < nfull) {
@@ -601,36 +628,53 @@ __global__ __launch_bounds__(64, 1) void rollout_tiles_kernel(const RolloutArgs 
                             mfma_rowsum<r, true>(ac, At + tri(r), V);
                             const double acc = ac[0] + ac[1];
                             V[r] = mfma_zero_a(At[tri(r) + r], acc);
+                            Vlast = V[r];
+                        }
+                    } else if constexpr (r < NRV) {
+                        if (r < nfull) {
+                            double ac[2] = {V[r], 0.0};
+                            mfma_rowsum<r, false>(ac, Bt + (tri(r) - tri(NRA)), V);
+                            const double acc = ac[0] + ac[1];
+                            V[r] = mfma_zero_v(Bt[tri(r) - tri(NRA) + r], acc);
+                            Vlast = V[r];
                         }
                     }
                     if (part && r == nfull) {
                         double cur[r + 1];
 #pragma unroll
                         for (int p = 0; p <= r; ++p) cur[p] = tile_load(lane8, tri(r) + p);
-#pragma unroll
-                        for (int p = 0; p < r; ++p) cur[p] = rowex ? cur[p] : 0.0;
                         double ac[2] = {V[r], 0.0};
                         mfma_rowsum<r, false>(ac, cur, V);
-                        const double acc = ac[0] + ac[1];
+                        const double acc = accex ? ac[0] + ac[1] : 0.0;
                         V[r] = mfma_zero_v(cur[r], acc);
+                        Vlast = V[r];
                     }
                 });
 #endif
             } else {                                              // regime (ii)
-                // the first streamed rows (NRA .. ring_hi(NRA)) are requested behind the resident rows, a few tiles in
-                // front of each row's MFMAs: 50+ loads issued in one burst by the CU's four waves keep the vector-memory
-                // issue port busy for thousands of cycles before the first MFMA
-                constexpr int E0 = tri(NRA), E1 = tri(ring_hi(NRA) + 1), PER = (E1 - E0 + NRA - 1) / NRA;
+                // the first RC streamed tiles are requested behind the resident rows, a few tiles in front of each row's
+                // MFMAs: 50+ loads issued in one burst by the CU's four waves keep the vector-memory issue port busy for
+                // thousands of cycles before the first MFMA
+                constexpr int PER = (RC + NRA - 1) / NRA;
                 static_for<0, NRA>([&](auto rc) {
                     constexpr int r = decltype(rc)::value;
-                    constexpr int e0 = E0 + r * PER, e1 = (e0 + PER < E1) ? e0 + PER : E1;
-#pragma unroll
-                    for (int e = e0; e < e1; ++e) ring[e & 63] = tile_load(lane8, e);
+                    constexpr int e0 = E0 + r * PER, e1 = (e0 + PER < E0 + RC) ? e0 + PER : E0 + RC;
+                    request(std::integral_constant<int, e0>{}, std::integral_constant<int, e1>{});
                     __builtin_amdgcn_sched_barrier(0);
                     double ac[2] = {V[r], 0.0};
                     mfma_rowsum<r, true>(ac, At + tri(r), V);
                     const double acc = ac[0] + ac[1];
                     V[r] = mfma_zero_a(At[tri(r) + r], acc);
+                    Vlast = V[r];
+                    __builtin_amdgcn_sched_barrier(0);
+                });
+                static_for<NRA, NRV>([&](auto rc) {
+                    constexpr int r = decltype(rc)::value;
+                    double ac[2] = {V[r], 0.0};
+                    mfma_rowsum<r, false>(ac, Bt + (tri(r) - tri(NRA)), V);
+                    const double acc = ac[0] + ac[1];
+                    V[r] = mfma_zero_v(Bt[tri(r) - tri(NRA) + r], acc);
+                    Vlast = V[r];
                     __builtin_amdgcn_sched_barrier(0);
                 });
                 __builtin_amdgcn_sched_barrier(0);
@@ -639,16 +683,12 @@ __global__ __launch_bounds__(64, 1) void rollout_tiles_kernel(const RolloutArgs 
                     constexpr int r = decltype(rc)::value;
                     if constexpr (r < NT) {
                         if (r < nt) {                             // uniform; the only way out is the end of the phase
-                            constexpr int q0 = ring_hi(r - 1) + 1, q1 = (ring_hi(r) < NT - 1) ? ring_hi(r) : NT - 1;
-                            if constexpr (r > NRA) static_for<q0, q1 + 1>(fetch_row);
-                            __builtin_amdgcn_sched_barrier(0);
                             streamed_row(rc);
-                            __builtin_amdgcn_sched_barrier(0);
                             self(self, std::integral_constant<int, r + 1>{});
                         }
                     }
                 };
-                rest(rest, std::integral_constant<int, NRA>{});
+                rest(rest, std::integral_constant<int, NRV>{});
             }
             TPH(2);
             // S' += V_r^T V_r, eight tiles per statement (tiles >= nt are zero)
@@ -793,11 +833,8 @@ __global__ __launch_bounds__(64, 1) void rollout_tiles_kernel(const RolloutArgs 
                 }
             });
             // the tile pairs that involve tile tn itself (old rows of the incomplete tile) and the new tile tn+1
-            double Vtn = 0.0;
-            static_for<0, NT>([&](auto pcn) {
-                constexpr int p = decltype(pcn)::value;
-                if (p == tn) Vtn = V[p];
-            });
+            // (a search for V[tn] over the register array turns it into a scratch array: hipcc makes a table lookup of it)
+            const double Vtn = ((n_h & 3) != 0) ? Vlast : 0.0;    // tile row tn exists only if it is incomplete
             const bool wraps = i0 >= 2;                           // rows n_h .. n_h+2 reach into tile tn+1
             // diagonal tile tn: U = L^T (natural), its row / column scalings
             auto diag_scal = [&](int Rt, double oldv, bool rowwise) -> double {
@@ -865,6 +902,16 @@ __global__ __launch_bounds__(64, 1) void rollout_tiles_kernel(const RolloutArgs 
                     if (r == tn) load_row_agpr<r + 1>(wsr, lane8, tri(r) * 512, At + tri(r));   // loads + their wait: one statement
                 });
             }
+            if (i0 >= 1 && tn >= NRA && tn < NRV) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                static_for<NRA, NRV>([&](auto rc) {
+                    constexpr int r = decltype(rc)::value;
+                    if (r == tn) {
+#pragma unroll
+                        for (int p = 0; p <= r; ++p) Bt[tri(r) - tri(NRA) + p] = tile_load(lane8, tri(r) + p);
+                    }
+                });
+            }
             n_pts += 1;
         }
 
@@ -907,20 +954,35 @@ __global__ __launch_bounds__(64, 1) void rollout_tiles_kernel(const RolloutArgs 
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// host side
+// host side.  Instantiated for the reference's grids (pendulum1D 4 x 9, car 5 x 9: n_data_x x n_data_u of the shipped YAMLs)
+// and one size up each (5 x 9 / 6 x 9), with 32 tile rows (128 label rows per chain: H <= 43) or 48 (192: H <= 65, the
+// shipped car H = 50 included); anything else stays with the one-chain-per-wave kernels.
 // ---------------------------------------------------------------------------------------------------------------
-constexpr int kTilesNT = 32;                                     // 128 label rows per chain: H <= 43
-
 static int tiles_mode() {                                        // 0 auto, 1 forced, -1 disabled
     const char* e = std::getenv("GPMPC_ROLLOUT_TILES");
     if (!e) return 0;
     return (e[0] == '1') ? 1 : ((e[0] == '0') ? -1 : 0);
 }
 
+static int tiles_nt(int H) { const int n = 3 * (H - 1); return (n <= 128) ? 32 : ((n <= 160) ? 40 : ((n <= 192) ? 48 : 0)); }
+
 template <int N0, int N1>
 static size_t tiles_lds_bytes(int g_ny, int H) {
     const int gl = (g_ny == 1) ? 4 : 3;
     return (size_t)gl * TilesLds<N0, N1>::per_chain(H - 1 > 1 ? H - 1 : 1) * sizeof(double);
+}
+
+static size_t tiles_lds_for(const gpmpc_gp_desc_t* gp, const gpmpc_env_desc_t* env, int H) {       // 0: shape not instantiated
+    const int n0 = gp->grid_n0, n1 = gp->grid_n1;
+    if (env->env_id == GPMPC_ENV_PENDULUM1D && gp->g_ny == 1 && n1 == 9) {
+        if (n0 == 4) return tiles_lds_bytes<4, 9>(1, H);
+        if (n0 == 5) return tiles_lds_bytes<5, 9>(1, H);
+    }
+    if (env->env_id == GPMPC_ENV_CAR_RESIDUAL && gp->g_ny == 3 && n1 == 9) {
+        if (n0 == 5) return tiles_lds_bytes<5, 9>(3, H);
+        if (n0 == 6) return tiles_lds_bytes<6, 9>(3, H);
+    }
+    return 0;
 }
 
 bool rollout_tiles_eligible(const gpmpc_gp_desc_t* gp, const gpmpc_env_desc_t* env, int mode, int hall_tasks, int H, int64_t Ns) {
@@ -932,30 +994,32 @@ bool rollout_tiles_eligible(const gpmpc_gp_desc_t* gp, const gpmpc_env_desc_t* e
     if (eg && eg[0] == '1') return false;
     if (mode != GPMPC_MODE_RECONDITIONED || gp->T != 3 || gp->D != 2 || hall_tasks != 3 || gp->real_has_grad) return false;
     if (!plan_has_grid_root(gp->grid_n0, gp->grid_n1, gp->real_has_grad)) return false;
-    if (H < 2 || 3 * (H - 1) > 4 * kTilesNT) return false;
-    size_t lds = 0;
-    if (env->env_id == GPMPC_ENV_PENDULUM1D && gp->g_ny == 1 && gp->grid_n0 == 4 && gp->grid_n1 == 9) lds = tiles_lds_bytes<4, 9>(1, H);
-    else if (env->env_id == GPMPC_ENV_CAR_RESIDUAL && gp->g_ny == 3 && gp->grid_n0 == 5 && gp->grid_n1 == 9) lds = tiles_lds_bytes<5, 9>(3, H);
-    else return false;
-    if (lds > 160 * 1024 - 64) return false;
+    if (H < 2 || tiles_nt(H) == 0) return false;
+    if (tiles_nt(H) > 32 && !((env->env_id == GPMPC_ENV_PENDULUM1D && gp->grid_n0 == 4) || (env->env_id == GPMPC_ENV_CAR_RESIDUAL && gp->grid_n0 == 5)))
+        return false;
+    const size_t lds = tiles_lds_for(gp, env, H);
+    if (lds == 0 || lds > 160 * 1024 - 64) return false;
     if (md > 0) return true;
     // a wave carries four chains and takes ~2x as long as the one-chain-per-wave kernels do for a round of the chip
-    // (tools/bench_tiles.py: pendulum Ns = 1024: 0.20 vs 0.11 ms, Ns = 4096: 0.28 vs 0.43 ms; car Ns = 1024: 0.57 vs 0.85 ms)
+    // (tools/bench_tiles.py: pendulum Ns = 1024: 0.20 vs 0.11 ms, Ns = 4096: 0.27 vs 0.43 ms; car Ns = 1024: 0.46 vs 0.85 ms);
+    // shapes the tuned one-chain kernel does not take (other grids, 3 (H - 1) > 128) fall to the generic kernel, 4-10x
+    // slower: there the tiled kernel is the better choice from a single round on
     const int64_t chains = Ns * gp->g_ny;
-    return chains >= 3072;
+    const bool tuned_alt = rollout_fast_eligible(gp, env, mode, hall_tasks, H);
+    return chains >= (tuned_alt ? 3072 : 256);
 }
 
 size_t rollout_tiles_workspace_bytes(const gpmpc_gp_desc_t* gp, int64_t Ns, int H) {
-    (void)H;
+    const int nt = tiles_nt(H) ? tiles_nt(H) : 32;
     const int64_t waves = (gp->g_ny == 1) ? (Ns + 3) / 4 : Ns;
-    return (size_t)waves * tri(kTilesNT) * 64 * sizeof(double);
+    return (size_t)waves * tri(nt) * 64 * sizeof(double);
 }
 
-template <int N0, int N1, int ENV>
+template <int N0, int N1, int ENV, int NT>
 static int launch_tiles(RolloutArgs& args, int g_ny, hipStream_t st) {
     const size_t lds = tiles_lds_bytes<N0, N1>(g_ny, args.H);
     const long nblk = (g_ny == 1) ? (args.Ns + 3) / 4 : args.Ns;
-    auto k = rollout_tiles_kernel<N0, N1, ENV, kTilesNT>;
+    auto k = rollout_tiles_kernel<N0, N1, ENV, NT>;
     GPMPC_HIP_CHECK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(k, dim3((unsigned)nblk), dim3(64), lds, st, args);
     GPMPC_HIP_CHECK(hipGetLastError());
@@ -966,10 +1030,22 @@ int rollout_tiles_launch(const gpmpc_gp_desc_t* gp, const gpmpc_env_desc_t* env,
                          hipStream_t st) {
     if (!ws || ws_bytes < rollout_tiles_workspace_bytes(gp, args.Ns, args.H))
         return fail(GPMPC_E_WORKSPACE, "gpmpc_rollout: workspace too small");
+    const int nt = tiles_nt(args.H), n0 = gp->grid_n0;
     args.ws = (double*)ws;
-    args.ws_chain_stride = (long)tri(kTilesNT) * 64;             // doubles per wave
-    if (env->env_id == GPMPC_ENV_PENDULUM1D) return launch_tiles<4, 9, GPMPC_ENV_PENDULUM1D>(args, 1, st);
-    return launch_tiles<5, 9, GPMPC_ENV_CAR_RESIDUAL>(args, 3, st);
+    args.ws_chain_stride = (long)tri(nt) * 64;                   // doubles per wave
+    // the shipped grids with every tile-row count, the one-size-up grids with 32 tile rows
+    if (env->env_id == GPMPC_ENV_PENDULUM1D) {
+        if (n0 == 4 && nt == 32) return launch_tiles<4, 9, GPMPC_ENV_PENDULUM1D, 32>(args, 1, st);
+        if (n0 == 4 && nt == 40) return launch_tiles<4, 9, GPMPC_ENV_PENDULUM1D, 40>(args, 1, st);
+        if (n0 == 4 && nt == 48) return launch_tiles<4, 9, GPMPC_ENV_PENDULUM1D, 48>(args, 1, st);
+        if (n0 == 5 && nt == 32) return launch_tiles<5, 9, GPMPC_ENV_PENDULUM1D, 32>(args, 1, st);
+    } else {
+        if (n0 == 5 && nt == 32) return launch_tiles<5, 9, GPMPC_ENV_CAR_RESIDUAL, 32>(args, 3, st);
+        if (n0 == 5 && nt == 40) return launch_tiles<5, 9, GPMPC_ENV_CAR_RESIDUAL, 40>(args, 3, st);
+        if (n0 == 5 && nt == 48) return launch_tiles<5, 9, GPMPC_ENV_CAR_RESIDUAL, 48>(args, 3, st);
+        if (n0 == 6 && nt == 32) return launch_tiles<6, 9, GPMPC_ENV_CAR_RESIDUAL, 32>(args, 3, st);
+    }
+    return fail(GPMPC_E_UNSUPPORTED, "rollout_tiles: shape not instantiated");
 }
 
 }  // namespace gpmpc

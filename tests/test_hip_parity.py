@@ -191,31 +191,74 @@ def test_rollout_against_oracle(sg, pname, Ns, H, nograd, force_global, monkeypa
     np.testing.assert_allclose(Y, Yo, rtol=1e-4, atol=1e-8)
 
 
-@pytest.mark.parametrize("pname,Ns,H,feedback", [
-    ("params_pendulum1D_samples", 6, 3, None),        # two appended points: one incomplete tile row
-    ("params_pendulum1D_samples", 7, 12, None),       # ragged last wave (7 = 4 + 3 chains), 33 rows: every tile phase (n_h mod 4)
-    ("params_pendulum1D_samples", 9, 30, None),       # configs[1] horizon: 87 rows = 22 tile rows, 14 resident + 8 streamed
-    ("params_car_residual_fs", 3, 10, None),          # one sample = one wave (three outputs + the copy)
-    ("params_car_residual_fs", 5, 40, None),          # configs[2] horizon: 117 rows = 30 tile rows
-    ("params_car_residual_fs", 4, 43, False),         # the longest horizon the 32-tile kernel takes (126 rows), no feedback
+@pytest.mark.parametrize("pname,Ns,H,feedback,n_data_x", [
+    ("params_pendulum1D_samples", 6, 3, None, None),    # two appended points: one incomplete tile row
+    ("params_pendulum1D_samples", 7, 12, None, None),   # ragged last wave (7 = 4 + 3 chains), 33 rows: every tile phase (n_h mod 4)
+    ("params_pendulum1D_samples", 9, 30, None, None),   # configs[1] horizon: 87 rows = 22 tile rows, 12 resident + 10 streamed
+    ("params_car_residual_fs", 3, 10, None, None),      # one sample = one wave (three outputs + the copy)
+    ("params_car_residual_fs", 5, 40, None, None),      # configs[2] horizon: 117 rows = 30 tile rows
+    ("params_car_residual_fs", 4, 43, False, None),     # the longest horizon the 32-tile kernel takes (126 rows), no feedback
+    ("params_car_residual_fs", 3, 50, None, None),      # the shipped car horizon (params_car_residual.yaml): 147 rows, 40-tile kernel
+    ("params_car_residual_fs", 2, 65, None, None),      # 192 rows: all 48 tile rows of the largest instance
+    ("params_pendulum1D_samples", 5, 54, None, None),   # 159 rows of the 40-tile kernel, ragged wave
+    ("params_pendulum1D_samples", 6, 60, None, None),   # 48-tile kernel
+    ("params_pendulum1D_samples", 5, 25, None, 5),      # a 5 x 9 training grid
+    ("params_car_residual_fs", 3, 40, None, 6),         # a 6 x 9 training grid (four registers of grid entries, 11 resident rows)
 ])
-def test_tiled_rollout_against_oracle(sg, pname, Ns, H, feedback, monkeypatch):
+def test_tiled_rollout_against_oracle(sg, pname, Ns, H, feedback, n_data_x, monkeypatch):
     """rollout_tiles.hip (four chains per wave, forward substitution on the FP64 matrix pipe) is selected by size; forced
     here at small Ns against the oracle.  Same tolerances as the other rollout kernels."""
     from sampling_gpmpc_amd.rollout import forward_sampling_rollout
     monkeypatch.setenv("GPMPC_ROLLOUT_TILES", "1")
     p = fs_params(pname, Ns, H, nograd=False, feedback=feedback, beta=(3.0 if "car" in pname else None))
+    if n_data_x is not None:
+        p["env"]["n_data_x"] = n_data_x
     agent, oagent = make_agents(sg, p)
     u_ff = synthetic_u_ff(agent.nu, H)
+    if H > 45:
+        u_ff = u_ff * 0.5                                                   # keep the long rollouts near the data
     X, Y = forward_sampling_rollout(agent, u_ff, return_samples=True)
     assert sg._lib.load().gpmpc_debug_last_rollout_path() == 3, "the tiled kernel was not selected"
     Xo, Yo = ao.forward_sampling_rollout(oagent, u_ff, return_samples=True)
     ex, ey = relerr(X, Xo), relerr(Y, Yo)
-    print(f"tiled {pname} Ns={Ns} H={H}: rel err X_traj {ex:.2e}, Y {ey:.2e}")
+    print(f"tiled {pname} Ns={Ns} H={H} grid {n_data_x or 'shipped'} x 9: rel err X_traj {ex:.2e}, Y {ey:.2e}")
     assert np.isfinite(X).all()
     assert ex < RTOL_TRAJ and ex < RTOL_NORTH_STAR
     np.testing.assert_allclose(Y, Yo, rtol=1e-4, atol=1e-8)
     np.testing.assert_allclose(agent.Hallcinated_X_train[:, 0].cpu().numpy(), oagent.Hallcinated_X_train[:, 0].numpy(), rtol=1e-6, atol=1e-9)
+
+
+@pytest.mark.parametrize("pname,Ns,H,n_data_x", [
+    ("params_car_residual_fs", 90, 50, None),           # picked by itself: no tuned one-chain kernel for 147 rows, 270 chains
+    ("params_car_residual_fs", 86, 30, 6),              # 6 x 9 grid
+    ("params_pendulum1D_samples", 300, 20, 5),          # 5 x 9 grid
+    ("params_pendulum1D_samples", 4100, 30, None),      # configs[1] shape at a sample count where four chains per wave win
+])
+def test_tiled_kernel_agrees_with_generic_kernel(sg, pname, Ns, H, n_data_x, monkeypatch):
+    """Launch sizes at which the dispatcher picks the tiled kernel by itself (path 3), against the generic kernel
+    (GPMPC_DISABLE_FAST_ROLLOUT=1, path 0) on the same base samples: round-off apart."""
+    from sampling_gpmpc_amd.rollout import forward_sampling_rollout
+    p = fs_params(pname, Ns, H, nograd=False, beta=(3.0 if "car" in pname else None))
+    p["agent"]["base_sample_generator"] = "vectorized"
+    if n_data_x is not None:
+        p["env"]["n_data_x"] = n_data_x
+    torch.manual_seed(5)
+    pg = {**p, "common": {**p["common"], "use_cuda": True}}
+    agent = sg.Agent(pg, sg.make_env(pg))
+    u_ff = synthetic_u_ff(agent.nu, H) * (0.5 if H > 45 else 1.0)
+    lib = sg._lib.load()
+    X_t, Y_t = forward_sampling_rollout(agent, u_ff, return_samples=True)
+    assert lib.gpmpc_debug_last_rollout_path() == 3, "the tiled kernel was not selected"
+    monkeypatch.setenv("GPMPC_DISABLE_FAST_ROLLOUT", "1")
+    agent2 = sg.Agent(pg, sg.make_env(pg))
+    agent2.epistimic_random_vector = agent.epistimic_random_vector.clone()
+    X_g, Y_g = forward_sampling_rollout(agent2, u_ff, return_samples=True)
+    assert lib.gpmpc_debug_last_rollout_path() == 0, "the generic kernel was not selected"
+    print(f"{pname} Ns={Ns} H={H} grid {n_data_x or 'shipped'} x 9: tiled vs generic max abs diff X {np.abs(X_t - X_g).max():.2e} "
+          f"Y {np.abs(Y_t - Y_g).max():.2e}")
+    assert np.isfinite(X_t).all() and np.abs(X_t - X_g).max() > 0.0
+    np.testing.assert_allclose(X_t, X_g, rtol=1e-8, atol=1e-10)
+    np.testing.assert_allclose(Y_t, Y_g, rtol=1e-6, atol=1e-10)
 
 
 def test_rollout_sample_subset_invariance_full_size(sg):
@@ -252,7 +295,7 @@ def test_rollout_sample_subset_invariance_full_size(sg):
 @pytest.mark.parametrize("pname,Ns,H,nograd", [("params_car_residual_fs", 262144, 40, True),     # BASELINE configs[3] as shipped
                                                ("params_car_residual_fs", 4096, 40, False),      # configs[2]
                                                ("params_car_residual_fs", 262144, 40, False)])   # configs[3] re-conditioned (T=3)
-def test_car_rollout_full_size_properties(sg, pname, Ns, H, nograd):
+def test_car_rollout_full_size_properties(sg, pname, Ns, H, nograd, monkeypatch):
     """BASELINE full sizes of the car workloads (mode I, Ns=262144: the true-reachable-set launch of one GPU; mode R,
     Ns=4096; mode R at Ns=262144 - SURVEY cfg4's re-conditioned variant, 786432 chains, a 44 GB factor workspace): finite, error-free info words, every sample independent of what else is in the launch (bit-exact on
     re-launched subsets, incl. one that straddles workgroups and the ragged last one) and a 12-sample subset equal to
@@ -274,9 +317,14 @@ def test_car_rollout_full_size_properties(sg, pname, Ns, H, nograd):
     X = full.X_traj
     assert X.shape == (Ns, 4, H + 1) and bool(torch.isfinite(X).all())
     assert int(full.info.max().item()) & (_lib.INFO_TRAIN_CHOL_FAIL | _lib.INFO_ROOT_FAIL) == 0
-    for lo, hi in ((0, 5), (Ns // 2 - 37, Ns // 2 + 91), (Ns - 3, Ns)):
+    path = _lib.load().gpmpc_debug_last_rollout_path()
+    if not nograd:
+        assert path == 3, "mode R at these sizes belongs to the four-chains-per-wave kernel"
+        monkeypatch.setenv("GPMPC_ROLLOUT_TILES", "1")           # small launches pick the one-chain kernel by themselves:
+    for lo, hi in ((0, 5), (Ns // 2 - 37, Ns // 2 + 91), (Ns - 3, Ns)):   # bit-exactness is a property of ONE kernel
         sub = rollout_device(agent, u_ff, z, erv.shape[1] * per_slab, H=H, mode=mode,
                              use_model_without_derivatives=nograd, sample_slice=(lo, hi))
+        assert _lib.load().gpmpc_debug_last_rollout_path() == path
         assert torch.equal(sub.X_traj, X[lo:hi]), (lo, hi)
     lo = Ns // 3
     po = fs_params(pname, 12, H, nograd=nograd, beta=(None if nograd else 3.0))
