@@ -125,6 +125,25 @@ def current_stream_ptr() -> int:
     return torch.cuda.current_stream().cuda_stream
 
 
+def host_wait(t: Optional[torch.Tensor] = None) -> None:
+    """Wait on the host, by POLLING, for the work queued on the current stream; call it in front of every host read of a
+    device result (``.item()``, ``.cpu()``, ``.tolist()``) that may follow a kernel of more than a millisecond.
+
+    Why: the runtime's own wait spins briefly and then sleeps until the completion interrupt.  Where that interrupt is not
+    delivered promptly (profiles/r3_closed_loop_trace.md: on this pool every such wait ends on a 100 ms timer tick, which
+    made an SQP iteration of 8 ms of GPU work take 100 ms), polling ``hipEventQuery`` costs one busy host thread for the
+    length of the kernel and returns when the kernel does.  ``GPMPC_HOST_WAIT=block`` restores the runtime's wait.
+    CPU tensors (the gloo tests) need nothing."""
+    if t is not None and not t.is_cuda:
+        return
+    if not torch.cuda.is_available() or os.environ.get("GPMPC_HOST_WAIT") == "block":
+        return
+    ev = torch.cuda.Event()
+    ev.record()
+    while not ev.query():
+        pass
+
+
 def make_gp_desc(g_ny, D, T, N_r, real_has_grad, ell, outputscale, noise, jitter, var_floor=1e-10,
                  grid=(0, 0)) -> GpDesc:
     d = GpDesc()

@@ -370,6 +370,7 @@ class Agent(object):
         """Full-state value and Jacobians ``f + B_d g`` at the linearisation points (reference ``src/agent.py:532-564``).
         Returns numpy float64 ``gp_val (Ns,nx,H,1)``, ``y_grad (Ns,nx,H,nx)``, ``u_grad (Ns,nx,H,nu)``."""
         gp_val, y_grad, u_grad = self.dyn_fg_jacobians_device(xu_hat, sqp_iter)
+        _lib.host_wait(gp_val)
         out = (gp_val.cpu().numpy(), y_grad.cpu().numpy(), u_grad.cpu().numpy())
         if not (np.isfinite(out[0]).all() and np.isfinite(out[1]).all() and np.isfinite(out[2]).all()):
             print("Nan/inf in y_sample")
@@ -393,6 +394,7 @@ class Agent(object):
                                        _lib.dptr(gp_val), _lib.dptr(x_h_d), _lib.dptr(u_h_d), _lib.dptr(xg_d),
                                        _lib.dptr(w_d), _lib.dptr(te), _lib.dptr(p_lin), _lib.current_stream_ptr()),
                    "gpmpc_pack_plin")
+        _lib.host_wait(p_lin)
         return p_lin.cpu().numpy()
 
     # ---------------------------------------------------------------------------------------------------------
@@ -443,6 +445,7 @@ class Agent(object):
         if self.dist_group is not None:            # every rank must take the same path (the per-step one has collectives)
             import torch.distributed as dist
             dist.all_reduce(has_nan, op=dist.ReduceOp.MAX, group=self.dist_group)
+        _lib.host_wait(has_nan)
         fusable = (steps >= 3 and T == 1 + self.in_dim_x and seeds_fit(self, n_hall, 1, steps - 1, T, 1)
                    and not bool(has_nan.item()))
         if fused is None:
@@ -483,7 +486,7 @@ class Agent(object):
             from .distributed import replace_rejected_samples
             self.Hallcinated_X_train, self.Hallcinated_Y_train = replace_rejected_samples(
                 self.Hallcinated_X_train, self.Hallcinated_Y_train, alive, self.ns_global, rng, self.dist_group)
-        elif int(alive.sum().item()) > 0:
+        elif (_lib.host_wait(alive), int(alive.sum().item()))[1] > 0:
             rejected = alive == 0
             n_rejected = int(rejected.sum().item())
             survivors = torch.nonzero(alive > 0).reshape(-1).cpu().numpy()

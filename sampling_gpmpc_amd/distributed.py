@@ -27,6 +27,8 @@ from typing import Callable, Optional, Tuple
 import torch
 import torch.distributed as dist
 
+from . import _lib
+
 
 def shard_range(Ns: int, rank: int, world: int) -> Tuple[int, int]:
     """Contiguous, as-even-as-possible split of ``Ns`` global sample ids."""
@@ -211,6 +213,7 @@ def replace_rejected_samples(X_local: torch.Tensor, Y_local: torch.Tensor, left_
     rank, world = dist.get_rank(group), dist.get_world_size(group)
     lo, hi = shard_range(Ns, rank, world)
     left = all_gather_samples(left_local.reshape(-1, 1).to(torch.int64), Ns, group).reshape(-1)
+    _lib.host_wait(left)
     if int(left.sum().item()) == 0:
         return X_local, Y_local
     Xg = all_gather_samples(X_local, Ns, group)
@@ -256,7 +259,9 @@ def gather_jacobians(arrays, Ns: int, group=None, dst: int = 0):
     dist.gather(packed, parts, dst=dst, group=group)
     if rank != dst:
         return None
-    full = torch.cat([parts[r][: hi - lo] for r, (lo, hi) in enumerate(sizes)], dim=0).cpu().numpy()   # one D2H copy
+    full = torch.cat([parts[r][: hi - lo] for r, (lo, hi) in enumerate(sizes)], dim=0)
+    _lib.host_wait(full)
+    full = full.cpu().numpy()                                     # one D2H copy
     assert full.shape[0] == Ns
     out, c0 = [], 0
     for w in widths:

@@ -96,6 +96,7 @@ class RealDataPlan:
         info = torch.zeros(hyper.g_ny, dtype=torch.int32, device=dev)
         _lib.check(lib.gpmpc_plan_build(self.desc, _lib.dptr(self.X_r), _lib.dptr(self.Y_r), _lib.dptr(self.buf),
                                         _lib.dptr(info), _lib.current_stream_ptr()), "gpmpc_plan_build")
+        _lib.host_wait(info)
         if int(info.max().item()) != 0:
             raise NotPSDError("Cholesky of the real-data covariance K_rr + Sigma failed")
         self.n_r = N_r * hyper.T if has_grad else N_r
@@ -330,6 +331,7 @@ class HipPosterior:
         flags = torch.tensor([1 if (bits & _lib.INFO_TRAIN_CHOL_FAIL) else 0, 1 if self.used_eigh else 0],
                              dtype=torch.int32, device=self._x.device)
         dist.all_reduce(flags, op=dist.ReduceOp.MAX, group=group)
+        _lib.host_wait(flags)
         chol_fail, any_eigh = (int(v) for v in flags.tolist())
         if chol_fail:
             raise NotPSDError("Cholesky of the training covariance (real + hallucinated data) failed"
@@ -361,6 +363,7 @@ def _or_reduce(info: torch.Tensor, group=None) -> int:
         import torch.distributed as dist
         dist.all_reduce(packed, op=dist.ReduceOp.MAX, group=group)
     bits = 0
+    _lib.host_wait(packed)
     for x in packed.tolist():
         bits |= int(x)
     return bits

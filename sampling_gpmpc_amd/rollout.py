@@ -136,6 +136,7 @@ class RolloutState:
 
     def counts(self):
         """(seed points, appended points) per sample, read back from the device (uniform over samples)."""
+        _lib.host_wait(self.buf)
         return int(self.buf[0].item()), int(self.buf[1].item())
 
 
@@ -233,6 +234,7 @@ def forward_sampling_rollout(agent: Agent, u_ff, x0=None, return_samples: bool =
         [agent.Hallcinated_X_train, res.Xi.unsqueeze(1).expand(-1, agent.g_ny, -1, -1)], dim=2)
     agent.Hallcinated_Y_train = torch.cat([agent.Hallcinated_Y_train, res.Y], dim=2)
     agent.model_i_samples = res.Y[:, :, [H - 1], :]
+    _lib.host_wait(res.X_traj)
     X = res.X_traj.cpu().numpy()
     if return_samples:
         return X, res.Y.cpu().numpy()

@@ -299,3 +299,17 @@ def test_joint_factor_cache_bookkeeping():
     assert c2.n_valid == 60 and torch.equal(c2.X, X[:, :, :20])
     c.enabled = False
     assert c.prepare(mk(20), Ns, 60) == (None, 0, 0)
+
+
+def test_host_thread_budget_follows_the_cgroup_quota(tmp_path):
+    """Thread pools are lowered only when they exceed the CPUs the cgroup grants (profiles/r3_closed_loop_trace.md)."""
+    from sampling_gpmpc_amd import _host_threads as ht
+    assert ht.parse_cpu_max("1600000 100000\n") == 16.0 and ht.parse_cpu_max("max 100000") is None
+    assert ht.parse_cpu_max("garbage") is None
+    (tmp_path / "cpu.max").write_text("250000 100000\n")
+    assert ht.cgroup_cpu_quota(str(tmp_path)) == 2.5
+    assert ht.cgroup_cpu_quota(str(tmp_path / "missing")) is None
+    assert ht.host_thread_budget(visible=256, quota=16.0, current=128) == 8      # the GPU boxes of this project
+    assert ht.host_thread_budget(visible=256, quota=2.5, current=256) == 1
+    assert ht.host_thread_budget(visible=8, quota=None, current=8) is None       # nothing oversubscribed: hands off
+    assert ht.host_thread_budget(visible=64, quota=16.0, current=4) is None

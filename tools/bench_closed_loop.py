@@ -24,7 +24,10 @@ def main():
     ap.add_argument("--iters", type=int, default=4)
     ap.add_argument("--mpc-steps", type=int, default=4)
     ap.add_argument("--jitter", type=float, default=None, help="override Dyn_gp_jitter (default: as shipped, 1e-20 -> eigh root)")
+    ap.add_argument("--block", action="store_true", help="let the runtime wait for completions (GPMPC_HOST_WAIT=block) instead of polling")
     a = ap.parse_args()
+    if a.block:
+        os.environ["GPMPC_HOST_WAIT"] = "block"
     p = closed_loop_params(a.params, a.ns, a.horizon, a.mpc_steps, a.iters)
     p["common"]["use_cuda"] = True
     p["agent"]["base_sample_generator"] = "counter"
@@ -34,6 +37,7 @@ def main():
     agent = sg.Agent(p, sg.make_env(p))
     agent.update_current_state(np.asarray(p["env"]["start"], dtype=np.float64))
     loop = ClosedLoop(p, agent, SurrogateSolver(p))
+    print(f"host waits: {'runtime (interrupt)' if a.block else 'polled'}; HSA_ENABLE_INTERRUPT={os.environ.get('HSA_ENABLE_INTERRUPT', 'unset')}")
     print(f"{a.params}: Ns={a.ns} H={a.horizon} ({a.ns * agent.g_ny} chains), {a.iters} SQP iterations per MPC step; "
           f"jitter {p['agent']['Dyn_gp_jitter']:g}; GP side per SQP iteration in ms (train + x_hat + fg_jac + p_lin)")
     with warnings.catch_warnings():

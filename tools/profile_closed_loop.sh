@@ -13,3 +13,4 @@ python3 $ROOT/tools/bench_closed_loop.py --mpc-steps $STEPS > $OUT/untraced.log 
 rocprofv3 --hip-trace --kernel-trace --stats --output-format csv -d $OUT/trace -o cl -- python3 $ROOT/tools/bench_closed_loop.py --mpc-steps $STEPS > $OUT/traced.log 2>&1
 cd $ROOT
 python3 tools/summarise_closed_loop_trace.py $OUT $TAG
+rm -f $OUT/trace/*hip_api_trace.csv $OUT/trace/*kernel_trace.csv     # tens of MB; the summary and the *_stats.csv stay
