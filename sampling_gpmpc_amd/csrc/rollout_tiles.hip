@@ -39,6 +39,7 @@ namespace gpmpc {
 
 typedef double double2_v __attribute__((ext_vector_type(2)));
 typedef unsigned u32x2_v __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4_v __attribute__((ext_vector_type(4)));
 
 // GPMPC_TILES_DEBUG (build.py: GPMPC_EXTRA_DEFS=-DGPMPC_TILES_DEBUG): wave 0 dumps its solved tiles and the tiles it appends
 // at step GPMPC_TILES_DEBUG_STEP into g_tiles_dbg (tools/debug/tiles_dbg.py compares them with a dense numpy factor)
@@ -314,25 +315,28 @@ __global__ __launch_bounds__(64, 1) void rollout_tiles_kernel(const RolloutArgs 
     };
     // MFMA side constants: the identity in natural layout, and this lane's slot in the wave's factor workspace
     const double Inat = (kq == jq) ? 1.0 : 0.0;
-    // tile e of the wave: 512 bytes at wsu + 512 e, this lane's double at + 8 lane.  Accessed through a buffer descriptor
-    // (uniform base, scalar tile offset, 32-bit lane offset): with per-lane 64-bit addresses hipcc hoists the address
-    // arithmetic of all 528 tiles out of the step loop and spills it.
+    // Tiles of the wave's factor are stored in PAIRS: tiles 2q and 2q + 1 share 1024 bytes at wsu + 1024 q in which lane
+    // (bm, kq, jq) owns 16 bytes (tile 2q's double, then tile 2q + 1's): the ring of streamed tiles fetches a pair with ONE
+    // 16-byte load per lane (tools/ubench/stream_tiles.hip: 0.80 ms against 0.93 ms for this launch's loads at 8 bytes).
+    // Accessed through a buffer descriptor (uniform base, scalar tile offset, 32-bit lane offset): with per-lane 64-bit
+    // addresses hipcc hoists the address arithmetic of all 528 tiles out of the step loop and spills it.
     char* wsu = reinterpret_cast<char*>(a.ws + blk * a.ws_chain_stride);
     // lanes of a chain that carries no sample (the car's fourth quad, the tail of the last pendulum wave) address past the
     // descriptor's end: their loads return zero and their stores are dropped without memory traffic
     const bool live_m = (G_NY == 1) ? (4 * blk + bm < a.Ns) : (bm < 3);
-    // inside a tile the 64 doubles are ordered chain-major (chain bm owns one 128-byte line): the line of a chain without a
-    // sample is never fetched - in lane order every line would carry 32 dead bytes and all four would move
-    const unsigned lane8 = live_m ? (unsigned)(bm * 16 + kq * 4 + jq) * 8u : 0x7ffff000u;
+    // inside a pair the 128 doubles are ordered chain-major (chain bm owns two 128-byte lines): the lines of a chain without
+    // a sample are never fetched - in lane order every line would carry 32 dead bytes and all of them would move
+    const unsigned lane16 = live_m ? (unsigned)(bm * 16 + kq * 4 + jq) * 16u : 0x7ffff000u;
     const __amdgpu_buffer_rsrc_t wsr = __builtin_amdgcn_make_buffer_rsrc(wsu, 0, (int)(a.ws_chain_stride * 8), 0x00020000);
+    auto tile_off = [](int e) -> int { return (e >> 1) * 1024 + (e & 1) * 8; };
     auto tile_load = [&](unsigned voff, int e) -> double {
         // sc1 (aux bit 4): served by L2.  A tile row is re-read after this wave has stored into it (rows arrive three at a
         // time, the diagonal tile is rewritten); the CU's L1 keeps the line it fetched BEFORE the store (measured: stale
         // tiles at the third step), and streaming 4x the L1's size per step gains nothing from L1 anyway
-        return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(wsr, voff, e * 512, 16));
+        return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(wsr, voff, tile_off(e), 16));
     };
     auto tile_store = [&](unsigned voff, int e, double v) {
-        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2_v, v), wsr, voff, e * 512, 0);
+        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2_v, v), wsr, voff, tile_off(e), 0);
     };
 
     Parked xP[NX], xiP[D], uP, pP[2], xptP[NPS][D], ucP, dcP;     // state; test point; last input; P0 / P1; the lane's points; U, 1/diag
@@ -572,10 +576,14 @@ __global__ __launch_bounds__(64, 1) void rollout_tiles_kernel(const RolloutArgs 
             //        tiles beyond row nt-1 are requested and never used (inside the wave's workspace) - and early exits only.
             constexpr int TOT = tri(NT), E0 = tri(NRV);
             double ring[RC];
-            auto request = [&](auto loc, auto hic) {              // tiles [lo, hi) of the triangle, clamped to the workspace
-                constexpr int lo = decltype(loc)::value, hi = decltype(hic)::value;
+            auto request = [&](auto loc, auto hic) {              // tile PAIRS of [lo & ~1, hi & ~1), clamped to the workspace
+                constexpr int lo = decltype(loc)::value & ~1, hi = (decltype(hic)::value < TOT ? decltype(hic)::value : TOT) & ~1;
 #pragma unroll
-                for (int e = lo; e < (hi < TOT ? hi : TOT); ++e) ring[e % RC] = tile_load(lane8, e);
+                for (int e = lo; e < hi; e += 2) {
+                    const u32x4_v v = __builtin_amdgcn_raw_buffer_load_b128(wsr, lane16, (e >> 1) * 1024, 16);
+                    ring[e % RC] = __builtin_bit_cast(double, u32x2_v{v.x, v.y});
+                    ring[(e + 1) % RC] = __builtin_bit_cast(double, u32x2_v{v.z, v.w});
+                }
             };
             auto streamed_row = [&](auto rc) {
                 constexpr int r = decltype(rc)::value, base = tri(r), NCH = (r + 11) / 12;
@@ -608,7 +616,7 @@ __global__ __launch_bounds__(64, 1) void rollout_tiles_kernel(const RolloutArgs 
                     if (r < nt) {
                         double cur[r + 1];
 #pragma unroll
-                        for (int p = 0; p <= r; ++p) cur[p] = tile_load(lane8, tri(r) + p);
+                        for (int p = 0; p <= r; ++p) cur[p] = tile_load(lane16, tri(r) + p);
                         double ac[2] = {V[r], 0.0};
                         mfma_rowsum<r, false>(ac, cur, V);
                         const double acc = (r < nt - 1 || accex) ? ac[0] + ac[1] : 0.0;
@@ -642,7 +650,7 @@ __global__ __launch_bounds__(64, 1) void rollout_tiles_kernel(const RolloutArgs 
                     if (part && r == nfull) {
                         double cur[r + 1];
 #pragma unroll
-                        for (int p = 0; p <= r; ++p) cur[p] = tile_load(lane8, tri(r) + p);
+                        for (int p = 0; p <= r; ++p) cur[p] = tile_load(lane16, tri(r) + p);
                         double ac[2] = {V[r], 0.0};
                         mfma_rowsum<r, false>(ac, cur, V);
                         const double acc = accex ? ac[0] + ac[1] : 0.0;
@@ -824,12 +832,15 @@ __global__ __launch_bounds__(64, 1) void rollout_tiles_kernel(const RolloutArgs 
             // which tile row does this lane's new row belong to (columns i0.. stay in tile tn, the wrapped ones open tn+1)
             const bool isnew = jq != ycol;                        // column jq carries the new row (n_h + c), c = (jq - i0) & 3 <= 2
             const int myrow = (jq >= i0) ? tn : tn + 1;
-            const unsigned rowoff = (unsigned)tri(myrow) * 512u + lane8;   // per-lane: the two target tile rows differ
+            const unsigned rowtile = (unsigned)tri(myrow);       // per-lane: the two target tile rows differ
             // off-diagonal tiles against complete old tile rows p < tn: -v
             static_for<0, NT>([&](auto pcn) {
                 constexpr int p = decltype(pcn)::value;
                 if (p < tn) {
-                    if (isnew) tile_store(rowoff, p, -V[p]);
+                    if (isnew) {
+                        const unsigned e = rowtile + p;
+                        tile_store(lane16 + (e >> 1) * 1024u + (e & 1u) * 8u, 0, -V[p]);
+                    }
                 }
             });
             // the tile pairs that involve tile tn itself (old rows of the incomplete tile) and the new tile tn+1
@@ -867,12 +878,12 @@ __global__ __launch_bounds__(64, 1) void rollout_tiles_kernel(const RolloutArgs 
                 TDBG(27, drow);
                 TDBG(28, dcol);
                 TDBG(29, Gt);
-                tile_store(lane8, tri(tn) + tn, Gt);
+                tile_store(lane16, tri(tn) + tn, Gt);
                 double Unext = U, dnext = (kq == jq) ? drow : 0.0;
                 if (wraps) {
                     const double X = entry(tn + 1, tn, Vtn, 0.0);
                     const bool newrow1 = jq <= i0 - 2;            // rows of tile tn+1 that exist now
-                    if (newrow1) tile_store(lane8, tri(tn + 1) + tn, -X);
+                    if (newrow1) tile_store(lane16, tri(tn + 1) + tn, -X);
                     const double U1 = entry(tn + 1, tn + 1, 0.0, 0.0);
                     const double drow1 = diag_scal(tn + 1, 1.0, true), dcol1 = diag_scal(tn + 1, 1.0, false);
                     const double G1 = inverse_tile(U1, drow1, dcol1);
@@ -881,7 +892,7 @@ __global__ __launch_bounds__(64, 1) void rollout_tiles_kernel(const RolloutArgs 
                     TDBG(32, dcol1);
                     TDBG(33, G1);
                     TDBG(34, X);
-                    tile_store(lane8, tri(tn + 1) + tn + 1, G1);
+                    tile_store(lane16, tri(tn + 1) + tn + 1, G1);
                     Unext = U1;
                     dnext = (kq == jq) ? drow1 : 0.0;
                 }
@@ -899,7 +910,7 @@ __global__ __launch_bounds__(64, 1) void rollout_tiles_kernel(const RolloutArgs 
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this lane re-reads only its own slots
                 static_for<0, NRA>([&](auto rc) {
                     constexpr int r = decltype(rc)::value;
-                    if (r == tn) load_row_agpr<r + 1>(wsr, lane8, tri(r) * 512, At + tri(r));   // loads + their wait: one statement
+                    if (r == tn) load_row_agpr<r + 1, (tri(r) & 1)>(wsr, lane16, (tri(r) >> 1) * 1024, At + tri(r));   // loads + their wait: one statement
                 });
             }
             if (i0 >= 1 && tn >= NRA && tn < NRV) {
@@ -908,7 +919,7 @@ __global__ __launch_bounds__(64, 1) void rollout_tiles_kernel(const RolloutArgs 
                     constexpr int r = decltype(rc)::value;
                     if (r == tn) {
 #pragma unroll
-                        for (int p = 0; p <= r; ++p) Bt[tri(r) - tri(NRA) + p] = tile_load(lane8, tri(r) + p);
+                        for (int p = 0; p <= r; ++p) Bt[tri(r) - tri(NRA) + p] = tile_load(lane16, tri(r) + p);
                     }
                 });
             }
