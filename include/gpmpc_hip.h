@@ -224,7 +224,16 @@ int    gpmpc_rollout_seeded(const gpmpc_gp_desc_t* gp, const gpmpc_env_desc_t* e
  *           that h_slots[:n_cached] and their points X_h are the ones of the call that filled it (labels may differ:
  *           the factor does not depend on them) - and every call writes the rows it computed (n_ho <= cache_rows).
  *           Results are bit-identical with and without the cache.
- *   limits: m*T <= 256 and n_ho + 1 + m*T <= 2048 label rows per chain (GPMPC_E_UNSUPPORTED beyond)
+ *           The cache may cover fewer chains than the batch: the host splits the batch into one call over the samples it
+ *           has cache room for and one over the rest (factor_cache NULL); results are the same (a call's chains are
+ *           independent), the caller applies the whole-batch eigh rule across the two calls (root_mode GPMPC_ROOT_EIGH).
+ *   limits (the CONTRACT of this entry point): m*T <= 256 test slots and n_ho + 1 + m*T <= 2048 label rows per chain,
+ *           GPMPC_E_UNSUPPORTED beyond.  In the SQP loop the hallucinated set grows by m*T = H*T slots per iteration and
+ *           is reset at sqp_iter == 0, so a draw is possible for (2048 - 1 - H*T) / (H*T) iterations after a reset: 16 at
+ *           H = 40 (configs[4] as benchmarked), 12 at the shipped H = 50 (reference params_car_residual.yaml:88 allows
+ *           max_sqp_iter 150, which the reference itself cannot reach: its dense re-factorisation grows with the cube of
+ *           the rows; shipped runs use <= 4).  The limit is the one-row-per-thread mapping (four rows per thread beyond
+ *           512 rows); lifting it means tiling the row dimension over a second grid axis and is not done.
  */
 size_t gpmpc_joint_cache_bytes(const gpmpc_gp_desc_t* gp, int64_t Ns, int32_t cache_rows);
 size_t gpmpc_joint_workspace_bytes(const gpmpc_gp_desc_t* gp, int64_t Ns, int32_t n_ho, int32_t m);

@@ -125,7 +125,8 @@ class JointFactorCache:
     at the previous call are reused.  The façade vouches for validity by comparing the current slot list and the points of
     the cached rows with a snapshot taken when they were written (the factor does not depend on the labels)."""
 
-    MAX_BYTES = 24 << 30          # do not cache beyond this (the per-GPU shard of BASELINE configs[4] needs ~7 GB)
+    MAX_BYTES = 24 << 30          # cache budget (the per-GPU shard of BASELINE configs[4] needs ~7 GB); a batch that needs
+                                  # more caches the factor rows of a PREFIX of its samples (``n_samples``), the others recompute
 
     def __init__(self):
         self.buf = None
@@ -134,6 +135,7 @@ class JointFactorCache:
         self.slots = None             # int32 device tensor: the slots whose rows are valid
         self.Xbuf = None              # (Ns, g_ny, rows, D) snapshot buffer of the points behind them, n_pts of it in use
         self.n_pts = 0
+        self.n_samples = 0            # samples whose chains are cached (== Ns unless the budget is too small for all)
         self.enabled = True
 
     def invalidate(self):
@@ -153,13 +155,18 @@ class JointFactorCache:
         key = (Ns, hy.g_ny, mdl.plan.n_r, hy.T, mdl.plan.version)
         if self.buf is None or key != self.key or n_ho > self.rows:
             # the set grows by the same number of slots every SQP iteration: room for four of them where that fits
+            n_samp = Ns
             for mult in (4.0, 2.0, 1.25):
                 rows = min(MAX_JOINT_ROWS, max(256, -(-int(mult * n_ho) // 128) * 128))
                 nbytes = lib.gpmpc_joint_cache_bytes(mdl.plan.desc, Ns, rows)
                 if 0 < nbytes <= self.MAX_BYTES:
                     break
-            if nbytes == 0 or nbytes > self.MAX_BYTES:
-                self.buf, self.rows, self.key = None, 0, None
+            if nbytes > self.MAX_BYTES:                                        # not for every sample: a prefix of them
+                per_sample = lib.gpmpc_joint_cache_bytes(mdl.plan.desc, 1, rows)
+                n_samp = int(self.MAX_BYTES // per_sample) if per_sample > 0 else 0
+                nbytes = lib.gpmpc_joint_cache_bytes(mdl.plan.desc, n_samp, rows) if n_samp > 0 else 0
+            if nbytes == 0:
+                self.buf, self.rows, self.key, self.n_samples = None, 0, None, 0
                 self.invalidate()
                 return None, 0, 0
             had = self.buf is not None
@@ -167,7 +174,8 @@ class JointFactorCache:
             if had and mdl.plan.X_r.is_cuda:
                 torch.cuda.empty_cache()
             self.buf = torch.empty(nbytes // 8, dtype=F64, device=mdl.plan.X_r.device)
-            self.Xbuf = torch.empty(Ns, hy.g_ny, rows, hy.D, dtype=F64, device=mdl.plan.X_r.device)
+            self.Xbuf = torch.empty(n_samp, hy.g_ny, rows, hy.D, dtype=F64, device=mdl.plan.X_r.device)
+            self.n_samples = n_samp
             self.rows, self.key = rows, key
             self.invalidate()
         n_c = 0
@@ -175,7 +183,7 @@ class JointFactorCache:
             n_old, n_pts = int(self.slots.numel()), self.n_pts
             # append-only growth: the old slot list is a prefix of the new one and the points it was built on are unchanged
             if n_old <= n_ho and n_pts <= mdl.n_h and bool(torch.equal(mdl.h_slots[:n_old], self.slots)) \
-                    and bool(torch.equal(mdl.hall_X[:, :, :n_pts], self.X)):
+                    and bool(torch.equal(mdl.hall_X[:self.n_samples, :, :n_pts], self.X)):
                 n_c = n_old
         return self.buf, self.rows, n_c
 
@@ -198,7 +206,7 @@ class JointFactorCache:
             return                                                 # nothing new was written (mean- / covariance-only repeats)
         # `prepare` has just verified the first n_pts points against the snapshot: only the appended ones are copied
         keep = self.n_pts if (self.slots is not None and n_cached > 0) else 0
-        self.Xbuf[:, :, keep:mdl.n_h] = mdl.hall_X[:, :, keep:]
+        self.Xbuf[:, :, keep:mdl.n_h] = mdl.hall_X[:self.n_samples, :, keep:]
         self.n_pts = mdl.n_h
         self.slots = mdl.h_slots[:n_ho].clone()
 
@@ -245,14 +253,34 @@ class HipPosterior:
         ws = mdl._workspace(ws_bytes)
         fcache = mdl._ws_cache.setdefault("joint_factor_cache", JointFactorCache())
         fbuf, frows, n_c = fcache.prepare(mdl, Ns, n_ho)
-        rc = lib.gpmpc_joint_sample(
-            mdl.plan.desc, _lib.dptr(mdl.plan.buf), _lib.dptr(mdl.plan.X_r), Ns, mdl.n_h,
-            _lib.dptr(mdl.hall_X) if mdl.n_h else None, _lib.dptr(mdl.hall_Y) if mdl.n_h else None,
-            _lib.dptr(mdl.h_slots) if n_ho else None, n_ho, m, _lib.dptr(self._x), _lib.dptr(z),
-            float(var_zero_thr), float(beta), int(bool(clip)), _lib.dptr(mean), _lib.dptr(var), _lib.dptr(y),
-            _lib.dptr(covar), _lib.dptr(root), int(root_mode), _lib.dptr(info), _lib.dptr(ws), ws.numel() * 8,
-            _lib.current_stream_ptr(), _lib.dptr(fbuf), int(frows), int(n_c))
-        _lib.check(rc, "gpmpc_joint_sample")
+        n_cs = fcache.n_samples if fbuf is not None else Ns       # samples [0, n_cs) use the cache, the rest recompute
+
+        def call(lo, hi, cache, mode):
+            sl = lambda t: None if t is None else t[lo:hi]
+            _lib.check(lib.gpmpc_joint_sample(
+                mdl.plan.desc, _lib.dptr(mdl.plan.buf), _lib.dptr(mdl.plan.X_r), hi - lo, mdl.n_h,
+                _lib.dptr(sl(mdl.hall_X)) if mdl.n_h else None, _lib.dptr(sl(mdl.hall_Y)) if mdl.n_h else None,
+                _lib.dptr(mdl.h_slots) if n_ho else None, n_ho, m, _lib.dptr(sl(self._x)), _lib.dptr(sl(z)),
+                float(var_zero_thr), float(beta), int(bool(clip)), _lib.dptr(sl(mean)), _lib.dptr(sl(var)), _lib.dptr(sl(y)),
+                _lib.dptr(sl(covar)), _lib.dptr(sl(root)), int(mode), _lib.dptr(sl(info)), _lib.dptr(ws), ws.numel() * 8,
+                _lib.current_stream_ptr(), _lib.dptr(fbuf) if cache else None, int(frows) if cache else 0,
+                int(n_c) if cache else 0), "gpmpc_joint_sample")
+
+        if n_cs >= Ns:
+            call(0, Ns, fbuf is not None, root_mode)
+        else:
+            # The cache holds a prefix of the samples: two launches.  "One chain failed every retry => the WHOLE batch takes
+            # the eigendecomposition root" (A.7 step 4) spans both: the part that did not fall back by itself is redrawn.
+            call(0, n_cs, True, root_mode)
+            call(n_cs, Ns, False, root_mode)
+            if root_mode == _lib.ROOT_AUTO and m * hy.T > 1:
+                e = [bool(_or_reduce(info[a:b]) & _lib.INFO_ROOT_EIGH) for a, b in ((0, n_cs), (n_cs, Ns))]
+                if e[0] != e[1]:
+                    if e[0]:
+                        call(n_cs, Ns, False, _lib.ROOT_EIGH)
+                    else:
+                        info[:n_cs] = 0
+                        call(0, n_cs, True, _lib.ROOT_EIGH)
         self.n_cached_rows = n_c
         self._mean, self._var = mean, var
         if want_covar:

@@ -71,8 +71,10 @@ def test_closed_loop_as_shipped_car_runs_the_eigh_root(sg):
     print("as shipped car closed loop: GP side per SQP iteration (ms):", [round(t, 2) for t in loop.solver.gp_ms])
 
 
-@pytest.mark.parametrize("pname,Ns,H", [("params_pendulum1D_samples", 5, 30), ("params_car_residual", 4, 40)])
-def test_joint_factor_cache_is_bit_exact_and_used(sg, pname, Ns, H):
+@pytest.mark.parametrize("pname,Ns,H,budget", [("params_pendulum1D_samples", 5, 30, None), ("params_car_residual", 4, 40, None),
+                                                ("params_car_residual", 5, 40, 0.5),        # room for 2 of 5 samples only
+                                                ("params_pendulum1D_samples", 7, 30, 0.3)])         # all samples while the set is small, then 3 of 7
+def test_joint_factor_cache_is_bit_exact_and_used(sg, pname, Ns, H, budget):
     """The factor cache of gpmpc_joint_sample: between two resets the hallucinated set only grows, so the rows of the slots
     that were already there are reused (the reference re-factorises everything on every call).  Two MPC steps x four SQP
     iterations with and without the cache: bit-identical Jacobians; the cache is hit at k >= 1 and at k = 0 of the second
@@ -85,9 +87,15 @@ def test_joint_factor_cache_is_bit_exact_and_used(sg, pname, Ns, H):
     off = JointFactorCache()
     off.enabled = False
     plain._ws_cache["joint_factor_cache"] = off
+    if budget is not None:
+        # a budget too small for the batch: the factor rows of a PREFIX of the samples are cached, the draw is two launches
+        # (car as shipped: the eigh-for-the-whole-batch rule spans both)
+        small = JointFactorCache()
+        small.MAX_BYTES = int(budget * sg._lib.load().gpmpc_joint_cache_bytes(agent._plan(use_grad=True).desc, Ns, 512))
+        agent._ws_cache["joint_factor_cache"] = small
     x0 = np.array(p["env"]["start"], dtype=np.float64)[: agent.nx]
     u_h = np.zeros((H, agent.nu))
-    hits = []
+    hits, cached_samples = [], []
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
         for step in range(2):
@@ -101,15 +109,26 @@ def test_joint_factor_cache_is_bit_exact_and_used(sg, pname, Ns, H):
                 for u, v in zip(*outs):
                     np.testing.assert_array_equal(u, v)
                 hits.append(agent.model_i_call.n_cached_rows)
+                cached_samples.append(agent._ws_cache["joint_factor_cache"].n_samples)
                 assert plain.model_i_call.n_cached_rows == 0
                 mean_next = outs[0][0][:, :, :, 0].mean(axis=0).T
                 x_h = np.tile(np.vstack([x0[None, :], mean_next[:-1]]), (1, Ns))
         T = 3
-        print(f"{pname}: cached rows per call {hits}")
+        fc = agent._ws_cache["joint_factor_cache"]
+        print(f"{pname}: cached rows per call {hits}; samples cached {fc.n_samples} of {Ns}")
+        if budget is None:
+            assert fc.n_samples == Ns
+        else:
+            per_sample = sg._lib.load().gpmpc_joint_cache_bytes(agent.model_i.plan.desc, 1, fc.rows)
+            assert 0 < fc.n_samples < Ns and fc.n_samples == fc.MAX_BYTES // per_sample
         assert hits[0] == 0 and hits[1] == 0                         # k = 0: empty set; k = 1: its rows are new
-        assert hits[2] == H * T and hits[3] == 2 * H * T
-        assert hits[4] == 3 * H * T                                  # next MPC step, k = 0: the pre-reset set
-        assert hits[5] == 0                                          # after the reset: other points
+        if budget is None:
+            assert hits[2] == H * T and hits[3] == 2 * H * T
+            assert hits[4] == 3 * H * T                              # next MPC step, k = 0: the pre-reset set
+            assert hits[5] == 0                                      # after the reset: other points
+        else:                                                        # (a buffer that had to grow starts empty: fewer hits)
+            print(f"samples cached per call {cached_samples}")
+            assert any(h > 0 and c < Ns for h, c in zip(hits, cached_samples)), "the prefix cache was never hit"
         # changing a cached point (survivor replacement does that) invalidates the cache
         agent.Hallcinated_X_train[0, :, 0, :] += 1e-3
         plain.Hallcinated_X_train[0, :, 0, :] += 1e-3
