@@ -98,6 +98,9 @@ __device__ long long g_joint_phase[16];
 #define GPMPC_JOINT_NB 16          // pivot columns per block of the launches of <= 256 rows (experiment knob; 24 at three waves per
                                    // SIMD measured: car k=0 / k=2 2.47 / 6.85 ms against 2.47 / 6.97, pendulum k=1 1.12 against 0.83)
 #endif
+#ifndef GPMPC_JOINT_S_MFMA_MIN
+#define GPMPC_JOINT_S_MFMA_MIN 128       // conditioning slots from which S -= V V^T runs on the matrix pipe (1 << 30: never)
+#endif
 #ifndef GPMPC_JOINT_LDS_BCAST
 #define GPMPC_JOINT_LDS_BCAST 0          // 1: the broadcast-ds_read_b128 update (comparison builds, tools/joint_sweep.sh)
 #endif
@@ -310,6 +313,77 @@ __device__ __forceinline__ void block_solve(const double (&acc)[NB], double (&x)
         x[q] = (q < nb && q <= qmax) ? v * dinv[q] : 0.0;
         // row q of blk is consumed before row q+1 is read: otherwise all NB(NB-1)/2 broadcast reads are hoisted (spills)
         asm volatile("" : "+v"(x[q]) : : "memory");
+    }
+}
+
+// S -= V V^T on the FP64 matrix pipe (lower triangle; S column-major mT x mT, V[t][k] at Vt[k * ld + t], k < n_o).
+// The VALU form streams every test row once per 16-column block of S with half-rate DPP broadcasts and keeps only the
+// waves that own test rows busy; here the workgroup's waves split S into 16-row tile columns (column J together with
+// column np-1-J: equal work), a wave holds the <= CH tiles of a column segment in 8 CH accumulator registers and reads the
+// column's 16 rows once plus each tile's 16 rows per 4 conditioning slots: ~1.1 fragment loads (512 B) per
+// v_mfma_f64_16x16x4_f64 (2048 FLOP).  Fragment layout as in eigh_gram: A[i][k], B[k][j] at lane (i | j) + 16 k,
+// D[4 v + (lane >> 4)][lane & 15].  A = the column's rows, B = the tile's rows, so that D's lane index runs along the rows
+// of S (coalesced update).
+template <int NT, int CH>
+__device__ __forceinline__ void syrk_lower_mfma(const double* __restrict__ Vt, int ld, int n_o, int mT, double* __restrict__ Sm) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    constexpr int nw = NT / 64;
+    const int np = (mT + 15) >> 4;
+    const int jl = lane & 15, kr = lane >> 4;
+    for (int q = wave; 2 * q < np; q += nw) {
+        for (int side = 0; side < 2; ++side) {
+            const int J = side ? np - 1 - q : q;
+            if (side && J == q) break;                            // odd np: the middle column once
+            const int rj = J * 16 + jl;
+            const bool vj = rj < mT;
+            for (int I0 = J; I0 < np; I0 += CH) {
+                // the accumulators START at K** and the products are subtracted from them (A holds -V): where the posterior is
+                // nearly degenerate the running value shrinks towards S as it does in the sequential VALU form, instead of
+                // forming V V^T ~ K** first and cancelling at the end
+                double4_e acc[CH];
+                const int nti = min(CH, np - I0);
+#pragma unroll
+                for (int u = 0; u < CH; ++u) {
+                    const int row = (I0 + u) * 16 + jl;
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) {
+                        const int colS = J * 16 + kr + 4 * v;
+                        acc[u][v] = (u < nti && row >= colS && row < mT && colS < mT) ? Sm[(long)colS * mT + row] : 0.0;
+                    }
+                }
+                for (int k0 = 0; k0 < n_o; k0 += 8) {
+                    double af[2], bf[2][CH];
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const int k = k0 + 4 * h + kr;
+                        const bool vk = k < n_o;
+                        const double* col = Vt + (long)(vk ? k : 0) * ld;
+                        af[h] = (vk && vj) ? -col[rj] : 0.0;
+#pragma unroll
+                        for (int u = 0; u < CH; ++u) {
+                            const int ri = (I0 + u) * 16 + jl;
+                            bf[h][u] = (u < nti && vk && ri < mT) ? col[ri] : 0.0;
+                        }
+                    }
+#pragma unroll
+                    for (int h = 0; h < 2; ++h)
+#pragma unroll
+                        for (int u = 0; u < CH; ++u)
+                            if (u < nti) acc[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[h], bf[h][u], acc[u], 0, 0, 0);
+                }
+#pragma unroll
+                for (int u = 0; u < CH; ++u) {
+                    if (u < nti) {
+                        const int row = (I0 + u) * 16 + jl;       // D's lane index: the row of S
+#pragma unroll
+                        for (int v = 0; v < 4; ++v) {
+                            const int colS = J * 16 + kr + 4 * v;
+                            if (row >= colS && row < mT && colS < mT) Sm[(long)colS * mT + row] = acc[u][v];
+                        }
+                    }
+                }
+            }
+        }
     }
 }
 
@@ -578,6 +652,10 @@ __global__ __launch_bounds__(NT, WPE) void joint_kernel(const JointArgs a) {
                 if (tau < mT) muv[tau] = -accw[rs][0];
             }
         }
+        // S = K** - V V^T.  Short conditioning sets: the blocked VALU update, one pass per column block (closed-loop k = 0:
+        // 0.84 ms against 0.92 with the matrix-pipe form, whose set-up is per tile); from GPMPC_JOINT_S_MFMA_MIN slots on the
+        // kernel entries only are formed here and V V^T comes off them on the matrix pipe (k = 3: 8.07 against 8.35 ms)
+        const bool s_mfma = n_o >= GPMPC_JOINT_S_MFMA_MIN;
         for (int c0 = 0; c0 < mT; c0 += NB) {
             const int nb = min(NB, mT - c0);
             double acc[RPT][NB];
@@ -603,7 +681,7 @@ __global__ __launch_bounds__(NT, WPE) void joint_kernel(const JointArgs a) {
                 (void)row;
             }
             // rows are offset by trow0 inside M: shift the base pointer so that "row" == test slot index
-            block_update<NB, RPT, KC, NT>(M + trow0, ld, n_o, M + trow0 + c0, 1, ld, nb, c0, mT, acc, piv);
+            if (!s_mfma) block_update<NB, RPT, KC, NT>(M + trow0, ld, n_o, M + trow0 + c0, 1, ld, nb, c0, mT, acc, piv);
 #pragma unroll
             for (int rs = 0; rs < RPT; ++rs) {
                 const int t1 = tid + rs * nt;
@@ -615,6 +693,10 @@ __global__ __launch_bounds__(NT, WPE) void joint_kernel(const JointArgs a) {
             }
         }
         __syncthreads();
+        if (s_mfma) {                                             // K** is in Sm: subtract V V^T, all waves of the workgroup
+            syrk_lower_mfma<NT, (WPE >= 4) ? 4 : 8>(M + trow0, ld, n_o, mT, Sm);
+            __syncthreads();
+        }
 
         JPH(5);
         // ---- root: blocked Cholesky of S with the jitter-on-failure chain (A.7) -----------------------------------
