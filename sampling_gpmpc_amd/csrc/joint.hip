@@ -324,7 +324,7 @@ __device__ __forceinline__ void block_solve(const double (&acc)[NB], double (&x)
 // v_mfma_f64_16x16x4_f64 (2048 FLOP).  Fragment layout as in eigh_gram: A[i][k], B[k][j] at lane (i | j) + 16 k,
 // D[4 v + (lane >> 4)][lane & 15].  A = the column's rows, B = the tile's rows, so that D's lane index runs along the rows
 // of S (coalesced update).
-template <int NT, int CH>
+template <int NT, int CH, bool DBUF>
 __device__ __forceinline__ void syrk_lower_mfma(const double* __restrict__ Vt, int ld, int n_o, int mT, double* __restrict__ Sm) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     constexpr int nw = NT / 64;
@@ -351,8 +351,10 @@ __device__ __forceinline__ void syrk_lower_mfma(const double* __restrict__ Vt, i
                         acc[u][v] = (u < nti && row >= colS && row < mT && colS < mT) ? Sm[(long)colS * mT + row] : 0.0;
                     }
                 }
-                for (int k0 = 0; k0 < n_o; k0 += 8) {
-                    double af[2], bf[2][CH];
+                // fragments of 8 conditioning slots per step, double buffered: the next step's loads are in flight while this
+                // step's MFMAs run (one wave per SIMD works here and M streams from HBM/L2: undivided, every step would pay
+                // the full load latency)
+                auto load_frags = [&](int k0, double (&af)[2], double (&bf)[2][CH]) {
 #pragma unroll
                     for (int h = 0; h < 2; ++h) {
                         const int k = k0 + 4 * h + kr;
@@ -365,11 +367,29 @@ __device__ __forceinline__ void syrk_lower_mfma(const double* __restrict__ Vt, i
                             bf[h][u] = (u < nti && vk && ri < mT) ? col[ri] : 0.0;
                         }
                     }
+                };
+                auto run_frags = [&](const double (&af)[2], const double (&bf)[2][CH]) {
 #pragma unroll
                     for (int h = 0; h < 2; ++h)
 #pragma unroll
                         for (int u = 0; u < CH; ++u)
                             if (u < nti) acc[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[h], bf[h][u], acc[u], 0, 0, 0);
+                };
+                if constexpr (DBUF) {
+                    double af0[2], bf0[2][CH], af1[2], bf1[2][CH];
+                    load_frags(0, af0, bf0);
+                    for (int k0 = 0; k0 < n_o; k0 += 16) {
+                        load_frags(k0 + 8, af1, bf1);             // beyond n_o: zeros
+                        run_frags(af0, bf0);
+                        load_frags(k0 + 16, af0, bf0);
+                        run_frags(af1, bf1);
+                    }
+                } else {                                          // 128-register kernels: a second buffer spills
+                    for (int k0 = 0; k0 < n_o; k0 += 8) {
+                        double af0[2], bf0[2][CH];
+                        load_frags(k0, af0, bf0);
+                        run_frags(af0, bf0);
+                    }
                 }
 #pragma unroll
                 for (int u = 0; u < CH; ++u) {
@@ -655,7 +675,8 @@ __global__ __launch_bounds__(NT, WPE) void joint_kernel(const JointArgs a) {
         // S = K** - V V^T.  Short conditioning sets: the blocked VALU update, one pass per column block (closed-loop k = 0:
         // 0.84 ms against 0.92 with the matrix-pipe form, whose set-up is per tile); from GPMPC_JOINT_S_MFMA_MIN slots on the
         // kernel entries only are formed here and V V^T comes off them on the matrix pipe (k = 3: 8.07 against 8.35 ms)
-        const bool s_mfma = n_o >= GPMPC_JOINT_S_MFMA_MIN;
+        // (the 128-thread kernel only ever sees <= 7 hallucinated slots: it keeps the VALU form and its register allocation)
+        const bool s_mfma = NT >= 256 && n_o >= GPMPC_JOINT_S_MFMA_MIN;
         for (int c0 = 0; c0 < mT; c0 += NB) {
             const int nb = min(NB, mT - c0);
             double acc[RPT][NB];
@@ -693,9 +714,11 @@ __global__ __launch_bounds__(NT, WPE) void joint_kernel(const JointArgs a) {
             }
         }
         __syncthreads();
-        if (s_mfma) {                                             // K** is in Sm: subtract V V^T, all waves of the workgroup
-            syrk_lower_mfma<NT, (WPE >= 4) ? 4 : 8>(M + trow0, ld, n_o, mT, Sm);
-            __syncthreads();
+        if constexpr (NT >= 256) {
+            if (s_mfma) {                                         // K** is in Sm: subtract V V^T, all waves of the workgroup
+                syrk_lower_mfma<NT, (WPE >= 4) ? 4 : 8, (WPE < 4)>(M + trow0, ld, n_o, mT, Sm);
+                __syncthreads();
+            }
         }
 
         JPH(5);
