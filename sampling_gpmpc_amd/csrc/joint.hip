@@ -48,7 +48,7 @@ struct JointArgs {
     double* ws;
     long ws_chain_stride;   // doubles
     int ld;                 // rows of M (padded)
-    double* Sall;           // [chains][mT*mT] posterior covariance, column-major, lower part valid
+    double* Sall;           // [chains][mT*mT] posterior covariance, column-major, both triangles written
     int* any_fail;          // set when a chain's jitter chain failed (read by joint_eigh_kernel)
     // factor cache (caller-owned, persists between calls): per chain the hallucinated rows of the factor, row-major
     // [rows_cap][fc_cs] (columns: real slots, then hallucinated slots; the diagonal blocks as block_factor left them) and
@@ -398,7 +398,10 @@ __device__ __forceinline__ void syrk_lower_mfma(const double* __restrict__ Vt, i
 #pragma unroll
                         for (int v = 0; v < 4; ++v) {
                             const int colS = J * 16 + kr + 4 * v;
-                            if (row >= colS && row < mT && colS < mT) Sm[(long)colS * mT + row] = acc[u][v];
+                            if (row >= colS && row < mT && colS < mT) {
+                                Sm[(long)colS * mT + row] = acc[u][v];
+                                Sm[(long)row * mT + colS] = acc[u][v];   // mirror: joint_eigh_kernel reads whole columns
+                            }
                         }
                     }
                 }
@@ -709,7 +712,11 @@ __global__ __launch_bounds__(NT, WPE) void joint_kernel(const JointArgs a) {
                 if (t1 >= c0 && t1 < mT) {
 #pragma unroll
                     for (int q = 0; q < NB; ++q)
-                        if (q < nb) Sm[(long)(c0 + q) * mT + t1] = acc[rs][q];
+                        if (q < nb) {
+                            Sm[(long)(c0 + q) * mT + t1] = acc[rs][q];
+                            // mirror (the final values only): joint_eigh_kernel reads whole columns of S, coalesced
+                            if (!s_mfma && t1 > c0 + q) Sm[(long)t1 * mT + c0 + q] = acc[rs][q];
+                        }
                 }
             }
         }

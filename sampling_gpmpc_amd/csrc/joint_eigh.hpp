@@ -44,7 +44,7 @@ struct EighArgs {
     const double* var;
     double* y;
     int* info;
-    const double* Sall;      // [chains][n*n]  column-major, lower part valid
+    const double* Sall;      // [chains][n*n]  column-major, both triangles valid (joint_kernel mirrors the lower one)
     const int* any_fail;     // device flag set by joint_kernel when a chain's jitter chain failed
     int force;
     double* ws;              // per slot: L [n*n] | 2 x packed G [np*(np+1)/2] | rotation log [EIGH_MAX_SWEEPS/2 * np*np]
@@ -66,7 +66,10 @@ constexpr int EIGH_MAX_SWEEPS = 16;
 constexpr double EIGH_TINY_ROT = 1e-8; // a sweep whose largest rotation tangent is below this is the last one
 constexpr int EIGH_LDS_RANK = 64;      // packed 64 x 64 Gram matrix = 16.6 KB of LDS per chain: ~7 chains per CU
 constexpr int EIGH_PB = 8;             // candidate pivots per pass of the pivoted Cholesky
-constexpr double EIGH_PIVOT_THRESHOLD = 1.0 / 16.0;   // accepted pivot >= this x the largest residual diagonal left
+#ifndef GPMPC_EIGH_PIVOT_THRESHOLD
+#define GPMPC_EIGH_PIVOT_THRESHOLD (1.0 / 16.0)
+#endif
+constexpr double EIGH_PIVOT_THRESHOLD = GPMPC_EIGH_PIVOT_THRESHOLD;   // accepted pivot >= this x the largest residual diagonal left
 constexpr int EIGH_MAXIT = 8;          // off-diagonal 2x2 blocks per lane at the LDS rank cap: 16 * 32 / 64
 
 typedef double double4_e __attribute__((ext_vector_type(4)));
@@ -465,7 +468,7 @@ __global__ __launch_bounds__(64, 2) void joint_eigh_kernel(const EighArgs a) {
 #pragma unroll
                 for (int c = 0; c < EIGH_PB; ++c) {
                     const int p = cand[c];
-                    acc[i][c] = (c < nc) ? ((t >= p) ? Sm[(long)p * n + t] : Sm[(long)t * n + p]) : 0.0;
+                    acc[i][c] = (c < nc) ? Sm[(long)p * n + t] : 0.0;     // joint_kernel mirrors S: a column is contiguous
                 }
             }
             // minus the previous columns: chunks of 32 columns, the candidates' rows of L staged in LDS ([column][cand])
