@@ -926,6 +926,15 @@ int gpmpc_debug_read_joint_phases(long long* out /*[host] 16*/) {
     return GPMPC_OK;
 }
 
+int gpmpc_debug_read_eigh_work(unsigned long long* out /*[host] 4*/, int reset) {
+    GPMPC_HIP_CHECK(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_eigh_work), 4 * sizeof(unsigned long long)));
+    if (reset) {
+        const unsigned long long zero[4] = {0, 0, 0, 0};
+        GPMPC_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_eigh_work), zero, sizeof(zero)));
+    }
+    return GPMPC_OK;
+}
+
 int gpmpc_debug_read_eigh_phases(long long* out /*[host] 8*/) {
     GPMPC_HIP_CHECK(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_eigh_phase), 8 * sizeof(long long)));
     return GPMPC_OK;

@@ -56,6 +56,11 @@ struct EighArgs {
 
 __device__ long long g_eigh_phase[8];
 __device__ int g_eigh_stat[4];         // phase-timer builds: max rank, chains on the HBM/L2 path
+// work the eigh kernel actually did since the last reset (bench.py's roofline sub-object): FLOP, chains, sum of ranks, sum of
+// sweeps.  Two atomics per chain.  FLOP = pivoted Cholesky passes (2 n per candidate and previous column, 2 n per accepted
+// pivot and remaining candidate) + Gram tiles (2048 per MFMA issued) + Jacobi (per round: rp/2 rotations of ~30 and
+// (rp/2)^2 two-sided 2x2 block updates of 24) + replay (6 per pair and round) + y = mean + L t (2 n r)
+__device__ unsigned long long g_eigh_work[4];
 #ifdef GPMPC_PHASE_TIMERS
 #define EPH(idx) do { const long long _n = __builtin_readcyclecounter(); eph[idx] += _n - et; et = _n; } while (0)
 #else
@@ -427,6 +432,7 @@ __global__ __launch_bounds__(64, 2) void joint_eigh_kernel(const EighArgs a) {
             pivoted[i] = !(t < n);
         }
         int r = 0;
+        unsigned long long work = 0;                             // FLOP of this chain (see g_eigh_work)
         while (r < n) {
             // candidates: repeated arg max; the row index rides in the low mantissa byte (ties -> lowest row)
             bool taken[RPL];
@@ -503,6 +509,7 @@ __global__ __launch_bounds__(64, 2) void joint_eigh_kernel(const EighArgs a) {
                     }
                 }
             }
+            work += 2ull * n * nc * r;
             // eliminate the candidates against each other, greedily by their current residual
             unsigned used = 0;
             for (int q = 0; q < nc; ++q) {
@@ -570,6 +577,7 @@ __global__ __launch_bounds__(64, 2) void joint_eigh_kernel(const EighArgs a) {
                         for (int i = 0; i < RPL; ++i) acc[i][c] = fma(-col[i], lpc, acc[i][c]);
                     }
                 }
+                work += 2ull * n * nc;
                 ++r;
             }
         }
@@ -606,6 +614,13 @@ __global__ __launch_bounds__(64, 2) void joint_eigh_kernel(const EighArgs a) {
                 for (int i = lane; i < r; i += 64) e_y[i] = Gc[tri_idx(i, i, rp)];
             }
             if (!conv) info |= GPMPC_INFO_EIGH_NOCONV;
+            {
+                const unsigned long long nt16 = (rp + 15) / 16, kst = (n + 15) / 16 * 4, hh = rp / 2;
+                work += nt16 * (nt16 + 1) / 2 * kst * 2048ull;                              // Gram
+                work += (unsigned long long)sweeps * (rp - 1) * (hh * 30ull + hh * hh * 24ull + hh * 6ull);   // Jacobi + replay
+                work += 2ull * n * r;
+                if (lane == 0) atomicAdd(&g_eigh_work[3], (unsigned long long)sweeps);
+            }
             EPH(2);
 #ifdef GPMPC_PHASE_TIMERS
             eph[6] = sweeps;
@@ -699,7 +714,12 @@ __global__ __launch_bounds__(64, 2) void joint_eigh_kernel(const EighArgs a) {
             g_eigh_phase[4] = g_eigh_stat[0] * 100000LL + g_eigh_stat[1];
         }
 #endif
-        if (lane == 0) a.info[chain] |= info;
+        if (lane == 0) {
+            a.info[chain] |= info;
+            atomicAdd(&g_eigh_work[0], work);
+            atomicAdd(&g_eigh_work[1], 1ull);
+            atomicAdd(&g_eigh_work[2], (unsigned long long)r);
+        }
         __syncthreads();
     }
 }
