@@ -231,22 +231,24 @@ class Agent(object):
     def get_batch_x_hat_u_diff(self, x_h, u_h):
         """x_h (H, Ns*nx), u_h (H, Ns, nu) -> (Ns, nx, H, nx+nu), state row replicated nx times (:480-501)."""
         H = self.params["optimizer"]["H"]
-        x_h = torch.as_tensor(x_h, dtype=F64)
-        u_h = torch.as_tensor(u_h, dtype=F64)
+        # the (H, Ns*nx) / (H, Ns, nu) iterates go to the device as they are; the nx-fold replication happens there (the
+        # replicated tensor is nx times the bytes: 8 MB over PCIe per SQP iteration at the configs[4] shard)
+        x_h = torch.as_tensor(x_h, dtype=F64).to(self.torch_device)
+        u_h = torch.as_tensor(u_h, dtype=F64).to(self.torch_device)
         xb = x_h.transpose(0, 1).reshape(self.ns, self.nx, H).transpose(1, 2)
         ub = u_h.transpose(0, 1).reshape(self.ns, H, self.nu)
         ret = torch.cat([xb, ub], 2)
-        return torch.stack([ret] * self.nx, dim=1).to(self.torch_device)
+        return ret.unsqueeze(1).expand(-1, self.nx, -1, -1).contiguous()
 
     def get_batch_x_hat(self, x_h, u_h):
         """x_h (H, Ns*nx), u_h (H, nu) shared by all samples -> (Ns, nx, H, nx+nu)   (:503-527)."""
         H = self.params["optimizer"]["H"]
-        x_h = torch.as_tensor(x_h, dtype=F64)
-        u_h = torch.as_tensor(u_h, dtype=F64)
+        x_h = torch.as_tensor(x_h, dtype=F64).to(self.torch_device)
+        u_h = torch.as_tensor(u_h, dtype=F64).to(self.torch_device)
         xb = x_h.transpose(0, 1).reshape(self.ns, self.nx, H).transpose(1, 2)
-        ub = torch.ones(self.ns, H, 1, dtype=F64) * u_h
+        ub = torch.ones(self.ns, H, 1, dtype=F64, device=self.torch_device) * u_h
         ret = torch.cat([xb, ub], 2)
-        return torch.stack([ret] * self.nx, dim=1).to(self.torch_device)
+        return ret.unsqueeze(1).expand(-1, self.nx, -1, -1).contiguous()
 
     # ---------------------------------------------------------------------------------------------------------
     # GP (device)
