@@ -242,6 +242,7 @@ __global__ __launch_bounds__(64, 1) void rollout_tiles_kernel(const RolloutArgs 
 #endif
     using L = TilesLds<N0, N1>;
     static_assert(N0 + N1 <= 16 && NE <= 4 && NT % 8 == 0 && NT > NRA, "grid / tile limits");
+    static_assert(RC >= 16 && RC % 2 == 0, "the ring holds a statement's 12 tiles + the diagonal tile, requested in pairs");
     extern __shared__ __attribute__((aligned(16))) double smem[];
 
     const GpParams& gp = a.gp;
