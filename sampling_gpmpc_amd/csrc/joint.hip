@@ -20,6 +20,7 @@
 //   * root = Cholesky of S with the jitter-on-failure chain (A.7), y = mean + R z, post-processing of sample_gp.
 //   * S is left in a per-chain buffer: when any chain of the batch fails all retries, joint_eigh_kernel
 //     (joint_eigh.hpp, launched right behind this kernel) redraws the whole batch with the eigendecomposition root.
+#include <type_traits>
 #include "gpmpc_host.hpp"
 #include "joint_eigh.hpp"
 
@@ -269,6 +270,19 @@ __device__ __forceinline__ void block_update(const double* __restrict__ W, int l
 // Factor the nb x nb diagonal block held (lower part) in blk; LAPACK failure rule; result, 1/diag and flag via LDS.
 // Executed by ONE WAVE (lane = row, the row lives in registers, row j is broadcast with v_readlane): a single thread
 // walking the block through LDS costs ~70k cycles per block (dependent ~100-cycle LDS reads), this ~5k.
+// sacc -= r_k(lane j) * r_k(this lane): lane j's entry comes through the DPP (lane J of the reader's 16-lane row), no SGPR trip
+// (s_nop 1: a VGPR written by the VALU may be read through the DPP two wait states later, and hipcc pads nothing inside asm)
+template <int J>
+__device__ __forceinline__ void fmac_neg_bcast(double& sacc, double rk) {
+    asm("s_nop 1\n\tv_fmac_f64_dpp %0, %1, -%1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "+v"(sacc) : "v"(rk), "n"(J));
+}
+template <int B, int E, class F>
+__device__ __forceinline__ void jstatic_for(F&& f) {
+    if constexpr (B < E) {
+        f(std::integral_constant<int, B>{});
+        jstatic_for<B + 1, E>(f);
+    }
+}
 template <int NB>
 __device__ __forceinline__ void block_factor(double (*blk)[NB + 1], double* dinv, int nb, int* flag) {
     const int lane = threadIdx.x & 63;
@@ -277,12 +291,23 @@ __device__ __forceinline__ void block_factor(double (*blk)[NB + 1], double* dinv
 #pragma unroll
     for (int k = 0; k < NB; ++k) r[k] = (lane < nb && k <= lane) ? blk[li][k] : 0.0;
     bool bad = false;
-#pragma unroll
-    for (int j = 0; j < NB; ++j) {
+    // Row j's finished entries r[0..j-1] live in lane j.  Rows 16 i .. 16 i + 15 share a DPP row, so for the rows below j in
+    // j's own 16-row group they are one v_fmac_f64_dpp row_newbcast away (~8 cycles; the v_readlane pair + FMA they replace
+    // ~25); only the rows of the NEXT group (NB = 32, j < 16) still need the SGPR broadcast.  Same operations in the same
+    // order as before: bit-identical.
+    jstatic_for<0, NB>([&](auto jc) {
+        constexpr int j = decltype(jc)::value;
         double sacc = r[j];
+        if constexpr (NB == 16 || j >= 16) {
+            jstatic_for<0, j>([&](auto kc) {
+                constexpr int k = decltype(kc)::value;
+                fmac_neg_bcast<(j & 15)>(sacc, r[k]);
+            });
+        } else {
 #pragma unroll
-        for (int k = 0; k < NB; ++k)
-            if (k < j) sacc = fma(-r[k], readlane_f64(r[k], j), sacc);       // row j's finished entries, broadcast
+            for (int k = 0; k < NB; ++k)
+                if (k < j) sacc = fma(-r[k], readlane_f64(r[k], j), sacc);       // row j's finished entries, broadcast
+        }
         const double d = readlane_f64(sacc, j);
         if (j < nb) {
             if (!(d > 0.0)) bad = true;
@@ -290,7 +315,7 @@ __device__ __forceinline__ void block_factor(double (*blk)[NB + 1], double* dinv
             r[j] = (lane == j) ? sd : ((lane > j) ? sacc * inv : 0.0);
             if (lane == j) dinv[j] = inv;
         }
-    }
+    });
     if (lane < nb) {
 #pragma unroll
         for (int k = 0; k < NB; ++k)
@@ -461,6 +486,7 @@ __global__ __launch_bounds__(NT, WPE) void joint_kernel(const JointArgs a) {
         __syncthreads();
 #ifdef GPMPC_PHASE_TIMERS
         long long jph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        long long jroot_blocks = 0, jroot_attempts = 0;             // root phase: column blocks walked / attempts made
         long long jt = __builtin_readcyclecounter();
 #endif
 
@@ -743,8 +769,14 @@ __global__ __launch_bounds__(NT, WPE) void joint_kernel(const JointArgs a) {
         }
         while (!rooted) {
             bool failed = false;
+#ifdef GPMPC_PHASE_TIMERS
+            ++jroot_attempts;
+#endif
             for (int c0 = 0; c0 < mT && !failed; c0 += NB) {
                 const int nb = min(NB, mT - c0);
+#ifdef GPMPC_PHASE_TIMERS
+                ++jroot_blocks;
+#endif
                 double acc[RPT][NB];
 #pragma unroll
                 for (int rs = 0; rs < RPT; ++rs) {
@@ -867,6 +899,8 @@ __global__ __launch_bounds__(NT, WPE) void joint_kernel(const JointArgs a) {
 #ifdef GPMPC_PHASE_TIMERS
         if (blockIdx.x == 0 && tid == 0)
             for (int i = 0; i < 8; ++i) g_joint_phase[i] = jph[i];
+            g_joint_phase[8] = jroot_blocks;
+            g_joint_phase[9] = jroot_attempts;
 #endif
         if (info_acc) atomicOr(&s_info, info_acc);
         __syncthreads();

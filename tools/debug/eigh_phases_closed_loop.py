@@ -28,7 +28,7 @@ def traced(x, base_samples=None):
     e = (C.c_longlong * 8)(); lib.gpmpc_debug_read_eigh_phases(e)
     jn = ["realcols", "init", "update", "factor", "solve", "mean+S", "root", "sample"]
     en = ["pivchol", "gram", "jacobi", "reverse", "sample", "ticks_100MHz", "sweeps", "rank"]
-    print(f"n_ho={agent.model_i.h_slots.numel():4d} draw {e0.elapsed_time(e1):6.2f} ms | joint", {n: j[i] for i, n in enumerate(jn)},
+    print(f"n_ho={agent.model_i.h_slots.numel():4d} draw {e0.elapsed_time(e1):6.2f} ms | root: {j[9]} attempts, {j[8]} column blocks | joint", {n: j[i] for i, n in enumerate(jn)},
           "| eigh", {n: e[i] for i, n in enumerate(en)}, flush=True)
     return y
 
