@@ -174,7 +174,36 @@ def extra_car_rollout(sg, _lib, RolloutRunner, wl):
             "kernel_path": int(_lib.load().gpmpc_debug_last_rollout_path()),
             "roofline": roofline(flop, ms, "rollout_tiles_kernel<5,9,car_residual,32> (four chains per wave, FP64 4x4x4 MFMA solve)"
                                  if _lib.load().gpmpc_debug_last_rollout_path() == 3 else "rollout_fast_kernel<3,45,3,car_residual,grid root>",
-                                 wl.min_hbm_bytes(4, 3, 3) * Ns * H)}
+                                 wl.min_hbm_bytes(4, 3, 3) * Ns * H,
+                                 **({"bound": "fp64_mfma"} if _lib.load().gpmpc_debug_last_rollout_path() == 3 else {}))}
+
+
+def extra_pendulum_throughput(sg, _lib, RolloutRunner, wl):
+    """configs[1]'s workload (pendulum1D, mode R, H=30) at Ns=16384: the throughput point of the same path.  The headline
+    launch has exactly one chain per SIMD (its time is one wave's latency through 30 steps); from 3072 chains on the
+    dispatcher takes the four-chains-per-wave kernel."""
+    Ns, H = 16384, 30
+    p = wl.fs_params("params_pendulum1D_samples", Ns, H)
+    p["common"]["use_cuda"] = True
+    p["agent"]["base_sample_generator"] = "counter"
+    agent = sg.Agent(p, sg.make_env(p))
+    erv = agent.epistimic_random_vector
+    per = Ns * agent.g_ny * 3
+    runner = RolloutRunner(agent, wl.synthetic_u_ff(agent.nu, H), erv.reshape(-1)[per:], erv.shape[1] * per, H,
+                           _lib.MODE_RECONDITIONED, False)
+    for _ in range(100):
+        runner.launch()
+    torch.cuda.synchronize()
+    ms, ms_min = time_launches(runner.launch, 30)
+    path = int(_lib.load().gpmpc_debug_last_rollout_path())
+    bits = int(runner.info.max().item())
+    ok = bool(torch.isfinite(runner.X_traj).all()) and not (bits & (_lib.INFO_TRAIN_CHOL_FAIL | _lib.INFO_ROOT_FAIL))
+    flop = wl.flop_mode_r(1, 3, 36, 36, H) * Ns * H
+    return {"workload": "BASELINE configs[1] workload at Ns=16384 (throughput point): params_pendulum1D_samples, mode R, H=30, 1 GPU",
+            "value": Ns * H / (ms * 1e-3), "unit": "trajectory-steps/s", "ms_per_rollout": ms, "finite": ok, "kernel_path": path,
+            "roofline": roofline(flop, ms, "rollout_tiles_kernel<4,9,pendulum1D,32> (four chains per wave, FP64 4x4x4 MFMA solve)"
+                                 if path == 3 else "rollout_fast_kernel<3,36,1,pendulum1D>", wl.min_hbm_bytes(2, 1, 3) * Ns * H,
+                                 **({"bound": "fp64_mfma"} if path == 3 else {}))}
 
 
 def extra_closed_loop(sg, _lib, wl, name="params_car_residual", Ns=1024, H=40, iters=4, next_step=True, label=None):
@@ -654,7 +683,7 @@ def main():
         if not multi and not a.no_extra:
             extra = []
             for fn, args in ((extra_car_rollout, (sg, _lib, RolloutRunner, wl)), (extra_closed_loop, (sg, _lib, wl)),
-                             (extra_pendulum_joint, (sg, _lib, wl))):
+                             (extra_pendulum_joint, (sg, _lib, wl)), (extra_pendulum_throughput, (sg, _lib, RolloutRunner, wl))):
                 try:
                     extra.append(fn(*args))
                 except Exception as e:                            # noqa: BLE001 - never fatal for the bench line
