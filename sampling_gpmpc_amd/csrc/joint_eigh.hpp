@@ -67,6 +67,9 @@ __device__ unsigned long long g_eigh_work[4];
 #define EPH(idx)
 #endif
 
+#ifndef GPMPC_EIGH_WPE
+#define GPMPC_EIGH_WPE 2               // waves per SIMD the eigh kernel is compiled for (one wave per chain)
+#endif
 constexpr int EIGH_MAX_SWEEPS = 16;
 constexpr double EIGH_TINY_ROT = 1e-8; // a sweep whose largest rotation tangent is below this is the last one
 constexpr int EIGH_LDS_RANK = 64;      // packed 64 x 64 Gram matrix = 16.6 KB of LDS per chain: ~7 chains per CU
@@ -380,7 +383,7 @@ __device__ __forceinline__ void eigh_replay(double* e_vec, const double* __restr
 }
 
 template <int T, int RPL>
-__global__ __launch_bounds__(64, 2) void joint_eigh_kernel(const EighArgs a) {
+__global__ __launch_bounds__(64, GPMPC_EIGH_WPE) void joint_eigh_kernel(const EighArgs a) {
     // dynamic LDS, sized by the launch (eigh_lds_doubles): packed Gram matrix + pad slot | rotations (c, s) | staging /
     // eigenvalues / raw sample | rotated base samples | ranks, candidates
     extern __shared__ __attribute__((aligned(16))) double e_dyn[];
