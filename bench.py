@@ -180,8 +180,8 @@ def extra_car_rollout(sg, _lib, RolloutRunner, wl):
 
 def extra_pendulum_throughput(sg, _lib, RolloutRunner, wl):
     """configs[1]'s workload (pendulum1D, mode R, H=30) at Ns=16384: the throughput point of the same path.  The headline
-    launch has exactly one chain per SIMD (its time is one wave's latency through 30 steps); from 3072 chains on the
-    dispatcher takes the four-chains-per-wave kernel."""
+    launch has exactly one chain per SIMD (its time is one wave's latency through 30 steps); beyond one round of
+    the chip the dispatcher takes the four-chains-per-wave kernel."""
     Ns, H = 16384, 30
     p = wl.fs_params("params_pendulum1D_samples", Ns, H)
     p["common"]["use_cuda"] = True

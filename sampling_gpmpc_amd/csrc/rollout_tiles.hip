@@ -1012,13 +1012,15 @@ bool rollout_tiles_eligible(const gpmpc_gp_desc_t* gp, const gpmpc_env_desc_t* e
     const size_t lds = tiles_lds_for(gp, env, H);
     if (lds == 0 || lds > 160 * 1024 - 64) return false;
     if (md > 0) return true;
-    // a wave carries four chains and takes ~2x as long as the one-chain-per-wave kernels do for a round of the chip
-    // (tools/bench_tiles.py: pendulum Ns = 1024: 0.20 vs 0.11 ms, Ns = 4096: 0.27 vs 0.43 ms; car Ns = 1024: 0.46 vs 0.85 ms);
-    // shapes the tuned one-chain kernel does not take (other grids, 3 (H - 1) > 128) fall to the generic kernel, 4-10x
-    // slower: there the tiled kernel is the better choice from a single round on
+    // A wave carries four chains and takes ~1.6-1.9x as long as a wave of the one-chain-per-wave kernel: the tuned kernel
+    // wins while it needs ONE round of the chip (pendulum: 1024 chains, one per SIMD; car: 256 samples, one three-wave
+    // workgroup per CU) and loses from its second round on (tools/debug/tiles_threshold.py, sustained clocks: pendulum
+    // Ns = 1024 0.109 vs 0.191 ms, 1536 0.215 vs 0.202, 3072 0.323 vs 0.231; car Ns = 256 0.215 vs 0.327, 384 0.425 vs
+    // 0.346, 768 0.641 vs 0.403).  Shapes the tuned kernel does not take (other grids, 3 (H - 1) > 128) fall to the generic
+    // kernel, 4-20x slower: there the tiled kernel is taken from 256 chains on.
     const int64_t chains = Ns * gp->g_ny;
     const bool tuned_alt = rollout_fast_eligible(gp, env, mode, hall_tasks, H);
-    return chains >= (tuned_alt ? 3072 : 256);
+    return tuned_alt ? (chains > (gp->g_ny == 1 ? 1024 : 768)) : (chains >= 256);
 }
 
 size_t rollout_tiles_workspace_bytes(const gpmpc_gp_desc_t* gp, int64_t Ns, int H) {
