@@ -372,8 +372,7 @@ class Agent(object):
         """Full-state value and Jacobians ``f + B_d g`` at the linearisation points (reference ``src/agent.py:532-564``).
         Returns numpy float64 ``gp_val (Ns,nx,H,1)``, ``y_grad (Ns,nx,H,nx)``, ``u_grad (Ns,nx,H,nu)``."""
         gp_val, y_grad, u_grad = self.dyn_fg_jacobians_device(xu_hat, sqp_iter)
-        _lib.host_wait(gp_val)
-        out = (gp_val.cpu().numpy(), y_grad.cpu().numpy(), u_grad.cpu().numpy())
+        out = (_lib.to_host(gp_val), _lib.to_host(y_grad), _lib.to_host(u_grad))
         if not (np.isfinite(out[0]).all() and np.isfinite(out[1]).all() and np.isfinite(out[2]).all()):
             print("Nan/inf in y_sample")
         return out
@@ -396,8 +395,7 @@ class Agent(object):
                                        _lib.dptr(gp_val), _lib.dptr(x_h_d), _lib.dptr(u_h_d), _lib.dptr(xg_d),
                                        _lib.dptr(w_d), _lib.dptr(te), _lib.dptr(p_lin), _lib.current_stream_ptr()),
                    "gpmpc_pack_plin")
-        _lib.host_wait(p_lin)
-        return p_lin.cpu().numpy()
+        return _lib.to_host(p_lin)
 
     # ---------------------------------------------------------------------------------------------------------
     # forward sampling with rejection (reference src/agent.py:331-443)

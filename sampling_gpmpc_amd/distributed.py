@@ -260,8 +260,7 @@ def gather_jacobians(arrays, Ns: int, group=None, dst: int = 0):
     if rank != dst:
         return None
     full = torch.cat([parts[r][: hi - lo] for r, (lo, hi) in enumerate(sizes)], dim=0)
-    _lib.host_wait(full)
-    full = full.cpu().numpy()                                     # one D2H copy
+    full = _lib.to_host(full)                                     # one D2H copy (pinned staging)
     assert full.shape[0] == Ns
     out, c0 = [], 0
     for w in widths:
