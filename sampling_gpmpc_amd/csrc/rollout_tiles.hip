@@ -535,11 +535,9 @@ __global__ __launch_bounds__(64, 1) void rollout_tiles_kernel(const RolloutArgs 
                     dst[ycol] = ex ? yt[aa] : 0.0;
                 }
                 tiles_sync_lds();
-                static_for<0, 12>([&](auto wc) {
+                static_for<0, 12>([&](auto wc) {                  // (rows of points that do not exist yet were written as zeros)
                     constexpr int w = decltype(wc)::value, tg = 12 * q + w;
-                    if constexpr (tg < NT) {
-                        if (tg < nt) V[tg] = SCRm[(4 * w + kq) * 4 + jq];
-                    }
+                    if constexpr (tg < NT) V[tg] = SCRm[(4 * w + kq) * 4 + jq];
                 });
                 tiles_sync_lds();
             }
@@ -835,15 +833,21 @@ __global__ __launch_bounds__(64, 1) void rollout_tiles_kernel(const RolloutArgs 
             const int myrow = (jq >= i0) ? tn : tn + 1;
             const unsigned rowtile = (unsigned)tri(myrow);       // per-lane: the two target tile rows differ
             // off-diagonal tiles against complete old tile rows p < tn: -v
-            static_for<0, NT>([&](auto pcn) {
-                constexpr int p = decltype(pcn)::value;
-                if (p < tn) {
-                    if (isnew) {
-                        const unsigned e = rowtile + p;
-                        tile_store(lane16 + (e >> 1) * 1024u + (e & 1u) * 8u, 0, -V[p]);
+            {
+                auto store_from = [&](auto self, auto pcn) -> void {     // early exit: tn branches instead of NT
+                    constexpr int p = decltype(pcn)::value;
+                    if constexpr (p < NT) {
+                        if (p < tn) {
+                            if (isnew) {
+                                const unsigned e = rowtile + p;
+                                tile_store(lane16 + (e >> 1) * 1024u + (e & 1u) * 8u, 0, -V[p]);
+                            }
+                            self(self, std::integral_constant<int, p + 1>{});
+                        }
                     }
-                }
-            });
+                };
+                store_from(store_from, std::integral_constant<int, 0>{});
+            }
             // the tile pairs that involve tile tn itself (old rows of the incomplete tile) and the new tile tn+1
             // (a search for V[tn] over the register array turns it into a scratch array: hipcc makes a table lookup of it)
             const double Vtn = ((n_h & 3) != 0) ? Vlast : 0.0;    // tile row tn exists only if it is incomplete
