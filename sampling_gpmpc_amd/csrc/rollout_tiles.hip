@@ -626,37 +626,40 @@ __global__ __launch_bounds__(64, 1) void rollout_tiles_kernel(const RolloutArgs 
 #else
                 // the complete rows 0 .. nfull-1 are resident (each was loaded when it completed); only the incomplete row
                 // nfull streams (its own registers, requested when its turn comes: one exposed L2 latency per step while the
-                // factor is this small - requesting it ahead through the ring costs more in spills than it hides)
-                static_for<0, NRV + 1>([&](auto rc) {
+                // factor is this small - requesting it ahead through the ring costs more in spills than it hides).
+                // (A chain with early exit: nfull + 1 uniform branches instead of two per possible row - a taken branch of a
+                // lone wave costs an instruction fetch, ~30 cycles)
+                auto small_from = [&](auto self, auto rc) -> void {
                     constexpr int r = decltype(rc)::value;
-                    if constexpr (r < NRA) {
+                    if constexpr (r <= NRV) {
                         if (r < nfull) {
-                            double ac[2] = {V[r], 0.0};
-                            mfma_rowsum<r, true>(ac, At + tri(r), V);
-                            const double acc = ac[0] + ac[1];
-                            V[r] = mfma_zero_a(At[tri(r) + r], acc);
-                            Vlast = V[r];
-                        }
-                    } else if constexpr (r < NRV) {
-                        if (r < nfull) {
-                            double ac[2] = {V[r], 0.0};
-                            mfma_rowsum<r, false>(ac, Bt + (tri(r) - tri(NRA)), V);
-                            const double acc = ac[0] + ac[1];
-                            V[r] = mfma_zero_v(Bt[tri(r) - tri(NRA) + r], acc);
-                            Vlast = V[r];
-                        }
-                    }
-                    if (part && r == nfull) {
-                        double cur[r + 1];
+                            if constexpr (r < NRA) {
+                                double ac[2] = {V[r], 0.0};
+                                mfma_rowsum<r, true>(ac, At + tri(r), V);
+                                const double acc = ac[0] + ac[1];
+                                V[r] = mfma_zero_a(At[tri(r) + r], acc);
+                                Vlast = V[r];
+                            } else if constexpr (r < NRV) {
+                                double ac[2] = {V[r], 0.0};
+                                mfma_rowsum<r, false>(ac, Bt + (tri(r) - tri(NRA)), V);
+                                const double acc = ac[0] + ac[1];
+                                V[r] = mfma_zero_v(Bt[tri(r) - tri(NRA) + r], acc);
+                                Vlast = V[r];
+                            }
+                            self(self, std::integral_constant<int, r + 1>{});
+                        } else if (part) {                        // r == nfull: the incomplete row
+                            double cur[r + 1];
 #pragma unroll
-                        for (int p = 0; p <= r; ++p) cur[p] = tile_load(lane16, tri(r) + p);
-                        double ac[2] = {V[r], 0.0};
-                        mfma_rowsum<r, false>(ac, cur, V);
-                        const double acc = accex ? ac[0] + ac[1] : 0.0;
-                        V[r] = mfma_zero_v(cur[r], acc);
-                        Vlast = V[r];
+                            for (int p = 0; p <= r; ++p) cur[p] = tile_load(lane16, tri(r) + p);
+                            double ac[2] = {V[r], 0.0};
+                            mfma_rowsum<r, false>(ac, cur, V);
+                            const double acc = accex ? ac[0] + ac[1] : 0.0;
+                            V[r] = mfma_zero_v(cur[r], acc);
+                            Vlast = V[r];
+                        }
                     }
-                });
+                };
+                small_from(small_from, std::integral_constant<int, 0>{});
 #endif
             } else {                                              // regime (ii)
                 // the first RC streamed tiles are requested behind the resident rows, a few tiles in front of each row's
