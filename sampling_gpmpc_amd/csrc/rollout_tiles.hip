@@ -1022,8 +1022,8 @@ bool rollout_tiles_eligible(const gpmpc_gp_desc_t* gp, const gpmpc_env_desc_t* e
     // A wave carries four chains and takes ~1.6-1.9x as long as a wave of the one-chain-per-wave kernel: the tuned kernel
     // wins while it needs ONE round of the chip (pendulum: 1024 chains, one per SIMD; car: 256 samples, one three-wave
     // workgroup per CU) and loses from its second round on (tools/debug/tiles_threshold.py, sustained clocks: pendulum
-    // Ns = 1024 0.109 vs 0.191 ms, 1536 0.215 vs 0.202, 3072 0.323 vs 0.231; car Ns = 256 0.215 vs 0.327, 384 0.425 vs
-    // 0.346, 768 0.641 vs 0.403).  Shapes the tuned kernel does not take (other grids, 3 (H - 1) > 128) fall to the generic
+    // Ns = 1024 0.109 vs 0.170 ms, 1536 0.214 vs 0.181, 3072 0.323 vs 0.208; car Ns = 256 0.216 vs 0.306, 384 0.425 vs
+    // 0.324, 768 0.639 vs 0.380).  Shapes the tuned kernel does not take (other grids, 3 (H - 1) > 128) fall to the generic
     // kernel, 4-20x slower: there the tiled kernel is taken from 256 chains on.
     const int64_t chains = Ns * gp->g_ny;
     const bool tuned_alt = rollout_fast_eligible(gp, env, mode, hall_tasks, H);
