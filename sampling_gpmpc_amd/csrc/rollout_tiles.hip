@@ -702,10 +702,16 @@ __global__ __launch_bounds__(64, 1) void rollout_tiles_kernel(const RolloutArgs 
             }
             TPH(2);
             // S' += V_r^T V_r, eight tiles per statement (tiles >= nt are zero)
-            static_for<0, NT / 8>([&](auto gc) {
+            auto gram_from = [&](auto self, auto gc) -> void {    // early exit (see store_from)
                 constexpr int g = decltype(gc)::value;
-                if (8 * g < nt) mfma_rowsum<8, false>(Sh, V + 8 * g, V + 8 * g);
-            });
+                if constexpr (g < NT / 8) {
+                    if (8 * g < nt) {
+                        mfma_rowsum<8, false>(Sh, V + 8 * g, V + 8 * g);
+                        self(self, std::integral_constant<int, g + 1>{});
+                    }
+                }
+            };
+            gram_from(gram_from, std::integral_constant<int, 0>{});
         }
         TDBG(4, V[0]);
         TDBG(5, V[1]);
