@@ -688,18 +688,47 @@ __global__ __launch_bounds__(NT, WPE) void joint_kernel(const JointArgs a) {
 
         JPH(4);
         // ---- posterior mean; covariance S = K** - V V^T (same blocked update, no factor step) ---------------------
-        {   // mu = V^T w: the same blocked update with the w row (index -1 relative to the test rows) as the only pivot
-            double accw[RPT][NB];
+        {   // mu = V^T w.  A dot product per test row: the w row (n_o entries) goes through LDS in chunks, every test-row
+            // thread streams its own row with MU_U loads in flight.  (It used to be the blocked update with the w row as the
+            // only pivot: NB DPP FMAs per conditioning slot for one useful column - 159 k of 2.7 M cycles per chain at k = 3.)
+            // Same operations in the same order as that update: acc = fma(-V[t][k], w[k], acc), k ascending; mu = -acc.
+            constexpr int MU_U = (WPE < 4) ? 32 : 16;
+            constexpr int MU_CH = KC * NB;                        // doubles of `piv`
+            double* wl = &piv[0][0];
+            const int tau = tid;                                  // RPT == 1 layout for the test rows: tau < mT <= 256 <= NT ... or strided
+            double accm[RPT];
 #pragma unroll
-            for (int rs = 0; rs < RPT; ++rs)
+            for (int rs = 0; rs < RPT; ++rs) accm[rs] = 0.0;
+            (void)tau;
+            for (int kb = 0; kb < n_o; kb += MU_CH) {
+                const int kn = min(MU_CH, n_o - kb);
+                __syncthreads();
+                for (int k = tid; k < kn; k += nt) wl[k] = M[(long)(kb + k) * ld + wrow];
+                __syncthreads();
 #pragma unroll
-                for (int q = 0; q < NB; ++q) accw[rs][q] = 0.0;
-            block_update<NB, RPT, KC, NT>(M + trow0, ld, n_o, M + wrow, 1, ld, 1, 0, mT, accw, piv);
+                for (int rs = 0; rs < RPT; ++rs) {
+                    const int t1 = tid + rs * nt;
+                    if (t1 < mT) {
+                        const double* vr = M + trow0 + t1 + (long)kb * ld;
+                        double a = accm[rs];
+                        for (int k0 = 0; k0 < kn; k0 += MU_U) {
+                            double v[MU_U];
+#pragma unroll
+                            for (int u = 0; u < MU_U; ++u) v[u] = vr[(long)min(k0 + u, kn - 1) * ld];
+#pragma unroll
+                            for (int u = 0; u < MU_U; ++u)
+                                if (k0 + u < kn) a = fma(-v[u], wl[k0 + u], a);
+                        }
+                        accm[rs] = a;
+                    }
+                }
+            }
 #pragma unroll
             for (int rs = 0; rs < RPT; ++rs) {
-                const int tau = tid + rs * nt;
-                if (tau < mT) muv[tau] = -accw[rs][0];
+                const int t1 = tid + rs * nt;
+                if (t1 < mT) muv[t1] = -accm[rs];
             }
+            __syncthreads();
         }
         // S = K** - V V^T.  Short conditioning sets: the blocked VALU update, one pass per column block (closed-loop k = 0:
         // 0.84 ms against 0.92 with the matrix-pipe form, whose set-up is per tile); from GPMPC_JOINT_S_MFMA_MIN slots on the
