@@ -12,7 +12,7 @@ from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 REPO = os.path.dirname(os.path.dirname(HERE))
-SOURCES = ["capi.hip", "rollout.hip", "rollout_fast.hip", "rollout_tiles.hip", "rollout_indep.hip", "joint.hip", "assemble.hip"]
+SOURCES = ["capi.hip", "rollout.hip", "rollout_fast.hip", "rollout_tiles.hip", "rollout_one.hip", "rollout_indep.hip", "joint.hip", "assemble.hip"]
 HEADERS = ["gpmpc_device.hpp", "gpmpc_host.hpp", "rollout_args.hpp", "joint_eigh.hpp",
            os.path.join(REPO, "include", "gpmpc_hip.h")]
 OUT = os.path.join(os.path.dirname(HERE), "libgpmpc_hip.so")
@@ -35,6 +35,7 @@ EXTRA_FLAGS = {"rollout_fast.hip": os.environ.get("GPMPC_FAST_FLAGS", "-mllvm -d
                # either way); the sample-per-lane kernels of rollout_indep.hip measure 0.093 / 0.543 ms with it off, 0.097 / 0.547 on
                "rollout.hip": os.environ.get("GPMPC_ROLLOUT_FLAGS", "-mllvm -disable-machine-licm").split(),
                "rollout_tiles.hip": os.environ.get("GPMPC_TILES_FLAGS", "").split(),
+               "rollout_one.hip": os.environ.get("GPMPC_ONE_FLAGS", "").split(),
                "rollout_indep.hip": os.environ.get("GPMPC_INDEP_FLAGS", "").split()}
 
 

@@ -600,6 +600,10 @@ static int rollout_impl(const gpmpc_gp_desc_t* gp, const gpmpc_env_desc_t* env, 
         if (!ws || ws_bytes < need) return fail(GPMPC_E_WORKSPACE, "gpmpc_rollout: workspace too small");
     }
     hipStream_t st = (hipStream_t)stream;
+    if (!seeded && rollout_one_eligible(gp, env, mode, hall_tasks, H, Ns)) {
+        g_last_rollout_path = 4;
+        return rollout_one_launch(gp, env, args, st);
+    }
     if (!seeded && rollout_tiles_eligible(gp, env, mode, hall_tasks, H, Ns)) {
         g_last_rollout_path = 3;
         return rollout_tiles_launch(gp, env, args, ws, ws_bytes, st);

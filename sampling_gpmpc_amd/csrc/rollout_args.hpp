@@ -65,6 +65,10 @@ size_t rollout_tiles_workspace_bytes(const gpmpc_gp_desc_t* gp, int64_t Ns, int 
 int rollout_tiles_launch(const gpmpc_gp_desc_t* gp, const gpmpc_env_desc_t* env, RolloutArgs& args, void* ws, size_t ws_bytes,
                          hipStream_t st);
 
+// latency path: one chain per wave, the chain's factor in AGPR panels, forward substitution on the FP64 matrix pipe (rollout_one.hip)
+bool rollout_one_eligible(const gpmpc_gp_desc_t* gp, const gpmpc_env_desc_t* env, int mode, int hall_tasks, int H, int64_t Ns);
+int rollout_one_launch(const gpmpc_gp_desc_t* gp, const gpmpc_env_desc_t* env, RolloutArgs& args, hipStream_t st);
+
 // mode-I thread-per-sample path (rollout_indep.hip)
 bool rollout_indep_eligible(const gpmpc_gp_desc_t* gp, const gpmpc_env_desc_t* env, int mode);
 int rollout_indep_launch(const gpmpc_gp_desc_t* gp, const gpmpc_env_desc_t* env, RolloutArgs& args, hipStream_t st);
