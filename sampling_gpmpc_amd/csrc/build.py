@@ -35,7 +35,8 @@ EXTRA_FLAGS = {"rollout_fast.hip": os.environ.get("GPMPC_FAST_FLAGS", "-mllvm -d
                # either way); the sample-per-lane kernels of rollout_indep.hip measure 0.093 / 0.543 ms with it off, 0.097 / 0.547 on
                "rollout.hip": os.environ.get("GPMPC_ROLLOUT_FLAGS", "-mllvm -disable-machine-licm").split(),
                "rollout_tiles.hip": os.environ.get("GPMPC_TILES_FLAGS", "").split(),
-               "rollout_one.hip": os.environ.get("GPMPC_ONE_FLAGS", "").split(),
+               # rollout_one.hip: without machine-LICM no SGPR is spilled (28 otherwise: v_readlane / v_writelane pairs in the step)
+               "rollout_one.hip": os.environ.get("GPMPC_ONE_FLAGS", "-mllvm -disable-machine-licm").split(),
                "rollout_indep.hip": os.environ.get("GPMPC_INDEP_FLAGS", "").split()}
 
 

@@ -184,7 +184,9 @@ __global__ __launch_bounds__(64, 1) void rollout_one_kernel(const RolloutArgs a)
     for (int c = 0; c < T; ++c) zq[c] = (lane < H) ? a.z[(long)lane * a.z_step_stride + s * T + c] : 0.0;
     uq = (lane < H) ? a.u_ff[lane] : 0.0;
     double xh[D] = {0.0, 0.0}, yt[T] = {0.0, 0.0, 0.0};           // lane = appended point: its GP input and label residuals
-    double uc = Inat, dc = Inat;                                  // the incomplete diagonal tile: L^T (natural) and 1 / diag
+    // the diagonal tiles of the super row being appended to (one tile per block): L^T in the natural map and 1 / diag along its
+    // rows / columns; the same for the next super row (rows that wrap into it)
+    double ud = Inat, drow = 1.0, dcol = 1.0, ud1 = Inat, drow1 = 1.0, dcol1 = 1.0;
     int info_acc = 0;
     int n_h = 0, t = 0;
 
@@ -299,7 +301,7 @@ __global__ __launch_bounds__(64, 1) void rollout_one_kernel(const RolloutArgs a)
         double Vrep[NTK];
 #pragma unroll
         for (int p = 0; p < NTK; ++p) Vrep[p] = 0.0;
-        double Sh0 = 0.0, Sh1 = 0.0;
+        double Sh0 = Sr0, Sh1 = Sr1;                              // the appended rows accumulate on top of the real block
         double Vinc = 0.0;                                        // V of the incomplete tile row (phase H wants it)
         if (n_h > 0) {
             one_for<0, K + 1>([&](auto Rc) {
@@ -333,20 +335,30 @@ __global__ __launch_bounds__(64, 1) void rollout_one_kernel(const RolloutArgs a)
                         ODBG(10, acc);
                         ODBG(12, one_gdm_k9<0>(P, Inat));
                     }
-                    one_for<0, 4>([&](auto qc) {
+                    // tile rows of the partial super row that do not exist yet are skipped (early-exit chain: a taken branch
+                    // of a lone wave costs an instruction fetch)
+                    const int rem = n_h - 16 * K;
+                    auto tile_from = [&](auto self, auto qc) -> void {
                         constexpr int q = decltype(qc)::value;
-                        double w;
-                        if constexpr (R < kOneRes) w = one_gdm_k9<R>(P, acc);
-                        else w = one_mfma_zero(gd5, acc);
-                        if constexpr (R == 0 && q == 0) ODBG(11, w);
-                        w = one_replicate<q>(w);
-                        Vrep[4 * R + q] = w;
-                        if constexpr (q < 3) {
-                            if constexpr (R < kOneRes) one_pcm_k9<R, q>(P, acc, w);
-                            else one_mfma_nacc(acc, pc5[q], w);
+                        if constexpr (q < 4) {
+                            if (R < K || rem > 4 * q) {
+                                double w;
+                                if constexpr (R < kOneRes) w = one_gdm_k9<R>(P, acc);
+                                else w = one_mfma_zero(gd5, acc);
+                                if constexpr (R == 0 && q == 0) ODBG(11, w);
+                                w = one_replicate<q>(w);
+                                Vrep[4 * R + q] = w;
+                                if constexpr (q < 3) {
+                                    if constexpr (R < kOneRes) one_pcm_k9<R, q>(P, acc, w);
+                                    else one_mfma_nacc(acc, pc5[q], w);
+                                }
+                                if constexpr (R == K) one_pchain<1>(Sh0, Sh1, Vrep + 4 * R + q, Vrep + 4 * R + q);
+                                self(self, std::integral_constant<int, q + 1>{});
+                            }
                         }
-                    });
-                    one_pchain<4>(Sh0, Sh1, Vrep + 4 * R, Vrep + 4 * R);
+                    };
+                    tile_from(tile_from, std::integral_constant<int, 0>{});
+                    if constexpr (R < K) one_pchain<4>(Sh0, Sh1, Vrep + 4 * R, Vrep + 4 * R);
                 }
             });
             if ((n_h & 3) != 0) {
@@ -365,10 +377,8 @@ __global__ __launch_bounds__(64, 1) void rollout_one_kernel(const RolloutArgs a)
         // ---- S' to scalars: entry [k][j] sits in lane 16 k + j of block 0 ------------------------------------------------
         double mu[T], S[T][T];
         {
-            const double Srr = Sr0 + Sr1;
-            const double Stot = Srr + (Sh0 + Sh1);
+            const double Stot = Sh0 + Sh1;
             ODBG(6, Stot);
-            ODBG(7, Srr);
             const int cb[T] = {cb0, cb1, cb2};
 #pragma unroll
             for (int b = 0; b < T; ++b) {
@@ -441,7 +451,7 @@ __global__ __launch_bounds__(64, 1) void rollout_one_kernel(const RolloutArgs a)
 #pragma unroll
                 for (int b = 0; b < T; ++b) yt[b] = mine ? y[b] : yt[b];   // the label column is whitened by the same MFMAs (PR w_r = mu_real)
             }
-            const int base = n_h, tn = n_h >> 2, bt = tn & 3, lo = n_h - 16 * K;
+            const int tn = n_h >> 2, bt = tn & 3, lo = n_h - 16 * K;
             // C[ci][ck] by lane-varying indices (clamped to 0 .. 2); by VALUE: a select between captured references is a
             // select of addresses, which hipcc turns into a table of pointers in scratch memory
             const double c00 = C[0][0], c10 = C[1][0], c11 = C[1][1], c20 = C[2][0], c21 = C[2][1], c22 = C[2][2];
@@ -451,19 +461,20 @@ __global__ __launch_bounds__(64, 1) void rollout_one_kernel(const RolloutArgs a)
                 const double r1 = one_pick3(ci, c11, c11, c21);
                 return one_pick3(ck, r0, r1, c22);
             };
-            auto cinv_pick = [=](int c) -> double { return one_pick3(c, ci0, ci1, ci2); };
-            // new rows of this lane's panel entries: in super row K (rows lo .. lo + 2) or wrapped into K + 1
+            // A new row (super-row-local index ri = 0 .. 2 counted from the first new row) against column rk (same origin):
+            // old columns (rk < 0) carry v of the incomplete tile row, new ones the 3 x 3 factor.  `up` = 16 for the lanes
+            // whose new row wrapped into super row K + 1.
+            auto new_entry = [&](int ri, int rk) -> double {
+                const int ci = min(max(ri, 0), 2), ck = min(max(rk, 0), 2);
+                const double cval = (rk <= ri) ? c_pick(ci, ck) : 0.0;
+                return (rk < 0) ? Vinc : cval;
+            };
+            // rows lo .. lo + 2 of super row K (panel lanes: row rA = 4 bm + jq), or wrapped into K + 1 (its block 0)
             const bool newK = (rA >= lo) && (rA < lo + 3);
             const bool newK1 = rA < lo + 3 - 16;
             const unsigned long long mK = __ballot(newK), mK1 = __ballot(newK1);
-            // a new row against the columns of the incomplete tile tn: old columns carry v, new ones the 3 x 3 factor
-            double mix;
-            {
-                const int gi = (newK1 ? 16 * (K + 1) : 16 * K) + rA, gk = 4 * tn + kq;
-                const int ci = min(max(gi - base, 0), 2), ck = min(max(gk - base, 0), 2);
-                const double cval = (gk <= gi) ? c_pick(ci, ck) : 0.0;
-                mix = (gk < base) ? Vinc : cval;
-            }
+            const int ri = rA - lo + (newK1 ? 16 : 0);
+            const double mixC = new_entry(ri, kq - (n_h & 3));                    // against the columns of the incomplete tile tn
             // super row K
             if constexpr (K < kOneRes) {
                 one_set_pr_k9<K>(P, mK, VrRep);
@@ -471,7 +482,7 @@ __global__ __launch_bounds__(64, 1) void rollout_one_kernel(const RolloutArgs a)
                 one_for<0, 3>([&](auto qc) {
                     constexpr int q = decltype(qc)::value;
                     const unsigned long long mq = __ballot(newK && bm > q);
-                    one_set_pc_k9<K, q>(P, mq, (bt == q) ? mix : Vrep[4 * K + q]);
+                    one_set_pc_k9<K, q>(P, mq, (bt == q) ? mixC : Vrep[4 * K + q]);
                 });
             } else {
                 if (newK) {
@@ -481,16 +492,44 @@ __global__ __launch_bounds__(64, 1) void rollout_one_kernel(const RolloutArgs a)
                     for (int i = 0; i < 4 * kOneRes; ++i) P5b[(NKT + i) * 64 + lane] = Vrep[i];
 #pragma unroll
                     for (int q = 0; q < 3; ++q) {
-                        if (bm > q) P5b[(NKT + 20 + q) * 64 + lane] = (bt == q) ? mix : Vrep[4 * K + q];
+                        if (bm > q) P5b[(NKT + 20 + q) * 64 + lane] = (bt == q) ? mixC : Vrep[4 * K + q];
                     }
                 }
+            }
+            OPH(5);
+            // The diagonal tiles of super row K: ud = L^T of the lane's own tile (natural map, one tile per block), drow / dcol =
+            // 1 / diag along its rows / columns.  New rows enter by select; ALL FOUR tile inverses come out of the same three
+            // MFMAs, U^-1 = (I + M)(I + M^2) D^-1 with U = D (I - M) (rollout_tiles.hip, phase H) - complete tiles reproduce
+            // what they had, so the whole register is committed.
+            auto inverse_tiles = [&](double U, double dr, double dcl) -> double {
+                const double M = Inat - dr * U;
+                const double Mt = one_mfma_zero(M, Inat);                     // M^T
+                const double M2 = one_mfma_zero(Mt, M);                       // M M
+                const double Pq = one_mfma_zero(Inat + Mt, Inat + M2);        // (I + M)(I + M^2)
+                return Pq * dcl;
+            };
+            {
+                // natural map of L^T: row index of L = 4 bm + jq (= rA), column index = 4 bm + kq
+                const int rkD = 4 * bm + kq - lo;
+                const double mixD = new_entry(rA - lo, rkD);
+                ud = newK ? mixD : ud;
+                const bool newRowK = (rkD >= 0) && (rkD < 3);            // the lane's L-column index is a new row
+                const double cK = one_pick3(min(max(rkD, 0), 2), ci0, ci1, ci2);
+                const double cJ = one_pick3(min(max(rA - lo, 0), 2), ci0, ci1, ci2);
+                drow = newRowK ? cK : drow;
+                dcol = newK ? cJ : dcol;
+                const double Gt = inverse_tiles(ud, drow, dcol);
+                ODBG(8, ud);
+                ODBG(9, Gt);
+                if constexpr (K < kOneRes) one_set_gd_k9<K>(P, ~0ull, Gt);
+                else P5b[(L::NP5 - 1) * 64 + lane] = Gt;
             }
             // rows that wrap into super row K + 1 (its block 0): every column tile of super row K is old or the mix
             if (lo + 3 > 16) {                                    // uniform
                 double Vt[NTK];
 #pragma unroll
                 for (int p = 0; p < NTK; ++p) Vt[p] = Vrep[p];
-                Vt[NTK - 1] = mix;                                // wrapping implies tn = 4 K + 3
+                Vt[NTK - 1] = mixC;                               // wrapping implies tn = 4 K + 3
                 if constexpr (K + 1 < kOneRes) {
                     one_set_pr_k9<K + 1>(P, mK1, VrRep);
                     one_set_ph_k9<K + 1>(P, mK1, Vt);
@@ -502,70 +541,22 @@ __global__ __launch_bounds__(64, 1) void rollout_one_kernel(const RolloutArgs a)
                         for (int i = 0; i < NTK; ++i) P5b[(NKT + i) * 64 + lane] = Vt[i];
                     }
                 }
-            }
-            // the diagonal tile(s): U = L^T (natural), inverted through (I + M)(I + M^2) D^-1 (rollout_tiles.hip, phase H)
-            {
-                auto entry = [&](int Rt_, int Pt, double vown, double old) -> double {
-                    const int gi = 4 * Rt_ + jq, gk = 4 * Pt + kq;
-                    const int ci = min(max(gi - base, 0), 2), ck = min(max(gk - base, 0), 2);
-                    double val = (gk <= gi) ? c_pick(ci, ck) : 0.0;              // both new
-                    val = (gk < base) ? vown : val;                              // new row, old column
-                    val = (gi >= base + 3) ? ((gi == gk) ? 1.0 : 0.0) : val;     // rows that do not exist yet: identity
-                    val = (gi < base) ? old : val;                               // old rows keep what they had
-                    return val;
-                };
-                auto diag_scal = [&](int Rt_, double oldv, bool rowwise) -> double {
-                    const int g = 4 * Rt_ + (rowwise ? kq : jq);
-                    const int c = min(max(g - base, 0), 2);
-                    double v = (g >= base + 3) ? 1.0 : cinv_pick(c);
-                    v = (g < base) ? oldv : v;
-                    return v;
-                };
-                auto inverse_tile = [&](double U, double drow, double dcol) -> double {
-                    const double M = Inat - drow * U;
-                    const double Mt = one_mfma_zero(M, Inat);                     // M^T
-                    const double M2 = one_mfma_zero(Mt, M);                       // M M
-                    const double Pq = one_mfma_zero(Inat + Mt, Inat + M2);        // (I + M)(I + M^2)
-                    return Pq * dcol;
-                };
-                auto commit_gd = [&](auto Rc, int blk, double G) {
-                    constexpr int R = decltype(Rc)::value;
-                    const unsigned long long mb = __ballot(bm == blk);
-                    if constexpr (R < kOneRes) one_set_gd_k9<R>(P, mb, G);
-                    else if constexpr (R == kOneRes) {
-                        if (bm == blk) P5b[(L::NP5 - 1) * 64 + lane] = G;
-                    }
-                };
-                const double ones = 1.0;
-                const double drow_old = one_mfma_zero(dc, ones);  // [k][i] = 1 / d_k
-                const double dcol_old = one_mfma_zero(ones, dc);  // [k][i] = 1 / d_i
-                const double U = entry(tn, tn, Vinc, uc);
-                const double drow = diag_scal(tn, drow_old, true), dcol = diag_scal(tn, dcol_old, false);
-                const double Gt = inverse_tile(U, drow, dcol);
-                ODBG(8, U);
-                ODBG(9, Gt);
-                commit_gd(std::integral_constant<int, K>{}, bt, Gt);
-                double Unext = U, dnext = (kq == jq) ? drow : 0.0;
-                if (i0 >= 2) {                                    // rows n_h .. n_h + 2 reach into tile tn + 1
-                    const double U1 = entry(tn + 1, tn + 1, 0.0, 0.0);
-                    const double drow1 = diag_scal(tn + 1, 1.0, true), dcol1 = diag_scal(tn + 1, 1.0, false);
-                    const double G1 = inverse_tile(U1, drow1, dcol1);
-                    if (bt < 3) commit_gd(std::integral_constant<int, K>{}, bt + 1, G1);
-                    else commit_gd(std::integral_constant<int, K + 1>{}, 0, G1);
-                    Unext = U1;
-                    dnext = (kq == jq) ? drow1 : 0.0;
-                }
-                if (i0 == 1) {                                    // tile tn is complete now, the next one is untouched
-                    Unext = Inat;
-                    dnext = Inat;
-                }
-                uc = Unext;
-                dc = dnext;
+                // its first diagonal tile: rows ri = rA + 16 - lo, columns 4 bm + kq + 16 - lo (all new)
+                const int rkD1 = 4 * bm + kq + 16 - lo;
+                const double mixD1 = new_entry(rA + 16 - lo, rkD1);
+                ud1 = newK1 ? mixD1 : ud1;
+                const double cK1 = one_pick3(min(max(rkD1, 0), 2), ci0, ci1, ci2);
+                const double cJ1 = one_pick3(min(max(rA + 16 - lo, 0), 2), ci0, ci1, ci2);
+                drow1 = (rkD1 < 3) ? cK1 : drow1;
+                dcol1 = newK1 ? cJ1 : dcol1;
+                const double G1 = inverse_tiles(ud1, drow1, dcol1);
+                if constexpr (K + 1 < kOneRes) one_set_gd_k9<K + 1>(P, ~0ull, G1);
+                else if constexpr (K + 1 == kOneRes) P5b[(L::NP5 - 1) * 64 + lane] = G1;
             }
             n_h += T;
             one_sync_lds();
         }
-        OPH(5);
+        OPH(6);
 
         // ---- state hand-over ---------------------------------------------------------------------------------------------
         {
@@ -574,13 +565,15 @@ __global__ __launch_bounds__(64, 1) void rollout_one_kernel(const RolloutArgs a)
             x[0] = x0n;
         }
         t += 1;
-        OPH(6);
+        OPH(7);
     };
 
     one_for<0, kOneMaxRows / 16>([&](auto Kc) {
         constexpr int K = decltype(Kc)::value;
 #pragma unroll 1
         while (t < H && (n_h >> 4) == K) step(Kc);
+        ud = ud1, drow = drow1, dcol = dcol1;                     // the next super row becomes the current one
+        ud1 = Inat, drow1 = 1.0, dcol1 = 1.0;
     });
 
     if (lane <= H) {
