@@ -1,32 +1,35 @@
 // rollout_one_kernel: the LATENCY form of the re-conditioned rollout (mode R, T = 3 label slots per point, value-only real
-// labels on an N0 x 9 tensor grid, at most 96 appended label rows: H <= 33).  gfx950, wave64, ONE chain per wave, one wave
+// labels on the 4 x 9 tensor grid, at most 88 appended label rows: H <= 30).  gfx950, wave64, ONE chain per wave, one wave
 // per SIMD (512 registers).  This is the kernel of BASELINE configs[1] (pendulum1D, Ns = 1024, H = 30: 1024 chains = one per
 // SIMD of the chip), where the run time is one wave's latency through H steps.
 //
 // rollout_fast.hip walks the chain's triangular solve pivot by pivot on the VALU (v_fmac_f64_dpp, ~22 cycles per pivot on
 // the dependency chain) and its L_hr v_r product row by row (36 DPP fmacs x 3): 49 % of its step.  Here both run on the
-// FP64 matrix pipe with the four blocks of v_mfma_f64_4x4x4_4b_f64 working on FOUR TILE ROWS OF THE SAME CHAIN:
+// FP64 matrix pipe, the four blocks of v_mfma_f64_4x4x4_4b_f64 working on FOUR COLUMN TILES OF THE SAME TILE ROW:
 //
 //   * lane maps (tools/ubench/mfma64_layout.hip): with kq = lane >> 4, bm = (lane >> 2) & 3, jq = lane & 3, block bm computes
 //     D[kq][jq] += sum_k A[.][k] B[k][jq]; B and D use the "natural" map (row kq, column jq), and a natural register X used
-//     as the A operand acts as X^T.  A SUPER ROW R is the 16 label rows 16 R .. 16 R + 15 = tile rows 4 R + bm.
-//   * the factor is a set of PANELS, one FP64 register each, pinned in AGPRs (rollout_one_gen.inc): panel (R, p) holds
-//     L[16 R + 4 bm + jq][4 p + kq] - the A operand that multiplies column tile p into all four tile rows of super row R at
-//     once.  The whitened real-data block (grid root, gpmpc_device.hpp) is simply the first NKT = N_r / 4 column tiles.
-//   * the right-hand sides are 16 x 4 blocks in the natural map: three kernel-entry columns and the whitened-label column
-//     (so the mean falls out of the same Gram product as the covariance, no reduction ladder); the column tile V_p of the
-//     solution is kept REPLICATED in all four blocks (the B operand every tile row needs).
-//   * left-looking over super rows:  acc = rhs_R - sum_kt PR[R][kt] v_r[kt] - sum_{p < 4R} PH[R][p] V_p  (MFMAs only, the
-//     panels straight from AGPRs), then the 16 x 16 diagonal block tile row by tile row: W = GD acc (block q valid),
-//     copy block q to the other three blocks with three bank-masked DPP row rotations, acc -= PC[R][q] W.
+//     as the A operand acts as X^T.
+//   * UNIFIED column tiles: the 9 tiles of the whitened real-data block (grid root, gpmpc_device.hpp) first, then the tiles
+//     of the appended rows: tile row r of the appended block is unified tile u = 9 + r.  GROUP g = unified tiles 4 g .. 4 g + 3,
+//     one per block.  The solution of a step is kept in one natural register per group, Vu[g] (block b = the 4 x 4 block
+//     "rows of tile 4 g + b x {three right-hand sides, the whitened-label column}"): never replicated.
+//   * the factor is a set of PANELS, one FP64 register each, pinned in AGPRs (rollout_one_gen.inc): panel (r, g) holds the
+//     entries of tile row r against the column tiles of group g in the A-operand map (lane (kq, bm, jq): L[4 r + jq][4 (4 g + bm)
+//     + kq]), so  acc -= panel(r, g) Vu[g]  multiplies four column tiles at once; 122 panels for 22 tile rows.
+//   * per tile row: the MFMAs of its groups, ONE cross-block sum (two DPP row rotations), W = G_r acc (the inverted diagonal
+//     tile, one register per group), and W's block moves into Vu with a bank-masked DPP move.  The Gram product  sum_g Vu[g]^T
+//     Vu[g]  yields the posterior covariance's subtrahend and - through the label column - the mean: no reduction ladder.
 //   * appended rows are LANES of the panels: in step t the right-hand side of task c sits in column (n_h + c) & 3, so the
-//     lane that holds v_p[c] is the lane of the new row's entry (the trick of rollout_tiles.hip) and appending is an
-//     EXEC-masked v_accvgpr_write per panel.  No LDS or HBM traffic for the factor at all.
+//     lane that holds v[c] of a column is the lane of the new row's entry (the trick of rollout_tiles.hip) and appending is
+//     an EXEC-masked v_accvgpr_write per panel of the new rows' tile row(s): ~ 2 (g + 1) writes.  No LDS or HBM traffic
+//     for the factor at all.
 //   * everything else (kernel entries, the grid-root product, the 3 x 3 roots, the sample) is the VALU code of
 //     rollout_fast.hip with lane == conditioning point; two small LDS buffers convert "lane = point" into the natural map.
-//   * the step loop is unrolled by EPOCH K = n_h >> 4 (number of complete super rows): every register index is static.
-//     Super rows 0 .. 4 are register resident; the sixth (rows 80 .. 95: three steps of a 30-step horizon) lives in LDS.
+//   * the step loop is unrolled by EPOCH K = group of the incomplete tile: every register index is static.
 //
+// (A first version grouped FOUR TILE ROWS per MFMA with the solution tiles replicated in all blocks: 1.5x the MFMAs, three
+// times the masked writes; tools/experiments/rollout_one_superrow/.)
 // Reference: the loop of benchmarking/simulate_true_reachable_set.py:179-258 / src/agent.py:362-415 (one launch here).
 #include "gpmpc_host.hpp"
 #include "rollout_args.hpp"
@@ -53,14 +56,16 @@ __device__ double g_one_dbg[64 * 64];
 #ifndef GPMPC_ONE_DEBUG_STEP
 #define GPMPC_ONE_DEBUG_STEP 2
 #endif
+#ifndef GPMPC_ONE_DEBUG_ROW
+#define GPMPC_ONE_DEBUG_ROW 0
+#endif
 #ifdef GPMPC_ONE_DEBUG
 #define ODBG(slot, val) do { if (blockIdx.x == 0 && t == GPMPC_ONE_DEBUG_STEP) g_one_dbg[(slot) * 64 + lane] = (val); } while (0)
 #else
 #define ODBG(slot, val)
 #endif
 
-constexpr int kOneMaxRows = 96;                                  // six super rows
-constexpr int kOneRes = 5;                                       // of which register resident
+constexpr int kOneMaxRows = 4 * kOneNTR;                         // 88 appended label rows
 constexpr int kOneRS = 5;                                        // row stride (doubles) of the lane-map converters: conflict-free b64 access
 
 __device__ __forceinline__ void one_sync_lds() {
@@ -80,21 +85,19 @@ __device__ __forceinline__ double one_mfma_zero(double a, double b) {
     asm volatile("s_nop 1\n\tv_mfma_f64_4x4x4_4b_f64 %0, %1, %2, 0\n\ts_nop 5" : "=&v"(d) : "v"(a), "v"(b));
     return d;
 }
-// acc -= A B
-__device__ __forceinline__ void one_mfma_nacc(double& acc, double a, double b) {
-    asm volatile("s_nop 1\n\tv_mfma_f64_4x4x4_4b_f64 %0, %1, %2, %0 neg:[1,0,0]\n\ts_nop 5" : "+v"(acc) : "v"(a), "v"(b));
+// v + (v rotated by N lanes inside every DPP row): row_ror:8 then row_ror:4 sum the four blocks into every block
+template <int CTRL>
+__device__ __forceinline__ double one_add_rot(double v) {
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, false);
+    return v + __hiloint2double(hi, lo);
 }
-// Copy block Q (the Q-th quad of every DPP row) of w into the other three blocks: three bank-masked row rotations per
-// dword.  row_ror:n moves lane i of a row to lane i + n; the write is confined to bank (Q + d) & 3.
-template <int Q>
-__device__ __forceinline__ double one_replicate(double w) {
-    int lo = __double2loint(w), hi = __double2hiint(w);
-    lo = __builtin_amdgcn_update_dpp(lo, lo, 0x124, 0xf, 1 << ((Q + 1) & 3), false);
-    hi = __builtin_amdgcn_update_dpp(hi, hi, 0x124, 0xf, 1 << ((Q + 1) & 3), false);
-    lo = __builtin_amdgcn_update_dpp(lo, lo, 0x128, 0xf, 1 << ((Q + 2) & 3), false);
-    hi = __builtin_amdgcn_update_dpp(hi, hi, 0x128, 0xf, 1 << ((Q + 2) & 3), false);
-    lo = __builtin_amdgcn_update_dpp(lo, lo, 0x12c, 0xf, 1 << ((Q + 3) & 3), false);
-    hi = __builtin_amdgcn_update_dpp(hi, hi, 0x12c, 0xf, 1 << ((Q + 3) & 3), false);
+__device__ __forceinline__ double one_block_sum(double v) { return one_add_rot<0x124>(one_add_rot<0x128>(v)); }
+// block BQ of dst := block BQ of w (bank-masked identity move)
+template <int BQ>
+__device__ __forceinline__ double one_merge(double dst, double w) {
+    const int lo = __builtin_amdgcn_update_dpp(__double2loint(dst), __double2loint(w), 0xe4, 0xf, 1 << BQ, false);
+    const int hi = __builtin_amdgcn_update_dpp(__double2hiint(dst), __double2hiint(w), 0xe4, 0xf, 1 << BQ, false);
     return __hiloint2double(hi, lo);
 }
 __device__ __forceinline__ double one_bpermute(double v, int addr) {
@@ -118,30 +121,24 @@ __device__ __forceinline__ void one_axis_product(double& P0, double& P1, double 
         one_axis_product<N, OFS, J + 1>(P0, P1, R0, R1, coef);
     }
 }
-
 __device__ __forceinline__ double one_pick3(int i, double v0, double v1, double v2) {
     const double t = (i == 1) ? v1 : v2;
     return (i == 0) ? v0 : t;
 }
 
-template <int N0>
 struct OneLds {
-    static constexpr int NKT = (N0 * 9 + 3) / 4;
-    static constexpr int NP5 = NKT + 4 * kOneRes + 4;             // panels of the LDS-resident super row: PR | PH | PC | GD
     static constexpr int VR = 0;                                  // [4 NKT][RS]  v_r rows (natural-map source)
-    static constexpr int HS = ((4 * NKT * kOneRS + 1) & ~1);      // [96][RS]     right-hand sides of the appended rows
-    static constexpr int P5 = HS + kOneMaxRows * kOneRS;          // [NP5][64]
-    static constexpr int TOTAL = P5 + NP5 * 64;
+    static constexpr int HS = ((4 * kOneNKT * kOneRS + 1) & ~1);  // [96][RS]     right-hand sides of the appended rows
+    static constexpr int TOTAL = HS + 96 * kOneRS;
 };
 
 template <int N0, int ENV>
 __global__ __launch_bounds__(64, 1) void rollout_one_kernel(const RolloutArgs a) {
     static_assert(ENV == GPMPC_ENV_PENDULUM1D && N0 == 4, "instantiated for the pendulum1D 4 x 9 grid");
     constexpr int D = 2, T = 3, N1 = 9, NR = N0 * N1, NX = 2;
-    using L = OneLds<N0>;
-    constexpr int NKT = L::NKT;
-    using Panels = OnePanels_k9;
-    static_assert(NKT == 9 && N0 + N1 <= 16, "panel map generated for NKT = 9");
+    constexpr int NKT = kOneNKT;
+    constexpr int KFIRST = NKT >> 2, KLAST = (NKT + kOneNTR - 1) >> 2;       // groups that hold diagonal tiles: 2 .. 7
+    static_assert(4 * NKT == NR && N0 + N1 <= 16, "panel map generated for N_r = 36");
     extern __shared__ __attribute__((aligned(16))) double smem[];
 
     const GpParams& gp = a.gp;
@@ -149,9 +146,8 @@ __global__ __launch_bounds__(64, 1) void rollout_one_kernel(const RolloutArgs a)
     const int kq = lane >> 4, bm = (lane >> 2) & 3, jq = lane & 3;
     const long s = blockIdx.x;
     const int H = a.H;
-    double* VRb = smem + L::VR;
-    double* HSb = smem + L::HS;
-    double* P5b = smem + L::P5;
+    double* VRb = smem + OneLds::VR;
+    double* HSb = smem + OneLds::HS;
 
     // ---- per-lane constants ------------------------------------------------------------------------------------------
     const double il0 = gp.inv_l2[0][0], il1 = gp.inv_l2[0][1], os = gp.os[0];
@@ -170,10 +166,10 @@ __global__ __launch_bounds__(64, 1) void rollout_one_kernel(const RolloutArgs a)
     const double g_x = a.X_r[g_pt * D + (g_ax0 ? 0 : 1)], g_il2 = g_ax0 ? il0 : il1;
     const int bp_addr = (lane & 15) << 2;                         // ds_bpermute address of "my lane of DPP row 0"
     const double Inat = (kq == jq) ? 1.0 : 0.0;
-    // lane-map converter addresses (doubles): natural-map reads
-    const int vr_rd = kq * kOneRS + jq;                           // + 4 kt RS
-    const int hs_rd = (4 * bm + kq) * kOneRS + jq;                // + 16 R RS
-    const int rA = 4 * bm + jq;                                   // row of this lane's panel entry inside its super row
+    // natural-map reads of the lane-map converters (doubles): unified tile 4 g + bm, row kq, column jq
+    const int vr_rd = (4 * bm + kq) * kOneRS + jq;                // + 16 g RS (g = 0, 1), group 2: block 0 only
+    const int hs_rd = (4 * (bm - NKT) + kq) * kOneRS + jq;        // + 16 g RS; blocks of real-data tiles are clamped to row 0
+    const int rA = 4 * bm + jq;                                   // row of this lane's diagonal-tile entry inside its group
 
     double x[NX];
 #pragma unroll
@@ -183,38 +179,20 @@ __global__ __launch_bounds__(64, 1) void rollout_one_kernel(const RolloutArgs a)
 #pragma unroll
     for (int c = 0; c < T; ++c) zq[c] = (lane < H) ? a.z[(long)lane * a.z_step_stride + s * T + c] : 0.0;
     uq = (lane < H) ? a.u_ff[lane] : 0.0;
-    double xh[D] = {0.0, 0.0}, yt[T] = {0.0, 0.0, 0.0};           // lane = appended point: its GP input and label residuals
-    // the diagonal tiles of the super row being appended to (one tile per block): L^T in the natural map and 1 / diag along its
-    // rows / columns; the same for the next super row (rows that wrap into it)
+    double xh[D] = {0.0, 0.0}, yt[T] = {0.0, 0.0, 0.0};           // lane = appended point: its GP input and labels
+    // the diagonal tiles of the group being appended to (one tile per block): L^T in the natural map and 1 / diag along its
+    // rows / columns; the same for the next group (rows that wrap into it)
     double ud = Inat, drow = 1.0, dcol = 1.0, ud1 = Inat, drow1 = 1.0, dcol1 = 1.0;
     int info_acc = 0;
     int n_h = 0, t = 0;
 
-    // ---- the factor --------------------------------------------------------------------------------------------------
-    Panels P;
-    {
-        const unsigned long long all = ~0ull;
-        double zeros[4 * kOneRes];
-#pragma unroll
-        for (int i = 0; i < 4 * kOneRes; ++i) zeros[i] = 0.0;
-        one_for<0, kOneRes>([&](auto Rc) {
-            constexpr int R = decltype(Rc)::value;
-            one_set_pr_k9<R>(P, all, zeros);
-            one_set_ph_k9<R>(P, all, zeros);
-            one_set_pc_k9<R, 0>(P, all, 0.0);
-            one_set_pc_k9<R, 1>(P, all, 0.0);
-            one_set_pc_k9<R, 2>(P, all, 0.0);
-            one_set_gd_k9<R>(P, all, Inat);
-        });
-#pragma unroll
-        for (int i = 0; i < L::NP5; ++i) P5b[i * 64 + lane] = (i == L::NP5 - 1) ? Inat : 0.0;
-    }
-    one_sync_lds();
+    OnePanels P;
+    one_init(P, Inat);
     OPH_DECL;
 
     auto step = [&](auto Kc) {
-        constexpr int K = decltype(Kc)::value;                    // complete super rows; row K is the partial one
-        constexpr int NTK = 4 * K + 4;                            // column tiles this epoch can touch
+        constexpr int K = decltype(Kc)::value;                    // group of the incomplete tile (unified tile 9 + (n_h >> 2))
+        constexpr int R0 = 4 * K - NKT;                           // first tile row of the group (may be negative: real-data tiles)
         const int i0 = n_h & 3, ycol = (i0 + 3) & 3, npts = t;
         const int cb0 = i0, cb1 = (i0 + 1) & 3, cb2 = (i0 + 2) & 3;
         // ---- input, GP input ---------------------------------------------------------------------------------------
@@ -256,16 +234,16 @@ __global__ __launch_bounds__(64, 1) void rollout_one_kernel(const RolloutArgs a)
         // ---- v_r = W k_r through the grid root (rollout_fast.hip, step 2): lane = real point ------------------------------
         double vr[T];
         {
-            const double R0 = one_bpermute(ea, bp_addr), R1 = one_bpermute(ea * gq, bp_addr);
+            const double R0_ = one_bpermute(ea, bp_addr), R1_ = one_bpermute(ea * gq, bp_addr);
             double PA0 = 0.0, PA1 = 0.0, PB0 = 0.0, PB1 = 0.0;
-            one_axis_product<N0, 0>(PA0, PA1, R0, R1, qa);
-            one_axis_product<N1, N0>(PB0, PB1, R0, R1, qb);
+            one_axis_product<N0, 0>(PA0, PA1, R0_, R1_, qa);
+            one_axis_product<N1, N0>(PB0, PB1, R0_, R1_, qb);
             const double s0 = dsc * PB0;
             vr[0] = s0 * PA0;
             vr[1] = s0 * PA1;
             vr[2] = dsc * PA0 * PB1;
         }
-        if (lane < 4 * NKT) {                                     // rows of v_r, task column c at (i0 + c) & 3, whitened label beside
+        if (lane < NR) {                                          // rows of v_r, task column c at (i0 + c) & 3, whitened label beside
             double* dst = VRb + lane * kOneRS;
             dst[cb0] = vr[0];
             dst[cb1] = vr[1];
@@ -273,7 +251,7 @@ __global__ __launch_bounds__(64, 1) void rollout_one_kernel(const RolloutArgs a)
             dst[ycol] = w_lane;
         }
         // ---- right-hand sides of the appended rows: lane = point, cov(task a of the point, task b of the test point) ----
-        if (n_h > 0 && lane < kOneMaxRows / 3) {
+        if (n_h > 0 && lane < 32) {
             const double Aa[T] = {1.0, -q0, -q1}, Bb[T] = {1.0, q0, q1}, cd[T] = {0.0, il0, il1};
 #pragma unroll
             for (int aa = 0; aa < T; ++aa) {
@@ -285,110 +263,72 @@ __global__ __launch_bounds__(64, 1) void rollout_one_kernel(const RolloutArgs a)
             }
         }
         one_sync_lds();
-        double VrRep[NKT], RN[K + 1];
+        // the solution, one natural register per group: the real-data tiles now, the appended tiles as they are solved
+        double Vu[K + 1], RN[K + 1];
+        Vu[0] = VRb[vr_rd];
+        Vu[1] = VRb[vr_rd + 16 * kOneRS];
+        {
+            const double t8 = VRb[(32 + kq) * kOneRS + jq];
+            Vu[2] = (bm == 0) ? t8 : 0.0;
+        }
 #pragma unroll
-        for (int kt = 0; kt < NKT; ++kt) VrRep[kt] = VRb[vr_rd + 4 * kt * kOneRS];
+        for (int g = 3; g <= K; ++g) Vu[g] = 0.0;
 #pragma unroll
-        for (int R = 0; R <= K; ++R) RN[R] = HSb[hs_rd + 16 * R * kOneRS];
+        for (int g = KFIRST; g <= K; ++g) RN[g] = HSb[max(hs_rd + 16 * g * kOneRS, 0)];
         OPH(0);
 
-        // ---- Gram of the real block: S_r' = sum_kt v_r[kt]^T v_r[kt] (every block holds the whole sum) ------------------
-        double Sr0 = 0.0, Sr1 = 0.0;
-        one_pchain<NKT>(Sr0, Sr1, VrRep, VrRep);
-        OPH(1);
-
-        // ---- forward substitution, left-looking over super rows; S_h' += V_p^T V_p --------------------------------------
-        double Vrep[NTK];
-#pragma unroll
-        for (int p = 0; p < NTK; ++p) Vrep[p] = 0.0;
-        double Sh0 = Sr0, Sh1 = Sr1;                              // the appended rows accumulate on top of the real block
-        double Vinc = 0.0;                                        // V of the incomplete tile row (phase H wants it)
-        if (n_h > 0) {
-            one_for<0, K + 1>([&](auto Rc) {
-                constexpr int R = decltype(Rc)::value;
-                if (R < K || n_h > 16 * K) {                      // (uniform) the partial super row may be empty
-                    double c0 = RN[R], c1 = 0.0;
-                    double gd5 = 0.0, pc5[3] = {0.0, 0.0, 0.0};
-                    if constexpr (R < kOneRes) {
-                        one_off_k9<R>(P, c0, c1, VrRep, Vrep);
-                    } else {
-                        // the LDS-resident super row: panels as ordinary operands, a dozen at a time
-                        double A[12];
-#pragma unroll
-                        for (int i = 0; i < NKT; ++i) A[i] = P5b[i * 64 + lane];
-                        one_nchain<NKT>(c0, c1, A, VrRep);
-                        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                        for (int i = 0; i < 12; ++i) A[i] = P5b[(NKT + i) * 64 + lane];
-                        one_nchain<12>(c0, c1, A, Vrep);
-                        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                        for (int i = 0; i < 8; ++i) A[i] = P5b[(NKT + 12 + i) * 64 + lane];
-                        one_nchain<8>(c0, c1, A, Vrep + 12);
-                        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                        for (int i = 0; i < 3; ++i) pc5[i] = P5b[(NKT + 20 + i) * 64 + lane];
-                        gd5 = P5b[(NKT + 23) * 64 + lane];
-                    }
-                    double acc = c0 + c1;
-                    if constexpr (R == 0) {
-                        ODBG(10, acc);
-                        ODBG(12, one_gdm_k9<0>(P, Inat));
-                    }
-                    // tile rows of the partial super row that do not exist yet are skipped (early-exit chain: a taken branch
-                    // of a lone wave costs an instruction fetch)
-                    const int rem = n_h - 16 * K;
-                    auto tile_from = [&](auto self, auto qc) -> void {
-                        constexpr int q = decltype(qc)::value;
-                        if constexpr (q < 4) {
-                            if (R < K || rem > 4 * q) {
-                                double w;
-                                if constexpr (R < kOneRes) w = one_gdm_k9<R>(P, acc);
-                                else w = one_mfma_zero(gd5, acc);
-                                if constexpr (R == 0 && q == 0) ODBG(11, w);
-                                w = one_replicate<q>(w);
-                                Vrep[4 * R + q] = w;
-                                if constexpr (q < 3) {
-                                    if constexpr (R < kOneRes) one_pcm_k9<R, q>(P, acc, w);
-                                    else one_mfma_nacc(acc, pc5[q], w);
-                                }
-                                if constexpr (R == K) one_pchain<1>(Sh0, Sh1, Vrep + 4 * R + q, Vrep + 4 * R + q);
-                                self(self, std::integral_constant<int, q + 1>{});
-                            }
-                        }
-                    };
-                    tile_from(tile_from, std::integral_constant<int, 0>{});
-                    if constexpr (R < K) one_pchain<4>(Sh0, Sh1, Vrep + 4 * R, Vrep + 4 * R);
-                }
-            });
-            if ((n_h & 3) != 0) {
-                const int bt = (n_h >> 2) & 3;
-                Vinc = (bt == 0) ? Vrep[4 * K] : ((bt == 1) ? Vrep[4 * K + 1] : ((bt == 2) ? Vrep[4 * K + 2] : Vrep[4 * K + 3]));
+        // ---- forward substitution, left-looking over tile rows ------------------------------------------------------------
+        auto tile_row = [&](auto rc) {
+            constexpr int r = decltype(rc)::value, g = (NKT + r) >> 2, b = (NKT + r) & 3;
+            double c0 = 0.0, c1 = 0.0;
+            one_row<r>(P, c0, c1, Vu);
+            const double acc = one_block_sum(c0 + c1) + RN[g];   // block b: rhs - sum over all earlier columns
+            const double w = one_gdm<g>(P, acc);
+            if constexpr (r == GPMPC_ONE_DEBUG_ROW) {
+                ODBG(10, acc);
+                ODBG(11, w);
             }
+            Vu[g] = one_merge<b>(Vu[g], w);
+        };
+        if (n_h > 0) {
+            one_for<0, (R0 > 0 ? R0 : 0)>(tile_row);              // every tile row of the earlier groups is complete
+            // the group of the incomplete tile: rows that do not exist yet end the chain (a taken branch of a lone wave
+            // costs an instruction fetch)
+            auto cur_from = [&](auto self, auto rc) -> void {
+                constexpr int r = decltype(rc)::value;
+                if constexpr (r < R0 + 4 && r < kOneNTR) {
+                    if (4 * r < n_h) {
+                        tile_row(rc);
+                        self(self, std::integral_constant<int, r + 1>{});
+                    }
+                }
+            };
+            cur_from(cur_from, std::integral_constant<int, (R0 > 0 ? R0 : 0)>{});
         }
-        ODBG(0, Vrep[0]);
-        ODBG(1, Vrep[1]);
-        ODBG(2, Vrep[2]);
-        ODBG(3, Vrep[3]);
-        ODBG(4, VrRep[0]);
-        ODBG(5, RN[0]);
+        ODBG(0, Vu[0]);
+        ODBG(1, Vu[1]);
+        ODBG(2, Vu[2]);
+        if constexpr (K >= 3) ODBG(3, Vu[3]);
+        ODBG(5, RN[2]);
         OPH(2);
 
-        // ---- S' to scalars: entry [k][j] sits in lane 16 k + j of block 0 ------------------------------------------------
+        // ---- S' = sum_g Vu[g]^T Vu[g] (each block sums its own tiles), summed over the blocks; entry [k][j] in lane 16 k + j ---
         double mu[T], S[T][T];
         {
-            const double Stot = Sh0 + Sh1;
+            double S0 = 0.0, S1 = 0.0;
+            one_pchain<K + 1>(S0, S1, Vu, Vu);
+            const double Stot = one_block_sum(S0 + S1);
             ODBG(6, Stot);
             const int cb[T] = {cb0, cb1, cb2};
 #pragma unroll
-            for (int b = 0; b < T; ++b) {
-                mu[b] = readlane_f64(Stot, 16 * cb[b] + ycol);
+            for (int bq = 0; bq < T; ++bq) {
+                mu[bq] = readlane_f64(Stot, 16 * cb[bq] + ycol);
 #pragma unroll
-                for (int c = 0; c <= b; ++c) {
-                    const double kss = (b == c) ? ((b == 0) ? os : ((b == 1) ? os * il0 : os * il1)) : 0.0;
-                    const double val = kss - readlane_f64(Stot, 16 * cb[b] + cb[c]);
-                    S[b][c] = val;
-                    S[c][b] = val;
+                for (int c = 0; c <= bq; ++c) {
+                    const double kss = (bq == c) ? ((bq == 0) ? os : ((bq == 1) ? os * il0 : os * il1)) : 0.0;
+                    const double val = kss - readlane_f64(Stot, 16 * cb[bq] + cb[c]);
+                    S[bq][c] = val;
+                    S[c][bq] = val;
                 }
             }
         }
@@ -397,22 +337,22 @@ __global__ __launch_bounds__(64, 1) void rollout_one_kernel(const RolloutArgs a)
         double var[T];
         bool all_zero = (a.var_zero_thr >= 0.0);
 #pragma unroll
-        for (int b = 0; b < T; ++b) {
-            var[b] = S[b][b];
-            if (var[b] < gp.var_floor) {
-                var[b] = gp.var_floor;
+        for (int bq = 0; bq < T; ++bq) {
+            var[bq] = S[bq][bq];
+            if (var[bq] < gp.var_floor) {
+                var[bq] = gp.var_floor;
                 info_acc |= GPMPC_INFO_VAR_CLAMPED;
             }
-            all_zero = all_zero && (var[b] <= a.var_zero_thr);
+            all_zero = all_zero && (var[bq] <= a.var_zero_thr);
         }
         double Rt[T][T], C[T][T], cinv[T];
         bool c_ok;
         {
             double Sn[T][T], rinv[T];
 #pragma unroll
-            for (int b = 0; b < T; ++b)
+            for (int bq = 0; bq < T; ++bq)
 #pragma unroll
-                for (int c = 0; c < T; ++c) Sn[b][c] = S[b][c] + ((b == c) ? gp.noise[b] : 0.0);
+                for (int c = 0; c < T; ++c) Sn[bq][c] = S[bq][c] + ((bq == c) ? gp.noise[bq] : 0.0);
             bool r_ok;
             chol3_pair_fast(Sn, S, C, Rt, cinv, rinv, c_ok, r_ok);
             if (!r_ok) info_acc |= root_small_fast_retry<T>(S, gp.jitter, Rt);
@@ -422,22 +362,22 @@ __global__ __launch_bounds__(64, 1) void rollout_one_kernel(const RolloutArgs a)
         for (int c = 0; c < T; ++c) zt[c] = readlane_f64(zq[c], t);
         double y[T];
 #pragma unroll
-        for (int b = 0; b < T; ++b) {
+        for (int bq = 0; bq < T; ++bq) {
             double acc = 0.0;
 #pragma unroll
-            for (int c = 0; c <= b; ++c) acc = fma(Rt[b][c], zt[c], acc);
-            double yb = acc + mu[b];
-            if (all_zero) yb = mu[b];
-            const double dlt = yb - mu[b];
-            if (dlt * dlt > a.beta * a.beta * var[b]) {
-                const double sd = a.beta * sqrt(var[b]);
-                yb = fmin(fmax(yb, mu[b] - sd), mu[b] + sd);
+            for (int c = 0; c <= bq; ++c) acc = fma(Rt[bq][c], zt[c], acc);
+            double yb = acc + mu[bq];
+            if (all_zero) yb = mu[bq];
+            const double dlt = yb - mu[bq];
+            if (dlt * dlt > a.beta * a.beta * var[bq]) {
+                const double sd = a.beta * sqrt(var[bq]);
+                yb = fmin(fmax(yb, mu[bq] - sd), mu[bq] + sd);
             }
-            y[b] = yb;
+            y[bq] = yb;
         }
         if (lane == 0 && a.Y) {
 #pragma unroll
-            for (int b = 0; b < T; ++b) a.Y[(s * H + t) * T + b] = y[b];
+            for (int bq = 0; bq < T; ++bq) a.Y[(s * H + t) * T + bq] = y[bq];
         }
         OPH(4);
 
@@ -449,9 +389,11 @@ __global__ __launch_bounds__(64, 1) void rollout_one_kernel(const RolloutArgs a)
                 xh[0] = mine ? xi[0] : xh[0];
                 xh[1] = mine ? xi[1] : xh[1];
 #pragma unroll
-                for (int b = 0; b < T; ++b) yt[b] = mine ? y[b] : yt[b];   // the label column is whitened by the same MFMAs (PR w_r = mu_real)
+                for (int bq = 0; bq < T; ++bq) yt[bq] = mine ? y[bq] : yt[bq];   // the label column is whitened by the same MFMAs (w_r rides in Vu)
             }
-            const int tn = n_h >> 2, bt = tn & 3, lo = n_h - 16 * K;
+            const int tn = n_h >> 2;                              // the incomplete tile row; its unified tile is 4 K + bt
+            const int bt = (NKT + tn) & 3;
+            const int lo = n_h - 4 * R0;                          // first new row inside group K's 16 rows
             // C[ci][ck] by lane-varying indices (clamped to 0 .. 2); by VALUE: a select between captured references is a
             // select of addresses, which hipcc turns into a table of pointers in scratch memory
             const double c00 = C[0][0], c10 = C[1][0], c11 = C[1][1], c20 = C[2][0], c21 = C[2][1], c22 = C[2][2];
@@ -461,43 +403,36 @@ __global__ __launch_bounds__(64, 1) void rollout_one_kernel(const RolloutArgs a)
                 const double r1 = one_pick3(ci, c11, c11, c21);
                 return one_pick3(ck, r0, r1, c22);
             };
-            // A new row (super-row-local index ri = 0 .. 2 counted from the first new row) against column rk (same origin):
-            // old columns (rk < 0) carry v of the incomplete tile row, new ones the 3 x 3 factor.  `up` = 16 for the lanes
-            // whose new row wrapped into super row K + 1.
-            auto new_entry = [&](int ri, int rk) -> double {
+            // A new row (index ri = 0 .. 2 counted from the first new row) against column rk (same origin): old columns
+            // (rk < 0) carry v of the incomplete tile row (`vold`), new ones the 3 x 3 factor
+            auto new_entry = [&](int ri, int rk, double vold) -> double {
                 const int ci = min(max(ri, 0), 2), ck = min(max(rk, 0), 2);
                 const double cval = (rk <= ri) ? c_pick(ci, ck) : 0.0;
-                return (rk < 0) ? Vinc : cval;
+                return (rk < 0) ? vold : cval;
             };
-            // rows lo .. lo + 2 of super row K (panel lanes: row rA = 4 bm + jq), or wrapped into K + 1 (its block 0)
-            const bool newK = (rA >= lo) && (rA < lo + 3);
-            const bool newK1 = rA < lo + 3 - 16;
-            const unsigned long long mK = __ballot(newK), mK1 = __ballot(newK1);
-            const int ri = rA - lo + (newK1 ? 16 : 0);
-            const double mixC = new_entry(ri, kq - (n_h & 3));                    // against the columns of the incomplete tile tn
-            // super row K
-            if constexpr (K < kOneRes) {
-                one_set_pr_k9<K>(P, mK, VrRep);
-                one_set_ph_k9<K>(P, mK, Vrep);
-                one_for<0, 3>([&](auto qc) {
-                    constexpr int q = decltype(qc)::value;
-                    const unsigned long long mq = __ballot(newK && bm > q);
-                    one_set_pc_k9<K, q>(P, mq, (bt == q) ? mixC : Vrep[4 * K + q]);
-                });
-            } else {
-                if (newK) {
+            // panels of the new rows' tile rows: lane (kq, bm, jq) of panel (r, g) is row 4 r + jq against column 4 (4 g + bm) + kq,
+            // and the value is v of that column for the row's right-hand side = this very lane of Vu[g]
+            // Every candidate tile row of the group (and the first of the next) is visited with its own lane mask - empty for
+            // the rows that get nothing, which the statement skips by itself (no C++ branch around a pinned register).
+            // Against the incomplete tile's columns a row of the NEXT tile has old columns (v) and new ones (the 3 x 3
+            // factor): those lanes of Vu[K] are replaced; for the incomplete tile's own row they are masked out.
+            double Vm[K + 2];
 #pragma unroll
-                    for (int i = 0; i < NKT; ++i) P5b[i * 64 + lane] = VrRep[i];
-#pragma unroll
-                    for (int i = 0; i < 4 * kOneRes; ++i) P5b[(NKT + i) * 64 + lane] = Vrep[i];
-#pragma unroll
-                    for (int q = 0; q < 3; ++q) {
-                        if (bm > q) P5b[(NKT + 20 + q) * 64 + lane] = (bt == q) ? mixC : Vrep[4 * K + q];
-                    }
-                }
+            for (int gg = 0; gg <= K; ++gg) Vm[gg] = Vu[gg];
+            Vm[K + 1] = 0.0;
+            {
+                const double mixC = new_entry(4 + jq - i0, kq - i0, Vu[K]);
+                Vm[K] = (bm == bt) ? mixC : Vu[K];
             }
+            one_for<(R0 > 0 ? R0 : 0), (R0 + 5 < kOneNTR ? R0 + 5 : kOneNTR)>([&](auto rc) {
+                constexpr int r = decltype(rc)::value, b = (NKT + r) & 3;
+                const int rowg = 4 * r + jq;
+                const bool nw = (rowg >= n_h) && (rowg < n_h + 3);
+                const unsigned long long mBase = __ballot(nw), mLast = __ballot(nw && bm < b);
+                one_set_row<r>(P, mBase, mLast, Vm);
+            });
             OPH(5);
-            // The diagonal tiles of super row K: ud = L^T of the lane's own tile (natural map, one tile per block), drow / dcol =
+            // The diagonal tiles of group K: ud = L^T of the lane's own tile (natural map, one tile per block), drow / dcol =
             // 1 / diag along its rows / columns.  New rows enter by select; ALL FOUR tile inverses come out of the same three
             // MFMAs, U^-1 = (I + M)(I + M^2) D^-1 with U = D (I - M) (rollout_tiles.hip, phase H) - complete tiles reproduce
             // what they had, so the whole register is committed.
@@ -509,9 +444,10 @@ __global__ __launch_bounds__(64, 1) void rollout_one_kernel(const RolloutArgs a)
                 return Pq * dcl;
             };
             {
-                // natural map of L^T: row index of L = 4 bm + jq (= rA), column index = 4 bm + kq
+                // natural map of L^T: row index of L = 4 bm + jq (= rA), column index = 4 bm + kq, both inside the group
+                const bool newK = (rA >= lo) && (rA < lo + 3);
                 const int rkD = 4 * bm + kq - lo;
-                const double mixD = new_entry(rA - lo, rkD);
+                const double mixD = new_entry(rA - lo, rkD, Vu[K]);
                 ud = newK ? mixD : ud;
                 const bool newRowK = (rkD >= 0) && (rkD < 3);            // the lane's L-column index is a new row
                 const double cK = one_pick3(min(max(rkD, 0), 2), ci0, ci1, ci2);
@@ -521,40 +457,25 @@ __global__ __launch_bounds__(64, 1) void rollout_one_kernel(const RolloutArgs a)
                 const double Gt = inverse_tiles(ud, drow, dcol);
                 ODBG(8, ud);
                 ODBG(9, Gt);
-                if constexpr (K < kOneRes) one_set_gd_k9<K>(P, ~0ull, Gt);
-                else P5b[(L::NP5 - 1) * 64 + lane] = Gt;
+                one_set_gd<K>(P, ~0ull, Gt);
             }
-            // rows that wrap into super row K + 1 (its block 0): every column tile of super row K is old or the mix
-            if (lo + 3 > 16) {                                    // uniform
-                double Vt[NTK];
-#pragma unroll
-                for (int p = 0; p < NTK; ++p) Vt[p] = Vrep[p];
-                Vt[NTK - 1] = mixC;                               // wrapping implies tn = 4 K + 3
-                if constexpr (K + 1 < kOneRes) {
-                    one_set_pr_k9<K + 1>(P, mK1, VrRep);
-                    one_set_ph_k9<K + 1>(P, mK1, Vt);
-                } else if constexpr (K + 1 == kOneRes) {
-                    if (newK1) {
-#pragma unroll
-                        for (int i = 0; i < NKT; ++i) P5b[i * 64 + lane] = VrRep[i];
-#pragma unroll
-                        for (int i = 0; i < NTK; ++i) P5b[(NKT + i) * 64 + lane] = Vt[i];
-                    }
+            if constexpr (K < KLAST) {
+                const bool wrap = lo + 3 > 16;                    // (uniform) rows wrapped into group K + 1: its first diagonal tile
+                double G1 = 0.0;
+                if (wrap) {
+                    const bool newK1 = rA < lo + 3 - 16;
+                    const int rkD1 = 4 * bm + kq + 16 - lo;       // >= 1: all of its columns are new
+                    const double mixD1 = new_entry(rA + 16 - lo, rkD1, 0.0);
+                    ud1 = newK1 ? mixD1 : ud1;
+                    const double cK1 = one_pick3(min(max(rkD1, 0), 2), ci0, ci1, ci2);
+                    const double cJ1 = one_pick3(min(max(rA + 16 - lo, 0), 2), ci0, ci1, ci2);
+                    drow1 = (rkD1 < 3) ? cK1 : drow1;
+                    dcol1 = newK1 ? cJ1 : dcol1;
+                    G1 = inverse_tiles(ud1, drow1, dcol1);
                 }
-                // its first diagonal tile: rows ri = rA + 16 - lo, columns 4 bm + kq + 16 - lo (all new)
-                const int rkD1 = 4 * bm + kq + 16 - lo;
-                const double mixD1 = new_entry(rA + 16 - lo, rkD1);
-                ud1 = newK1 ? mixD1 : ud1;
-                const double cK1 = one_pick3(min(max(rkD1, 0), 2), ci0, ci1, ci2);
-                const double cJ1 = one_pick3(min(max(rA + 16 - lo, 0), 2), ci0, ci1, ci2);
-                drow1 = (rkD1 < 3) ? cK1 : drow1;
-                dcol1 = newK1 ? cJ1 : dcol1;
-                const double G1 = inverse_tiles(ud1, drow1, dcol1);
-                if constexpr (K + 1 < kOneRes) one_set_gd_k9<K + 1>(P, ~0ull, G1);
-                else if constexpr (K + 1 == kOneRes) P5b[(L::NP5 - 1) * 64 + lane] = G1;
+                one_set_gd<K + 1>(P, __ballot(wrap), G1);
             }
             n_h += T;
-            one_sync_lds();
         }
         OPH(6);
 
@@ -568,11 +489,11 @@ __global__ __launch_bounds__(64, 1) void rollout_one_kernel(const RolloutArgs a)
         OPH(7);
     };
 
-    one_for<0, kOneMaxRows / 16>([&](auto Kc) {
+    one_for<KFIRST, KLAST + 1>([&](auto Kc) {
         constexpr int K = decltype(Kc)::value;
 #pragma unroll 1
-        while (t < H && (n_h >> 4) == K) step(Kc);
-        ud = ud1, drow = drow1, dcol = dcol1;                     // the next super row becomes the current one
+        while (t < H && ((NKT + (n_h >> 2)) >> 2) == K) step(Kc);
+        ud = ud1, drow = drow1, dcol = dcol1;                     // the next group becomes the current one
         ud1 = Inat, drow1 = 1.0, dcol1 = 1.0;
     });
 
@@ -605,7 +526,7 @@ bool rollout_one_eligible(const gpmpc_gp_desc_t* gp, const gpmpc_env_desc_t* env
     if (mode != GPMPC_MODE_RECONDITIONED || gp->T != 3 || gp->D != 2 || hall_tasks != 3 || gp->real_has_grad) return false;
     if (!plan_has_grid_root(gp->grid_n0, gp->grid_n1, gp->real_has_grad)) return false;
     if (env->env_id != GPMPC_ENV_PENDULUM1D || gp->g_ny != 1 || gp->grid_n0 != 4 || gp->grid_n1 != 9) return false;
-    if (H < 2 || 3 * (H - 1) > kOneMaxRows) return false;
+    if (H < 2 || 3 * (H - 1) > kOneMaxRows) return false;           // 22 tile rows of panels fit the AGPR file
     if (md > 0) return true;
     // one chain per wave, one wave per SIMD: up to two rounds of the chip (2048 chains) it beats four chains per wave
     return Ns <= 2048;
@@ -614,7 +535,7 @@ bool rollout_one_eligible(const gpmpc_gp_desc_t* gp, const gpmpc_env_desc_t* env
 int rollout_one_launch(const gpmpc_gp_desc_t* gp, const gpmpc_env_desc_t* env, RolloutArgs& args, hipStream_t st) {
     (void)gp;
     (void)env;
-    const size_t lds = (size_t)OneLds<4>::TOTAL * sizeof(double);
+    const size_t lds = (size_t)OneLds::TOTAL * sizeof(double);
     auto k = rollout_one_kernel<4, GPMPC_ENV_PENDULUM1D>;
     GPMPC_HIP_CHECK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(k, dim3((unsigned)args.Ns), dim3(64), lds, st, args);

@@ -22,36 +22,39 @@ import os
 import sys
 
 OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "sampling_gpmpc_amd", "csrc", "rollout_one_gen.inc")
-NRES = 5          # super rows resident in AGPRs (the sixth lives in LDS: three steps of a 30-step horizon touch it)
 MF = "v_mfma_f64_4x4x4_4b_f64"
 
 
+NKT = 9           # real-data column tiles (N_r = 36)
+NTR = 22          # tile rows of appended labels (3 (H - 1) <= 88)
+
+
+def u_of(r):
+    return NKT + r
+
+
 class Map:
-    def __init__(self, nkt):
-        self.nkt = nkt
+    """panel (r, g): tile row r of the appended labels against column GROUP g (unified column tiles 4 g .. 4 g + 3, the
+    real-data tiles first); the group that holds the row's own diagonal tile stops in front of it and is absent when the
+    diagonal tile is the group's first block."""
+    def __init__(self):
         self.idx = {}
+        self.groups = {}
         n = 0
-        for R in range(NRES):
-            for kt in range(nkt):
-                self.idx[("pr", R, kt)] = n; n += 1
-            for p in range(4 * R):
-                self.idx[("ph", R, p)] = n; n += 1
-            for q in range(3):
-                self.idx[("pc", R, q)] = n; n += 1
-            self.idx[("gd", R, 0)] = n; n += 1
+        for r in range(NTR):
+            u = u_of(r)
+            gs = list(range(u >> 2)) + ([u >> 2] if (u & 3) else [])
+            self.groups[r] = gs
+            for g in gs:
+                self.idx[("p", r, g)] = n; n += 1
+        self.gd = list(range(NKT >> 2, (u_of(NTR - 1) >> 2) + 1))
+        for g in self.gd:
+            self.idx[("gd", g, 0)] = n; n += 1
         self.count = n
         assert 2 * n <= 256, "panels exceed the AGPR file"
 
-    def reg(self, kind, R, i):
-        n = self.idx[(kind, R, i)]
-        return 2 * n
-
-    def member(self, kind, R, i):
-        if kind == "ph":
-            return f"P.ph[{2 * R * (R - 1) + i}]"
-        if kind == "gd":
-            return f"P.gd[{R}]"
-        return f"P.{kind}[{R}][{i}]"
+    def reg(self, kind, a, b):
+        return 2 * self.idx[(kind, a, b)]
 
 
 def chain_stmt(items, neg):
@@ -74,13 +77,15 @@ def chain_stmt(items, neg):
     return f"    asm volatile({body}\n        : \"+v\"(c0), \"+v\"(c1)\n        : {', '.join(ops_in)});\n"
 
 
-def set_stmt(items):
+def set_stmt(items, mask="mask"):
     """items: list of (areg, member_expr, value_expr): masked lane update of up to 6 panels in one statement."""
     k = len(items)
     # operands: 0 = saved exec, 1.. = k tied panels, then mask, then lo / hi pairs
-    lines = ['"s_mov_b64 %0, exec\\n\\t"', f'"s_mov_b64 exec, %{1 + k}\\n\\t"']
+    # an empty mask skips the writes INSIDE the statement: a C++ `if` around a tied physical-register operand makes hipcc keep
+    # the panel in a virtual register across the branch (copies in and out of the pinned register, spills of the rest)
+    lines = ['"s_mov_b64 %0, exec\\n\\t"', f'"s_mov_b64 exec, %{1 + k}\\n\\t"', '"s_cbranch_execz .Lone_skip_%=\\n\\t"']
     outs = ['"=&s"(sv_)']
-    ins = ['"s"(mask)']
+    ins = [f'"s"({mask})']
     for i, (areg, member, val) in enumerate(items):
         outs.append(f'"+{{a[{areg}:{areg + 1}]}}"({member})')
         lo = 2 + k + 2 * i
@@ -88,72 +93,60 @@ def set_stmt(items):
         lines.append(f'"v_accvgpr_write_b32 a{areg + 1}, %{lo + 1}\\n\\t"')
         ins.append(f'"v"(__double2loint({val}))')
         ins.append(f'"v"(__double2hiint({val}))')
+    lines.append('".Lone_skip_%=:\\n\\t"')
     lines.append('"s_mov_b64 exec, %0"')
     body = "\n        ".join(lines)
     return f"    asm volatile({body}\n        : {', '.join(outs)}\n        : {', '.join(ins)});\n"
 
 
-def emit(nkt, f):
-    m = Map(nkt)
-    sfx = f"k{nkt}"
-    f.write(f"// ---- NKT = {nkt}: {m.count} resident panels in a[0:{2 * m.count - 1}] -------------------------------------------------------\n")
-    f.write(f"struct OnePanels_{sfx} {{\n    double pr[{NRES}][{nkt}];\n    double ph[{2 * NRES * (NRES - 1)}];\n    double pc[{NRES}][3];\n    double gd[{NRES}];\n}};\n")
-    P = f"OnePanels_{sfx}"
-    # off-diagonal part of super row R:  c -= PR[R] VrRep, c -= PH[R] Vrep
-    for R in range(NRES):
-        items = [(m.reg("pr", R, kt), m.member("pr", R, kt), f"VrRep[{kt}]") for kt in range(nkt)]
-        items += [(m.reg("ph", R, p), m.member("ph", R, p), f"Vrep[{p}]") for p in range(4 * R)]
-        f.write(f"__device__ __forceinline__ void one_off_{sfx}_{R}({P}& P, double& c0, double& c1, const double* VrRep, const double* Vrep) {{\n")
-        for s in range(0, len(items), 12):
-            f.write(chain_stmt(items[s:s + 12], True))
+def emit(f):
+    m = Map()
+    f.write(f"// ---- NKT = {NKT}, {NTR} tile rows: {m.count} panels in a[0:{2 * m.count - 1}] ----------------------------------------------------\n")
+    f.write(f"struct OnePanels {{\n    double p[{m.count - len(m.gd)}];\n    double gd[{max(m.gd) + 1}];\n}};\n")
+    f.write(f"constexpr int kOneNKT = {NKT}, kOneNTR = {NTR};\n")
+    member = lambda r, g: f"P.p[{m.idx[('p', r, g)]}]"
+    for r in range(NTR):
+        gs = m.groups[r]
+        # off-diagonal part of tile row r: c -= panel(r, g) Vu[g]  (block b of the product: column tile 4 g + b)
+        f.write(f"__device__ __forceinline__ void one_row_{r}(OnePanels& P, double& c0, double& c1, const double* Vu) {{\n")
+        f.write(chain_stmt([(m.reg("p", r, g), member(r, g), f"Vu[{g}]") for g in gs], True))
         f.write("}\n")
-        # W = GD[R] acc
-        g = m.reg("gd", R, 0)
-        f.write(f"__device__ __forceinline__ double one_gdm_{sfx}_{R}({P}& P, double acc) {{\n    double d;\n"
-                f"    asm volatile(\"s_nop 1\\n\\t{MF} %0, a[{g}:{g + 1}], %2, 0\\n\\ts_nop 5\" : \"=&v\"(d) : \"{{a[{g}:{g + 1}]}}\"({m.member('gd', R, 0)}), \"v\"(acc));\n"
+        # masked lane update: the full groups under mBase, the row's own (partial) group under mLast
+        u = u_of(r)
+        full = [g for g in gs if g < (u >> 2)]
+        f.write(f"__device__ __forceinline__ void one_set_row_{r}(OnePanels& P, unsigned long long mBase, unsigned long long mLast, const double* V) {{\n    unsigned long long sv_;\n    (void)mLast;\n")
+        for s in range(0, len(full), 6):
+            f.write(set_stmt([(m.reg("p", r, g), member(r, g), f"V[{g}]") for g in full[s:s + 6]], "mBase"))
+        if u & 3:
+            g = u >> 2
+            f.write(set_stmt([(m.reg("p", r, g), member(r, g), f"V[{g}]")], "mLast"))
+        f.write("}\n")
+    for g in m.gd:
+        a = m.reg("gd", g, 0)
+        f.write(f"__device__ __forceinline__ double one_gdm_{g}(OnePanels& P, double acc) {{\n    double d;\n"
+                f"    asm volatile(\"s_nop 1\\n\\t{MF} %0, a[{a}:{a + 1}], %2, 0\\n\\ts_nop 5\" : \"=&v\"(d) : \"{{a[{a}:{a + 1}]}}\"(P.gd[{g}]), \"v\"(acc));\n"
                 f"    return d;\n}}\n")
-        for q in range(3):
-            r = m.reg("pc", R, q)
-            f.write(f"__device__ __forceinline__ void one_pcm_{sfx}_{R}_{q}({P}& P, double& acc, double w) {{\n"
-                    f"    asm volatile(\"s_nop 1\\n\\t{MF} %0, a[{r}:{r + 1}], %2, %0 neg:[1,0,0]\\n\\ts_nop 5\" : \"+v\"(acc) : \"{{a[{r}:{r + 1}]}}\"({m.member('pc', R, q)}), \"v\"(w));\n}}\n")
-        # masked lane updates
-        f.write(f"__device__ __forceinline__ void one_set_pr_{sfx}_{R}({P}& P, unsigned long long mask, const double* V) {{\n    unsigned long long sv_;\n")
-        items = [(m.reg("pr", R, kt), m.member("pr", R, kt), f"V[{kt}]") for kt in range(nkt)]
-        for s in range(0, len(items), 6):
-            f.write(set_stmt(items[s:s + 6]))
+        f.write(f"__device__ __forceinline__ void one_set_gd_{g}(OnePanels& P, unsigned long long mask, double v) {{\n    unsigned long long sv_;\n")
+        f.write(set_stmt([(a, f"P.gd[{g}]", "v")]))
         f.write("}\n")
-        f.write(f"__device__ __forceinline__ void one_set_ph_{sfx}_{R}({P}& P, unsigned long long mask, const double* V) {{\n    unsigned long long sv_;\n    (void)sv_; (void)mask; (void)V; (void)P;\n")
-        items = [(m.reg("ph", R, p), m.member("ph", R, p), f"V[{p}]") for p in range(4 * R)]
-        for s in range(0, len(items), 6):
-            f.write(set_stmt(items[s:s + 6]))
+    # everything to zero, the diagonal tiles to the identity
+    f.write("__device__ __forceinline__ void one_init(OnePanels& P, double inat) {\n    unsigned long long sv_;\n    unsigned long long mask = ~0ull;\n    double z = 0.0;\n")
+    allp = [(m.reg("p", r, g), member(r, g), "z") for r in range(NTR) for g in m.groups[r]]
+    for s in range(0, len(allp), 6):
+        f.write(set_stmt(allp[s:s + 6]))
+    for g in m.gd:
+        f.write(set_stmt([(m.reg("gd", g, 0), f"P.gd[{g}]", "inat")]))
+    f.write("}\n")
+
+    def disp(name, ret, params, args, rng):
+        f.write(f"template <int R>\n__device__ __forceinline__ {ret} {name}({params}) {{\n")
+        for i, r in enumerate(rng):
+            f.write(f"    {'if' if i == 0 else 'else if'} constexpr (R == {r}) {'return ' if ret != 'void' else ''}{name}_{r}({args});\n")
         f.write("}\n")
-        for q in range(3):
-            f.write(f"__device__ __forceinline__ void one_set_pc_{sfx}_{R}_{q}({P}& P, unsigned long long mask, double v) {{\n    unsigned long long sv_;\n")
-            f.write(set_stmt([(m.reg("pc", R, q), m.member("pc", R, q), "v")]))
-            f.write("}\n")
-        f.write(f"__device__ __forceinline__ void one_set_gd_{sfx}_{R}({P}& P, unsigned long long mask, double v) {{\n    unsigned long long sv_;\n")
-        f.write(set_stmt([(m.reg("gd", R, 0), m.member("gd", R, 0), "v")]))
-        f.write("}\n")
-    # compile-time dispatchers
-    def disp(name, ret, params, args, per_q=False):
-        f.write(f"template <int R{', int Q' if per_q else ''}>\n__device__ __forceinline__ {ret} {name}_{sfx}({params}) {{\n")
-        first = True
-        for R in range(NRES):
-            if per_q:
-                for q in range(3):
-                    f.write(f"    {'if' if first else 'else if'} constexpr (R == {R} && Q == {q}) {'return ' if ret != 'void' else ''}{name}_{sfx}_{R}_{q}({args});\n")
-                    first = False
-            else:
-                f.write(f"    {'if' if first else 'else if'} constexpr (R == {R}) {'return ' if ret != 'void' else ''}{name}_{sfx}_{R}({args});\n")
-                first = False
-        f.write("}\n")
-    disp("one_off", "void", f"{P}& P, double& c0, double& c1, const double* VrRep, const double* Vrep", "P, c0, c1, VrRep, Vrep")
-    disp("one_gdm", "double", f"{P}& P, double acc", "P, acc")
-    disp("one_pcm", "void", f"{P}& P, double& acc, double w", "P, acc, w", per_q=True)
-    disp("one_set_pr", "void", f"{P}& P, unsigned long long mask, const double* V", "P, mask, V")
-    disp("one_set_ph", "void", f"{P}& P, unsigned long long mask, const double* V", "P, mask, V")
-    disp("one_set_pc", "void", f"{P}& P, unsigned long long mask, double v", "P, mask, v", per_q=True)
-    disp("one_set_gd", "void", f"{P}& P, unsigned long long mask, double v", "P, mask, v")
+    disp("one_row", "void", "OnePanels& P, double& c0, double& c1, const double* Vu", "P, c0, c1, Vu", range(NTR))
+    disp("one_set_row", "void", "OnePanels& P, unsigned long long mBase, unsigned long long mLast, const double* V", "P, mBase, mLast, V", range(NTR))
+    disp("one_gdm", "double", "OnePanels& P, double acc", "P, acc", m.gd)
+    disp("one_set_gd", "void", "OnePanels& P, unsigned long long mask, double v", "P, mask, v", m.gd)
 
 
 def generic(f):
@@ -177,6 +170,5 @@ if __name__ == "__main__":
     with open(OUT, "w") as f:
         f.write("// GENERATED by tools/gen_rollout_one.py - do not edit.  Register-pinned panel operations of rollout_one.hip.\n")
         generic(f)
-        for nkt in (9,):
-            emit(nkt, f)
+        emit(f)
     print(OUT)
