@@ -282,7 +282,7 @@ __device__ __forceinline__ double bits_f64(unsigned long long u) { return __buil
     __builtin_amdgcn_sched_barrier(0)
 template <int N>
 __device__ __forceinline__ void expn_neg(const double (&x)[N], double (&e)[N]) {
-    static_assert(N >= 2 && N <= 4, "two to four chains");
+    static_assert(N >= 1 && N <= 4, "one to four chains");
     const double log2e = bits_f64(0x3FF71547652B82FEull), nln2h = bits_f64(0xBFE62E42FEFA39EFull),
                  nln2l = bits_f64(0xBC7ABC9E3B39803Full);
     const double c2 = bits_f64(0x3FE000000000000Bull), c3 = bits_f64(0x3FC5555555555511ull), c4 = bits_f64(0x3FA55555555502A1ull),
@@ -311,7 +311,7 @@ __device__ __forceinline__ void expn_neg(const double (&x)[N], double (&e)[N]) {
     // all results are due HERE: keeps the optimiser from sinking a chain to its (later) first use, out of the lockstep rows
     if constexpr (N == 4) asm volatile("" ::"v"(e[0]), "v"(e[1]), "v"(e[2]), "v"(e[3]));
     else if constexpr (N == 3) asm volatile("" ::"v"(e[0]), "v"(e[1]), "v"(e[2]));
-    else asm volatile("" ::"v"(e[0]), "v"(e[1]));
+    else if constexpr (N == 2) asm volatile("" ::"v"(e[0]), "v"(e[1]));
 }
 __device__ __forceinline__ void exp3_neg(const double (&x)[3], double (&e)[3]) { expn_neg<3>(x, e); }
 

@@ -165,6 +165,9 @@ __global__ __launch_bounds__(64, 1) void rollout_one_kernel(const RolloutArgs a)
     const int g_pt = g_ax0 ? lane * N1 : ((lane < N0 + N1) ? lane - N0 : 0);
     const double g_x = a.X_r[g_pt * D + (g_ax0 ? 0 : 1)], g_il2 = g_ax0 ? il0 : il1;
     const int bp_addr = (lane & 15) << 2;                         // ds_bpermute address of "my lane of DPP row 0"
+    // appended point j lives in lane kPt0 + j: behind the N0 + N1 axis lanes, so that ONE exponential per step serves both roles
+    constexpr int kPt0 = N0 + N1;
+    const int jpt = lane - kPt0;                                  // this lane's appended point (valid: 0 <= jpt < 32)
     const double Inat = (kq == jq) ? 1.0 : 0.0;
     // natural-map reads of the lane-map converters (doubles): unified tile 4 g + bm, row kq, column jq
     const int vr_rd = (4 * bm + kq) * kOneRS + jq;                // + 16 g RS (g = 0, 1), group 2: block 0 only
@@ -217,7 +220,7 @@ __global__ __launch_bounds__(64, 1) void rollout_one_kernel(const RolloutArgs a)
             for (int d = 0; d < D; ++d) a.Xi[(s * H + t) * D + d] = xi[d];
         }
 
-        // ---- kernel factors: the grid axis factor of this lane and the appended point of this lane, in lockstep --------
+        // ---- kernel factors: ONE exponential per lane - the grid axis factor (lanes < N0 + N1) or the appended point jpt -----
         double ea, gq, kk, q0, q1;
         {
             const double gr = g_x - (g_ax0 ? xi[0] : xi[1]);
@@ -225,16 +228,29 @@ __global__ __launch_bounds__(64, 1) void rollout_one_kernel(const RolloutArgs a)
             const double d0 = xh[0] - xi[0], d1 = xh[1] - xi[1];
             q0 = d0 * il0;
             q1 = d1 * il1;
-            const double a2[2] = {-0.5 * gr * gq, -0.5 * (d0 * q0 + d1 * q1)};
-            double e2[2];
-            expn_neg<2>(a2, e2);
-            ea = e2[0];
-            kk = (lane < npts) ? os * e2[1] : 0.0;
+            const double a1[1] = {(lane < kPt0) ? -0.5 * gr * gq : -0.5 * (d0 * q0 + d1 * q1)};
+            double e1[1];
+            expn_neg<1>(a1, e1);
+            ea = e1[0];
+            kk = (jpt >= 0 && jpt < npts) ? os * e1[0] : 0.0;
+        }
+        // the axis factors to all DPP rows (requested now, used after the appended rows' entries)
+        const double R0_ = one_bpermute(ea, bp_addr), R1_ = one_bpermute(ea * gq, bp_addr);
+        // ---- right-hand sides of the appended rows: lane = point, cov(task a of the point, task b of the test point) ----
+        if (n_h > 0 && jpt >= 0 && jpt < 32) {
+            const double Aa[T] = {1.0, -q0, -q1}, Bb[T] = {1.0, q0, q1}, cd[T] = {0.0, il0, il1};
+#pragma unroll
+            for (int aa = 0; aa < T; ++aa) {
+                double* dst = HSb + (3 * jpt + aa) * kOneRS;
+                dst[cb0] = kk * Aa[aa];
+                dst[cb1] = kk * fma(Aa[aa], Bb[1], (aa == 1) ? cd[1] : 0.0);
+                dst[cb2] = kk * fma(Aa[aa], Bb[2], (aa == 2) ? cd[2] : 0.0);
+                dst[ycol] = (jpt < npts) ? yt[aa] : 0.0;
+            }
         }
         // ---- v_r = W k_r through the grid root (rollout_fast.hip, step 2): lane = real point ------------------------------
         double vr[T];
         {
-            const double R0_ = one_bpermute(ea, bp_addr), R1_ = one_bpermute(ea * gq, bp_addr);
             double PA0 = 0.0, PA1 = 0.0, PB0 = 0.0, PB1 = 0.0;
             one_axis_product<N0, 0>(PA0, PA1, R0_, R1_, qa);
             one_axis_product<N1, N0>(PB0, PB1, R0_, R1_, qb);
@@ -249,18 +265,6 @@ __global__ __launch_bounds__(64, 1) void rollout_one_kernel(const RolloutArgs a)
             dst[cb1] = vr[1];
             dst[cb2] = vr[2];
             dst[ycol] = w_lane;
-        }
-        // ---- right-hand sides of the appended rows: lane = point, cov(task a of the point, task b of the test point) ----
-        if (n_h > 0 && lane < 32) {
-            const double Aa[T] = {1.0, -q0, -q1}, Bb[T] = {1.0, q0, q1}, cd[T] = {0.0, il0, il1};
-#pragma unroll
-            for (int aa = 0; aa < T; ++aa) {
-                double* dst = HSb + (3 * lane + aa) * kOneRS;
-                dst[cb0] = kk * Aa[aa];
-                dst[cb1] = kk * fma(Aa[aa], Bb[1], (aa == 1) ? cd[1] : 0.0);
-                dst[cb2] = kk * fma(Aa[aa], Bb[2], (aa == 2) ? cd[2] : 0.0);
-                dst[ycol] = (lane < npts) ? yt[aa] : 0.0;
-            }
         }
         one_sync_lds();
         // the solution, one natural register per group: the real-data tiles now, the appended tiles as they are solved
@@ -385,7 +389,7 @@ __global__ __launch_bounds__(64, 1) void rollout_one_kernel(const RolloutArgs a)
         if (t + 1 < H) {
             if (!c_ok) info_acc |= GPMPC_INFO_TRAIN_CHOL_FAIL;
             {
-                const bool mine = lane == npts;
+                const bool mine = jpt == npts;
                 xh[0] = mine ? xi[0] : xh[0];
                 xh[1] = mine ? xi[1] : xh[1];
 #pragma unroll
@@ -412,25 +416,38 @@ __global__ __launch_bounds__(64, 1) void rollout_one_kernel(const RolloutArgs a)
             };
             // panels of the new rows' tile rows: lane (kq, bm, jq) of panel (r, g) is row 4 r + jq against column 4 (4 g + bm) + kq,
             // and the value is v of that column for the row's right-hand side = this very lane of Vu[g]
-            // Every candidate tile row of the group (and the first of the next) is visited with its own lane mask - empty for
-            // the rows that get nothing, which the statement skips by itself (no C++ branch around a pinned register).
-            // Against the incomplete tile's columns a row of the NEXT tile has old columns (v) and new ones (the 3 x 3
-            // factor): those lanes of Vu[K] are replaced; for the incomplete tile's own row they are masked out.
-            double Vm[K + 2];
-#pragma unroll
-            for (int gg = 0; gg <= K; ++gg) Vm[gg] = Vu[gg];
-            Vm[K + 1] = 0.0;
-            {
-                const double mixC = new_entry(4 + jq - i0, kq - i0, Vu[K]);
-                Vm[K] = (bm == bt) ? mixC : Vu[K];
-            }
-            one_for<(R0 > 0 ? R0 : 0), (R0 + 5 < kOneNTR ? R0 + 5 : kOneNTR)>([&](auto rc) {
-                constexpr int r = decltype(rc)::value, b = (NKT + r) & 3;
+            // The masked writes run under uniform C++ branches (only the incomplete tile row and, when the new rows reach into
+            // it, the next one have anything to receive) WITHOUT naming the panels as operands - a tied physical-register
+            // operand defined under a branch makes hipcc carry the panel in a virtual register across it; one_touch_row
+            // (no instruction) tells the compiler afterwards that the panels of the candidate rows may have changed.
+            auto row_masks = [&](int r, int b, unsigned long long& mBase, unsigned long long& mLast) {
                 const int rowg = 4 * r + jq;
                 const bool nw = (rowg >= n_h) && (rowg < n_h + 3);
-                const unsigned long long mBase = __ballot(nw), mLast = __ballot(nw && bm < b);
-                one_set_row<r>(P, mBase, mLast, Vm);
+                mBase = __ballot(nw);
+                mLast = __ballot(nw && bm < b);
+            };
+            one_for<(R0 > 0 ? R0 : 0), (R0 + 4 < kOneNTR ? R0 + 4 : kOneNTR)>([&](auto rc) {
+                constexpr int r = decltype(rc)::value;
+                if (tn == r) {                                    // uniform
+                    unsigned long long mBase, mLast;
+                    row_masks(r, (NKT + r) & 3, mBase, mLast);
+                    one_hset_row<r>(mBase, mLast, Vu);
+                    if constexpr (r + 1 < kOneNTR) {
+                        if (i0 >= 2) {                            // rows n_h .. n_h + 2 reach into tile row r + 1
+                            // against the incomplete tile's columns that row has old columns (v) and new ones (the 3 x 3 factor)
+                            double Vm[K + 2];
+#pragma unroll
+                            for (int gg = 0; gg <= K; ++gg) Vm[gg] = Vu[gg];
+                            Vm[K + 1] = 0.0;
+                            const double mixC = new_entry(4 + jq - i0, kq - i0, Vu[K]);
+                            Vm[K] = (bm == bt) ? mixC : Vu[K];
+                            row_masks(r + 1, (NKT + r + 1) & 3, mBase, mLast);
+                            one_hset_row<r + 1>(mBase, mLast, Vm);
+                        }
+                    }
+                }
             });
+            one_for<(R0 > 0 ? R0 : 0), (R0 + 5 < kOneNTR ? R0 + 5 : kOneNTR)>([&](auto rc) { one_touch_row<decltype(rc)::value>(P); });
             OPH(5);
             // The diagonal tiles of group K: ud = L^T of the lane's own tile (natural map, one tile per block), drow / dcol =
             // 1 / diag along its rows / columns.  New rows enter by select; ALL FOUR tile inverses come out of the same three
@@ -460,9 +477,7 @@ __global__ __launch_bounds__(64, 1) void rollout_one_kernel(const RolloutArgs a)
                 one_set_gd<K>(P, ~0ull, Gt);
             }
             if constexpr (K < KLAST) {
-                const bool wrap = lo + 3 > 16;                    // (uniform) rows wrapped into group K + 1: its first diagonal tile
-                double G1 = 0.0;
-                if (wrap) {
+                if (lo + 3 > 16) {                                // (uniform) rows wrapped into group K + 1: its first diagonal tile
                     const bool newK1 = rA < lo + 3 - 16;
                     const int rkD1 = 4 * bm + kq + 16 - lo;       // >= 1: all of its columns are new
                     const double mixD1 = new_entry(rA + 16 - lo, rkD1, 0.0);
@@ -471,9 +486,10 @@ __global__ __launch_bounds__(64, 1) void rollout_one_kernel(const RolloutArgs a)
                     const double cJ1 = one_pick3(min(max(rA + 16 - lo, 0), 2), ci0, ci1, ci2);
                     drow1 = (rkD1 < 3) ? cK1 : drow1;
                     dcol1 = newK1 ? cJ1 : dcol1;
-                    G1 = inverse_tiles(ud1, drow1, dcol1);
+                    const double G1 = inverse_tiles(ud1, drow1, dcol1);
+                    one_hset_gd<K + 1>(G1);                       // (hidden write under the branch, see above)
                 }
-                one_set_gd<K + 1>(P, __ballot(wrap), G1);
+                one_touch_gd<K + 1>(P);
             }
             n_h += T;
         }

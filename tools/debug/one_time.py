@@ -14,7 +14,7 @@ for (ns, h) in CASES:
     print("   path", _lib.load().gpmpc_debug_last_rollout_path(), flush=True)
     if os.environ.get("GPMPC_PHASE_TIMERS") == "1" and _lib.load().gpmpc_debug_last_rollout_path() == 4:
         raw = C.CDLL(_lib.LIB_PATH); out = (C.c_longlong * 16)(); raw.gpmpc_debug_read_one_phases(out)
-        names = ["entries+vr+lds", "gram real", "solve", "extract", "sample", "append sets", "append diag", "state"]
+        names = ["entries+vr+lds", "-", "solve", "gram+extract", "sample", "append sets", "append diag", "state"]
         tot = sum(out[:8])
         print("   total cycles", tot, "per step", tot // h)
         for n, v in zip(names, out[:8]): print(f"   {n:16s} {v:9d} {v // h:7d}/step {100.0 * v / max(tot, 1):5.1f}%%")

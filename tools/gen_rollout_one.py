@@ -99,6 +99,24 @@ def set_stmt(items, mask="mask"):
     return f"    asm volatile({body}\n        : {', '.join(outs)}\n        : {', '.join(ins)});\n"
 
 
+def hidden_set_stmt(items, mask):
+    """the same masked update WITHOUT naming the panels as operands: for use under a C++ branch (a tied physical-register
+    operand defined inside a branch makes hipcc carry the panel in a virtual register across it); one_touch() afterwards tells
+    the compiler that the panels may have changed."""
+    k = len(items)
+    lines = ['"s_mov_b64 %0, exec\\n\\t"', '"s_mov_b64 exec, %1\\n\\t"']
+    ins = [f'"s"({mask})']
+    for i, (areg, val) in enumerate(items):
+        lo = 2 + 2 * i
+        lines.append(f'"v_accvgpr_write_b32 a{areg}, %{lo}\\n\\t"')
+        lines.append(f'"v_accvgpr_write_b32 a{areg + 1}, %{lo + 1}\\n\\t"')
+        ins.append(f'"v"(__double2loint({val}))')
+        ins.append(f'"v"(__double2hiint({val}))')
+    lines.append('"s_mov_b64 exec, %0"')
+    body = "\n        ".join(lines)
+    return f"    asm volatile({body}\n        : \"=&s\"(sv_)\n        : {', '.join(ins)});\n"
+
+
 def emit(f):
     m = Map()
     f.write(f"// ---- NKT = {NKT}, {NTR} tile rows: {m.count} panels in a[0:{2 * m.count - 1}] ----------------------------------------------------\n")
@@ -121,11 +139,30 @@ def emit(f):
             g = u >> 2
             f.write(set_stmt([(m.reg("p", r, g), member(r, g), f"V[{g}]")], "mLast"))
         f.write("}\n")
+    for r in range(NTR):
+        u = u_of(r)
+        full = [g for g in m.groups[r] if g < (u >> 2)]
+        f.write(f"__device__ __forceinline__ void one_hset_row_{r}(unsigned long long mBase, unsigned long long mLast, const double* V) {{\n    unsigned long long sv_;\n    (void)mLast;\n")
+        for s_ in range(0, len(full), 12):
+            f.write(hidden_set_stmt([(m.reg("p", r, g), f"V[{g}]") for g in full[s_:s_ + 12]], "mBase"))
+        if u & 3:
+            g = u >> 2
+            f.write(hidden_set_stmt([(m.reg("p", r, g), f"V[{g}]")], "mLast"))
+        f.write("}\n")
+    # "the panels of tile rows R .. R + N - 1 may have changed": empty statements with tied operands
+    f.write("template <int R>\n__device__ __forceinline__ void one_touch_row(OnePanels& P) {\n")
+    for r in range(NTR):
+        ops = ", ".join([f'"+{{a[{m.reg("p", r, g)}:{m.reg("p", r, g) + 1}]}}"({member(r, g)})' for g in m.groups[r]])
+        f.write(f"    {'if' if r == 0 else 'else if'} constexpr (R == {r}) asm volatile(\"\" : {ops});\n")
+    f.write("}\n")
     for g in m.gd:
         a = m.reg("gd", g, 0)
         f.write(f"__device__ __forceinline__ double one_gdm_{g}(OnePanels& P, double acc) {{\n    double d;\n"
                 f"    asm volatile(\"s_nop 1\\n\\t{MF} %0, a[{a}:{a + 1}], %2, 0\\n\\ts_nop 5\" : \"=&v\"(d) : \"{{a[{a}:{a + 1}]}}\"(P.gd[{g}]), \"v\"(acc));\n"
                 f"    return d;\n}}\n")
+        f.write(f"__device__ __forceinline__ void one_hset_gd_{g}(double v) {{\n"
+                f"    asm volatile(\"v_accvgpr_write_b32 a{a}, %0\\n\\tv_accvgpr_write_b32 a{a + 1}, %1\" : : \"v\"(__double2loint(v)), \"v\"(__double2hiint(v)));\n}}\n")
+        f.write(f"__device__ __forceinline__ void one_touch_gd_{g}(OnePanels& P) {{ asm volatile(\"\" : \"+{{a[{a}:{a + 1}]}}\"(P.gd[{g}])); }}\n")
         f.write(f"__device__ __forceinline__ void one_set_gd_{g}(OnePanels& P, unsigned long long mask, double v) {{\n    unsigned long long sv_;\n")
         f.write(set_stmt([(a, f"P.gd[{g}]", "v")]))
         f.write("}\n")
@@ -145,8 +182,11 @@ def emit(f):
         f.write("}\n")
     disp("one_row", "void", "OnePanels& P, double& c0, double& c1, const double* Vu", "P, c0, c1, Vu", range(NTR))
     disp("one_set_row", "void", "OnePanels& P, unsigned long long mBase, unsigned long long mLast, const double* V", "P, mBase, mLast, V", range(NTR))
+    disp("one_hset_row", "void", "unsigned long long mBase, unsigned long long mLast, const double* V", "mBase, mLast, V", range(NTR))
     disp("one_gdm", "double", "OnePanels& P, double acc", "P, acc", m.gd)
     disp("one_set_gd", "void", "OnePanels& P, unsigned long long mask, double v", "P, mask, v", m.gd)
+    disp("one_hset_gd", "void", "double v", "v", m.gd)
+    disp("one_touch_gd", "void", "OnePanels& P", "P", m.gd)
 
 
 def generic(f):
