@@ -88,8 +88,9 @@ __device__ __forceinline__ double one_mfma_zero(double a, double b) {
 // v + (v rotated by N lanes inside every DPP row): row_ror:8 then row_ror:4 sum the four blocks into every block
 template <int CTRL>
 __device__ __forceinline__ double one_add_rot(double v) {
-    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, false);
-    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, false);
+    // (mov_dpp: no "old" value to materialise - every lane of a rotation has a source)
+    const int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), CTRL, 0xf, 0xf, true);
+    const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), CTRL, 0xf, 0xf, true);
     return v + __hiloint2double(hi, lo);
 }
 __device__ __forceinline__ double one_block_sum(double v) { return one_add_rot<0x124>(one_add_rot<0x128>(v)); }
@@ -284,7 +285,7 @@ __global__ __launch_bounds__(64, 1) void rollout_one_kernel(const RolloutArgs a)
         // ---- forward substitution, left-looking over tile rows ------------------------------------------------------------
         auto tile_row = [&](auto rc) {
             constexpr int r = decltype(rc)::value, g = (NKT + r) >> 2, b = (NKT + r) & 3;
-            double c0 = 0.0, c1 = 0.0;
+            double c0, c1;                                        // (the chain starts both accumulators at zero)
             one_row<r>(P, c0, c1, Vu);
             const double acc = one_block_sum(c0 + c1) + RN[g];   // block b: rhs - sum over all earlier columns
             const double w = one_gdm<g>(P, acc);
@@ -319,8 +320,8 @@ __global__ __launch_bounds__(64, 1) void rollout_one_kernel(const RolloutArgs a)
         // ---- S' = sum_g Vu[g]^T Vu[g] (each block sums its own tiles), summed over the blocks; entry [k][j] in lane 16 k + j ---
         double mu[T], S[T][T];
         {
-            double S0 = 0.0, S1 = 0.0;
-            one_pchain<K + 1>(S0, S1, Vu, Vu);
+            double S0, S1;
+            one_fchain<K + 1>(S0, S1, Vu, Vu);
             const double Stot = one_block_sum(S0 + S1);
             ODBG(6, Stot);
             const int cb[T] = {cb0, cb1, cb2};

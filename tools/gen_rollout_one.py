@@ -57,24 +57,28 @@ class Map:
         return 2 * self.idx[(kind, a, b)]
 
 
-def chain_stmt(items, neg):
+def chain_stmt(items, neg, fresh=False):
     """items: list of (areg or None, a_expr, b_expr): one asm statement accumulating alternately into c0 / c1.
-    areg None: the A operand is an ordinary VGPR value."""
+    areg None: the A operand is an ordinary VGPR value.  fresh: the accumulators start at zero (SrcC = 0 in the first MFMA of
+    each: no v_mov of zeros in front of every chain); needs at least two MFMAs."""
     lines = ['"s_nop 1\\n\\t"']
     ops_in = []
     k = len(items)
+    assert not fresh or k >= 2
     for i, (areg, aexpr, bexpr) in enumerate(items):
         c = i & 1
         a_txt = f"a[{areg}:{areg + 1}]" if areg is not None else f"%{2 + 2 * i}"
         b_txt = f"%{2 + 2 * i + 1}"
-        lines.append(f'"{MF} %{c}, {a_txt}, {b_txt}, %{c}{" neg:[1,0,0]" if neg else ""}\\n\\t"')
+        src_c = "0" if (fresh and i < 2) else f"%{c}"
+        lines.append(f'"{MF} %{c}, {a_txt}, {b_txt}, {src_c}{" neg:[1,0,0]" if neg else ""}\\n\\t"')
         if i + 1 < k:
             lines.append('"s_nop 1\\n\\t"')
         ops_in.append(f'"{{a[{areg}:{areg + 1}]}}"({aexpr})' if areg is not None else f'"v"({aexpr})')
         ops_in.append(f'"v"({bexpr})')
     lines.append('"s_nop 5"')
     body = "\n        ".join(lines)
-    return f"    asm volatile({body}\n        : \"+v\"(c0), \"+v\"(c1)\n        : {', '.join(ops_in)});\n"
+    cons = '"=&v"(c0), "=&v"(c1)' if fresh else '"+v"(c0), "+v"(c1)'
+    return f"    asm volatile({body}\n        : {cons}\n        : {', '.join(ops_in)});\n"
 
 
 def set_stmt(items, mask="mask"):
@@ -127,7 +131,7 @@ def emit(f):
         gs = m.groups[r]
         # off-diagonal part of tile row r: c -= panel(r, g) Vu[g]  (block b of the product: column tile 4 g + b)
         f.write(f"__device__ __forceinline__ void one_row_{r}(OnePanels& P, double& c0, double& c1, const double* Vu) {{\n")
-        f.write(chain_stmt([(m.reg("p", r, g), member(r, g), f"Vu[{g}]") for g in gs], True))
+        f.write(chain_stmt([(m.reg("p", r, g), member(r, g), f"Vu[{g}]") for g in gs], True, fresh=True))
         f.write("}\n")
         # masked lane update: the full groups under mBase, the row's own (partial) group under mLast
         u = u_of(r)
@@ -191,18 +195,18 @@ def emit(f):
 
 def generic(f):
     """chains with every operand in ordinary registers (the LDS-resident super row, the Gram products)"""
-    for neg in (False, True):
-        nm = "one_nchain" if neg else "one_pchain"
-        for k in range(1, 13):
+    for neg, fresh in ((False, False), (True, False), (False, True)):
+        nm = "one_fchain" if fresh else ("one_nchain" if neg else "one_pchain")
+        for k in range(2 if fresh else 1, 13):
             args = ", ".join([f"double a{i}" for i in range(k)] + [f"double b{i}" for i in range(k)])
             items = [(None, f"a{i}", f"b{i}") for i in range(k)]
             f.write(f"__device__ __forceinline__ void {nm}{k}(double& c0, double& c1, {args}) {{\n")
-            f.write(chain_stmt(items, neg))
+            f.write(chain_stmt(items, neg, fresh))
             f.write("}\n")
         f.write(f"template <int K>\n__device__ __forceinline__ void {nm}(double& c0, double& c1, const double* A, const double* B) {{\n")
-        for k in range(1, 13):
+        for k in range(2 if fresh else 1, 13):
             call = ", ".join([f"A[{i}]" for i in range(k)] + [f"B[{i}]" for i in range(k)])
-            f.write(f"    {'if' if k == 1 else 'else if'} constexpr (K == {k}) {nm}{k}(c0, c1, {call});\n")
+            f.write(f"    {'if' if k == (2 if fresh else 1) else 'else if'} constexpr (K == {k}) {nm}{k}(c0, c1, {call});\n")
         f.write("}\n")
 
 
