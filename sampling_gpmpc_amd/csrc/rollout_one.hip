@@ -106,21 +106,77 @@ __device__ __forceinline__ double one_bpermute(double v, int addr) {
     const int hi = __builtin_amdgcn_ds_bpermute(addr, __double2hiint(v));
     return __hiloint2double(hi, lo);
 }
-// acc0 += R0@(lane I of the DPP row) * l ; acc1 += R1@(lane I) * l
-template <int I>
-__device__ __forceinline__ void one_fmac2_bcast(double& acc0, double& acc1, double R0, double R1, double l) {
-    asm("s_nop 1\n\t"
-        "v_fmac_f64_dpp %0, %3, %2 row_newbcast:%5 row_mask:0xf bank_mask:0xf\n\t"
-        "v_fmac_f64_dpp %1, %4, %2 row_newbcast:%5 row_mask:0xf bank_mask:0xf"
-        : "+v"(acc0), "+v"(acc1)
-        : "v"(l), "v"(R0), "v"(R1), "n"(I));
-}
-template <int N, int OFS, int J = 0>
-__device__ __forceinline__ void one_axis_product(double& P0, double& P1, double R0, double R1, const double (&coef)[N]) {
-    if constexpr (J < N) {
-        one_fmac2_bcast<OFS + J>(P0, P1, R0, R1, coef[J]);
-        one_axis_product<N, OFS, J + 1>(P0, P1, R0, R1, coef);
+// exp(x), x <= 0: the algorithm of expn_neg (gpmpc_device.hpp: Cody-Waite reduction, degree-11 polynomial in Estrin form)
+// with its thirteen constants in registers that live across the step loop.  This file is compiled without machine-LICM
+// (an SGPR spill otherwise): left to hipcc, every step re-materialises the constants - 20 s_mov + 18 v_mov_b64.
+struct OneExpConsts {
+    double log2e, nln2h, nln2l, c2, c3, c4, c5, c6, c7, c8, c9, c10, c11;
+    __device__ __forceinline__ void load() {
+        log2e = bits_f64(0x3FF71547652B82FEull), nln2h = bits_f64(0xBFE62E42FEFA39EFull), nln2l = bits_f64(0xBC7ABC9E3B39803Full);
+        c2 = bits_f64(0x3FE000000000000Bull), c3 = bits_f64(0x3FC5555555555511ull), c4 = bits_f64(0x3FA55555555502A1ull);
+        c5 = bits_f64(0x3F81111111122322ull), c6 = bits_f64(0x3F56C16C1852B7B0ull), c7 = bits_f64(0x3F2A01A014761F6Eull);
+        c8 = bits_f64(0x3EFA01997C89E6B0ull), c9 = bits_f64(0x3EC71DEE623FDE64ull), c10 = bits_f64(0x3E928AF3FCA7AB0Cull);
+        c11 = bits_f64(0x3E5ADE156A5DCB37ull);
+        asm volatile("" : "+v"(log2e), "+v"(nln2h), "+v"(nln2l), "+v"(c2), "+v"(c3), "+v"(c4), "+v"(c5), "+v"(c6), "+v"(c7), "+v"(c8),
+                     "+v"(c9), "+v"(c10), "+v"(c11));
     }
+};
+__device__ __forceinline__ double one_exp_neg(double x, const OneExpConsts& k) {
+    const double n = rint(x * k.log2e);
+    double r = fma(n, k.nln2h, x);
+    r = fma(n, k.nln2l, r);
+    const double r2 = r * r;
+    double a0 = 1.0 + r;
+    const double a1 = fma(k.c3, r, k.c2);
+    double a2 = fma(k.c5, r, k.c4);
+    const double a3 = fma(k.c7, r, k.c6);
+    double a4 = fma(k.c9, r, k.c8);
+    const double a5 = fma(k.c11, r, k.c10);
+    const double r4 = r2 * r2;
+    a0 = fma(a1, r2, a0);
+    a2 = fma(a3, r2, a2);
+    a4 = fma(a5, r2, a4);
+    a2 = fma(a4, r4, a2);
+    a0 = fma(a2, r4, a0);
+    return ldexp(a0, (int)n);
+}
+// P0 += sum_j R0@(lane OFS + j) c[j], P1 likewise with R1: ONE statement per axis - the DPP read-after-VALU-write hazard can only
+// arise at its head (R0 / R1 come from ds_bpermute, nothing is scheduled inside)
+__device__ __forceinline__ void one_axis4(double& P0, double& P1, double R0, double R1, const double (&c)[4]) {
+    asm("s_nop 1\n\t"
+        "v_fmac_f64_dpp %0, %2, %4 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f64_dpp %1, %3, %4 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f64_dpp %0, %2, %5 row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f64_dpp %1, %3, %5 row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f64_dpp %0, %2, %6 row_newbcast:2 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f64_dpp %1, %3, %6 row_newbcast:2 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f64_dpp %0, %2, %7 row_newbcast:3 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f64_dpp %1, %3, %7 row_newbcast:3 row_mask:0xf bank_mask:0xf"
+        : "+v"(P0), "+v"(P1)
+        : "v"(R0), "v"(R1), "v"(c[0]), "v"(c[1]), "v"(c[2]), "v"(c[3]));
+}
+__device__ __forceinline__ void one_axis9(double& P0, double& P1, double R0, double R1, const double (&c)[9]) {
+    asm("s_nop 1\n\t"
+        "v_fmac_f64_dpp %0, %2, %4 row_newbcast:4 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f64_dpp %1, %3, %4 row_newbcast:4 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f64_dpp %0, %2, %5 row_newbcast:5 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f64_dpp %1, %3, %5 row_newbcast:5 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f64_dpp %0, %2, %6 row_newbcast:6 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f64_dpp %1, %3, %6 row_newbcast:6 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f64_dpp %0, %2, %7 row_newbcast:7 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f64_dpp %1, %3, %7 row_newbcast:7 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f64_dpp %0, %2, %8 row_newbcast:8 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f64_dpp %1, %3, %8 row_newbcast:8 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f64_dpp %0, %2, %9 row_newbcast:9 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f64_dpp %1, %3, %9 row_newbcast:9 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f64_dpp %0, %2, %10 row_newbcast:10 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f64_dpp %1, %3, %10 row_newbcast:10 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f64_dpp %0, %2, %11 row_newbcast:11 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f64_dpp %1, %3, %11 row_newbcast:11 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f64_dpp %0, %2, %12 row_newbcast:12 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f64_dpp %1, %3, %12 row_newbcast:12 row_mask:0xf bank_mask:0xf"
+        : "+v"(P0), "+v"(P1)
+        : "v"(R0), "v"(R1), "v"(c[0]), "v"(c[1]), "v"(c[2]), "v"(c[3]), "v"(c[4]), "v"(c[5]), "v"(c[6]), "v"(c[7]), "v"(c[8]));
 }
 __device__ __forceinline__ double one_pick3(int i, double v0, double v1, double v2) {
     const double t = (i == 1) ? v1 : v2;
@@ -190,6 +246,8 @@ __global__ __launch_bounds__(64, 1) void rollout_one_kernel(const RolloutArgs a)
     int info_acc = 0;
     int n_h = 0, t = 0;
 
+    OneExpConsts ek;
+    ek.load();
     OnePanels P;
     one_init(P, Inat);
     OPH_DECL;
@@ -229,11 +287,8 @@ __global__ __launch_bounds__(64, 1) void rollout_one_kernel(const RolloutArgs a)
             const double d0 = xh[0] - xi[0], d1 = xh[1] - xi[1];
             q0 = d0 * il0;
             q1 = d1 * il1;
-            const double a1[1] = {(lane < kPt0) ? -0.5 * gr * gq : -0.5 * (d0 * q0 + d1 * q1)};
-            double e1[1];
-            expn_neg<1>(a1, e1);
-            ea = e1[0];
-            kk = (jpt >= 0 && jpt < npts) ? os * e1[0] : 0.0;
+            ea = one_exp_neg((lane < kPt0) ? -0.5 * gr * gq : -0.5 * (d0 * q0 + d1 * q1), ek);
+            kk = (jpt >= 0 && jpt < npts) ? os * ea : 0.0;
         }
         // the axis factors to all DPP rows (requested now, used after the appended rows' entries)
         const double R0_ = one_bpermute(ea, bp_addr), R1_ = one_bpermute(ea * gq, bp_addr);
@@ -253,8 +308,8 @@ __global__ __launch_bounds__(64, 1) void rollout_one_kernel(const RolloutArgs a)
         double vr[T];
         {
             double PA0 = 0.0, PA1 = 0.0, PB0 = 0.0, PB1 = 0.0;
-            one_axis_product<N0, 0>(PA0, PA1, R0_, R1_, qa);
-            one_axis_product<N1, N0>(PB0, PB1, R0_, R1_, qb);
+            one_axis4(PA0, PA1, R0_, R1_, qa);                    // lanes 0 .. 3 of the row: axis 0
+            one_axis9(PB0, PB1, R0_, R1_, qb);                    // lanes 4 .. 12: axis 1
             const double s0 = dsc * PB0;
             vr[0] = s0 * PA0;
             vr[1] = s0 * PA1;
@@ -372,7 +427,7 @@ __global__ __launch_bounds__(64, 1) void rollout_one_kernel(const RolloutArgs a)
 #pragma unroll
             for (int c = 0; c <= bq; ++c) acc = fma(Rt[bq][c], zt[c], acc);
             double yb = acc + mu[bq];
-            if (all_zero) yb = mu[bq];
+            if (all_zero) yb = mu[bq];                            // (uniform; disabled in the shipped configurations)
             const double dlt = yb - mu[bq];
             if (dlt * dlt > a.beta * a.beta * var[bq]) {
                 const double sd = a.beta * sqrt(var[bq]);
