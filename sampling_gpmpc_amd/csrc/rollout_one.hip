@@ -301,7 +301,7 @@ __global__ __launch_bounds__(64, 1) void rollout_one_kernel(const RolloutArgs a)
                 dst[cb0] = kk * Aa[aa];
                 dst[cb1] = kk * fma(Aa[aa], Bb[1], (aa == 1) ? cd[1] : 0.0);
                 dst[cb2] = kk * fma(Aa[aa], Bb[2], (aa == 2) ? cd[2] : 0.0);
-                dst[ycol] = (jpt < npts) ? yt[aa] : 0.0;
+                dst[ycol] = yt[aa];                               // (zero until the lane's point exists)
             }
         }
         // ---- v_r = W k_r through the grid root (rollout_fast.hip, step 2): lane = real point ------------------------------
@@ -395,16 +395,12 @@ __global__ __launch_bounds__(64, 1) void rollout_one_kernel(const RolloutArgs a)
         OPH(3);
         // ---- variance floor, roots, sample (as sample_gp, src/agent.py:629-708) -------------------------------------------
         double var[T];
-        bool all_zero = (a.var_zero_thr >= 0.0);
 #pragma unroll
-        for (int bq = 0; bq < T; ++bq) {
-            var[bq] = S[bq][bq];
-            if (var[bq] < gp.var_floor) {
-                var[bq] = gp.var_floor;
-                info_acc |= GPMPC_INFO_VAR_CLAMPED;
-            }
-            all_zero = all_zero && (var[bq] <= a.var_zero_thr);
-        }
+        for (int bq = 0; bq < T; ++bq) var[bq] = fmax(S[bq][bq], gp.var_floor);
+        if (fmin(fmin(S[0][0], S[1][1]), S[2][2]) < gp.var_floor) info_acc |= GPMPC_INFO_VAR_CLAMPED;
+        // the variance-is-zero replacement (src/agent.py:646-660) is off (threshold < 0) in the shipped configurations: uniform branch
+        bool all_zero = false;
+        if (a.var_zero_thr >= 0.0) all_zero = (var[0] <= a.var_zero_thr) && (var[1] <= a.var_zero_thr) && (var[2] <= a.var_zero_thr);
         double Rt[T][T], C[T][T], cinv[T];
         bool c_ok;
         {
@@ -427,7 +423,9 @@ __global__ __launch_bounds__(64, 1) void rollout_one_kernel(const RolloutArgs a)
 #pragma unroll
             for (int c = 0; c <= bq; ++c) acc = fma(Rt[bq][c], zt[c], acc);
             double yb = acc + mu[bq];
-            if (all_zero) yb = mu[bq];                            // (uniform; disabled in the shipped configurations)
+            if (a.var_zero_thr >= 0.0) {                          // (uniform)
+                if (all_zero) yb = mu[bq];
+            }
             const double dlt = yb - mu[bq];
             if (dlt * dlt > a.beta * a.beta * var[bq]) {
                 const double sd = a.beta * sqrt(var[bq]);
