@@ -202,7 +202,8 @@ def extra_pendulum_throughput(sg, _lib, RolloutRunner, wl):
     return {"workload": "BASELINE configs[1] workload at Ns=16384 (throughput point): params_pendulum1D_samples, mode R, H=30, 1 GPU",
             "value": Ns * H / (ms * 1e-3), "unit": "trajectory-steps/s", "ms_per_rollout": ms, "finite": ok, "kernel_path": path,
             "roofline": roofline(flop, ms, "rollout_tiles_kernel<4,9,pendulum1D,32> (four chains per wave, FP64 4x4x4 MFMA solve)"
-                                 if path == 3 else "rollout_fast_kernel<3,36,1,pendulum1D>", wl.min_hbm_bytes(2, 1, 3) * Ns * H,
+                                 if path == 3 else ("rollout_one_kernel<4,pendulum1D>" if path == 4 else "rollout_fast_kernel<3,36,1,pendulum1D>"),
+                                 wl.min_hbm_bytes(2, 1, 3) * Ns * H,
                                  **({"bound": "fp64_mfma"} if path == 3 else {}))}
 
 
@@ -586,6 +587,7 @@ def main():
     # a launch cannot take longer than a step of the (un-instrumented) timed region it is part of: at N = 1 the region per
     # step is kernel + launch gap, and the event pairs of the second pass add a few microseconds of their own
     kern_ms = min(kern_ms_pairs, wall / a.steps * 1e3) if not multi else kern_ms_pairs
+    head_path = int(_lib.load().gpmpc_debug_last_rollout_path())   # 4: rollout_one_kernel, 1: rollout_fast_kernel, 3: rollout_tiles_kernel
     gather = None
     if multi:
         tube = pipe.tube(0)
@@ -646,11 +648,18 @@ def main():
                                       "X_traj per rollout on a side stream, overlapping the next rollout" % world,
                        "device": name, "cus": cus},
             "roofline": roofline(
-                flop, kern_ms, "rollout_fast_kernel<3,36,1,pendulum1D,L_hh in LDS,grid root>",
+                flop, kern_ms, {4: "rollout_one_kernel<4,pendulum1D> (one chain per wave, the factor in AGPR-pinned MFMA panels)",
+                                3: "rollout_tiles_kernel<4,9,pendulum1D,32>"}.get(
+                                    head_path, "rollout_fast_kernel<3,36,1,pendulum1D,L_hh in LDS,grid root>"),
                 wl.min_hbm_bytes(2, 1, 3) * Ns * H,
-                note="FP64 vector FMA (the FP64 MFMA peak is the same 78.6 TFLOP/s on MI355X; three right-hand sides cannot "
-                     "fill an FP64 MFMA tile, no MFMA is issued); algorithmic FLOP = 2.55e4 per trajectory-step (SURVEY 8d) "
-                     "x Ns x H; min HBM traffic 80 B per trajectory-step: latency / issue bound, not HBM bound",
+                note=("FP64 matrix pipe (v_mfma_f64_4x4x4_4b_f64: forward substitution, real-block correction and Gram products; "
+                      "FP64 MFMA and FP64 vector peak are the same 78.6 TFLOP/s on MI355X) + FP64 vector FMA for the kernel entries "
+                      "and the 3 x 3 roots; " if head_path in (3, 4) else
+                      "FP64 vector FMA (the FP64 MFMA peak is the same 78.6 TFLOP/s on MI355X), no MFMA is issued; ") +
+                     "algorithmic FLOP = 2.55e4 per trajectory-step (SURVEY 8d) x Ns x H; min HBM traffic 80 B per "
+                     "trajectory-step: one wave per SIMD, latency / issue bound, not HBM bound",
+                kernel_path=head_path,
+                **({"bound": "mfma"} if head_path in (3, 4) else {}),
                 traffic=traffic, traffic_source=prof.get("source"),
                 hbm_gbps=(traffic / (kern_ms * 1e-3) / 1e9) if traffic else None,
                 hbm_frac_of_8TBps=(traffic / (kern_ms * 1e-3) / 8e12) if traffic else None,
@@ -659,7 +668,7 @@ def main():
                 executed_flop_frac=(prof["valu_insts_per_launch"] * 128 / (kern_ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS)
                 if prof.get("valu_insts_per_launch") else None,
                 valu_active_frac=prof.get("valu_active_frac"),
-                mfma_busy=0.0,
+                mfma_busy=prof.get("mfma_busy_frac", 0.0 if head_path == 1 else None),
                 kernel_ms_per_launch_event_pairs=kern_ms_pairs),
             "gather": gather,
         }

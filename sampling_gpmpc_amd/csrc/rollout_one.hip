@@ -246,6 +246,8 @@ __global__ __launch_bounds__(64, 1) void rollout_one_kernel(const RolloutArgs a)
     int info_acc = 0;
     int n_h = 0, t = 0;
 
+    double* const Y_s = a.Y ? a.Y + s * H * T : nullptr;          // this sample's rows of the optional outputs
+    double* const Xi_s = a.Xi ? a.Xi + s * H * D : nullptr;
     OneExpConsts ek;
     ek.load();
     OnePanels P;
@@ -276,7 +278,7 @@ __global__ __launch_bounds__(64, 1) void rollout_one_kernel(const RolloutArgs a)
         for (int d = 0; d < NX; ++d) xq[d] = (lane == t) ? x[d] : xq[d];
         if (lane == 0 && a.Xi) {
 #pragma unroll
-            for (int d = 0; d < D; ++d) a.Xi[(s * H + t) * D + d] = xi[d];
+            for (int d = 0; d < D; ++d) Xi_s[t * D + d] = xi[d];
         }
 
         // ---- kernel factors: ONE exponential per lane - the grid axis factor (lanes < N0 + N1) or the appended point jpt -----
@@ -294,13 +296,14 @@ __global__ __launch_bounds__(64, 1) void rollout_one_kernel(const RolloutArgs a)
         const double R0_ = one_bpermute(ea, bp_addr), R1_ = one_bpermute(ea * gq, bp_addr);
         // ---- right-hand sides of the appended rows: lane = point, cov(task a of the point, task b of the test point) ----
         if (n_h > 0 && jpt >= 0 && jpt < 32) {
-            const double Aa[T] = {1.0, -q0, -q1}, Bb[T] = {1.0, q0, q1}, cd[T] = {0.0, il0, il1};
+            // k (A_a B_b + [a == b > 0] / l_a^2) with A = (1, -q0, -q1), B = (1, q0, q1)
+            const double kA[T] = {kk, -kk * q0, -kk * q1}, kd[T] = {0.0, kk * il0, kk * il1};
 #pragma unroll
             for (int aa = 0; aa < T; ++aa) {
                 double* dst = HSb + (3 * jpt + aa) * kOneRS;
-                dst[cb0] = kk * Aa[aa];
-                dst[cb1] = kk * fma(Aa[aa], Bb[1], (aa == 1) ? cd[1] : 0.0);
-                dst[cb2] = kk * fma(Aa[aa], Bb[2], (aa == 2) ? cd[2] : 0.0);
+                dst[cb0] = kA[aa];
+                dst[cb1] = fma(kA[aa], q0, (aa == 1) ? kd[1] : 0.0);
+                dst[cb2] = fma(kA[aa], q1, (aa == 2) ? kd[2] : 0.0);
                 dst[ycol] = yt[aa];                               // (zero until the lane's point exists)
             }
         }
@@ -435,7 +438,7 @@ __global__ __launch_bounds__(64, 1) void rollout_one_kernel(const RolloutArgs a)
         }
         if (lane == 0 && a.Y) {
 #pragma unroll
-            for (int bq = 0; bq < T; ++bq) a.Y[(s * H + t) * T + bq] = y[bq];
+            for (int bq = 0; bq < T; ++bq) Y_s[t * T + bq] = y[bq];
         }
         OPH(4);
 
@@ -593,6 +596,8 @@ bool rollout_one_eligible(const gpmpc_gp_desc_t* gp, const gpmpc_env_desc_t* env
     if (eg && eg[0] == '1') return false;
     const char* ef = std::getenv("GPMPC_FORCE_GLOBAL_FACTOR");
     if (ef && ef[0] == '1') return false;
+    const char* et = std::getenv("GPMPC_ROLLOUT_TILES");                      // the tiled kernel forced (tests, A/B timing)
+    if (md == 0 && et && et[0] == '1') return false;
     if (mode != GPMPC_MODE_RECONDITIONED || gp->T != 3 || gp->D != 2 || hall_tasks != 3 || gp->real_has_grad) return false;
     if (!plan_has_grid_root(gp->grid_n0, gp->grid_n1, gp->real_has_grad)) return false;
     if (env->env_id != GPMPC_ENV_PENDULUM1D || gp->g_ny != 1 || gp->grid_n0 != 4 || gp->grid_n1 != 9) return false;

@@ -32,7 +32,7 @@ def test_bench_line_contract():
     assert d["n_gpus"] == 1 and d["steps"] == 5 and d["dtype"] == "f64" and d["scaling"] == "weak" and d["vs_baseline"] is None
     assert "workload" in d["config"] and "model" not in d["config"]
     r = d["roofline"]
-    assert r["bound"] == "fp64_valu" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12 and r["kernel_ms"] > 0
+    assert r["bound"] == "mfma" and r["kernel_path"] == 4 and "rollout_one_kernel" in r["kernel"] and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12 and r["kernel_ms"] > 0
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0
     assert d["value"] > 1e6 and d["cold"]["ms_per_step"] > 0

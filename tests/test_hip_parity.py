@@ -228,6 +228,43 @@ def test_tiled_rollout_against_oracle(sg, pname, Ns, H, feedback, n_data_x, monk
     np.testing.assert_allclose(agent.Hallcinated_X_train[:, 0].cpu().numpy(), oagent.Hallcinated_X_train[:, 0].numpy(), rtol=1e-6, atol=1e-9)
 
 
+@pytest.mark.parametrize("Ns,H,feedback", [
+    (1, 2, None),       # one appended point: the first group of diagonal tiles only
+    (3, 3, None),       # two points: the first incomplete tile that wraps (rows 3, 4, 5)
+    (7, 7, None),       # 18 rows: groups 2 and 3, a tile row that starts a group
+    (5, 12, False),     # 33 rows, no feedback: every phase of n_h mod 4 and of the group boundaries
+    (9, 22, None),      # 63 rows
+    (6, 30, None),      # configs[1] horizon: 87 rows = all 22 tile rows, 122 panels
+    (70, 30, None),     # more chains than a CU holds
+])
+def test_one_chain_mfma_rollout_against_oracle(sg, Ns, H, feedback, monkeypatch):
+    """rollout_one.hip (one chain per wave, the factor as AGPR-pinned MFMA panels; BASELINE configs[1]'s kernel) against the
+    oracle, the kernel asserted (path 4), and against rollout_fast_kernel (GPMPC_ROLLOUT_ONE=0) on the same base samples:
+    two independent implementations of the same arithmetic agree to round-off."""
+    from sampling_gpmpc_amd.rollout import forward_sampling_rollout
+    pname = "params_pendulum1D_samples"
+    p = fs_params(pname, Ns, H, nograd=False, feedback=feedback)
+    agent, oagent = make_agents(sg, p)
+    u_ff = synthetic_u_ff(agent.nu, H)
+    lib = sg._lib.load()
+    X, Y = forward_sampling_rollout(agent, u_ff, return_samples=True)
+    assert lib.gpmpc_debug_last_rollout_path() == 4, "rollout_one_kernel was not selected"
+    Xo, Yo = ao.forward_sampling_rollout(oagent, u_ff, return_samples=True)
+    monkeypatch.setenv("GPMPC_ROLLOUT_ONE", "0")
+    agent2, _ = make_agents(sg, p, erv=agent.epistimic_random_vector.cpu().numpy())
+    X1, Y1 = forward_sampling_rollout(agent2, u_ff, return_samples=True)
+    assert lib.gpmpc_debug_last_rollout_path() == 1, "rollout_fast_kernel was not selected"
+    ex, ey = relerr(X, Xo), relerr(Y, Yo)
+    print(f"one-chain MFMA kernel Ns={Ns} H={H}: rel err X_traj {ex:.2e}, Y {ey:.2e}; vs rollout_fast max abs diff "
+          f"X {np.abs(X - X1).max():.2e} Y {np.abs(Y - Y1).max():.2e}")
+    assert np.isfinite(X).all()
+    assert ex < RTOL_TRAJ and ex < RTOL_NORTH_STAR
+    np.testing.assert_allclose(Y, Yo, rtol=1e-4, atol=1e-8)
+    np.testing.assert_allclose(agent.Hallcinated_X_train[:, 0].cpu().numpy(), oagent.Hallcinated_X_train[:, 0].numpy(), rtol=1e-6, atol=1e-9)
+    np.testing.assert_allclose(X, X1, rtol=1e-9, atol=1e-11)
+    np.testing.assert_allclose(Y, Y1, rtol=1e-7, atol=1e-11)
+
+
 @pytest.mark.parametrize("pname,Ns,H,n_data_x", [
     ("params_car_residual_fs", 90, 50, None),           # picked by itself: no tuned one-chain kernel for 147 rows, 270 chains
     ("params_car_residual_fs", 86, 30, 6),              # 6 x 9 grid
@@ -681,7 +718,8 @@ def test_generic_kernels_agree_with_tuned_kernels(sg, pname, Ns, H, nograd, monk
     u_ff = synthetic_u_ff(agent.nu, H)
     lib = sg._lib.load()
     X_fast, Y_fast = forward_sampling_rollout(agent, u_ff, return_samples=True)
-    assert lib.gpmpc_debug_last_rollout_path() == (2 if nograd else 1), "tuned kernel was not selected"
+    # pendulum1D on the 4 x 9 grid with at most 88 appended rows: the one-chain MFMA kernel (path 4); car: rollout_fast (1)
+    assert lib.gpmpc_debug_last_rollout_path() == (2 if nograd else (4 if "pendulum" in pname else 1)), "tuned kernel was not selected"
     monkeypatch.setenv("GPMPC_DISABLE_FAST_ROLLOUT", "1")
     agent2, _ = make_agents(sg, p, erv=agent.epistimic_random_vector.cpu().numpy())
     X_gen, Y_gen = forward_sampling_rollout(agent2, u_ff, return_samples=True)
@@ -712,7 +750,8 @@ def test_tuned_kernel_grid_root_vs_cholesky_root(sg, pname, Ns, H, nograd, monke
     u_ff = synthetic_u_ff(agent.nu, H)
     lib = sg._lib.load()
     X_grid, Y_grid = forward_sampling_rollout(agent, u_ff, return_samples=True)
-    assert lib.gpmpc_debug_last_rollout_path() == path
+    # (pendulum1D, mode R: the grid-root launch is the one-chain MFMA kernel, the Cholesky-root launch rollout_fast)
+    assert lib.gpmpc_debug_last_rollout_path() == (4 if (not nograd and "pendulum" in pname) else path)
     assert agent._plan(use_grad=not nograd).desc.grid_n1 == 9, "the facade did not detect the reference's training grid"
     monkeypatch.setenv("GPMPC_DISABLE_GRID_ROOT", "1")
     agent2, _ = make_agents(sg, p, erv=agent.epistimic_random_vector.cpu().numpy())
@@ -753,7 +792,8 @@ def test_rollout_edge_sizes(sg, pname, Ns, H):
     print(f"{pname} Ns={Ns} H={H}: kernel path {path}, rel err X {relerr(X, Xo):.2e} Y {relerr(Y, Yo):.2e}")
     chains = Ns * agent.g_ny
     tiled = chains > (1024 if agent.g_ny == 1 else 768)                  # the one-chain kernel would need a second round of the chip
-    assert path == (0 if H > 43 else (3 if tiled else 1))
+    one = agent.g_ny == 1 and 3 * (H - 1) <= 88 and Ns <= 2048          # rollout_one_kernel: pendulum1D 4 x 9, H <= 30
+    assert path == (0 if H > 43 else (4 if one else (3 if tiled else 1)))
     assert relerr(X, Xo) < RTOL_TRAJ
     np.testing.assert_allclose(Y, Yo, rtol=1e-4, atol=1e-8)
 

@@ -32,5 +32,40 @@ for sub in ["pmc_fetch", "pmc_write", "pmc_sq", "pmc_sq2"]:
             lines.append(f"| `{k}` | {c} | {len(vals)} | {sum(vals)/len(vals):.6g} |")
 lines += ["", "FETCH_SIZE / WRITE_SIZE are in KiB per launch as rocprofv3 reports them; per MI355X_MICROARCH.md (HBM section)",
           "FETCH_SIZE under-reports wide coalesced reads by 2x on gfx950, so HBM bytes <= (2*FETCH_SIZE + WRITE_SIZE) * 1024.", ""]
+# the counters of the headline launch's rollout kernel, for bench.py's `roofline` (PMC counters cannot be read in-process)
+import json
+def _mean(sub, counter, kernel_key):
+    f = os.path.join(src, sub, "pmc_counter_collection.csv")
+    if not os.path.exists(f):
+        return None, None
+    vals, name = [], None
+    for r in csv.DictReader(open(f)):
+        if kernel_key in r["Kernel_Name"] and r["Counter_Name"] == counter:
+            vals.append(float(r["Counter_Value"]))
+            name = r["Kernel_Name"]
+    return (sum(vals) / len(vals) if vals else None), name
+for key in ("rollout_one_kernel", "rollout_fast_kernel", "rollout_tiles_kernel"):
+    fetch, kname = _mean("pmc_fetch", "FETCH_SIZE", key)
+    if fetch is None:
+        continue
+    write, _ = _mean("pmc_write", "WRITE_SIZE", key)
+    valu, _ = _mean("pmc_sq", "SQ_INSTS_VALU", key)
+    act, _ = _mean("pmc_sq", "SQ_ACTIVE_INST_VALU", key)
+    cyc, _ = _mean("pmc_sq", "SQ_WAVE_CYCLES", key)
+    busy, _ = _mean("pmc_sq", "SQ_BUSY_CYCLES", key)
+    mfma_busy, _ = _mean("pmc_sq2", "SQ_VALU_MFMA_BUSY_CYCLES", key)
+    mops, _ = _mean("pmc_sq2", "SQ_INSTS_VALU_MFMA_MOPS_F64", key)
+    out = {"source": f"profiles/{tag}_summary.md (rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes, bench.py --steps 20)",
+           "kernel": kname[:80], "FETCH_SIZE_KiB": fetch, "WRITE_SIZE_KiB": write,
+           "hbm_bytes_per_launch_uncorrected": (fetch + (write or 0.0)) * 1024,
+           "hbm_bytes_per_launch_gfx950_corrected": (2 * fetch + (write or 0.0)) * 1024,
+           "workload": {"Ns": 1024, "H": 30}, "valu_insts_per_launch": valu,
+           "valu_active_frac": (act / cyc) if (act and cyc) else None,
+           "mfma_busy_frac": (mfma_busy / busy) if (mfma_busy and busy) else None,
+           "mfma_mops_f64_per_launch": mops,
+           "valu_source": f"profiles/{tag}_summary.md (SQ_INSTS_VALU; SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES; SQ_VALU_MFMA_BUSY_CYCLES / SQ_BUSY_CYCLES)"}
+    json.dump(out, open(os.path.join(dst, "latest_traffic.json"), "w"), indent=1)
+    lines += ["", "latest_traffic.json <- " + json.dumps(out)]
+    break
 open(os.path.join(dst, f"{tag}_summary.md"), "w").write("\n".join(lines))
 print("\n".join(lines))
