@@ -61,9 +61,10 @@ for key in ("rollout_one_kernel", "rollout_fast_kernel", "rollout_tiles_kernel")
            "hbm_bytes_per_launch_gfx950_corrected": (2 * fetch + (write or 0.0)) * 1024,
            "workload": {"Ns": 1024, "H": 30}, "valu_insts_per_launch": valu,
            "valu_active_frac": (act / cyc) if (act and cyc) else None,
-           "mfma_busy_frac": (mfma_busy / busy) if (mfma_busy and busy) else None,
+           # SQ_VALU_MFMA_BUSY_CYCLES counts cycles, SQ_WAVE_CYCLES quad-cycles; one wave per SIMD: wave time = SIMD time
+           "mfma_busy_frac": (mfma_busy / (4.0 * cyc)) if (mfma_busy and cyc) else None,
            "mfma_mops_f64_per_launch": mops,
-           "valu_source": f"profiles/{tag}_summary.md (SQ_INSTS_VALU; SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES; SQ_VALU_MFMA_BUSY_CYCLES / SQ_BUSY_CYCLES)"}
+           "valu_source": f"profiles/{tag}_summary.md (SQ_INSTS_VALU; SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES; SQ_VALU_MFMA_BUSY_CYCLES / (4 SQ_WAVE_CYCLES))"}
     json.dump(out, open(os.path.join(dst, "latest_traffic.json"), "w"), indent=1)
     lines += ["", "latest_traffic.json <- " + json.dumps(out)]
     break
