@@ -44,7 +44,25 @@ REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
 import numpy as np
-import torch
+
+
+def _wants_self_launch():
+    """`--gpus N` (N > 1, or GPMPC_BENCH_SELF_LAUNCH=1) without a launcher around us: this process only starts the ranks."""
+    if "WORLD_SIZE" in os.environ:
+        return False
+    n = 1
+    for i, tok in enumerate(sys.argv):
+        if tok == "--gpus" and i + 1 < len(sys.argv):
+            n = int(sys.argv[i + 1])
+        elif tok.startswith("--gpus="):
+            n = int(tok.split("=", 1)[1])
+    return n > 1 or os.environ.get("GPMPC_BENCH_SELF_LAUNCH") == "1"
+
+
+# The launching parent never imports torch: `import torch` maps libamdhip64 / libhsa-runtime64 into the process (link
+# dependencies of libtorch_hip), and a process with the GPU runtime in it must not fork / exec the ranks on this pool.
+if __name__ != "__main__" or not _wants_self_launch():
+    import torch
 
 FP64_PEAK_TFLOPS = 78.6                                # MI355X FP64 vector == matrix peak (vendor figure, SURVEY 8d)
 
@@ -68,15 +86,44 @@ def parse():
     return ap.parse_args()
 
 
+def kfd_gpu_count():
+    """GPUs of this node counted WITHOUT HIP: the kfd topology nodes that have SIMDs (CPU nodes have simd_count 0).  None when
+    the topology is not readable (no amdgpu driver in this container): then the ranks themselves report a missing device."""
+    import glob
+    nodes = glob.glob("/sys/class/kfd/kfd/topology/nodes/*/properties")
+    if not nodes:
+        return None
+    n = 0
+    for f in nodes:
+        try:
+            props = dict(ln.split()[:2] for ln in open(f).read().splitlines() if len(ln.split()) >= 2)
+        except OSError:
+            continue
+        n += int(props.get("simd_count", "0")) > 0
+    return n
+
+
+def hip_mapped_in_this_process():
+    """True when the HIP / HSA runtime libraries are mapped into this process (they are loaded lazily: `import torch` alone
+    does not map them on this image).  Checked right before the ranks are spawned."""
+    try:
+        maps = open("/proc/self/maps").read()
+    except OSError:
+        return None
+    return ("libamdhip64" in maps) or ("libhsa-runtime64" in maps)
+
+
 def self_launch(a):
     """`python bench.py --gpus N` with no launcher around it: start the N ranks as fresh processes (one per GPU, RCCL) and
-    forward what they print.  Runs BEFORE anything touches HIP in this process (no torch.cuda.is_available(), no library
-    load): a process that has initialised the GPU must never fork / exec the ranks."""
+    forward what they print.  Runs BEFORE anything touches HIP in this process - no torch.cuda call at all (the device count
+    comes from the kfd topology in sysfs), no library load: a process that has initialised the GPU must never fork / exec
+    the ranks.  GPMPC_BENCH_SELF_LAUNCH=1 takes this path at --gpus 1 too (how the path is proven on a one-GPU box)."""
     import socket
     import subprocess
     dry = os.environ.get("GPMPC_BENCH_DRY_LAUNCH") == "1"
-    if not dry and torch.cuda.device_count() < a.gpus:          # device_count() does not initialise the GPU on this image
-        sys.stderr.write("bench.py: --gpus %d but %d HIP device(s) visible\n" % (a.gpus, torch.cuda.device_count()))
+    ngpu = None if dry else kfd_gpu_count()
+    if ngpu is not None and ngpu < a.gpus:
+        sys.stderr.write("bench.py: --gpus %d but %d GPU node(s) in the kfd topology\n" % (a.gpus, ngpu))
         sys.exit(2)
     sk = socket.socket()
     sk.bind(("127.0.0.1", 0))
@@ -87,13 +134,18 @@ def self_launch(a):
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")           # dmabuf IPC only on this pool (RCCL needs it)
     env["GPMPC_BENCH_PARENT"] = str(os.getpid())
+    env.pop("GPMPC_BENCH_SELF_LAUNCH", None)                     # the ranks must not launch again
+    hip_mapped = hip_mapped_in_this_process()                    # at spawn time
     proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
     for line in proc.stdout:                                     # rank 0's JSON line (and the dry-launch markers)
         sys.stdout.write(line)
         sys.stdout.flush()
     rc = proc.wait()
     sys.stderr.write(json.dumps({"launcher": {"pid": os.getpid(), "ranks": a.gpus, "port": port, "rc": rc,
-                                              "hip_initialised_in_parent": bool(torch.cuda.is_initialized())}}) + "\n")
+                                              "kfd_gpu_nodes": ngpu, "hip_mapped_in_parent_at_spawn": hip_mapped,
+                                              "torch_imported_in_parent": "torch" in sys.modules,
+                                              "hip_initialised_in_parent": bool("torch" in sys.modules and
+                                                                                sys.modules["torch"].cuda.is_initialized())}}) + "\n")
     sys.exit(rc if rc == 0 or 0 < rc < 256 else 1)
 
 
@@ -493,7 +545,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if "WORLD_SIZE" not in os.environ and a.gpus > 1:
+    if "WORLD_SIZE" not in os.environ and (a.gpus > 1 or os.environ.get("GPMPC_BENCH_SELF_LAUNCH") == "1"):
         self_launch(a)                                           # never returns
     if os.environ.get("GPMPC_BENCH_DRY_LAUNCH") == "1" and world > 1:
         # launch-path check (tests, CPU): every rank joins the group, reports, leaves - nothing else runs

@@ -18,6 +18,10 @@ What is captured, and from which reference code:
                               post-processing, hallucinated-set growth, B_d / padding / velocity transform, state
                               hand-over).  They do NOT pin the GP algebra itself (gpytorch is not installable here;
                               "parity unpinned", see oracle/gp_oracle.py).
+* ``agent_e2e_prepare_dynamics_set_pendulum1D.npz`` .. reference ``Agent.prepare_dynamics_set`` (src/agent.py:331-443) itself,
+                              ``Tensor.cuda`` neutralised, its internal ``randn`` draws recorded as base samples
+* ``agent_e2e_pinned_samples.npz`` .. reference ``get_batch_gp_sensitivities`` (src/agent.py:582-624) with
+                              ``true_dyn_as_sample`` / ``mean_as_dyn_sample`` and the Ns = 1 / Ns = 2 short-circuits
 * ``conditioning_gp.npz`` ... reference ``extra/conditioning_gp.py`` executed as is (numpy RBF posterior sampler,
                               value-only) - an in-reference cross-check of kernel + Cholesky conditioning + sampling.
 * ``configs`` ............... the three runnable reference YAMLs re-serialised into sampling_gpmpc_amd/params/.
@@ -233,6 +237,139 @@ def fs_loop(agent, p, u_ff):
     return X_traj.numpy(), torch.cat(Ys, dim=2).numpy()
 
 
+class RecordDraws:
+    """The reference's ``prepare_dynamics_set`` calls ``.sample()`` WITHOUT base samples (src/agent.py:376): the library draws
+    ``randn`` internally.  While active, the stub's posterior draws the same ``randn`` (global torch generator), records it in
+    the layout of ``base_samples`` (batch..., m, T) and passes it on - so the capture holds exactly what was drawn."""
+
+    def __enter__(self):
+        import oracle.gp_oracle as go
+        self.go, self.orig, self.draws = go, go.OraclePosterior.sample, []
+        rec = self
+
+        def sample(post, base_samples=None):
+            if base_samples is None:
+                m, T = post.mean.shape[-2], post.mean.shape[-1]
+                z = torch.randn(*post.mean.shape[:-2], m * T, 1, dtype=post.mean.dtype)
+                base_samples = z.reshape(*post.mean.shape[:-2], m, T)
+                rec.draws.append(base_samples.clone())
+            return rec.orig(post, base_samples)
+
+        go.OraclePosterior.sample = sample
+        return self
+
+    def __exit__(self, *exc):
+        self.go.OraclePosterior.sample = self.orig
+
+
+def prepare_dynamics_set_fixture(ref_agent, RefPendulum1D):
+    """``agent_e2e_prepare_dynamics_set_pendulum1D.npz``: the reference's REAL ``Agent.prepare_dynamics_set`` (src/agent.py:331-443:
+    forward sampling with box rejection, re-training on real + forward-sampled value-only + hallucinated data at every step,
+    survivor replacement through the global ``np.random``), ``Tensor.cuda`` neutralised (the method is CUDA-only, no GPU here),
+    the GP algebra from the stub (oracle).  Two calls: a tube nobody leaves, then a tube on theta at the third state that
+    rejects part of the samples."""
+    import re
+    Ns, H = 10, 6
+    p = load_params("params_pendulum1D_samples")
+    p["common"]["use_cuda"] = False
+    p["agent"]["num_dyn_samples"], p["optimizer"]["H"] = Ns, H
+    p["common"]["num_MPC_itrs"], p["optimizer"]["SEMPC"]["max_sqp_iter"] = 1, 2
+    torch.manual_seed(123456)
+    agent = quiet(ref_agent.Agent, p, RefPendulum1D(p))
+    nx, nu = agent.nx, agent.nu
+    g = torch.Generator().manual_seed(21)
+    x0 = np.array(p["env"]["start"], dtype=np.float64)
+    x_h = np.tile(x0, (H, Ns)) + 0.05 * torch.randn(H, Ns * nx, generator=g, dtype=torch.float64).numpy()
+    u_h = 0.3 * torch.randn(H, Ns, nu, generator=g, dtype=torch.float64).numpy()
+    agent.mpc_iteration(0)
+    agent.train_hallucinated_dynGP(0)
+    quiet(agent.dyn_fg_jacobians, agent.get_batch_x_hat_u_diff(x_h, u_h), 0)
+    agent.train_hallucinated_dynGP(1)
+    out = {"Ns": Ns, "H": H, "epistimic_random_vector": agent.epistimic_random_vector.numpy(), "x_h": x_h, "u_h": u_h,
+           "hall_X_0": agent.Hallcinated_X_train.numpy().copy(), "hall_Y_0": agent.Hallcinated_Y_train.numpy().copy()}
+    U_soln = 0.5 * torch.randn(H + 1, nu, generator=g, dtype=torch.float64)
+    X_kp1 = torch.tensor(x0[:nx]).reshape(nx, 1)
+    X_soln = torch.zeros(H + 1, Ns * nx, dtype=torch.float64)
+    X_soln[1] = torch.tensor(x0[:nx]).repeat(Ns)
+    out.update({"U_soln": U_soln.numpy(), "X_kp1": X_kp1.numpy(), "X_soln_1": X_soln.numpy()})
+    cuda_orig = torch.Tensor.cuda
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    try:
+        def call(tag, Xs, ci, np_seed, torch_seed):
+            agent.ci_list = ci
+            agent.train_hallucinated_dynGP(1)
+            np.random.seed(np_seed)
+            torch.manual_seed(torch_seed)
+            buf = io.StringIO()
+            with RecordDraws() as rec, contextlib.redirect_stdout(buf):
+                agent.prepare_dynamics_set(Xs.clone(), U_soln, X_kp1)
+            counts = [int(c) for c in re.findall(r"are\s+tensor\((\d+)", buf.getvalue())]
+            assert len(rec.draws) == H - 1 and len(counts) == H, (len(rec.draws), counts)
+            out.update({f"z_{tag}": torch.stack(rec.draws).numpy(), f"survivors_{tag}": np.array(counts),
+                        f"FS_X_{tag}": agent.FS_X_train_batch.numpy().copy(), f"FS_Y_{tag}": agent.FS_Y_train_batch.numpy().copy(),
+                        f"hall_X_{tag}": agent.Hallcinated_X_train.numpy().copy(),
+                        f"hall_Y_{tag}": agent.Hallcinated_Y_train.numpy().copy(), f"np_seed_{tag}": np_seed})
+        call("1", X_soln, [1e9] * (H + 1), 5, 100)
+        x2 = agent.FS_X_train_batch[:, 0, 2, 0]                    # theta after two sampled steps
+        med = float(x2.median())
+        tol = float((x2 - med).abs().median()) + 1e-12
+        X_soln2 = X_soln.clone()
+        X_soln2[3] = torch.stack([torch.full((Ns,), med, dtype=torch.float64), torch.zeros(Ns, dtype=torch.float64)], dim=1).reshape(-1)
+        ci = [1e9] * (H + 1)
+        ci[2] = torch.tensor([tol, 1e9], dtype=torch.float64)
+        call("2", X_soln2, ci, 7, 100)                             # same internal draws as the first call: same sampled states
+        out.update({"X_soln_2": X_soln2.numpy(), "tube_med": med, "tube_tol": tol})
+        assert 0 < out["survivors_2"][-1] < Ns, out["survivors_2"]
+    finally:
+        torch.Tensor.cuda = cuda_orig
+    np.savez(f"{HERE}/agent_e2e_prepare_dynamics_set_pendulum1D.npz", **out)
+
+
+def pinned_samples_fixture(ref_agent, RefPendulum1D, RefCar):
+    """``agent_e2e_pinned_samples.npz``: the branches of ``get_batch_gp_sensitivities`` (src/agent.py:582-624) that overwrite
+    samples after the draw - ``true_dyn_as_sample`` (set by the shipped params_car_residual.yaml:50), ``mean_as_dyn_sample`` -
+    and their short-circuits (Ns == 1 with either flag, Ns == 2 with both: no draw, nothing appended), through the reference's
+    real ``dyn_fg_jacobians``."""
+    out = {}
+    cases = [("pend_true_ns1", "params_pendulum1D_samples", RefPendulum1D, 1, True, False),
+             ("pend_true_ns3", "params_pendulum1D_samples", RefPendulum1D, 3, True, False),
+             ("pend_mean_ns3", "params_pendulum1D_samples", RefPendulum1D, 3, False, True),
+             ("pend_both_ns2", "params_pendulum1D_samples", RefPendulum1D, 2, True, True),
+             ("pend_both_ns4", "params_pendulum1D_samples", RefPendulum1D, 4, True, True),
+             ("car_true_ns1", "params_car_residual", RefCar, 1, True, False),
+             ("car_true_ns3", "params_car_residual", RefCar, 3, True, False)]
+    for tag, pname, Env, Ns, td, md in cases:
+        H = 5
+        p = load_params(pname)
+        p["common"]["use_cuda"] = False
+        p["agent"]["num_dyn_samples"], p["optimizer"]["H"] = Ns, H
+        p["common"]["num_MPC_itrs"], p["optimizer"]["SEMPC"]["max_sqp_iter"] = 1, 2
+        p["agent"]["true_dyn_as_sample"], p["agent"]["mean_as_dyn_sample"] = td, md
+        if "car" in pname:
+            p["agent"]["Dyn_gp_jitter"] = 1e-8                     # the Cholesky-retry branch (the eigh root's signs are solver specific)
+        torch.manual_seed(123456)
+        agent = quiet(ref_agent.Agent, p, Env(p))
+        nx, nu = agent.nx, agent.nu
+        g = torch.Generator().manual_seed(17)
+        x0 = np.array(p["env"]["start"], dtype=np.float64)
+        x_h = np.tile(x0, (H, Ns)) + 0.02 * torch.randn(H, Ns * nx, generator=g, dtype=torch.float64).numpy()
+        u_h = 0.1 * torch.randn(H, Ns, nu, generator=g, dtype=torch.float64).numpy()
+        agent.mpc_iteration(0)
+        rec = {"Ns": Ns, "H": H, "true_dyn": td, "mean": md, "epistimic_random_vector": agent.epistimic_random_vector.numpy(),
+               "x_h": x_h, "u_h": u_h}
+        for it in range(2):
+            agent.train_hallucinated_dynGP(it)
+            gp_val, y_grad, u_grad = quiet(agent.dyn_fg_jacobians, agent.get_batch_x_hat_u_diff(x_h, u_h), it)
+            rec.update({f"gp_val_{it}": gp_val, f"y_grad_{it}": y_grad, f"u_grad_{it}": u_grad,
+                        f"hall_X_{it}": agent.Hallcinated_X_train.numpy().copy(), f"hall_Y_{it}": agent.Hallcinated_Y_train.numpy().copy(),
+                        f"mean_{it}": agent.model_i_call.mean.numpy().copy()})
+        for k, v in rec.items():
+            out[f"{tag}__{k}"] = v
+    out["cases"] = np.array([c[0] for c in cases])
+    out["case_params"] = np.array([c[1] for c in cases])
+    np.savez(f"{HERE}/agent_e2e_pinned_samples.npz", **out)
+
+
 def main():
     if "--real-gpytorch" in sys.argv:
         sys.exit(real_gpytorch_pin())
@@ -399,6 +536,10 @@ def main():
         x_h = x_h + 0.01 * torch.randn(H, Ns * 2, generator=g).numpy()
     outJ["u_h"] = u_h
     np.savez(f"{HERE}/agent_e2e_J_pendulum1D.npz", **outJ)
+
+    # ---------------- Agent.prepare_dynamics_set (src/agent.py:331-443) and the pinned-sample branches -------
+    prepare_dynamics_set_fixture(ref_agent, RefPendulum1D)
+    pinned_samples_fixture(ref_agent, RefPendulum1D, RefCar)
 
     # ---------------- extra/conditioning_gp.py executed as is -----------------------------------------------
     import matplotlib

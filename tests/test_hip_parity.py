@@ -1126,3 +1126,26 @@ def test_rollout_factor_state_export_and_resume(sg, pname):
     r3 = rollout_device(agent, u_ff[:1], z, stride, H=1, mode=sg._lib.MODE_RECONDITIONED,
                         use_model_without_derivatives=False, x0=x_mid, state=state, resume=True)
     assert int(r3.info.max().item()) & sg._lib.INFO_STATE_FULL and torch.isfinite(r3.X_traj).all()
+
+
+@pytest.mark.parametrize("fused", [True, False])
+def test_prepare_dynamics_set_against_reference_run(sg, fused):
+    """The HIP Agent against the reference's REAL ``Agent.prepare_dynamics_set`` (src/agent.py:331-443; golden captured by
+    make_goldens.py under the gpytorch stub): forward-sampled points, value-only labels, the rejection trace (survivor
+    counts), survivor replacement of the hallucinated tensors, for a tube nobody leaves and one that splits the samples."""
+    from tests.test_oracle_golden import _pds_params, replay_prepare_dynamics_set
+    d = np.load(os.path.join(GOLDEN, "agent_e2e_prepare_dynamics_set_pendulum1D.npz"))
+    p = _pds_params(d)
+    agent, _ = make_agents(sg, p, erv=d["epistimic_random_vector"])
+    replay_prepare_dynamics_set(agent, d, to_dev=lambda t: t.to(agent.torch_device), fused=fused)
+
+
+def test_pinned_sample_branches_against_reference_run(sg):
+    """true_dyn_as_sample / mean_as_dyn_sample and their Ns = 1 / Ns = 2 short-circuits (src/agent.py:582-624) on the HIP
+    Agent against the reference-run golden: value / Jacobian arrays, the hallucinated tensors, the posterior mean."""
+    from tests.test_oracle_golden import pinned_cases, replay_pinned
+    d = np.load(os.path.join(GOLDEN, "agent_e2e_pinned_samples.npz"))
+    for tag, p, c in pinned_cases(d):
+        agent, _ = make_agents(sg, p, erv=c["epistimic_random_vector"])
+        replay_pinned(agent, c)
+        print(f"pinned-sample case {tag}: ok")

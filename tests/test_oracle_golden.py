@@ -154,3 +154,87 @@ def test_oracle_against_real_gpytorch_goldens_when_present(tag, pname):
     X, Y = ao.forward_sampling_rollout(agent, d["u_ff"], return_samples=True)
     np.testing.assert_allclose(X, d["X_traj"], rtol=1e-6, atol=1e-9)
     np.testing.assert_allclose(Y, d["Y"], rtol=1e-5, atol=1e-8)
+
+
+def _pds_params(d):
+    p = load_params("params_pendulum1D_samples")
+    p["agent"]["num_dyn_samples"], p["optimizer"]["H"] = int(d["Ns"]), int(d["H"])
+    p["common"]["num_MPC_itrs"], p["optimizer"]["SEMPC"]["max_sqp_iter"] = 1, 2
+    return p
+
+
+def replay_prepare_dynamics_set(agent, d, to_dev=lambda t: t, **kw):
+    """Drives an Agent (oracle or HIP) through the scenario of agent_e2e_prepare_dynamics_set_pendulum1D.npz and compares with
+    what the reference's own ``Agent.prepare_dynamics_set`` (src/agent.py:331-443) produced."""
+    H = int(d["H"])
+    npy = lambda t: t.detach().cpu().numpy()
+    agent.train_hallucinated_dynGP(0)
+    agent.dyn_fg_jacobians(agent.get_batch_x_hat_u_diff(d["x_h"], d["u_h"]), 0)
+    np.testing.assert_allclose(npy(agent.Hallcinated_X_train), d["hall_X_0"], rtol=1e-9, atol=1e-12)
+    np.testing.assert_allclose(npy(agent.Hallcinated_Y_train), d["hall_Y_0"], rtol=1e-7, atol=1e-10)
+    U, Xk = torch.tensor(d["U_soln"]), torch.tensor(d["X_kp1"])
+    for tag, ci in (("1", [1e9] * (H + 1)),
+                    ("2", [1e9, 1e9, to_dev(torch.tensor([float(d["tube_tol"]), 1e9], dtype=F64))] + [1e9] * (H - 2))):
+        agent.ci_list = ci
+        agent.train_hallucinated_dynGP(1)
+        z = [torch.tensor(zz) for zz in d[f"z_{tag}"]]
+        agent.prepare_dynamics_set(torch.tensor(d[f"X_soln_{tag}"]), U, Xk, base_samples=z,
+                                   rng=np.random.RandomState(int(d[f"np_seed_{tag}"])), **kw)
+        assert [int(t.sum()) for t in agent.rejection_trace] == d[f"survivors_{tag}"].tolist()
+        np.testing.assert_allclose(npy(agent.FS_X_train_batch), d[f"FS_X_{tag}"], rtol=1e-8, atol=1e-10)
+        fy, fyr = npy(agent.FS_Y_train_batch), d[f"FS_Y_{tag}"]
+        assert fy.shape == fyr.shape and (np.isnan(fy) == np.isnan(fyr)).all() and np.isnan(fy[..., 1:]).all()
+        np.testing.assert_allclose(fy[..., 0], fyr[..., 0], rtol=1e-6, atol=1e-9)
+        np.testing.assert_allclose(npy(agent.Hallcinated_X_train), d[f"hall_X_{tag}"], rtol=1e-9, atol=1e-12)
+        np.testing.assert_allclose(npy(agent.Hallcinated_Y_train), d[f"hall_Y_{tag}"], rtol=1e-7, atol=1e-10)
+    assert 0 < d["survivors_2"][-1] < int(d["Ns"]) and not np.array_equal(d["hall_X_2"], d["hall_X_1"])
+
+
+def test_prepare_dynamics_set_against_reference_run():
+    """oracle/agent_oracle.py:prepare_dynamics_set against the reference's REAL method run under the gpytorch stub
+    (make_goldens.py: Tensor.cuda neutralised, the internal randn draws recorded as base samples, np.random seeded)."""
+    d = g("agent_e2e_prepare_dynamics_set_pendulum1D.npz")
+    p = _pds_params(d)
+    agent = ao.OracleAgent(p, ao.make_oracle_env(p), torch.tensor(d["epistimic_random_vector"]))
+    replay_prepare_dynamics_set(agent, d)
+
+
+def pinned_cases(d):
+    for tag, pname in zip(d["cases"].tolist(), d["case_params"].tolist()):
+        c = {k.split("__", 1)[1]: d[k] for k in d.files if k.startswith(tag + "__")}
+        p = load_params(pname)
+        p["agent"]["num_dyn_samples"], p["optimizer"]["H"] = int(c["Ns"]), int(c["H"])
+        p["common"]["num_MPC_itrs"], p["optimizer"]["SEMPC"]["max_sqp_iter"] = 1, 2
+        p["agent"]["true_dyn_as_sample"], p["agent"]["mean_as_dyn_sample"] = bool(c["true_dyn"]), bool(c["mean"])
+        if "car" in pname:
+            p["agent"]["Dyn_gp_jitter"] = 1e-8
+        yield tag, p, c
+
+
+def replay_pinned(agent, c):
+    """two SQP iterations of ``dyn_fg_jacobians`` with the leading samples pinned (src/agent.py:582-624)"""
+    npy = lambda t: t.detach().cpu().numpy()
+    for it in range(2):
+        agent.train_hallucinated_dynGP(it)
+        gp_val, y_grad, u_grad = agent.dyn_fg_jacobians(agent.get_batch_x_hat_u_diff(c["x_h"], c["u_h"]), it)
+        np.testing.assert_allclose(gp_val, c[f"gp_val_{it}"], rtol=1e-7, atol=1e-10)
+        np.testing.assert_allclose(y_grad, c[f"y_grad_{it}"], rtol=1e-6, atol=1e-9)
+        np.testing.assert_allclose(u_grad, c[f"u_grad_{it}"], rtol=1e-6, atol=1e-9)
+        assert npy(agent.Hallcinated_X_train).shape == c[f"hall_X_{it}"].shape
+        np.testing.assert_allclose(npy(agent.Hallcinated_X_train), c[f"hall_X_{it}"], rtol=1e-9, atol=1e-12)
+        np.testing.assert_allclose(npy(agent.Hallcinated_Y_train), c[f"hall_Y_{it}"], rtol=1e-6, atol=1e-9)
+        np.testing.assert_allclose(npy(agent.model_i_call.mean), c[f"mean_{it}"], rtol=1e-7, atol=1e-10)
+
+
+def test_pinned_sample_branches_against_reference_run():
+    """true_dyn_as_sample (params_car_residual.yaml:50 ships it) / mean_as_dyn_sample and the Ns = 1 / Ns = 2 short-circuits:
+    the oracle's restatement against the reference's own get_batch_gp_sensitivities (through dyn_fg_jacobians)."""
+    d = g("agent_e2e_pinned_samples.npz")
+    n = 0
+    for tag, p, c in pinned_cases(d):
+        agent = ao.OracleAgent(p, ao.make_oracle_env(p), torch.tensor(c["epistimic_random_vector"]))
+        replay_pinned(agent, c)
+        n += 1
+        short = (int(c["Ns"]) == 1) or (int(c["Ns"]) == 2 and bool(c["true_dyn"]) and bool(c["mean"]))
+        assert (c["hall_X_1"].shape[2] == 0) == short, tag       # the short-circuits append nothing
+    assert n == 7
