@@ -1137,7 +1137,7 @@ def test_prepare_dynamics_set_against_reference_run(sg, fused):
     d = np.load(os.path.join(GOLDEN, "agent_e2e_prepare_dynamics_set_pendulum1D.npz"))
     p = _pds_params(d)
     agent, _ = make_agents(sg, p, erv=d["epistimic_random_vector"])
-    replay_prepare_dynamics_set(agent, d, to_dev=lambda t: t.to(agent.torch_device), fused=fused)
+    replay_prepare_dynamics_set(agent, d, to_dev=lambda t: t.to(agent.torch_device), joint_draw_exact=False, fused=fused)
 
 
 def test_pinned_sample_branches_against_reference_run(sg):
@@ -1147,5 +1147,5 @@ def test_pinned_sample_branches_against_reference_run(sg):
     d = np.load(os.path.join(GOLDEN, "agent_e2e_pinned_samples.npz"))
     for tag, p, c in pinned_cases(d):
         agent, _ = make_agents(sg, p, erv=c["epistimic_random_vector"])
-        replay_pinned(agent, c)
+        replay_pinned(agent, c, to_dev=lambda t: t.to(agent.torch_device), drawn_exact=False)
         print(f"pinned-sample case {tag}: ok")
