@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define GPMPC_ABI_VERSION 5
+#define GPMPC_ABI_VERSION 6
 
 #define GPMPC_MAX_NY 4   /* GP outputs            (reference agent.g_dim.ny : 1 pendulum1D, 3 car)          */
 #define GPMPC_MAX_D  4   /* GP input dimension    (g_nx + g_nu : 2 in all shipped configs)                 */
@@ -153,6 +153,28 @@ int    gpmpc_plan_build(const gpmpc_gp_desc_t* gp, const double* X_r, const doub
  */
 size_t gpmpc_rollout_workspace_bytes(const gpmpc_gp_desc_t* gp, int32_t mode, int32_t hall_tasks,
                                      int64_t Ns, int32_t H);
+/*
+ * Kernel choice of gpmpc_rollout.  The dispatcher picks by shape AND launch size: GPMPC_KERNEL_ONE (one chain per wave, the
+ * factor in AGPR-pinned MFMA panels: pendulum1D 4 x 9 grid, H <= 30, up to 2048 chains), GPMPC_KERNEL_TILES (four chains per
+ * wave: larger launches), GPMPC_KERNEL_FAST (one chain per wave on the VALU), GPMPC_KERNEL_INDEP (mode I), GPMPC_KERNEL_GENERIC.
+ * The kernels sum in different orders: a sample's trajectory is bit-identical between two launches ONLY if both ran the same
+ * kernel (then it is independent of what else is in the launch).  A caller that needs bit-equality across launch sizes - a
+ * sample-sharded run against the single-GPU run of the same samples - pins the kernel: gpmpc_rollout_pin_kernel(k) makes
+ * every later gpmpc_rollout of this process take kernel k where the shape allows it (else the generic kernel),
+ * GPMPC_KERNEL_AUTO restores the size heuristic.  Returns the previous pin.  gpmpc_rollout_last_kernel(): what the last
+ * launch of this process ran.  (Environment: GPMPC_ROLLOUT_ONE=0/1, GPMPC_ROLLOUT_TILES=0/1, GPMPC_DISABLE_FAST_ROLLOUT=1.)
+ */
+#define GPMPC_KERNEL_AUTO    (-1)
+#define GPMPC_KERNEL_GENERIC 0
+#define GPMPC_KERNEL_FAST    1
+#define GPMPC_KERNEL_INDEP   2
+#define GPMPC_KERNEL_TILES   3
+#define GPMPC_KERNEL_ONE     4
+int    gpmpc_rollout_pin_kernel(int32_t kernel);
+int    gpmpc_rollout_last_kernel(void);
+/* the kernel gpmpc_rollout would take for this shape and launch size under the current pin (GPMPC_KERNEL_AUTO: bad descriptor) */
+int    gpmpc_rollout_kernel_for(const gpmpc_gp_desc_t* gp, const gpmpc_env_desc_t* env, int32_t mode, int32_t hall_tasks,
+                                int64_t Ns, int32_t H);
 int    gpmpc_rollout(const gpmpc_gp_desc_t* gp, const gpmpc_env_desc_t* env, const void* plan,
                      const double* X_r, int32_t mode, int32_t hall_tasks, double var_zero_thr, double beta,
                      int64_t Ns, int32_t H,

@@ -60,9 +60,19 @@ def limit_host_threads() -> Optional[int]:
         visible = len(os.sched_getaffinity(0))
     except AttributeError:
         visible = os.cpu_count() or 1
+    if mode.isdigit() and int(mode) < 1:                  # torch.set_num_threads(0) raises: an import must not
+        import logging
+        logging.getLogger("sampling_gpmpc_amd").warning("GPMPC_HOST_THREADS=%s ignored (a positive thread count or 'keep')", mode)
+        mode = ""
     want = int(mode) if mode.isdigit() else host_thread_budget(visible, cgroup_cpu_quota(), torch.get_num_threads())
     if want is None:
         return None
+    if want < torch.get_num_threads():
+        import logging
+        logging.getLogger("sampling_gpmpc_amd").warning(
+            "host thread pools lowered from %d to %d (the container's CPU quota; GPMPC_HOST_THREADS=keep leaves them alone): "
+            "this caps every CPU pool of the process (torch, BLAS, OpenMP), including a host-side QP solver's",
+            torch.get_num_threads(), want)
     torch.set_num_threads(want)
     try:                                                  # numpy / scipy BLAS and OpenMP pools that are already loaded
         import threadpoolctl

@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libgpmpc_hip.so")
 
 MAX_NY, MAX_D, MAX_T, MAX_NX, MAX_NU = 4, 4, 5, 8, 4
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 ENV_PENDULUM1D, ENV_CAR_RESIDUAL = 0, 1
 MODE_INDEPENDENT, MODE_RECONDITIONED = 0, 1
@@ -58,6 +58,9 @@ SYMBOLS = {
     "gpmpc_rollout": (C.c_int, [C.POINTER(GpDesc), C.POINTER(EnvDesc), _P, _P, _I32, _I32, _D, _D, _I64, _I32,
                                 _P, _I32, _P, _P, _I64, _P, _P, _P, _P, _P, _SZ, _P]),
     "gpmpc_rollout_state_bytes": (_SZ, [C.POINTER(GpDesc), _I64, _I32, _I32]),
+    "gpmpc_rollout_pin_kernel": (C.c_int, [_I32]),
+    "gpmpc_rollout_last_kernel": (C.c_int, []),
+    "gpmpc_rollout_kernel_for": (C.c_int, [C.POINTER(GpDesc), C.POINTER(EnvDesc), _I32, _I32, _I64, _I32]),
     "gpmpc_rollout_seeded_workspace_bytes": (_SZ, [C.POINTER(GpDesc), _I32, _I32, _I64, _I32, _I32, _I32]),
     "gpmpc_rollout_seeded": (C.c_int, [C.POINTER(GpDesc), C.POINTER(EnvDesc), _P, _P, _I32, _I32, _D, _D, _I64, _I32,
                                        _P, _I32, _P, _P, _I64, _P, _P, _P, _P, _P, _SZ, _P, _P, _P, _I32, _P, _P, _I32, _P, _I32, _I32, _I32]),
@@ -134,7 +137,15 @@ def to_host(t: torch.Tensor):
         return t.detach().numpy()
     out = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
     out.copy_(t.detach(), non_blocking=True)
-    host_wait(t)
+    # the copy is asynchronous and nothing blocking follows it here: wait for ITS completion in either wait mode (polling, or
+    # the runtime's blocking wait under GPMPC_HOST_WAIT=block) before the host memory is handed out
+    ev = torch.cuda.Event()
+    ev.record()
+    if os.environ.get("GPMPC_HOST_WAIT") == "block":
+        ev.synchronize()
+    else:
+        while not ev.query():
+            pass
     return out.numpy()
 
 

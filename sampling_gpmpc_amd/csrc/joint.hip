@@ -768,7 +768,10 @@ __global__ __launch_bounds__(NT, WPE) void joint_kernel(const JointArgs a) {
 #pragma unroll
                     for (int q = 0; q < NB; ++q)
                         if (q < nb) {
-                            Sm[(long)(c0 + q) * mT + t1] = acc[rs][q];
+                            // the direct store covers the diagonal and below only; the mirror store is the ONE writer of the upper
+                            // triangle (inside a diagonal block both used to write it: a last-bit asymmetric kern_entry would have
+                            // made the eigh root's input depend on the race)
+                            if (s_mfma || t1 >= c0 + q) Sm[(long)(c0 + q) * mT + t1] = acc[rs][q];
                             // mirror (the final values only): joint_eigh_kernel reads whole columns of S, coalesced
                             if (!s_mfma && t1 > c0 + q) Sm[(long)t1 * mT + c0 + q] = acc[rs][q];
                         }
@@ -926,10 +929,11 @@ __global__ __launch_bounds__(NT, WPE) void joint_kernel(const JointArgs a) {
         }
         JPH(7);
 #ifdef GPMPC_PHASE_TIMERS
-        if (blockIdx.x == 0 && tid == 0)
+        if (blockIdx.x == 0 && tid == 0) {
             for (int i = 0; i < 8; ++i) g_joint_phase[i] = jph[i];
             g_joint_phase[8] = jroot_blocks;
             g_joint_phase[9] = jroot_attempts;
+        }
 #endif
         if (info_acc) atomicOr(&s_info, info_acc);
         __syncthreads();

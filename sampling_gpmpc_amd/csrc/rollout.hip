@@ -488,6 +488,8 @@ static int launch_rollout(const RolloutArgs& args, const RolloutPlan& rp, int g_
     return GPMPC_OK;
 }
 
+int g_rollout_pin = GPMPC_KERNEL_AUTO;
+
 }  // namespace gpmpc
 
 using namespace gpmpc;
@@ -497,6 +499,26 @@ extern "C" {
 // debug helpers, deliberately not declared in include/gpmpc_hip.h
 static int g_last_rollout_path = -1;     // 0 generic, 1 tuned re-conditioned (rollout_fast), 2 thread-per-sample (rollout_indep), 3 tiled (rollout_tiles)
 int gpmpc_debug_last_rollout_path(void) { return g_last_rollout_path; }
+int gpmpc_rollout_last_kernel(void) { return g_last_rollout_path; }
+// the kernel an (unseeded) launch of this shape and size takes under the current pin / environment
+static int select_rollout_kernel(const gpmpc_gp_desc_t* gp, const gpmpc_env_desc_t* env, int mode, int hall_tasks, int H, int64_t Ns) {
+    if (rollout_one_eligible(gp, env, mode, hall_tasks, H, Ns)) return GPMPC_KERNEL_ONE;
+    if (rollout_tiles_eligible(gp, env, mode, hall_tasks, H, Ns)) return GPMPC_KERNEL_TILES;
+    if (rollout_fast_eligible(gp, env, mode, hall_tasks, H)) return GPMPC_KERNEL_FAST;
+    if (rollout_indep_eligible(gp, env, mode)) return GPMPC_KERNEL_INDEP;
+    return GPMPC_KERNEL_GENERIC;
+}
+int gpmpc_rollout_kernel_for(const gpmpc_gp_desc_t* gp, const gpmpc_env_desc_t* env, int32_t mode, int32_t hall_tasks, int64_t Ns,
+                             int32_t H) {
+    if (check_gp(gp) != GPMPC_OK || check_env(gp, env) != GPMPC_OK) return GPMPC_KERNEL_AUTO;
+    if (mode == GPMPC_MODE_INDEPENDENT) hall_tasks = gp->T;
+    return select_rollout_kernel(gp, env, mode, hall_tasks, H, Ns);
+}
+int gpmpc_rollout_pin_kernel(int32_t kernel) {
+    const int prev = gpmpc::g_rollout_pin;
+    gpmpc::g_rollout_pin = (kernel >= GPMPC_KERNEL_GENERIC && kernel <= GPMPC_KERNEL_ONE) ? kernel : GPMPC_KERNEL_AUTO;
+    return prev;
+}
 
 int gpmpc_debug_read_phases(long long* out /*[host] 16*/) {
     GPMPC_HIP_CHECK(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_phase_cycles), 16 * sizeof(long long)));
@@ -600,23 +622,12 @@ static int rollout_impl(const gpmpc_gp_desc_t* gp, const gpmpc_env_desc_t* env, 
         if (!ws || ws_bytes < need) return fail(GPMPC_E_WORKSPACE, "gpmpc_rollout: workspace too small");
     }
     hipStream_t st = (hipStream_t)stream;
-    if (!seeded && rollout_one_eligible(gp, env, mode, hall_tasks, H, Ns)) {
-        g_last_rollout_path = 4;
-        return rollout_one_launch(gp, env, args, st);
-    }
-    if (!seeded && rollout_tiles_eligible(gp, env, mode, hall_tasks, H, Ns)) {
-        g_last_rollout_path = 3;
-        return rollout_tiles_launch(gp, env, args, ws, ws_bytes, st);
-    }
-    if (!seeded && rollout_fast_eligible(gp, env, mode, hall_tasks, H)) {
-        g_last_rollout_path = 1;
-        return rollout_fast_launch(gp, env, args, ws, ws_bytes, st);
-    }
-    if (!seeded && rollout_indep_eligible(gp, env, mode)) {
-        g_last_rollout_path = 2;
-        return rollout_indep_launch(gp, env, args, st);
-    }
-    g_last_rollout_path = 0;
+    const int kernel = seeded ? GPMPC_KERNEL_GENERIC : select_rollout_kernel(gp, env, mode, hall_tasks, H, Ns);
+    g_last_rollout_path = kernel;
+    if (kernel == GPMPC_KERNEL_ONE) return rollout_one_launch(gp, env, args, st);
+    if (kernel == GPMPC_KERNEL_TILES) return rollout_tiles_launch(gp, env, args, ws, ws_bytes, st);
+    if (kernel == GPMPC_KERNEL_FAST) return rollout_fast_launch(gp, env, args, ws, ws_bytes, st);
+    if (kernel == GPMPC_KERNEL_INDEP) return rollout_indep_launch(gp, env, args, st);
     const int T = gp->T;
     if (T == 1) {
         if (rp.rpl == 1) return launch_rollout<1, 1>(args, rp, gp->g_ny, st);

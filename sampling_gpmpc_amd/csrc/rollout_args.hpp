@@ -53,6 +53,9 @@ __host__ __device__ __forceinline__ long state_sample_doubles(int g_ny, int n_r,
 // packed lower-triangular, column-major: element (row, col) at col_ofs(col) + row - col, rows col..nh_max-1
 __host__ __device__ __forceinline__ long col_ofs(int p, int nh_max) { return (long)p * nh_max - ((long)p * (p - 1)) / 2; }
 
+// gpmpc_rollout_pin_kernel (rollout.hip): GPMPC_KERNEL_AUTO or the kernel every launch must take where its shape allows
+extern int g_rollout_pin;
+
 // tuned path (rollout_fast.hip)
 bool rollout_fast_eligible(const gpmpc_gp_desc_t* gp, const gpmpc_env_desc_t* env, int mode, int hall_tasks, int H);
 size_t rollout_fast_workspace_bytes(const gpmpc_gp_desc_t* gp, int64_t Ns, int H);

@@ -1033,6 +1033,7 @@ struct FastPlan {
 };
 
 static bool fast_disabled() {
+    if (g_rollout_pin != GPMPC_KERNEL_AUTO) return g_rollout_pin != GPMPC_KERNEL_FAST;
     const char* e = std::getenv("GPMPC_DISABLE_FAST_ROLLOUT");
     return e && e[0] == '1';
 }

@@ -483,6 +483,7 @@ __global__ __launch_bounds__(64 * G_NY) void rollout_indep_grid_kernel(const Rol
 
 
 bool rollout_indep_eligible(const gpmpc_gp_desc_t* gp, const gpmpc_env_desc_t* env, int mode) {
+    if (g_rollout_pin == GPMPC_KERNEL_GENERIC) return false;    // (the other pins name mode-R kernels: mode I is unaffected)
     const char* e = std::getenv("GPMPC_DISABLE_FAST_ROLLOUT");
     if (e && e[0] == '1') return false;
     if (mode != GPMPC_MODE_INDEPENDENT || gp->T != 1 || gp->D != 2 || gp->real_has_grad) return false;

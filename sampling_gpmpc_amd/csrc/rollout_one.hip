@@ -625,6 +625,7 @@ __global__ __launch_bounds__(64, 1) void rollout_one_kernel(const RolloutArgs a)
 // host side
 // ---------------------------------------------------------------------------------------------------------------
 static int one_mode() {                                          // 0 auto, 1 forced, -1 disabled
+    if (g_rollout_pin != GPMPC_KERNEL_AUTO) return (g_rollout_pin == GPMPC_KERNEL_ONE) ? 1 : -1;
     const char* e = std::getenv("GPMPC_ROLLOUT_ONE");
     if (!e) return 0;
     return (e[0] == '1') ? 1 : ((e[0] == '0') ? -1 : 0);

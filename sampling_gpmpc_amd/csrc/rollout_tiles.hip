@@ -984,6 +984,7 @@ __global__ __launch_bounds__(64, 1) void rollout_tiles_kernel(const RolloutArgs 
 // shipped car H = 50 included); anything else stays with the one-chain-per-wave kernels.
 // ---------------------------------------------------------------------------------------------------------------
 static int tiles_mode() {                                        // 0 auto, 1 forced, -1 disabled
+    if (g_rollout_pin != GPMPC_KERNEL_AUTO) return (g_rollout_pin == GPMPC_KERNEL_TILES) ? 1 : -1;
     const char* e = std::getenv("GPMPC_ROLLOUT_TILES");
     if (!e) return 0;
     return (e[0] == '1') ? 1 : ((e[0] == '0') ? -1 : 0);

@@ -33,6 +33,22 @@ class RolloutResult:
         self.X_traj, self.Y, self.Xi, self.info = X_traj, Y, Xi, info
 
 
+def pin_rollout_kernel_like(agent: Agent, *, H: int, Ns_launch: int, mode: int = _lib.MODE_RECONDITIONED,
+                            use_model_without_derivatives: bool = False) -> int:
+    """Pin ``gpmpc_rollout``'s kernel to the one a launch of ``Ns_launch`` samples of this shape would take, and return it.
+
+    The dispatcher picks by launch size, and the kernels sum in different orders: a sample's trajectory is bit-identical
+    between two launches only if both ran the same kernel.  A sample-sharded run that must reproduce the single-GPU run of the
+    same samples bit for bit calls this with the GLOBAL sample count before its shard-sized launches (at the price of the
+    kernel that is best for the shard size); ``_lib.load().gpmpc_rollout_pin_kernel(-1)`` restores the size heuristic."""
+    lib = _lib.load()
+    lib.gpmpc_rollout_pin_kernel(-1)
+    plan = agent._plan(use_grad=not use_model_without_derivatives)
+    k = lib.gpmpc_rollout_kernel_for(plan.desc, agent.env_desc(), mode, plan.hyper.T, int(Ns_launch), int(H))
+    lib.gpmpc_rollout_pin_kernel(k)
+    return k
+
+
 def rollout_device(agent: Agent, u_ff, z: torch.Tensor, z_step_stride: int, *, H: int, mode: int,
                    use_model_without_derivatives: bool, use_feedback: Optional[bool] = None,
                    x0=None, hall_tasks: Optional[int] = None, var_zero_thr: Optional[float] = None,

@@ -1149,3 +1149,50 @@ def test_pinned_sample_branches_against_reference_run(sg):
         agent, _ = make_agents(sg, p, erv=c["epistimic_random_vector"])
         replay_pinned(agent, c, to_dev=lambda t: t.to(agent.torch_device), drawn_exact=False)
         print(f"pinned-sample case {tag}: ok")
+
+
+@pytest.mark.parametrize("mode", ["block", "poll"])
+def test_to_host_waits_for_its_copy_in_both_wait_modes(sg, mode, monkeypatch):
+    """_lib.to_host: the pinned D2H copy is asynchronous and nothing blocking follows it - it must be complete when the array
+    is handed out, also under GPMPC_HOST_WAIT=block where host_wait() returns at once."""
+    monkeypatch.setenv("GPMPC_HOST_WAIT", mode)
+    dev = torch.device("cuda")
+    for rep in range(20):
+        a_ = torch.full((4096, 257), float(rep), dtype=F64, device=dev)
+        b_ = (a_ * 2.0 + 1.0).cumsum(0)                    # some queued work in front of the copy
+        h = sg._lib.to_host(b_)
+        np.testing.assert_array_equal(h, b_.cpu().numpy())
+
+
+def test_pinned_kernel_makes_shard_launches_bit_equal_to_the_full_launch(sg):
+    """The dispatcher picks the kernel by launch size and the kernels sum in different orders: a 512-sample shard of a
+    4096-sample pendulum launch runs rollout_one_kernel where the full launch runs rollout_tiles_kernel - equal to round-off,
+    not bit for bit.  gpmpc_rollout_pin_kernel (rollout.pin_rollout_kernel_like) gives the shard the full launch's kernel:
+    bit-equal again."""
+    from sampling_gpmpc_amd.rollout import forward_sampling_rollout, rollout_device, pin_rollout_kernel_like
+    from sampling_gpmpc_amd import _lib
+    Ns, H = 4096, 30
+    p = fs_params("params_pendulum1D_samples", Ns, H)
+    p["agent"]["base_sample_generator"] = "vectorized"
+    torch.manual_seed(11)
+    pg = {**p, "common": {**p["common"], "use_cuda": True}}
+    agent = sg.Agent(pg, sg.make_env(pg))
+    u_ff = synthetic_u_ff(1, H)
+    lib = _lib.load()
+    try:
+        X = forward_sampling_rollout(agent, u_ff)
+        assert lib.gpmpc_rollout_last_kernel() == 3
+        erv = agent.epistimic_random_vector
+        per_slab = Ns * 3
+        z = erv.reshape(-1)[per_slab:]
+        kw = dict(H=H, mode=_lib.MODE_RECONDITIONED, use_model_without_derivatives=False, sample_slice=(1024, 1536))
+        sub = rollout_device(agent, u_ff, z, erv.shape[1] * per_slab, **kw).X_traj.cpu().numpy()
+        assert lib.gpmpc_rollout_last_kernel() == 4
+        assert not np.array_equal(sub, X[1024:1536])
+        np.testing.assert_allclose(sub, X[1024:1536], rtol=1e-9, atol=1e-11)
+        assert pin_rollout_kernel_like(agent, H=H, Ns_launch=Ns) == 3
+        sub = rollout_device(agent, u_ff, z, erv.shape[1] * per_slab, **kw).X_traj.cpu().numpy()
+        assert lib.gpmpc_rollout_last_kernel() == 3
+        np.testing.assert_array_equal(sub, X[1024:1536])
+    finally:
+        lib.gpmpc_rollout_pin_kernel(-1)

@@ -313,3 +313,14 @@ def test_host_thread_budget_follows_the_cgroup_quota(tmp_path):
     assert ht.host_thread_budget(visible=256, quota=2.5, current=256) == 1
     assert ht.host_thread_budget(visible=8, quota=None, current=8) is None       # nothing oversubscribed: hands off
     assert ht.host_thread_budget(visible=64, quota=16.0, current=4) is None
+
+
+def test_host_thread_env_below_one_is_ignored(monkeypatch):
+    """GPMPC_HOST_THREADS=0 used to reach torch.set_num_threads(0), which raises - at package import."""
+    from sampling_gpmpc_amd import _host_threads as ht
+    monkeypatch.setenv("GPMPC_HOST_THREADS", "0")
+    monkeypatch.delenv("OMP_NUM_THREADS", raising=False)
+    before = torch.get_num_threads()
+    got = ht.limit_host_threads()
+    assert got is None or 1 <= got <= before
+    assert torch.get_num_threads() >= 1
