@@ -294,6 +294,15 @@ int     gpmpc_pack_plin(int32_t nx, int32_t nu, int64_t Ns, int32_t H,
                         const double* y_grad, const double* u_grad, const double* gp_val,
                         const double* x_h, const double* u_h, const double* xg, const double* w,
                         const double* tilde_eps, double* p_lin, void* stream);
+/* the same with the feedback law folded in: A_i = y_grad + u_grad K (reference src/solver.py:90), K [dev] (nu, nx) or NULL */
+int     gpmpc_pack_plin_fb(int32_t nx, int32_t nu, int64_t Ns, int32_t H,
+                           const double* y_grad, const double* u_grad, const double* gp_val,
+                           const double* x_h, const double* u_h, const double* xg, const double* w,
+                           const double* tilde_eps, const double* K, double* p_lin, void* stream);
+/* bitwise OR of n int32 words ([dev], e.g. the per-chain info words of a launch) into out[0] ([dev], zeroed by the caller):
+ * one launch and one word to read where the facade used a reduction per flag bit (nothing of the reference is replaced:
+ * gpytorch raises / warns from host-side checks of its own, src/agent.py:629-641) */
+int     gpmpc_or_reduce_words(const int32_t* v, int64_t n, int32_t* out, void* stream);
 
 #ifdef __cplusplus
 }

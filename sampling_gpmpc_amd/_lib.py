@@ -71,6 +71,8 @@ SYMBOLS = {
     "gpmpc_assemble_jacobians": (C.c_int, [C.POINTER(GpDesc), C.POINTER(EnvDesc), _I64, _I32, _P, _P, _P, _P, _P, _P]),
     "gpmpc_plin_len": (_I64, [_I32, _I32, _I64]),
     "gpmpc_pack_plin": (C.c_int, [_I32, _I32, _I64, _I32, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "gpmpc_pack_plin_fb": (C.c_int, [_I32, _I32, _I64, _I32, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "gpmpc_or_reduce_words": (C.c_int, [_P, _I64, _P, _P]),
 }
 
 _lib: Optional[C.CDLL] = None

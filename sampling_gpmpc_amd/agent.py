@@ -20,6 +20,8 @@ from __future__ import annotations
 import warnings
 from typing import Optional
 
+import itertools
+
 import numpy as np
 import torch
 
@@ -129,6 +131,9 @@ def counter_base_samples(n_mpc, n_itrs, n_dyn, g_ny, H, T, beta, seed=123456, of
     return out.reshape(n_mpc, n_itrs, n_dyn, g_ny, H, T)
 
 
+_HALL_GENERATION = itertools.count(1)
+
+
 class Agent(object):
     def __init__(self, params, env_model) -> None:
         self.my_key = 0
@@ -177,9 +182,40 @@ class Agent(object):
     # ---------------------------------------------------------------------------------------------------------
     # host-side bookkeeping
     # ---------------------------------------------------------------------------------------------------------
+    # The hallucinated set ``Hallcinated_{X,Y}_train`` (reference attribute names, src/agent.py:52-62) with a LINEAGE: a
+    # generation number that changes whenever the tensors are replaced other than by appending points, and a flag "no NaN
+    # label".  ``train_hallucinated_dynGP`` hands both to the model: the joint factor cache then vouches for its rows by
+    # comparing two integers (no ``torch.equal`` + host sync per draw) and the observed-slot scan is skipped.  Assigning the
+    # attributes from outside starts a new generation; code that edits them IN PLACE calls ``invalidate_factor_cache()``.
+    @property
+    def Hallcinated_X_train(self):
+        return self._hall_X
+
+    @Hallcinated_X_train.setter
+    def Hallcinated_X_train(self, t):
+        self._hall_X = t
+        self._hall_gen = next(_HALL_GENERATION)
+
+    @property
+    def Hallcinated_Y_train(self):
+        return self._hall_Y
+
+    @Hallcinated_Y_train.setter
+    def Hallcinated_Y_train(self, t):
+        self._hall_Y = t
+        self._hall_gen = next(_HALL_GENERATION)
+        self._hall_all_observed = False                   # unknown labels: scan them
+
+    def invalidate_factor_cache(self):
+        """after an in-place edit of the hallucinated tensors (``prepare_dynamics_set``'s survivor replacement does one)"""
+        self._hall_gen = next(_HALL_GENERATION)
+        self._hall_all_observed = False
+
     def _reset_hallucinated(self):
-        self.Hallcinated_X_train = torch.empty(self.ns, self.g_ny, 0, self.in_dim_x, dtype=F64, device=self.torch_device)
-        self.Hallcinated_Y_train = torch.empty(self.ns, self.g_ny, 0, self.in_dim_y, dtype=F64, device=self.torch_device)
+        self._hall_X = torch.empty(self.ns, self.g_ny, 0, self.in_dim_x, dtype=F64, device=self.torch_device)
+        self._hall_Y = torch.empty(self.ns, self.g_ny, 0, self.in_dim_y, dtype=F64, device=self.torch_device)
+        self._hall_gen = next(_HALL_GENERATION)
+        self._hall_all_observed = True
 
     def random_vector_within_bounds(self):
         return random_vector_within_bounds(self.params, self.g_ny, self.in_dim_y, device=self.torch_device)
@@ -225,8 +261,12 @@ class Agent(object):
                 all_s = torch.all(filt, dim=0)
             keep = ~torch.any(all_s, dim=0)                                        # filtered in ALL samples -> drop
             newX, newY = newX[:, :, keep, :], newY[:, :, keep, :]
-        self.Hallcinated_X_train = torch.cat([self.Hallcinated_X_train, newX], 2)
-        self.Hallcinated_Y_train = torch.cat([self.Hallcinated_Y_train, newY], 2)
+        # appended behind what is there: same generation (the factor rows of the earlier points stay valid); the labels are
+        # draws (no NaN) unless the min-distance filter ran
+        self._hall_X = torch.cat([self._hall_X, newX], 2)
+        self._hall_Y = torch.cat([self._hall_Y, newY], 2)
+        if min_distance >= 0.0:
+            self._hall_all_observed = False
 
     def get_batch_x_hat_u_diff(self, x_h, u_h):
         """x_h (H, Ns*nx), u_h (H, Ns, nu) -> (Ns, nx, H, nx+nu), state row replicated nx times (:480-501)."""
@@ -285,7 +325,10 @@ class Agent(object):
             hy = torch.empty(self.ns, self.g_ny, 0, 1, dtype=F64, device=self.torch_device)
         else:
             hx, hy = self.Hallcinated_X_train, self.Hallcinated_Y_train
-        self.model_i = HipGPModel(plan, hx, hy, self.batch_shape, self._ws_cache, dist_group=self.dist_group)
+        own = not use_model_without_derivatives
+        self.model_i = HipGPModel(plan, hx, hy, self.batch_shape, self._ws_cache, dist_group=self.dist_group,
+                                  all_observed=(own and self._hall_all_observed and self.dist_group is None),
+                                  lineage=((self._hall_gen, int(hx.shape[2])) if own else None))
         self.likelihood = plan.hyper
         if sqp_iter == 0:
             self._reset_hallucinated()
@@ -358,9 +401,13 @@ class Agent(object):
         ns, nH = xu_hat.shape[0], xu_hat.shape[2]
         y = self.get_batch_gp_sensitivities(xu_hat, sqp_iter).contiguous()
         dev = _lib.require_hip_device(self.torch_device)
-        gp_val = torch.empty(ns, self.nx, nH, 1, dtype=F64, device=dev)
-        y_grad = torch.empty(ns, self.nx, nH, self.nx, dtype=F64, device=dev)
-        u_grad = torch.empty(ns, self.nx, nH, self.nu, dtype=F64, device=dev)
+        # the three arrays are consecutive pieces of ONE buffer: a single device-to-host copy moves them all
+        n1, n2, n3 = ns * self.nx * nH, ns * self.nx * nH * self.nx, ns * self.nx * nH * self.nu
+        flat = torch.empty(n1 + n2 + n3, dtype=F64, device=dev)
+        gp_val = flat[:n1].view(ns, self.nx, nH, 1)
+        y_grad = flat[n1:n1 + n2].view(ns, self.nx, nH, self.nx)
+        u_grad = flat[n1 + n2:].view(ns, self.nx, nH, self.nu)
+        self._last_device_jacobians_flat = flat
         plan = self.model_i.plan
         _lib.check(lib.gpmpc_assemble_jacobians(plan.desc, self.env_desc(), ns, nH, _lib.dptr(xu_hat), _lib.dptr(y),
                                                 _lib.dptr(gp_val), _lib.dptr(y_grad), _lib.dptr(u_grad),
@@ -372,7 +419,9 @@ class Agent(object):
         """Full-state value and Jacobians ``f + B_d g`` at the linearisation points (reference ``src/agent.py:532-564``).
         Returns numpy float64 ``gp_val (Ns,nx,H,1)``, ``y_grad (Ns,nx,H,nx)``, ``u_grad (Ns,nx,H,nu)``."""
         gp_val, y_grad, u_grad = self.dyn_fg_jacobians_device(xu_hat, sqp_iter)
-        out = (_lib.to_host(gp_val), _lib.to_host(y_grad), _lib.to_host(u_grad))
+        h = _lib.to_host(self._last_device_jacobians_flat)        # one pinned copy; the arrays are views of it
+        n1, n2 = gp_val.numel(), y_grad.numel()
+        out = (h[:n1].reshape(gp_val.shape), h[n1:n1 + n2].reshape(y_grad.shape), h[n1 + n2:].reshape(u_grad.shape))
         if not (np.isfinite(out[0]).all() and np.isfinite(out[1]).all() and np.isfinite(out[2]).all()):
             print("Nan/inf in y_sample")
         return out
@@ -384,17 +433,33 @@ class Agent(object):
         gp_val, y_grad, u_grad = self._last_device_jacobians
         dev = gp_val.device
         H = gp_val.shape[2]
-        if K is not None:                      # feedback: y_grad + u_grad @ K   (reference src/solver.py:90)
-            y_grad = (y_grad + u_grad @ torch.as_tensor(K, dtype=F64, device=dev)).contiguous()
-        t = lambda a: torch.as_tensor(np.asarray(a), dtype=F64).to(dev).contiguous()
-        x_h_d, u_h_d, xg_d, w_d = t(x_h), t(u_h), t(np.asarray(xg).reshape(-1)[:H]), t(np.asarray(w).reshape(-1)[:H])
-        te = t(np.stack(self.tilde_eps_list)[:H])
+        # everything that comes from the host goes up in ONE copy: [x_h | u_h | xg | w]; the tightenings and the feedback gain
+        # are constants of the Agent (uploaded once); the feedback product y_grad + u_grad K (reference src/solver.py:90)
+        # happens inside the packing kernel
+        x_np, u_np = np.asarray(x_h, dtype=np.float64).reshape(-1), np.asarray(u_h, dtype=np.float64).reshape(-1)
+        xg_np, w_np = np.asarray(xg, dtype=np.float64).reshape(-1)[:H], np.asarray(w, dtype=np.float64).reshape(-1)[:H]
+        up = torch.from_numpy(np.concatenate([x_np, u_np, xg_np, w_np])).to(dev)
+        o1, o2, o3 = x_np.size, x_np.size + u_np.size, x_np.size + u_np.size + H
+        const = self._ws_cache.get("plin_const")
+        if const is None or const[0] != H:
+            te = torch.as_tensor(np.stack(self.tilde_eps_list)[:H], dtype=F64).to(dev).contiguous()
+            const = (H, te, {})
+            self._ws_cache["plin_const"] = const
+        te, Kc = const[1], const[2]
+        K_d = None
+        if K is not None:
+            key = np.asarray(K, dtype=np.float64).tobytes()
+            K_d = Kc.get(key)
+            if K_d is None:
+                K_d = torch.as_tensor(np.asarray(K), dtype=F64).to(dev).contiguous()
+                Kc.clear()
+                Kc[key] = K_d
         n = lib.gpmpc_plin_len(self.nx, self.nu, self.ns)
         p_lin = torch.empty(H, n, dtype=F64, device=dev)
-        _lib.check(lib.gpmpc_pack_plin(self.nx, self.nu, self.ns, H, _lib.dptr(y_grad), _lib.dptr(u_grad),
-                                       _lib.dptr(gp_val), _lib.dptr(x_h_d), _lib.dptr(u_h_d), _lib.dptr(xg_d),
-                                       _lib.dptr(w_d), _lib.dptr(te), _lib.dptr(p_lin), _lib.current_stream_ptr()),
-                   "gpmpc_pack_plin")
+        _lib.check(lib.gpmpc_pack_plin_fb(self.nx, self.nu, self.ns, H, _lib.dptr(y_grad), _lib.dptr(u_grad),
+                                          _lib.dptr(gp_val), _lib.dptr(up[:o1]), _lib.dptr(up[o1:o2]), _lib.dptr(up[o2:o3]),
+                                          _lib.dptr(up[o3:]), _lib.dptr(te), _lib.dptr(K_d), _lib.dptr(p_lin),
+                                          _lib.current_stream_ptr()), "gpmpc_pack_plin_fb")
         return _lib.to_host(p_lin)
 
     # ---------------------------------------------------------------------------------------------------------
@@ -492,6 +557,7 @@ class Agent(object):
             survivors = torch.nonzero(alive > 0).reshape(-1).cpu().numpy()
             self.Hallcinated_X_train[rejected] = self.Hallcinated_X_train[rng.choice(survivors, n_rejected).tolist()]
             self.Hallcinated_Y_train[rejected] = self.Hallcinated_Y_train[rng.choice(survivors, n_rejected).tolist()]
+            self.invalidate_factor_cache()                        # edited in place
         self.train_hallucinated_dynGP(sqp_iter=self.params["optimizer"]["SEMPC"]["max_sqp_iter"])
 
     def _propagate_fused(self, X_soln, U_soln, x_next1, samples_left, base_samples, n_last, dev):

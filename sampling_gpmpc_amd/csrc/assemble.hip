@@ -63,7 +63,8 @@ __global__ __launch_bounds__(256) void plin_kernel(int nx, int nu, long Ns, int 
                                                    const double* __restrict__ u_grad, const double* __restrict__ gp_val,
                                                    const double* __restrict__ x_h, const double* __restrict__ u_h,
                                                    const double* __restrict__ xg, const double* __restrict__ w,
-                                                   const double* __restrict__ tilde_eps, double* __restrict__ p_lin) {
+                                                   const double* __restrict__ tilde_eps, const double* __restrict__ Kfb,
+                                                   double* __restrict__ p_lin) {
     const long per = (long)nx * nx + (long)nx * nu + 2L * nx;
     const long tail = nu + 2 + (nx + nu + 1);
     const long len = Ns * per + tail;
@@ -78,6 +79,12 @@ __global__ __launch_bounds__(256) void plin_kernel(int nx, int nu, long Ns, int 
             if (r < nx * nx) {
                 const int a = r / nx, b = r - a * nx;
                 v = y_grad[((i * nx + a) * H + h) * nx + b];
+                if (Kfb) {                                        // feedback: A_i = y_grad + u_grad K (reference src/solver.py:90)
+                    const double* ug = u_grad + ((i * nx + a) * H + h) * nu;
+                    double acc = 0.0;
+                    for (int j = 0; j < nu; ++j) acc += ug[j] * Kfb[j * nx + b];
+                    v += acc;
+                }
             } else if (r < nx * nx + nx * nu) {
                 const int rr = r - nx * nx;
                 const int a = rr / nu, b = rr - a * nu;
@@ -146,7 +153,39 @@ int gpmpc_pack_plin(int32_t nx, int32_t nu, int64_t Ns, int32_t H, const double*
     if (nx < 1 || nu < 1 || Ns < 1 || H < 1) return fail(GPMPC_E_ARG, "gpmpc_pack_plin: bad sizes");
     const long total = gpmpc_plin_len(nx, nu, Ns) * H;
     hipLaunchKernelGGL(plin_kernel, dim3(stream_grid(total)), dim3(256), 0, (hipStream_t)stream, nx, nu, (long)Ns, H,
-                       y_grad, u_grad, gp_val, x_h, u_h, xg, w, tilde_eps, p_lin);
+                       y_grad, u_grad, gp_val, x_h, u_h, xg, w, tilde_eps, (const double*)nullptr, p_lin);
+    GPMPC_HIP_CHECK(hipGetLastError());
+    return GPMPC_OK;
+}
+
+int gpmpc_pack_plin_fb(int32_t nx, int32_t nu, int64_t Ns, int32_t H, const double* y_grad, const double* u_grad,
+                       const double* gp_val, const double* x_h, const double* u_h, const double* xg, const double* w,
+                       const double* tilde_eps, const double* K, double* p_lin, void* stream) {
+    if (!y_grad || !u_grad || !gp_val || !x_h || !u_h || !xg || !w || !tilde_eps || !p_lin)
+        return fail(GPMPC_E_ARG, "gpmpc_pack_plin_fb: NULL pointer");
+    if (nx < 1 || nu < 1 || Ns < 1 || H < 1) return fail(GPMPC_E_ARG, "gpmpc_pack_plin_fb: bad sizes");
+    const long total = gpmpc_plin_len(nx, nu, Ns) * H;
+    hipLaunchKernelGGL(plin_kernel, dim3(stream_grid(total)), dim3(256), 0, (hipStream_t)stream, nx, nu, (long)Ns, H,
+                       y_grad, u_grad, gp_val, x_h, u_h, xg, w, tilde_eps, K, p_lin);
+    GPMPC_HIP_CHECK(hipGetLastError());
+    return GPMPC_OK;
+}
+
+// bitwise OR over n int32 words (the per-chain info words of a launch) into out[0], which the caller has zeroed - or keeps
+// accumulating into
+__global__ __launch_bounds__(256) void or_reduce_kernel(const int* __restrict__ v, long n, int* __restrict__ out) {
+    int acc = 0;
+    for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < n; e += (long)gridDim.x * blockDim.x) acc |= v[e];
+    for (int m = 32; m >= 1; m >>= 1) acc |= __shfl_xor(acc, m, 64);
+    if ((threadIdx.x & 63) == 0 && acc) atomicOr(out, acc);
+}
+
+int gpmpc_or_reduce_words(const int32_t* v, int64_t n, int32_t* out, void* stream) {
+    if (!out || (n > 0 && !v) || n < 0) return fail(GPMPC_E_ARG, "gpmpc_or_reduce_words: bad arguments");
+    if (n == 0) return GPMPC_OK;
+    long g = (n + 255) / 256;
+    if (g > 256) g = 256;
+    hipLaunchKernelGGL(or_reduce_kernel, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, (const int*)v, (long)n, (int*)out);
     GPMPC_HIP_CHECK(hipGetLastError());
     return GPMPC_OK;
 }

@@ -25,6 +25,13 @@ import torch
 from . import _lib
 
 F64 = torch.float64
+import os
+
+# GPMPC_VERIFY_FACTOR_CACHE=1: the joint factor cache compares the slot list and the points with its snapshots (two
+# torch.equal + host syncs per draw) even when the Agent's lineage counter vouches for them (tests; debugging foreign code that
+# edits Hallcinated_* in place without Agent.invalidate_factor_cache())
+_VERIFY_CACHE = os.environ.get("GPMPC_VERIFY_FACTOR_CACHE") == "1"
+
 MAX_JOINT_ROWS = 2048            # gpmpc_joint_sample: n_ho + 1 + m*T label rows per chain (include/gpmpc_hip.h)
 MAX_JOINT_TEST_SLOTS = 256       # m*T
 
@@ -141,6 +148,7 @@ class JointFactorCache:
     def invalidate(self):
         self.slots = None
         self.n_pts = 0
+        self.lineage = None
 
     @property
     def X(self):
@@ -182,9 +190,17 @@ class JointFactorCache:
         if self.slots is not None:
             n_old, n_pts = int(self.slots.numel()), self.n_pts
             # append-only growth: the old slot list is a prefix of the new one and the points it was built on are unchanged
-            if n_old <= n_ho and n_pts <= mdl.n_h and bool(torch.equal(mdl.h_slots[:n_old], self.slots)) \
-                    and bool(torch.equal(mdl.hall_X[:self.n_samples, :, :n_pts], self.X)):
-                n_c = n_old
+            if n_old <= n_ho and n_pts <= mdl.n_h:
+                lin = getattr(mdl, "lineage", None)
+                if lin is not None and self.lineage is not None and not _VERIFY_CACHE:
+                    # the Agent counts the history of its hallucinated set: same generation = the first n_pts points and
+                    # their (all observed) slots are the ones the rows were computed from - no tensor comparison, no sync
+                    same = lin[0] == self.lineage[0] and n_pts <= lin[1] and n_old == n_pts * mdl.hyper.T
+                else:
+                    same = bool(torch.equal(mdl.h_slots[:n_old], self.slots)) \
+                        and bool(torch.equal(mdl.hall_X[:self.n_samples, :, :n_pts], self.X))
+                if same:
+                    n_c = n_old
         return self.buf, self.rows, n_c
 
     def rewind(self, n_slots: int):
@@ -209,6 +225,9 @@ class JointFactorCache:
         self.Xbuf[:, :, keep:mdl.n_h] = mdl.hall_X[:self.n_samples, :, keep:]
         self.n_pts = mdl.n_h
         self.slots = mdl.h_slots[:n_ho].clone()
+        lin = getattr(mdl, "lineage", None)
+        # rows vouched for by lineage need every slot of every point observed (slot list == 0 .. T n_pts - 1)
+        self.lineage = lin if (lin is not None and n_ho == mdl.n_h * mdl.hyper.T) else None
 
 
 class HipPosterior:
@@ -378,23 +397,49 @@ _INFO_BITS = (0x1, 0x2, 0x4, 0x8, 0x10, 0x20, 0x40, 0x80, 0x100, 0x200)
 
 
 def _or_reduce(info: torch.Tensor, group=None) -> int:
-    """bitwise OR over an int32 tensor (tiny; one device->host sync) and, with ``group``, over its ranks."""
+    """bitwise OR over an int32 tensor and, with ``group``, over its ranks: ONE launch (``gpmpc_or_reduce_words``) and one word
+    read back (it used to be a reduction per flag bit: 21 launches per joint draw)."""
     if info.numel() == 0 and group is None:
         return 0
-    v = info.flatten()
-    # OR == max per bit: one small reduction per flag bit, a single transfer
-    if v.numel():
-        packed = torch.stack([(v & b).max() for b in _INFO_BITS])
-    else:
-        packed = torch.zeros(len(_INFO_BITS), dtype=info.dtype, device=info.device)
+    if info.is_cuda:
+        word = torch.zeros(1, dtype=torch.int32, device=info.device)
+        v = info.contiguous()
+        _lib.check(_lib.load().gpmpc_or_reduce_words(_lib.dptr(v), v.numel(), _lib.dptr(word), _lib.current_stream_ptr()),
+                   "gpmpc_or_reduce_words")
+        if group is not None:
+            import torch.distributed as dist
+            packed = torch.stack([(word[0] & b) for b in _INFO_BITS])          # all_reduce has MAX, not OR
+            dist.all_reduce(packed, op=dist.ReduceOp.MAX, group=group)
+            _lib.host_wait(packed)
+            bits = 0
+            for x in packed.tolist():
+                bits |= int(x)
+            return bits
+        return int(_lib.to_host(word)[0])
+    v = info.flatten()                                                         # CPU tensors (the gloo tests)
+    packed = torch.stack([(v & b).max() for b in _INFO_BITS]) if v.numel() else torch.zeros(len(_INFO_BITS), dtype=info.dtype)
     if group is not None:
         import torch.distributed as dist
         dist.all_reduce(packed, op=dist.ReduceOp.MAX, group=group)
     bits = 0
-    _lib.host_wait(packed)
     for x in packed.tolist():
         bits |= int(x)
     return bits
+
+
+_ALL_SLOTS: dict = {}
+
+
+def _all_slots(n: int, device) -> torch.Tensor:
+    """0 .. n-1 as int32 on ``device`` (cached: the slot list of a hallucinated set without NaN labels)."""
+    key = (str(device), n)
+    t = _ALL_SLOTS.get(key)
+    if t is None:
+        if len(_ALL_SLOTS) > 64:
+            _ALL_SLOTS.clear()
+        t = torch.arange(n, dtype=torch.int32, device=device)
+        _ALL_SLOTS[key] = t
+    return t
 
 
 def _observed_slots(hall_Y: torch.Tensor, dist_group=None) -> torch.Tensor:
@@ -415,7 +460,13 @@ class HipGPModel:
     """Conditioning set = shared real data (factorised plan) + per-sample hallucinated data."""
 
     def __init__(self, plan: RealDataPlan, hall_X: torch.Tensor, hall_Y: torch.Tensor, batch_shape,
-                 ws_cache: Optional[dict] = None, dist_group=None):
+                 ws_cache: Optional[dict] = None, dist_group=None, all_observed: bool = False, lineage=None):
+        """``all_observed``: the caller vouches that ``hall_Y`` holds no NaN (every appended label came out of a draw and no
+        min-distance filter ran): the observed-slot scan (isnan / any / nonzero: seven launches and a host sync) is skipped.
+        ``lineage = (generation, n_points)``: identifies an append-only history of the hallucinated set - two models with
+        the same generation hold the same first ``min(n_points)`` points (``Agent`` counts it) - which is what lets the joint
+        factor cache vouch for its rows without comparing tensors."""
+        self.lineage = lineage
         self.plan = plan
         self.dist_group = dist_group
         self.hyper = plan.hyper
@@ -426,7 +477,9 @@ class HipGPModel:
         self.hall_Y = hall_Y.to(device=dev, dtype=F64).contiguous()      # (Ns, g_ny, n_h, T)
         self.n_h = int(self.hall_X.shape[2])
         assert tuple(self.hall_X.shape[:2]) == (Ns, g_ny) and self.hall_Y.shape[-1] == self.hyper.T
-        if self.n_h:
+        if self.n_h and all_observed:
+            self.h_slots = _all_slots(self.n_h * self.hyper.T, dev)
+        elif self.n_h:
             self.h_slots = _observed_slots(self.hall_Y, dist_group)
         else:
             self.h_slots = torch.empty(0, dtype=torch.int32, device=dev)

@@ -129,9 +129,11 @@ def test_joint_factor_cache_is_bit_exact_and_used(sg, pname, Ns, H, budget):
         else:                                                        # (a buffer that had to grow starts empty: fewer hits)
             print(f"samples cached per call {cached_samples}")
             assert any(h > 0 and c < Ns for h, c in zip(hits, cached_samples)), "the prefix cache was never hit"
-        # changing a cached point (survivor replacement does that) invalidates the cache
+        # changing a cached point IN PLACE (survivor replacement does that) invalidates the cache: the Agent's lineage counter
+        # is told (Agent.invalidate_factor_cache - prepare_dynamics_set calls it; assigning the attribute does it by itself) ...
         agent.Hallcinated_X_train[0, :, 0, :] += 1e-3
         plain.Hallcinated_X_train[0, :, 0, :] += 1e-3
+        agent.invalidate_factor_cache()
         outs = []
         for a in (agent, plain):
             a.train_hallucinated_dynGP(iters)
@@ -139,3 +141,20 @@ def test_joint_factor_cache_is_bit_exact_and_used(sg, pname, Ns, H, budget):
         assert agent.model_i_call.n_cached_rows == 0
         for u, v in zip(*outs):
             np.testing.assert_array_equal(u, v)
+        # ... and with GPMPC_VERIFY_FACTOR_CACHE=1 the cache compares the points themselves: an in-place edit nobody announced
+        # is caught too
+        import sampling_gpmpc_amd.gp_model as gm
+        old_flag = gm._VERIFY_CACHE
+        gm._VERIFY_CACHE = True
+        try:
+            agent.Hallcinated_X_train[0, :, 1, :] += 1e-3
+            plain.Hallcinated_X_train[0, :, 1, :] += 1e-3
+            outs = []
+            for a in (agent, plain):
+                a.train_hallucinated_dynGP(iters)
+                outs.append(a.dyn_fg_jacobians(a.get_batch_x_hat(x_h, u_h), iters - 1))
+            assert agent.model_i_call.n_cached_rows == 0
+            for u, v in zip(*outs):
+                np.testing.assert_array_equal(u, v)
+        finally:
+            gm._VERIFY_CACHE = old_flag

@@ -23,6 +23,7 @@ def main():
     ap.add_argument("--horizon", type=int, default=40)
     ap.add_argument("--iters", type=int, default=4)
     ap.add_argument("--mpc-steps", type=int, default=4)
+    ap.add_argument("--run-steps", type=int, default=None, help="MPC steps actually run (default: all; the base samples are drawn for --mpc-steps either way)")
     ap.add_argument("--jitter", type=float, default=None, help="override Dyn_gp_jitter (default: as shipped, 1e-20 -> eigh root)")
     ap.add_argument("--block", action="store_true", help="let the runtime wait for completions (GPMPC_HOST_WAIT=block) instead of polling")
     a = ap.parse_args()
@@ -42,7 +43,7 @@ def main():
           f"jitter {p['agent']['Dyn_gp_jitter']:g}; GP side per SQP iteration in ms (train + x_hat + fg_jac + p_lin)")
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
-        for step in range(a.mpc_steps):
+        for step in range(a.mpc_steps if a.run_steps is None else min(a.run_steps, a.mpc_steps)):
             agent.mpc_iteration(step)
             x_curr = np.asarray(agent.current_state[: agent.nx], dtype=np.float64)
             st = np.array(x_curr.tolist() * a.ns)
