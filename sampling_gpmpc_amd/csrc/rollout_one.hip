@@ -383,34 +383,9 @@ __global__ __launch_bounds__(64, 1) void rollout_one_kernel(const RolloutArgs a)
         for (int g = KFIRST; g <= K; ++g) RN[g] = HSb[max(hs_rd + 16 * g * kOneRS, 0)];
         OPH(0);
 
-        // ---- forward substitution, left-looking over tile rows ------------------------------------------------------------
-        auto tile_row = [&](auto rc) {
-            constexpr int r = decltype(rc)::value, g = (NKT + r) >> 2, b = (NKT + r) & 3;
-            double c0, c1;                                        // (the chain starts both accumulators at zero)
-            one_row<r>(P, c0, c1, Vu);
-            const double acc = one_block_sum(c0 + c1) + RN[g];   // block b: rhs - sum over all earlier columns
-            const double w = one_gdm<g>(P, acc);
-            if constexpr (r == GPMPC_ONE_DEBUG_ROW) {
-                ODBG(10, acc);
-                ODBG(11, w);
-            }
-            Vu[g] = one_merge<b>(Vu[g], w);
-        };
-        if (n_h > 0) {
-            one_for<0, (R0 > 0 ? R0 : 0)>(tile_row);              // every tile row of the earlier groups is complete
-            // the group of the incomplete tile: rows that do not exist yet end the chain (a taken branch of a lone wave
-            // costs an instruction fetch)
-            auto cur_from = [&](auto self, auto rc) -> void {
-                constexpr int r = decltype(rc)::value;
-                if constexpr (r < R0 + 4 && r < kOneNTR) {
-                    if (4 * r < n_h) {
-                        tile_row(rc);
-                        self(self, std::integral_constant<int, r + 1>{});
-                    }
-                }
-            };
-            cur_from(cur_from, std::integral_constant<int, (R0 > 0 ? R0 : 0)>{});
-        }
+        // ---- forward substitution, left-looking over tile rows: ONE hand-scheduled statement (tools/gen_rollout_one.py:
+        // solve_stmt) - row r + 1's independent MFMAs stand in the wait states of row r, absent rows are left inside it -----
+        one_solve<K>(P, Vu, RN, n_h);
         ODBG(0, Vu[0]);
         ODBG(1, Vu[1]);
         ODBG(2, Vu[2]);

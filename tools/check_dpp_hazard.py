@@ -3,7 +3,10 @@
 not pad there (it neither sees into an asm statement nor pads its boundary beyond one wait state).
 
 Rules (measured on MI355X: tools/ubench/mfma64_hazard2.hip, mfma64_chain.hip, mfma64_war.hip; an `s_nop N` is N + 1 wait
-states, every other instruction one - an MFMA in between counts as ONE, whatever time it takes):
+states, every other instruction one - EXCEPT an independent FP64 MFMA standing between an MFMA and the reader of its result:
+tools/ubench/mfma64_fill.hip (round 4) shows that ONE such MFMA leaves nothing to pad for a VALU, a DPP or an MFMA SrcA/B reader
+(the reader then waits 16+ cycles behind the producer); it counts as MFMA_WS = 6 wait states for the rules M2-M4.  rollout_one.hip
+relies on it: the next tile row's independent MFMAs stand where the s_nop of the previous row would be):
 
   D1  VALU write of a VGPR -> the same VGPR read through DPP (row_newbcast source)            2 wait states
   M1  VALU write of a VGPR -> MFMA reading it as SrcA / SrcB / SrcC                           2
@@ -26,14 +29,15 @@ import tempfile
 
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(REPO, "sampling_gpmpc_amd", "csrc")
-SOURCES = ["rollout_indep.hip", "rollout_tiles.hip"]
+SOURCES = ["rollout_indep.hip", "rollout_tiles.hip", "rollout_one.hip"]
+EXTRA = {"rollout_one.hip": ["-mllvm", "-disable-machine-licm"]}        # as csrc/build.py compiles it
 
 
 def compile_to_isa(src):
     out = os.path.join(tempfile.mkdtemp(prefix="gpmpc_isa_"), src.replace(".hip", ".s"))
     cmd = [os.environ.get("HIPCC", "/opt/rocm/bin/hipcc"), "-x", "hip", "-S", "--cuda-device-only",
            os.path.join(CSRC, src), "-o", out, "--offload-arch=gfx950", "-O3", "-std=c++17",
-           "-fno-gpu-rdc", "-ffp-contract=on", "-I", os.path.join(REPO, "include"), "-I", CSRC]
+           "-fno-gpu-rdc", "-ffp-contract=on", "-I", os.path.join(REPO, "include"), "-I", CSRC] + EXTRA.get(src, [])
     subprocess.run(cmd, check=True, capture_output=True)
     return out
 
@@ -48,6 +52,7 @@ def regs(tok):
 
 
 TOK = r"-?[va]\[\d+:\d+\]|-?[va]\d+"
+MFMA_WS = 6
 
 
 def check(path):
@@ -99,7 +104,7 @@ def check(path):
             m = re.search(r"s_nop\s+(\d+)", code)
             window.append((int(m.group(1)) + 1 if m else 1, "nop", set()))
         elif is_mfma:
-            window.append((1, "mfma", tagged[0] if tagged else set()))
+            window.append((MFMA_WS, "mfma", tagged[0] if tagged else set()))
         elif op.startswith("v_") and tagged:
             window.append((1, "valu", tagged[0]))         # VALU: the destination is the first operand
         else:

@@ -61,12 +61,13 @@ def chain_stmt(items, neg, fresh=False):
     """items: list of (areg or None, a_expr, b_expr): one asm statement accumulating alternately into c0 / c1.
     areg None: the A operand is an ordinary VGPR value.  fresh: the accumulators start at zero (SrcC = 0 in the first MFMA of
     each: no v_mov of zeros in front of every chain); needs at least two MFMAs."""
+    head, tail, acc_first = True, "s_nop 5", 0
     lines = ['"s_nop 1\\n\\t"']
     ops_in = []
     k = len(items)
     assert not fresh or k >= 2
     for i, (areg, aexpr, bexpr) in enumerate(items):
-        c = i & 1
+        c = (i + acc_first) & 1
         a_txt = f"a[{areg}:{areg + 1}]" if areg is not None else f"%{2 + 2 * i}"
         b_txt = f"%{2 + 2 * i + 1}"
         src_c = "0" if (fresh and i < 2) else f"%{c}"
@@ -75,10 +76,143 @@ def chain_stmt(items, neg, fresh=False):
             lines.append('"s_nop 1\\n\\t"')
         ops_in.append(f'"{{a[{areg}:{areg + 1}]}}"({aexpr})' if areg is not None else f'"v"({aexpr})')
         ops_in.append(f'"v"({bexpr})')
-    lines.append('"s_nop 5"')
+    if tail:
+        lines.append(f'"{tail}"')
+    else:
+        lines[-1] = lines[-1][:-5] + '"'          # drop the trailing \n\t of the last instruction
     body = "\n        ".join(lines)
     cons = '"=&v"(c0), "=&v"(c1)' if fresh else '"+v"(c0), "+v"(c1)'
     return f"    asm volatile({body}\n        : {cons}\n        : {', '.join(ops_in)});\n"
+
+
+
+# ---- the forward substitution of one step as ONE statement ------------------------------------------------------------------
+# Registers of the statement (the kernel itself stays below v214; build.py / the ISA check assert it):
+#   v[216 + 2 g : 217 + 2 g]   Vu[g], the solution of column group g (tied operands with a physical constraint: the DPP merge
+#                              writes HALVES of it under a bank mask, and inline asm cannot name half of a %operand)
+#   v[232:233] T   v[234:235] T2 (the rotated copy)   v[236:237] W   v[238:245] X0 .. X3: the accumulators of two tile rows
+SOLVE_VU, SOLVE_T, SOLVE_T2, SOLVE_W, SOLVE_X = 216, 232, 234, 236, 238
+SOLVE_CLOBBER = list(range(232, 246))
+
+
+def vp(n):
+    return f"v[{n}:{n + 1}]"
+
+
+def solve_stmt(f, m, K, member):
+    """Row r: acc = rhs_r - sum_g panel(r, g) Vu[g]; W = G_r (block sum of acc); block b of Vu[g_r] := W.  Left to the compiler
+    (one statement per chain, per MFMA, per DPP pair) every MFMA result is fenced by s_nop 5 (the compiler neither sees the
+    MFMA nor may it schedule into the statement), twice per row: 48 of a row's ~190 cycles.  Here the row is software
+    pipelined by hand: only the row's LAST panel (the group that holds tile r - 1) depends on the previous row, the others are
+    issued INSIDE the previous row - behind its dependent MFMA, behind its diagonal MFMA and in the wait states in front of
+    the three DPP reads (tools/ubench/mfma64_fill.hip: ONE independent FP64 MFMA between an MFMA and the reader of its result
+    leaves nothing to pad).  The rows that may be absent this step (4 r >= n_h) are left by scalar branches inside the
+    statement; the last row of a step has nothing to hide behind and takes the padded form."""
+    R0 = 4 * K - NKT
+    rows = list(range(0, min(R0 + 4, NTR)))
+    L = []
+    used = []
+
+    def areg(kind, x, y):
+        n = m.reg(kind, x, y)
+        used.append((n, member(x, y) if kind == "p" else f"P.gd[{x}]"))
+        return f"a[{n}:{n + 1}]"
+    VU = lambda g: SOLVE_VU + 2 * g
+    T, T2, W = SOLVE_T, SOLVE_T2, SOLVE_W
+    accs = lambda r: (SOLVE_X + 4 * (r & 1), SOLVE_X + 4 * (r & 1) + 2)
+    rn_op = lambda g: f"%{K + 1 + (g - m.gd[0])}"
+    nh_op = f"%{K + 1 + (K - m.gd[0] + 1)}"
+
+    def ra_list(r):
+        return [(accs(r)[i & 1], areg("p", r, g), VU(g), i < 2) for i, g in enumerate(m.groups[r][:-1])]
+
+    def emit_ra(item):
+        acc, a, b, fresh = item
+        L.append(f"{MF} {vp(acc)}, {a}, {vp(b)}, {'0' if fresh else vp(acc)} neg:[1,0,0]")
+
+    def rot(ctrl):
+        L.append(f"v_mov_b32_dpp v{T2}, v{T} {ctrl} row_mask:0xf bank_mask:0xf bound_ctrl:1")
+        L.append(f"v_mov_b32_dpp v{T2 + 1}, v{T + 1} {ctrl} row_mask:0xf bank_mask:0xf bound_ctrl:1")
+        L.append(f"v_add_f64 {vp(T)}, {vp(T)}, {vp(T2)}")
+
+    def row(r, nxt):
+        """nxt: the independent MFMAs of row r + 1 (None: the padded form)"""
+        u = u_of(r)
+        g, b = u >> 2, u & 3
+        c0, c1 = accs(r)
+        dep = m.groups[r][-1]
+        n_ind = len(m.groups[r]) - 1
+        dacc = accs(r)[n_ind & 1]                       # the accumulator the independent MFMAs did not write last
+        q = list(nxt) if nxt is not None else []
+
+        def slot(pad):
+            """an MFMA of the next row where a wait would stand (it counts as one state for a VALU -> DPP / MFMA read)"""
+            if len(q) > 1:                              # (the last one stays for behind the diagonal MFMA)
+                emit_ra(q.pop(0))
+                L.append("s_nop 0")
+            else:
+                L.append(f"s_nop {pad}")
+        L.append("s_nop 1")                             # the merge in front wrote Vu[dep]: VALU write -> MFMA read
+        L.append(f"{MF} {vp(dacc)}, {areg('p', r, dep)}, {vp(VU(dep))}, {vp(dacc)} neg:[1,0,0]")
+        if q:
+            emit_ra(q.pop(0))
+        else:
+            L.append("s_nop 5")
+        L.append(f"v_add_f64 {vp(T)}, {vp(c0)}, {vp(c1)}")
+        slot(1)
+        rot("row_ror:8")
+        slot(1)
+        rot("row_ror:4")
+        L.append(f"v_add_f64 {vp(T)}, {vp(T)}, {rn_op(g)}")
+        slot(1)
+        L.append(f"{MF} {vp(W)}, {areg('gd', g, 0)}, {vp(T)}, 0")
+        if q:
+            while q:
+                emit_ra(q.pop(0))
+                if q:
+                    L.append("s_nop 1")
+        else:
+            L.append("s_nop 5")
+        L.append(f"v_mov_b32_dpp v{VU(g)}, v{W} quad_perm:[0,1,2,3] row_mask:0xf bank_mask:0x{1 << b:x}")
+        L.append(f"v_mov_b32_dpp v{VU(g) + 1}, v{W + 1} quad_perm:[0,1,2,3] row_mask:0xf bank_mask:0x{1 << b:x}")
+
+    if R0 <= 0:
+        L.append(f"s_cmp_eq_u32 {nh_op}, 0")
+        L.append("s_cbranch_scc1 .Lone_end_%=")
+    L.append("s_nop 1")
+    first = ra_list(0)
+    for i, it in enumerate(first):
+        emit_ra(it)
+        if i + 1 < len(first):
+            L.append("s_nop 1")
+    lasts = []
+    for r in rows:
+        if r + 1 in rows:
+            if r + 1 >= R0:                             # row r + 1 may be absent this step
+                L.append(f"s_cmp_gt_u32 {nh_op}, {4 * (r + 1)}")
+                L.append(f"s_cbranch_scc0 .Lone_last{r}_%=")
+                lasts.append(r)
+            row(r, ra_list(r + 1))
+        else:
+            row(r, None)
+    L.append("s_branch .Lone_end_%=")
+    for r in lasts:
+        L.append(f".Lone_last{r}_%=:")
+        row(r, None)
+        L.append("s_branch .Lone_end_%=")
+    L.pop()                                             # the last of them falls through
+    L.append(".Lone_end_%=:")
+    seen, ins = set(), []
+    for n, mem in used:
+        if n not in seen:
+            seen.add(n)
+            ins.append(f'"{{a[{n}:{n + 1}]}}"({mem})')
+    outs = ", ".join(f'"+{{v[{VU(g)}:{VU(g) + 1}]}}"(Vu[{g}])' for g in range(K + 1))
+    rn = ", ".join(f'"v"(RN[{g}])' for g in range(m.gd[0], K + 1))
+    clob = ", ".join(f'"v{n}"' for n in SOLVE_CLOBBER) + ', "scc"'
+    body = "\n        ".join(f'"{x}\\n\\t"' for x in L[:-1]) + f'\n        "{L[-1]}"'
+    f.write(f"__device__ __forceinline__ void one_solve_{K}(OnePanels& P, double* Vu, const double* RN, int nh) {{\n")
+    f.write(f"    asm volatile({body}\n        : {outs}\n        : {rn}, \"s\"(nh),\n          {', '.join(ins)}\n        : {clob});\n}}\n")
 
 
 def set_stmt(items, mask="mask"):
@@ -186,6 +320,9 @@ def emit(f):
         f.write("}\n")
     disp("one_row", "void", "OnePanels& P, double& c0, double& c1, const double* Vu", "P, c0, c1, Vu", range(NTR))
     disp("one_set_row", "void", "OnePanels& P, unsigned long long mBase, unsigned long long mLast, const double* V", "P, mBase, mLast, V", range(NTR))
+    for K in m.gd:
+        solve_stmt(f, m, K, member)
+    disp("one_solve", "void", "OnePanels& P, double* Vu, const double* RN, int nh", "P, Vu, RN, nh", m.gd)
     disp("one_hset_row", "void", "unsigned long long mBase, unsigned long long mLast, const double* V", "mBase, mLast, V", range(NTR))
     disp("one_gdm", "double", "OnePanels& P, double acc", "P, acc", m.gd)
     disp("one_set_gd", "void", "OnePanels& P, unsigned long long mask, double v", "P, mask, v", m.gd)
