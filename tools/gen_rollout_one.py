@@ -25,6 +25,7 @@ OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 
 MF = "v_mfma_f64_4x4x4_4b_f64"
 
 
+VARIANT = set()   # schedule experiments of tools/ubench/one_solve_chain.hip (--variant a,b,...); the shipped file has none
 NKT = 9           # real-data column tiles (N_r = 36)
 NTR = 22          # tile rows of appended labels (3 (H - 1) <= 88)
 
@@ -147,7 +148,7 @@ def solve_stmt(f, m, K, member):
 
         def slot(pad):
             """an MFMA of the next row where a wait would stand (it counts as one state for a VALU -> DPP / MFMA read)"""
-            if len(q) > 1:                              # (the last one stays for behind the diagonal MFMA)
+            if len(q) > 1 and "noslots" not in VARIANT:  # (the last one stays for behind the diagonal MFMA)
                 emit_ra(q.pop(0))
                 L.append("s_nop 0")
             else:
@@ -159,17 +160,22 @@ def solve_stmt(f, m, K, member):
         else:
             L.append("s_nop 5")
         L.append(f"v_add_f64 {vp(T)}, {vp(c0)}, {vp(c1)}")
-        slot(1)
-        rot("row_ror:8")
-        slot(1)
-        rot("row_ror:4")
-        L.append(f"v_add_f64 {vp(T)}, {vp(T)}, {rn_op(g)}")
-        slot(1)
+        if "nosum" in VARIANT:                          # (timing floor only: wrong results)
+            L.append(f"v_add_f64 {vp(T)}, {vp(T)}, {rn_op(g)}")
+            slot(1)
+        else:
+            slot(1)
+            rot("row_ror:8")
+            slot(1)
+            rot("row_ror:4")
+            if "nornadd" not in VARIANT:
+                L.append(f"v_add_f64 {vp(T)}, {vp(T)}, {rn_op(g)}")
+            slot(1)
         L.append(f"{MF} {vp(W)}, {areg('gd', g, 0)}, {vp(T)}, 0")
         if q:
             while q:
                 emit_ra(q.pop(0))
-                if q:
+                if q and "nomfmanop" not in VARIANT:
                     L.append("s_nop 1")
         else:
             L.append("s_nop 5")
@@ -348,6 +354,10 @@ def generic(f):
 
 
 if __name__ == "__main__":
+    if "--variant" in sys.argv:
+        VARIANT = set(sys.argv[sys.argv.index("--variant") + 1].split(","))
+    if "--out" in sys.argv:
+        OUT = sys.argv[sys.argv.index("--out") + 1]
     with open(OUT, "w") as f:
         f.write("// GENERATED by tools/gen_rollout_one.py - do not edit.  Register-pinned panel operations of rollout_one.hip.\n")
         generic(f)
