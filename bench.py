@@ -363,6 +363,14 @@ def extra_closed_loop(sg, _lib, wl, name="params_car_residual", Ns=1024, H=40, i
                                   "step 1"), "iterations": out}
 
 
+def extra_car_joint_cfg3_size(sg, _lib, wl):
+    """SURVEY 8d cfg3's size (car, Ns = 4096, H = 40) in mode J: the joint draw at SQP iterations k = 0..3 of one MPC step on
+    ONE GPU (the closed loop of configs[4] with four times the per-GPU shard)."""
+    return extra_closed_loop(sg, _lib, wl, "params_car_residual", 4096, 40, 4, next_step=False,
+                             label="SURVEY 8d cfg3 size in mode J: params_car_residual as shipped, Ns=4096, H=40 on one GPU, "
+                                   "joint draw at SQP iterations k=0..3")
+
+
 def extra_pendulum_joint(sg, _lib, wl):
     """SURVEY 8d cfg2, mode J: params_pendulum1D_samples as shipped (jitter 1e-6: Cholesky root), Ns=1024, H=30, k=0 and k=1."""
     return extra_closed_loop(sg, _lib, wl, "params_pendulum1D_samples", 1024, 30, 2, next_step=False,
@@ -744,7 +752,8 @@ def main():
         if not multi and not a.no_extra:
             extra = []
             for fn, args in ((extra_car_rollout, (sg, _lib, RolloutRunner, wl)), (extra_closed_loop, (sg, _lib, wl)),
-                             (extra_pendulum_joint, (sg, _lib, wl)), (extra_pendulum_throughput, (sg, _lib, RolloutRunner, wl))):
+                             (extra_pendulum_joint, (sg, _lib, wl)), (extra_pendulum_throughput, (sg, _lib, RolloutRunner, wl)),
+                             (extra_car_joint_cfg3_size, (sg, _lib, wl))):
                 try:
                     extra.append(fn(*args))
                 except Exception as e:                            # noqa: BLE001 - never fatal for the bench line

@@ -142,6 +142,8 @@ class JointFactorCache:
         self.slots = None             # int32 device tensor: the slots whose rows are valid
         self.Xbuf = None              # (Ns, g_ny, rows, D) snapshot buffer of the points behind them, n_pts of it in use
         self.n_pts = 0
+        self.T = 1
+        self.lineage = None
         self.n_samples = 0            # samples whose chains are cached (== Ns unless the budget is too small for all)
         self.enabled = True
 
@@ -207,7 +209,11 @@ class JointFactorCache:
         """Forget the rows beyond the first ``n_slots`` (benchmarks: put the cache back into the state it had before a
         draw, so that repeated timed draws do the work of the first one)."""
         if self.slots is not None:
-            self.slots = self.slots[:max(0, min(int(n_slots), int(self.slots.numel())))]
+            n = max(0, min(int(n_slots), int(self.slots.numel())))
+            self.slots = self.slots[:n]
+            if self.lineage is not None:                           # rows vouched for by lineage: whole points only
+                self.n_pts = min(self.n_pts, n // self.T)
+                self.slots = self.slots[:self.n_pts * self.T]
 
     @property
     def n_valid(self) -> int:
@@ -225,6 +231,7 @@ class JointFactorCache:
         self.Xbuf[:, :, keep:mdl.n_h] = mdl.hall_X[:self.n_samples, :, keep:]
         self.n_pts = mdl.n_h
         self.slots = mdl.h_slots[:n_ho].clone()
+        self.T = int(mdl.hyper.T)
         lin = getattr(mdl, "lineage", None)
         # rows vouched for by lineage need every slot of every point observed (slot list == 0 .. T n_pts - 1)
         self.lineage = lin if (lin is not None and n_ho == mdl.n_h * mdl.hyper.T) else None

@@ -297,6 +297,23 @@ def test_joint_factor_cache_bookkeeping():
     assert c2.prepare(mk(20), Ns, 60)[2] == 30
     c2.commit(mk(20), 60, ok=True, n_cached=30)
     assert c2.n_valid == 60 and torch.equal(c2.X, X[:, :, :20])
+    # validity by the Agent's lineage counter (no tensor comparison): same generation + append-only growth; a rewind (the
+    # benchmarks' "forget this draw") keeps whole points and stays valid - bench.py's closed-loop legs depend on it
+    c3 = JointFactorCache()
+    def lm(n_pts, gen):
+        m = mk(n_pts)
+        m.lineage = (gen, n_pts)
+        return m
+    c3.prepare(lm(10, 7), Ns, 30)
+    c3.commit(lm(10, 7), 30, ok=True)
+    assert c3.prepare(lm(20, 7), Ns, 60)[2] == 30
+    c3.commit(lm(20, 7), 60, ok=True, n_cached=30)
+    assert c3.prepare(lm(30, 7), Ns, 90)[2] == 60
+    c3.rewind(30)
+    assert c3.n_valid == 30 and c3.prepare(lm(20, 7), Ns, 60)[2] == 30
+    c3.rewind(31)                                        # not a whole point: rounded down
+    assert c3.n_valid == 30
+    assert c3.prepare(lm(20, 8), Ns, 60)[2] == 0        # another generation of the hallucinated set
     c.enabled = False
     assert c.prepare(mk(20), Ns, 60) == (None, 0, 0)
 
