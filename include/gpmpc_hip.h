@@ -199,7 +199,10 @@ int    gpmpc_rollout(const gpmpc_gp_desc_t* gp, const gpmpc_env_desc_t* env, con
  *   limits: state_slots <= 256; without a state n_h0*T + hall_tasks*(n_v0 + H-1) <= 256 label slots per chain
  *   info bit GPMPC_INFO_STATE_FULL: a resumed state had no room left (label slots or points) for a new point: the point
  *         is not appended, the draw itself and X_traj / Y / Xi are still valid
- * Runs the generic kernel (csrc/rollout.hip); the tuned kernels serve gpmpc_rollout.
+ * Kernel: without a state, T = 3 and 3 (n_h0 + n_v0 + H - 1) <= 192 the call runs the tiled FP64-MFMA kernel
+ * (csrc/rollout_tiles.hip; shapes and sizes as for gpmpc_rollout: from 256 chains on, or pinned) - the seed points are
+ * conditioning-only passes of its step body, a value-only point (hall_tasks = 1) keeps three row slots of which the two
+ * derivative rows are dead.  Otherwise, and with a kept / resumed state, the generic kernel (csrc/rollout.hip).
  */
 size_t gpmpc_rollout_state_bytes(const gpmpc_gp_desc_t* gp, int64_t Ns, int32_t state_slots, int32_t state_points);
 /* workspace of a seeded call WITHOUT a state: the chains' factor covers n_h0*T + hall_tasks*(n_v0 + H-1) label slots and

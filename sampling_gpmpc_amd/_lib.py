@@ -30,6 +30,8 @@ INFO_EIGH_NOCONV = 0x0100
 INFO_STATE_FULL = 0x0200
 
 ROOT_AUTO, ROOT_EIGH, ROOT_CHOLESKY = 0, 1, 2
+# gpmpc_rollout_pin_kernel / gpmpc_rollout_last_kernel (include/gpmpc_hip.h)
+KERNEL_AUTO, KERNEL_GENERIC, KERNEL_FAST, KERNEL_INDEP, KERNEL_TILES, KERNEL_ONE = -1, 0, 1, 2, 3, 4
 
 
 class GpDesc(C.Structure):

@@ -547,7 +547,12 @@ size_t gpmpc_rollout_seeded_workspace_bytes(const gpmpc_gp_desc_t* gp, int32_t m
     if (mode != GPMPC_MODE_RECONDITIONED) return 256;
     RolloutPlan rp;
     if (plan_rollout(gp, GPMPC_MAX_NX, mode, hall_tasks, H, &rp, n_h0, n_v0) != GPMPC_OK) return 0;
-    const size_t seeded = align_up((size_t)Ns * gp->g_ny * rp.chain_doubles * sizeof(double), 256) + 2048;
+    size_t seeded = align_up((size_t)Ns * gp->g_ny * rp.chain_doubles * sizeof(double), 256) + 2048;
+    // the tiled kernel, should the call be routed there (three row slots per point, value-only points included)
+    if (gp->T == 3 && 3 * (n_h0 + n_v0 + H - 1) <= 192) {
+        const size_t tl = rollout_tiles_workspace_bytes(gp, Ns, H, n_h0 + n_v0) + 256;
+        seeded = tl > seeded ? tl : seeded;
+    }
     const size_t plain = gpmpc_rollout_workspace_bytes(gp, mode, hall_tasks, Ns, H);
     return seeded > plain ? seeded : plain;
 }
@@ -622,7 +627,11 @@ static int rollout_impl(const gpmpc_gp_desc_t* gp, const gpmpc_env_desc_t* env, 
         if (!ws || ws_bytes < need) return fail(GPMPC_E_WORKSPACE, "gpmpc_rollout: workspace too small");
     }
     hipStream_t st = (hipStream_t)stream;
-    const int kernel = seeded ? GPMPC_KERNEL_GENERIC : select_rollout_kernel(gp, env, mode, hall_tasks, H, Ns);
+    // seed points without a kept factor state are conditioning-only passes of the tiled kernel's step body; a kept / resumed
+    // state is the generic kernel's own factor layout
+    int kernel = GPMPC_KERNEL_GENERIC;
+    if (!seeded) kernel = select_rollout_kernel(gp, env, mode, hall_tasks, H, Ns);
+    else if (!state && rollout_tiles_eligible(gp, env, mode, hall_tasks, H, Ns, n_h0, n_v0)) kernel = GPMPC_KERNEL_TILES;
     g_last_rollout_path = kernel;
     if (kernel == GPMPC_KERNEL_ONE) return rollout_one_launch(gp, env, args, st);
     if (kernel == GPMPC_KERNEL_TILES) return rollout_tiles_launch(gp, env, args, ws, ws_bytes, st);

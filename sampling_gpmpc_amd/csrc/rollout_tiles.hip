@@ -249,7 +249,13 @@ __global__ __launch_bounds__(64, 1) void rollout_tiles_kernel(const RolloutArgs 
     const int lane = threadIdx.x;
     const int cv = lane >> 4, l = lane & 15;                      // VALU side: chain = DPP row, lane l of the row
     const int kq = lane >> 4, bm = (lane >> 2) & 3, jq = lane & 3;    // MFMA side: chain = quad bm; row (A: column) kq, column (A: row) jq
-    const int H = a.H, npt_cap = max(H - 1, 1);
+    // conditioning-only passes in front of step 0 (gpmpc_rollout_seeded): n_h0 seed points observed with all T tasks, then
+    // n_v0 observed like the rollout's own draws.  hall_tasks == 1 (value-only appended labels, reference src/agent.py:399-405):
+    // a value-only point KEEPS its three row slots, the two derivative rows are dead - identity rows of the factor with a
+    // zero right-hand side, which contribute nothing to any product - so that every index of the tile layout stays as it is
+    const int n_pre = a.n_h0 + a.n_v0;
+    const bool th1 = a.hall_tasks == 1;
+    const int H = a.H, npt_cap = max(n_pre + H - 1, 1);
     const long blk = blockIdx.x;
     // chain -> (sample, output)
     auto chain_sample = [&](int c) -> long { return (G_NY == 1) ? min(4 * blk + c, a.Ns - 1) : blk; };
@@ -360,7 +366,11 @@ __global__ __launch_bounds__(64, 1) void rollout_tiles_kernel(const RolloutArgs 
 
     TPH_DECL;
 #pragma unroll 1
-    for (int t = 0; t < H; ++t) {
+    for (int tt = -n_pre; tt < H; ++tt) {
+        const bool seeding = tt < 0;                              // uniform: condition on a given point, draw nothing
+        const int t = seeding ? 0 : tt;
+        const bool seed_full = seeding && (tt + n_pre) < a.n_h0;
+        const bool vo_new = th1 && !seed_full;                    // this pass's point is observed in its value only
         const int n_h = 3 * n_pts, i0 = n_h & 3, nt = (n_h + 3) >> 2, nfull = n_h >> 2;
         const int ycol = (i0 + 3) & 3;
         // ---- input, GP input ---------------------------------------------------------------------------------------
@@ -383,10 +393,17 @@ __global__ __launch_bounds__(64, 1) void rollout_tiles_kernel(const RolloutArgs 
             }
             xi[0] = x[(ENV == GPMPC_ENV_PENDULUM1D) ? 0 : (NX > 2 ? 2 : 0)];
             xi[1] = u[0];
+            if (seeding) {                                        // the given point of this chain
+                const int pt = tt + n_pre;
+                const double* xs = seed_full ? a.X_h0 + ((s * G_NY + o) * (long)a.n_h0 + pt) * D
+                                             : a.X_v0 + ((s * G_NY + o) * (long)a.n_v0 + (pt - a.n_h0)) * D;
+                xi[0] = xs[0];
+                xi[1] = xs[1];
+            }
             xiP[0].put(xi[0]);
             xiP[1].put(xi[1]);
             uP.put(u[NU - 1]);
-            if (l == 0 && live && o == 0) {
+            if (l == 0 && live && o == 0 && !seeding) {
 #pragma unroll
                 for (int d = 0; d < NX; ++d) a.X_traj[(s * NX + d) * (H + 1) + t] = x[d];
                 if (a.Xi) {
@@ -469,6 +486,7 @@ __global__ __launch_bounds__(64, 1) void rollout_tiles_kernel(const RolloutArgs 
                 const double xpt0 = xptP[q][0].get(), xpt1 = xptP[q][1].get();
                 const int jp = 16 * q + l;
                 const bool ex = jp < n_pts;
+                const bool exd = ex && !(th1 && jp >= a.n_h0);    // the point's derivative rows exist (not value-only)
                 const int jr = min(jp, npt_cap - 1);
                 // kernel entries against the test point: cov(task a of the point, task b of the test point)
                 const double d0 = xpt0 - xi[0], d1 = xpt1 - xi[1];
@@ -529,10 +547,11 @@ __global__ __launch_bounds__(64, 1) void rollout_tiles_kernel(const RolloutArgs 
 #pragma unroll
                 for (int aa = 0; aa < T; ++aa) {
                     double* dst = SCR + (3 * l + aa) * 4;
-                    dst[i0] = ex ? out[aa][0] : 0.0;
-                    dst[(i0 + 1) & 3] = ex ? out[aa][1] : 0.0;
-                    dst[(i0 + 2) & 3] = ex ? out[aa][2] : 0.0;
-                    dst[ycol] = ex ? yt[aa] : 0.0;
+                    const bool er = (aa == 0) ? ex : exd;
+                    dst[i0] = er ? out[aa][0] : 0.0;
+                    dst[(i0 + 1) & 3] = er ? out[aa][1] : 0.0;
+                    dst[(i0 + 2) & 3] = er ? out[aa][2] : 0.0;
+                    dst[ycol] = er ? yt[aa] : 0.0;
                 }
                 tiles_sync_lds();
                 static_for<0, 12>([&](auto wc) {                  // (rows of points that do not exist yet were written as zeros)
@@ -769,7 +788,13 @@ __global__ __launch_bounds__(64, 1) void rollout_tiles_kernel(const RolloutArgs 
                 for (int c = 0; c < T; ++c) Sn[b][c] = S[b][c] + ((b == c) ? gp.noise[b] : 0.0);
             bool r_ok;
             chol3_pair_fast(Sn, S, C, R, cinv, rinv, c_ok, r_ok);
-            if (!r_ok) info_acc |= root_small_fast_retry<T>(S, gp.jitter, R);
+            if (!r_ok && !seeding) info_acc |= root_small_fast_retry<T>(S, gp.jitter, R);
+            if (vo_new) {                                         // value-only label: the 1 x 1 factor, two identity rows
+                c_ok = Sn[0][0] > 0.0;
+                C[1][0] = C[2][0] = C[2][1] = 0.0;
+                C[1][1] = C[2][2] = 1.0;
+                cinv[1] = cinv[2] = 1.0;
+            }
         }
         double y[T];
 #pragma unroll
@@ -786,14 +811,21 @@ __global__ __launch_bounds__(64, 1) void rollout_tiles_kernel(const RolloutArgs 
             }
             y[b] = yb;
         }
-        if (l == 0 && live && a.Y) {
+        if (seeding) {                                            // the given labels of the seed point
+            const int pt = tt + n_pre;
+            const double* ys = seed_full ? a.Y_h0 + ((s * G_NY + o) * (long)a.n_h0 + pt) * T
+                                         : a.Y_v0 + ((s * G_NY + o) * (long)a.n_v0 + (pt - a.n_h0)) * T;
+#pragma unroll
+            for (int b = 0; b < T; ++b) y[b] = ys[b];
+        }
+        if (l == 0 && live && a.Y && !seeding) {
 #pragma unroll
             for (int b = 0; b < T; ++b) a.Y[((s * G_NY + o) * H + t) * T + b] = y[b];
         }
 
         TPH(4);
         // ---- phase H: append the point (A.9): three rows of the factor, the point's record, its label residuals -------------
-        if (t + 1 < H) {
+        if (seeding || t + 1 < H) {
             if (!c_ok) info_acc |= GPMPC_INFO_TRAIN_CHOL_FAIL;
             const int jn = n_pts, tn = n_h >> 2;
             // VALU side: the record, the residuals y - mu_real, the point itself, and the chain's scalars for the MFMA side
@@ -832,13 +864,15 @@ __global__ __launch_bounds__(64, 1) void rollout_tiles_kernel(const RolloutArgs 
                 const int ci = min(max(gi - base, 0), 2), ck = min(max(gk - base, 0), 2);
                 const double cval = SXm[64 + 3 * ci + ck];
                 double val = (gk <= gi) ? cval : 0.0;             // both new
-                val = (gk < base) ? vown : val;                   // new row, old column
+                const bool dead = vo_new && gi > base;            // (only read for rows base .. base + 2)
+                val = (gk < base) ? (dead ? 0.0 : vown) : val;    // new row, old column
                 val = (gi >= base + 3) ? ((gi == gk) ? 1.0 : 0.0) : val;   // rows that do not exist yet: identity
                 val = (gi < base) ? old : val;                    // old rows keep what they had
                 return val;
             };
             // which tile row does this lane's new row belong to (columns i0.. stay in tile tn, the wrapped ones open tn+1)
             const bool isnew = jq != ycol;                        // column jq carries the new row (n_h + c), c = (jq - i0) & 3 <= 2
+            const bool deadrow = vo_new && (((jq - i0) & 3) >= 1);     // a derivative row of a value-only point
             const int myrow = (jq >= i0) ? tn : tn + 1;
             const unsigned rowtile = (unsigned)tri(myrow);       // per-lane: the two target tile rows differ
             // off-diagonal tiles against complete old tile rows p < tn: -v
@@ -849,7 +883,7 @@ __global__ __launch_bounds__(64, 1) void rollout_tiles_kernel(const RolloutArgs 
                         if (p < tn) {
                             if (isnew) {
                                 const unsigned e = rowtile + p;
-                                tile_store(lane16 + (e >> 1) * 1024u + (e & 1u) * 8u, 0, -V[p]);
+                                tile_store(lane16 + (e >> 1) * 1024u + (e & 1u) * 8u, 0, deadrow ? 0.0 : -V[p]);
                             }
                             self(self, std::integral_constant<int, p + 1>{});
                         }
@@ -942,7 +976,7 @@ __global__ __launch_bounds__(64, 1) void rollout_tiles_kernel(const RolloutArgs 
 
         TPH(5);
         // ---- state hand-over ---------------------------------------------------------------------------------------------
-        {
+        if (!seeding) {
             double x[NX];
 #pragma unroll
             for (int d = 0; d < NX; ++d) x[d] = xP[d].get();
@@ -990,40 +1024,50 @@ static int tiles_mode() {                                        // 0 auto, 1 fo
     return (e[0] == '1') ? 1 : ((e[0] == '0') ? -1 : 0);
 }
 
-static int tiles_nt(int H) { const int n = 3 * (H - 1); return (n <= 128) ? 32 : ((n <= 160) ? 40 : ((n <= 192) ? 48 : 0)); }
-
-template <int N0, int N1>
-static size_t tiles_lds_bytes(int g_ny, int H) {
-    const int gl = (g_ny == 1) ? 4 : 3;
-    return (size_t)gl * TilesLds<N0, N1>::per_chain(H - 1 > 1 ? H - 1 : 1) * sizeof(double);
+// tile rows for H steps behind n_pre conditioning-only points (three row slots per point, value-only points included)
+static int tiles_nt(int H, int n_pre = 0) {
+    const int n = 3 * (n_pre + H - 1);
+    return (n <= 128) ? 32 : ((n <= 160) ? 40 : ((n <= 192) ? 48 : 0));
 }
 
-static size_t tiles_lds_for(const gpmpc_gp_desc_t* gp, const gpmpc_env_desc_t* env, int H) {       // 0: shape not instantiated
+template <int N0, int N1>
+static size_t tiles_lds_bytes(int g_ny, int H, int n_pre) {
+    const int gl = (g_ny == 1) ? 4 : 3;
+    return (size_t)gl * TilesLds<N0, N1>::per_chain(n_pre + H - 1 > 1 ? n_pre + H - 1 : 1) * sizeof(double);
+}
+
+static size_t tiles_lds_for(const gpmpc_gp_desc_t* gp, const gpmpc_env_desc_t* env, int H, int n_pre) {       // 0: shape not instantiated
     const int n0 = gp->grid_n0, n1 = gp->grid_n1;
     if (env->env_id == GPMPC_ENV_PENDULUM1D && gp->g_ny == 1 && n1 == 9) {
-        if (n0 == 4) return tiles_lds_bytes<4, 9>(1, H);
-        if (n0 == 5) return tiles_lds_bytes<5, 9>(1, H);
+        if (n0 == 4) return tiles_lds_bytes<4, 9>(1, H, n_pre);
+        if (n0 == 5) return tiles_lds_bytes<5, 9>(1, H, n_pre);
     }
     if (env->env_id == GPMPC_ENV_CAR_RESIDUAL && gp->g_ny == 3 && n1 == 9) {
-        if (n0 == 5) return tiles_lds_bytes<5, 9>(3, H);
-        if (n0 == 6) return tiles_lds_bytes<6, 9>(3, H);
+        if (n0 == 5) return tiles_lds_bytes<5, 9>(3, H, n_pre);
+        if (n0 == 6) return tiles_lds_bytes<6, 9>(3, H, n_pre);
     }
     return 0;
 }
 
-bool rollout_tiles_eligible(const gpmpc_gp_desc_t* gp, const gpmpc_env_desc_t* env, int mode, int hall_tasks, int H, int64_t Ns) {
+// n_h0 / n_v0 > 0: a seeded call (gpmpc_rollout_seeded without a kept factor state) - the seed points are conditioning-only
+// passes of the same step body; hall_tasks == 1 only there (the unseeded value-only rollout stays with the generic kernel's
+// one-row-per-point layout, three times fewer rows)
+bool rollout_tiles_eligible(const gpmpc_gp_desc_t* gp, const gpmpc_env_desc_t* env, int mode, int hall_tasks, int H, int64_t Ns,
+                            int n_h0, int n_v0) {
     const int md = tiles_mode();
+    const int n_pre = n_h0 + n_v0;
     if (md < 0) return false;
     const char* e = std::getenv("GPMPC_DISABLE_FAST_ROLLOUT");
     if (e && e[0] == '1') return false;
     const char* eg = std::getenv("GPMPC_DISABLE_GRID_ROOT");
     if (eg && eg[0] == '1') return false;
-    if (mode != GPMPC_MODE_RECONDITIONED || gp->T != 3 || gp->D != 2 || hall_tasks != 3 || gp->real_has_grad) return false;
+    if (mode != GPMPC_MODE_RECONDITIONED || gp->T != 3 || gp->D != 2 || gp->real_has_grad) return false;
+    if (!(hall_tasks == 3 || (hall_tasks == 1 && n_pre > 0))) return false;
     if (!plan_has_grid_root(gp->grid_n0, gp->grid_n1, gp->real_has_grad)) return false;
-    if (H < 2 || tiles_nt(H) == 0) return false;
-    if (tiles_nt(H) > 32 && !((env->env_id == GPMPC_ENV_PENDULUM1D && gp->grid_n0 == 4) || (env->env_id == GPMPC_ENV_CAR_RESIDUAL && gp->grid_n0 == 5)))
+    if ((H < 2 && n_pre == 0) || H < 1 || tiles_nt(H, n_pre) == 0) return false;
+    if (tiles_nt(H, n_pre) > 32 && !((env->env_id == GPMPC_ENV_PENDULUM1D && gp->grid_n0 == 4) || (env->env_id == GPMPC_ENV_CAR_RESIDUAL && gp->grid_n0 == 5)))
         return false;
-    const size_t lds = tiles_lds_for(gp, env, H);
+    const size_t lds = tiles_lds_for(gp, env, H, n_pre);
     if (lds == 0 || lds > 160 * 1024 - 64) return false;
     if (md > 0) return true;
     // A wave carries four chains and takes ~1.6-1.9x as long as a wave of the one-chain-per-wave kernel: the tuned kernel
@@ -1033,19 +1077,19 @@ bool rollout_tiles_eligible(const gpmpc_gp_desc_t* gp, const gpmpc_env_desc_t* e
     // 0.324, 768 0.639 vs 0.380).  Shapes the tuned kernel does not take (other grids, 3 (H - 1) > 128) fall to the generic
     // kernel, 4-20x slower: there the tiled kernel is taken from 256 chains on.
     const int64_t chains = Ns * gp->g_ny;
-    const bool tuned_alt = rollout_fast_eligible(gp, env, mode, hall_tasks, H);
+    const bool tuned_alt = n_pre == 0 && rollout_fast_eligible(gp, env, mode, hall_tasks, H);
     return tuned_alt ? (chains > (gp->g_ny == 1 ? 1024 : 768)) : (chains >= 256);
 }
 
-size_t rollout_tiles_workspace_bytes(const gpmpc_gp_desc_t* gp, int64_t Ns, int H) {
-    const int nt = tiles_nt(H) ? tiles_nt(H) : 32;
+size_t rollout_tiles_workspace_bytes(const gpmpc_gp_desc_t* gp, int64_t Ns, int H, int n_pre) {
+    const int nt = tiles_nt(H, n_pre) ? tiles_nt(H, n_pre) : 32;
     const int64_t waves = (gp->g_ny == 1) ? (Ns + 3) / 4 : Ns;
     return (size_t)waves * tri(nt) * 64 * sizeof(double);
 }
 
 template <int N0, int N1, int ENV, int NT>
 static int launch_tiles(RolloutArgs& args, int g_ny, hipStream_t st) {
-    const size_t lds = tiles_lds_bytes<N0, N1>(g_ny, args.H);
+    const size_t lds = tiles_lds_bytes<N0, N1>(g_ny, args.H, args.n_h0 + args.n_v0);
     const long nblk = (g_ny == 1) ? (args.Ns + 3) / 4 : args.Ns;
     auto k = rollout_tiles_kernel<N0, N1, ENV, NT>;
     GPMPC_HIP_CHECK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -1056,9 +1100,9 @@ static int launch_tiles(RolloutArgs& args, int g_ny, hipStream_t st) {
 
 int rollout_tiles_launch(const gpmpc_gp_desc_t* gp, const gpmpc_env_desc_t* env, RolloutArgs& args, void* ws, size_t ws_bytes,
                          hipStream_t st) {
-    if (!ws || ws_bytes < rollout_tiles_workspace_bytes(gp, args.Ns, args.H))
+    if (!ws || ws_bytes < rollout_tiles_workspace_bytes(gp, args.Ns, args.H, args.n_h0 + args.n_v0))
         return fail(GPMPC_E_WORKSPACE, "gpmpc_rollout: workspace too small");
-    const int nt = tiles_nt(args.H), n0 = gp->grid_n0;
+    const int nt = tiles_nt(args.H, args.n_h0 + args.n_v0), n0 = gp->grid_n0;
     args.ws = (double*)ws;
     args.ws_chain_stride = (long)tri(nt) * 64;                   // doubles per wave
     // the shipped grids with every tile-row count, the one-size-up grids with 32 tile rows

@@ -934,8 +934,19 @@ def test_forward_sampling_with_min_data_dist(sg, pname, min_dist):
     np.testing.assert_allclose(hy[~nan], hyo[~nano], rtol=1e-5, atol=1e-9)
 
 
-@pytest.mark.parametrize("fused", [True, False])
-def test_prepare_dynamics_set_against_oracle(sg, fused):
+@pytest.fixture
+def pin_tiles_if(sg):
+    """fused == "tiles": the fused launch pinned to the tiled kernel (the size heuristic takes it from 256 chains on)"""
+    lib = sg._lib.load()
+    def pin(fused):
+        if fused == "tiles":
+            lib.gpmpc_rollout_pin_kernel(sg._lib.KERNEL_TILES)
+    yield pin
+    lib.gpmpc_rollout_pin_kernel(-1)
+
+
+@pytest.mark.parametrize("fused", [True, False, "tiles"])
+def test_prepare_dynamics_set_against_oracle(sg, fused, pin_tiles_if):
     """Forward sampling with rejection (reference src/agent.py:331-443): the GP is re-trained on real + forward-sampled
     (value-only labels) + hallucinated data at every step, samples leaving the tube are rejected and their
     hallucinated data replaced by survivors'.  Same base samples and the same RandomState on both sides.
@@ -967,7 +978,11 @@ def test_prepare_dynamics_set_against_oracle(sg, fused):
     for ag in (agent, oagent):
         ag.ci_list = [1e9] * (H + 1)
     # step 1: everything survives (huge tube); now tighten the tube of step 2 around the median sampled state
+    pin_tiles_if(fused)
+    tiles, fused = fused == "tiles", bool(fused)
     agent.prepare_dynamics_set(X_soln.clone(), U_soln, X_kp1, base_samples=z, rng=np.random.RandomState(5), fused=fused)
+    if tiles:
+        assert sg._lib.load().gpmpc_debug_last_rollout_path() == 3, "the fused launch did not run the tiled kernel"
     oagent.prepare_dynamics_set(X_soln.clone(), U_soln, X_kp1, base_samples=z, rng=np.random.RandomState(5))
     np.testing.assert_allclose(agent.FS_X_train_batch.cpu().numpy(), oagent.FS_X_train_batch.numpy(), rtol=1e-8, atol=1e-10)
     fy, fyo = agent.FS_Y_train_batch.cpu().numpy(), oagent.FS_Y_train_batch.numpy()
@@ -989,6 +1004,8 @@ def test_prepare_dynamics_set_against_oracle(sg, fused):
         ag.train_hallucinated_dynGP(1)
     hx_before = oagent.Hallcinated_X_train.clone()
     agent.prepare_dynamics_set(X_soln2.clone(), U_soln, X_kp1, base_samples=z, rng=np.random.RandomState(7), fused=fused)
+    if tiles:
+        assert sg._lib.load().gpmpc_debug_last_rollout_path() == 3
     oagent.prepare_dynamics_set(X_soln2.clone(), U_soln, X_kp1, base_samples=z, rng=np.random.RandomState(7))
     left = oagent.rejection_trace[-1].numpy()
     assert 0 < left.sum() < Ns, f"the tube should split the samples, survivors: {left}"
@@ -1066,6 +1083,88 @@ def test_second_fused_rollout_conditions_on_existing_points(sg):
     assert agent.Hallcinated_X_train.shape[2] == 12
 
 
+@pytest.mark.parametrize("pname", ["params_pendulum1D_samples", "params_car_residual_fs"])
+def test_seeded_rollout_on_the_tiled_kernel(sg, pname):
+    """a seeded call (no kept factor state) runs the tiled FP64-MFMA kernel - the seed points are
+    conditioning-only passes of its step body.  Second and third rollout on the same Agent (reference
+    simulate_forward_sampling_car.py:118: train_hallucinated_dynGP(1) never resets) against the oracle and against the generic
+    kernel, path asserted; the un-pinned dispatcher takes the tiled kernel from 256 chains on."""
+    from sampling_gpmpc_amd.rollout import forward_sampling_rollout
+    lib = sg._lib.load()
+    H = 7
+    p = fs_params(pname, 6, H, nograd=False, beta=(3.0 if "car" in pname else None))
+    u_ff = synthetic_u_ff(2 if "car" in pname else 1, H)
+    X = {}
+    for kern in (sg._lib.KERNEL_TILES, sg._lib.KERNEL_GENERIC):
+        agent, oagent = make_agents(sg, p)
+        try:
+            lib.gpmpc_rollout_pin_kernel(kern)
+            runs = []
+            for rep in range(3):                                  # 0, 7 and 14 seed points (21 rows per rollout)
+                runs.append(forward_sampling_rollout(agent, u_ff))
+                assert lib.gpmpc_debug_last_rollout_path() == (3 if kern == sg._lib.KERNEL_TILES else 0), (kern, rep)
+        finally:
+            lib.gpmpc_rollout_pin_kernel(-1)
+        X[kern] = runs
+        if kern == sg._lib.KERNEL_TILES:
+            for rep in range(3):
+                Xo = ao.forward_sampling_rollout(oagent, u_ff)
+                print(f"{pname} tiled kernel, rollout {rep} on the same agent ({7 * rep} seed points): rel err {relerr(runs[rep], Xo):.2e}")
+                assert relerr(runs[rep], Xo) < RTOL_TRAJ
+            assert agent.Hallcinated_X_train.shape[2] == 3 * H
+    for rep in range(3):
+        assert relerr(X[sg._lib.KERNEL_TILES][rep], X[sg._lib.KERNEL_GENERIC][rep]) < 1e-9
+    # the dispatcher by itself: 256 chains and more take the tiled kernel for a seeded call
+    plan = agent._plan(use_grad=True)
+    Ns_big = 256 if "pendulum" in pname else 96
+    pb = fs_params(pname, Ns_big, 5, nograd=False, beta=(3.0 if "car" in pname else None))
+    big, _ = make_agents(sg, pb)
+    ub = synthetic_u_ff(2 if "car" in pname else 1, 5)
+    forward_sampling_rollout(big, ub)
+    X2 = forward_sampling_rollout(big, ub)
+    assert lib.gpmpc_debug_last_rollout_path() == 3 and np.isfinite(X2).all()
+
+
+def test_value_only_seeded_rollout_on_the_tiled_kernel(sg):
+    """hall_tasks = 1 behind seed points (the fused prepare_dynamics_set's launch, reference src/agent.py:399-405): the tiled
+    kernel keeps three row slots per point and leaves the derivative rows of a value-only point dead (identity rows, zero
+    right-hand sides).  Same call on the generic kernel (one row per value-only point) must agree to round-off."""
+    from sampling_gpmpc_amd.rollout import rollout_device
+    from sampling_gpmpc_amd import _lib
+    lib = _lib.load()
+    Ns, H = 9, 6
+    p = fs_params("params_pendulum1D_samples", Ns, H, nograd=False)
+    agent, _ = make_agents(sg, p)
+    dev = agent.torch_device
+    g = torch.Generator().manual_seed(3)
+    n0, nv = 5, 2
+    Xs = (torch.tensor([0.3, 0.1], dtype=F64) + 0.4 * torch.randn(Ns, 1, n0, 2, generator=g, dtype=F64)).to(dev)
+    Ys = (0.2 * torch.randn(Ns, 1, n0, 3, generator=g, dtype=F64)).to(dev)
+    Xv = (torch.tensor([0.2, -0.1], dtype=F64) + 0.4 * torch.randn(Ns, 1, nv, 2, generator=g, dtype=F64)).to(dev)
+    Yv = (0.2 * torch.randn(Ns, 1, nv, 3, generator=g, dtype=F64)).to(dev)
+    z = torch.randn(H, Ns * 3, generator=g, dtype=F64).clamp(-2, 2).to(dev)
+    u_ff = synthetic_u_ff(1, H)
+    out = {}
+    for kern in (_lib.KERNEL_TILES, _lib.KERNEL_GENERIC):
+        try:
+            lib.gpmpc_rollout_pin_kernel(kern)
+            for ht, vs in ((1, (Xv, Yv)), (3, (Xv, Yv)), (1, None)):
+                res = rollout_device(agent, u_ff, z.reshape(-1), z.shape[1], H=H, mode=_lib.MODE_RECONDITIONED,
+                                     use_model_without_derivatives=False, hall_tasks=ht, seeds=(Xs, Ys), value_seeds=vs)
+                assert lib.gpmpc_debug_last_rollout_path() == (3 if kern == _lib.KERNEL_TILES else 0)
+                assert int(res.info.max().item()) & ~_lib.INFO_VAR_CLAMPED == 0
+                out[(kern, ht, vs is None)] = (res.X_traj.cpu().numpy(), res.Y.cpu().numpy())
+        finally:
+            lib.gpmpc_rollout_pin_kernel(-1)
+    for key in [(1, False), (3, False), (1, True)]:
+        Xt, Yt = out[(_lib.KERNEL_TILES,) + key]
+        Xg, Yg = out[(_lib.KERNEL_GENERIC,) + key]
+        print(f"hall_tasks={key[0]} value seeds={not key[1]}: tiled vs generic rel err X {relerr(Xt, Xg):.2e}, Y {relerr(Yt, Yg):.2e}")
+        assert relerr(Xt, Xg) < 1e-9 and relerr(Yt, Yg) < 1e-7
+    # value-only conditioning differs from conditioning on all tasks
+    assert relerr(out[(_lib.KERNEL_TILES, 1, False)][0], out[(_lib.KERNEL_TILES, 3, False)][0]) > 1e-6
+
+
 def test_seeded_rollout_with_more_than_200_seed_slots(sg):
     """a seeded rollout's factor covers the seed slots too (here 70 points x 3 tasks = 210 + 3 x 11 appended:
     far beyond what stays in LDS), so its workspace comes from gpmpc_rollout_seeded_workspace_bytes - the un-seeded query
@@ -1128,8 +1227,8 @@ def test_rollout_factor_state_export_and_resume(sg, pname):
     assert int(r3.info.max().item()) & sg._lib.INFO_STATE_FULL and torch.isfinite(r3.X_traj).all()
 
 
-@pytest.mark.parametrize("fused", [True, False])
-def test_prepare_dynamics_set_against_reference_run(sg, fused):
+@pytest.mark.parametrize("fused", [True, False, "tiles"])
+def test_prepare_dynamics_set_against_reference_run(sg, fused, pin_tiles_if):
     """The HIP Agent against the reference's REAL ``Agent.prepare_dynamics_set`` (src/agent.py:331-443; golden captured by
     make_goldens.py under the gpytorch stub): forward-sampled points, value-only labels, the rejection trace (survivor
     counts), survivor replacement of the hallucinated tensors, for a tube nobody leaves and one that splits the samples."""
@@ -1137,7 +1236,10 @@ def test_prepare_dynamics_set_against_reference_run(sg, fused):
     d = np.load(os.path.join(GOLDEN, "agent_e2e_prepare_dynamics_set_pendulum1D.npz"))
     p = _pds_params(d)
     agent, _ = make_agents(sg, p, erv=d["epistimic_random_vector"])
-    replay_prepare_dynamics_set(agent, d, to_dev=lambda t: t.to(agent.torch_device), joint_draw_exact=False, fused=fused)
+    pin_tiles_if(fused)
+    replay_prepare_dynamics_set(agent, d, to_dev=lambda t: t.to(agent.torch_device), joint_draw_exact=False, fused=bool(fused))
+    if fused == "tiles":
+        assert sg._lib.load().gpmpc_debug_last_rollout_path() == 3, "the fused launch did not run the tiled kernel"
 
 
 def test_pinned_sample_branches_against_reference_run(sg):
