@@ -85,10 +85,13 @@ typedef double double2_e __attribute__((ext_vector_type(2)));
 typedef __attribute__((address_space(3))) double lds_double;
 
 __host__ __device__ inline long eigh_packed(int np) { return (long)np * (np + 1) / 2; }
+// LDS form (round 4): rows 2 I and 2 I + 1 both start at column 2 I - every row starts on an even slot and the two columns of
+// a pair are one aligned 16-byte access (np even: np (np + 2) / 2 slots, np / 2 more than the packed triangle)
+__host__ __device__ inline long eigh_padded(int np) { return (long)np * (np + 2) / 2; }
 // dynamic LDS of one chain (doubles) for an n x n covariance with the Gram matrix of ranks <= cap in LDS
 __host__ __device__ inline long eigh_lds_doubles(int n, int cap) {
     const long np = (n + 1) & ~1;
-    return eigh_packed(cap) + 2 + 2 * (np / 2 + 2) + (n > 256 ? n : 256) + np + (np + 3) / 4 + 2;
+    return eigh_padded(cap) + 2 + 2 * (np / 2 + 2) + (n > 256 ? n : 256) + np + (np + 3) / 4 + 2;
 }
 __host__ __device__ inline long eigh_slot_doubles(int n) {
     const long np = (n + 1) & ~1;
@@ -100,6 +103,19 @@ __device__ __forceinline__ int tri_idx(int a, int b, int rp) { return a * rp - (
 __device__ __forceinline__ int sym_idx(int a, int b, int rp) { return a <= b ? tri_idx(a, b, rp) : tri_idx(b, a, rp); }
 // where the index at position a sits in the next round (round-robin: position 0 fixed, the others shift by one)
 __device__ __forceinline__ int rr_shift(int a, int rp) { return a == 0 ? 0 : (a == rp - 1 ? 1 : a + 1); }
+// The LDS path keeps the pairs of a round on ADJACENT positions (2 i, 2 i + 1): the tournament table with its top row on the
+// even and its bottom row on the odd positions - top[0] fixed, bottom[0] -> top[1], the top row moves right, top[h-1] ->
+// bottom[h-1], the bottom row moves left: one cycle over the other rp - 1 positions, back after rp - 1 rounds.
+__device__ __forceinline__ int adj_shift(int a, int rp) {
+    if (a == 0 || rp == 2) return a;
+    if (a & 1) return (a == 1) ? 2 : a - 2;
+    return (a == rp - 2) ? rp - 1 : a + 2;
+}
+__device__ __forceinline__ int adj_idx(int a, int b, int rp) {     // a <= b
+    const int I = a >> 1;
+    return 2 * I * (rp - I + 1) + (a & 1) * (rp - 2 * I) + (b - 2 * I);
+}
+__device__ __forceinline__ int adj_sym(int a, int b, int rp) { return a <= b ? adj_idx(a, b, rp) : adj_idx(b, a, rp); }
 
 // block b of the folded enumeration of the h (h + 1) / 2 blocks I <= K; false for the padding slots of odd h
 __device__ __forceinline__ bool rr_block(int b, int h, int& I, int& K) {
@@ -157,7 +173,7 @@ __device__ __forceinline__ void rot_block(double cI, double sI, double cK, doubl
 }
 
 // ---- B. G = L^T L (packed upper triangle), FP64 MFMA: A[i][k] = L[k0+k][I*16+i], B[k][j] = L[k0+k][J*16+j] -----------
-template <class GP>
+template <bool ADJ, class GP>
 __device__ __forceinline__ void eigh_gram(const double* __restrict__ Lm, int n, int r, int rp, GP G) {
     const int lane = threadIdx.x & 63;
     const int ntile = (rp + 15) / 16;
@@ -183,7 +199,7 @@ __device__ __forceinline__ void eigh_gram(const double* __restrict__ Lm, int n, 
 #pragma unroll
             for (int v = 0; v < 4; ++v) {                        // D: col = lane & 15, row = (lane >> 4) + 4 v
                 const int ra = I * 16 + kr + 4 * v, cc = J * 16 + (lane & 15);
-                if (ra <= cc && cc < rp) G[tri_idx(ra, cc, rp)] = acc[v];
+                if (ra <= cc && cc < rp) G[ADJ ? adj_idx(ra, cc, rp) : tri_idx(ra, cc, rp)] = acc[v];
             }
         }
     }
@@ -213,9 +229,10 @@ __device__ __forceinline__ long eigh_jacobi_lds(lds_double* G, int rp, double* _
                                                 bool& conv, int& sweeps) {
     const int lane = threadIdx.x & 63;
     const int h = rp / 2, nslots = (h / 2) * h;                  // ceil((h - 1) / 2) * h
-    const int pad = (int)eigh_packed(rp);
-    // this lane's blocks: packed slots read (ri) and written (wi: the slots of the shifted positions)
-    int ri[MAXIT][4], wi[MAXIT][4], bI[MAXIT], bK[MAXIT];
+    const int pad = (int)eigh_padded(rp);                        // (even: a dummy block's 16-byte reads are aligned)
+    // this lane's blocks: the slots of its two row halves (ri: columns 2 K, 2 K + 1 of rows 2 I and 2 I + 1 - one 16-byte read
+    // each) and the four slots written (wi: the slots of the shifted positions)
+    int ri[MAXIT][2], wi[MAXIT][4], bI[MAXIT], bK[MAXIT];
 #pragma unroll
     for (int it = 0; it < MAXIT; ++it) {
         const int b = lane + 64 * it;
@@ -223,25 +240,24 @@ __device__ __forceinline__ long eigh_jacobi_lds(lds_double* G, int rp, double* _
         const bool ok = (b < nslots) && rr_block_off(b, h, I, K);
         bI[it] = ok ? I : h;
         bK[it] = ok ? K : h;
-        const int pI = I, qI = rp - 1 - I, pK = K, qK = rp - 1 - K;
-        const int sp = rr_shift(pI, rp), sq = rr_shift(qI, rp), tp = rr_shift(pK, rp), tq = rr_shift(qK, rp);
-        ri[it][0] = ok ? sym_idx(pI, pK, rp) : pad;
-        ri[it][1] = ok ? sym_idx(pI, qK, rp) : pad;
-        ri[it][2] = ok ? sym_idx(qI, pK, rp) : pad;
-        ri[it][3] = ok ? sym_idx(qI, qK, rp) : pad;
-        wi[it][0] = ok ? sym_idx(sp, tp, rp) : pad;
-        wi[it][1] = ok ? sym_idx(sp, tq, rp) : pad;
-        wi[it][2] = ok ? sym_idx(sq, tp, rp) : pad;
-        wi[it][3] = ok ? sym_idx(sq, tq, rp) : pad;
+        const int pI = 2 * I, qI = 2 * I + 1, pK = 2 * K, qK = 2 * K + 1;
+        const int sp = adj_shift(pI, rp), sq = adj_shift(qI, rp), tp = adj_shift(pK, rp), tq = adj_shift(qK, rp);
+        ri[it][0] = ok ? adj_idx(pI, pK, rp) : pad;
+        ri[it][1] = ok ? adj_idx(qI, pK, rp) : pad;
+        wi[it][0] = ok ? adj_sym(sp, tp, rp) : pad;
+        wi[it][1] = ok ? adj_sym(sp, tq, rp) : pad;
+        wi[it][2] = ok ? adj_sym(sq, tp, rp) : pad;
+        wi[it][3] = ok ? adj_sym(sq, tq, rp) : pad;
     }
     const bool own = lane < h;
-    const int p1 = own ? lane : 0, q1 = rp - 1 - p1;             // this lane's pair
-    const int dpp_ = tri_idx(p1, p1, rp), dpq_ = tri_idx(p1, q1, rp), dqq_ = tri_idx(q1, q1, rp);
-    const int sp1 = rr_shift(p1, rp), sq1 = rr_shift(q1, rp);
-    const int wpp_ = own ? sym_idx(sp1, sp1, rp) : pad, wpq_ = own ? sym_idx(sp1, sq1, rp) : pad;
-    const int wqq_ = own ? sym_idx(sq1, sq1, rp) : pad;
+    const int p1 = own ? 2 * lane : 0, q1 = p1 + 1;              // this lane's pair
+    const int dpp_ = adj_idx(p1, p1, rp), dqq_ = adj_idx(q1, q1, rp);       // (g_pq sits right behind g_pp)
+    const int sp1 = adj_shift(p1, rp), sq1 = adj_shift(q1, rp);
+    const int wpp_ = own ? adj_sym(sp1, sp1, rp) : pad, wpq_ = own ? adj_sym(sp1, sq1, rp) : pad;
+    const int wqq_ = own ? adj_sym(sq1, sq1, rp) : pad;
     if (lane == 0) {
         G[pad] = 0.0;
+        G[pad + 1] = 0.0;
         e_cs[h][0] = 1.0;
         e_cs[h][1] = 0.0;
     }
@@ -255,12 +271,15 @@ __device__ __forceinline__ long eigh_jacobi_lds(lds_double* G, int rp, double* _
         for (int rho = 0; rho < nround; ++rho, ++g) {
             // every read of the round precedes every write (a block's write slot is another block's read slot); one
             // wave, LDS operations complete in order: no barrier.  The block reads are in flight under the rotation.
-            const double gpp = G[dpp_], gqq = G[dqq_], gpq = G[dpq_];
+            const double2_e gd = *reinterpret_cast<const __attribute__((address_space(3))) double2_e*>(G + dpp_);
+            const double gpp = gd.x, gpq = gd.y, gqq = G[dqq_];
             double b[MAXIT][4];
 #pragma unroll
-            for (int it = 0; it < MAXIT; ++it)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) b[it][e] = G[ri[it][e]];
+            for (int it = 0; it < MAXIT; ++it) {
+                const double2_e r0 = *reinterpret_cast<const __attribute__((address_space(3))) double2_e*>(G + ri[it][0]);
+                const double2_e r1 = *reinterpret_cast<const __attribute__((address_space(3))) double2_e*>(G + ri[it][1]);
+                b[it][0] = r0.x, b[it][1] = r0.y, b[it][2] = r1.x, b[it][3] = r1.y;
+            }
             double t, c, s;
             const bool rot = jacobi_rot(gpp, gqq, gpq, thr, t, c, s) && own;
             rot_any |= rot;
@@ -346,13 +365,17 @@ __device__ __forceinline__ long eigh_jacobi_global(double*& Gc, double*& Gn, int
 }
 
 // v <- Q_1 ... Q_K v: the logged rounds in reverse (Q_g = J_g Pi: un-shift the positions, then rotate the pairs)
+template <bool ADJ>
 __device__ __forceinline__ void eigh_replay(double* e_vec, const double* __restrict__ rlog, long gtot, int rp) {
     const int lane = threadIdx.x & 63;
     const int h = rp / 2;
     const int i0 = lane, i1 = lane + 64;                         // h <= 128: at most two pairs per lane
     const bool v0 = i0 < h, v1 = i1 < h;
-    const int a0 = v0 ? rr_shift(i0, rp) : 0, b0 = v0 ? rr_shift(rp - 1 - i0, rp) : 0;
-    const int a1 = v1 ? rr_shift(i1, rp) : 0, b1 = v1 ? rr_shift(rp - 1 - i1, rp) : 0;
+    // positions of the pairs (p, q) and where their indices sit one round later
+    const int p0 = ADJ ? 2 * i0 : i0, q0 = ADJ ? 2 * i0 + 1 : rp - 1 - i0;
+    const int p1 = ADJ ? 2 * i1 : i1, q1 = ADJ ? 2 * i1 + 1 : rp - 1 - i1;
+    const int a0 = v0 ? (ADJ ? adj_shift(p0, rp) : rr_shift(p0, rp)) : 0, b0 = v0 ? (ADJ ? adj_shift(q0, rp) : rr_shift(q0, rp)) : 0;
+    const int a1 = v1 ? (ADJ ? adj_shift(p1, rp) : rr_shift(p1, rp)) : 0, b1 = v1 ? (ADJ ? adj_shift(q1, rp) : rr_shift(q1, rp)) : 0;
     for (long g1 = gtot; g1 > 0; g1 -= 8) {
         double tq0[8], tq1[8];
 #pragma unroll
@@ -369,13 +392,13 @@ __device__ __forceinline__ void eigh_replay(double* e_vec, const double* __restr
                 if (v1) up1 = e_vec[a1], uq1 = e_vec[b1];
                 if (v0) {
                     const double c = rsqrt_fast(fma(tq0[u], tq0[u], 1.0)), s = tq0[u] * c;
-                    e_vec[i0] = c * up0 + s * uq0;
-                    e_vec[rp - 1 - i0] = c * uq0 - s * up0;
+                    e_vec[p0] = c * up0 + s * uq0;
+                    e_vec[q0] = c * uq0 - s * up0;
                 }
                 if (v1) {
                     const double c = rsqrt_fast(fma(tq1[u], tq1[u], 1.0)), s = tq1[u] * c;
-                    e_vec[i1] = c * up1 + s * uq1;
-                    e_vec[rp - 1 - i1] = c * uq1 - s * up1;
+                    e_vec[p1] = c * up1 + s * uq1;
+                    e_vec[q1] = c * uq1 - s * up1;
                 }
             }
         }
@@ -391,8 +414,8 @@ __global__ __launch_bounds__(64, GPMPC_EIGH_WPE) void joint_eigh_kernel(const Ei
     const GpParams& gp = a.gp;
     const int lane = threadIdx.x;
     const int n = a.m * T;
-    double (*e_cs)[2] = reinterpret_cast<double (*)[2]>(e_dyn + eigh_packed(a.lds_cap) + 2);
-    double* e_y = e_dyn + eigh_packed(a.lds_cap) + 2 + 2 * (((n + 1) & ~1) / 2 + 2);
+    double (*e_cs)[2] = reinterpret_cast<double (*)[2]>(e_dyn + eigh_padded(a.lds_cap) + 2);
+    double* e_y = e_dyn + eigh_padded(a.lds_cap) + 2 + 2 * (((n + 1) & ~1) / 2 + 2);
     double* e_vec = e_y + (n > 256 ? n : 256);
     short* e_rank = reinterpret_cast<short*>(e_vec + ((n + 1) & ~1));
     const long nchains = a.Ns * gp.g_ny;
@@ -600,17 +623,17 @@ __global__ __launch_bounds__(64, GPMPC_EIGH_WPE) void joint_eigh_kernel(const Ei
             int sweeps;
             if (rp <= a.lds_cap) {
                 lds_double* G = (lds_double*)e_dyn;
-                eigh_gram(Lm, n, r, rp, G);
+                eigh_gram<true>(Lm, n, r, rp, G);
                 EPH(1);
                 const int h = rp / 2, nsl = (h / 2) * h;
                 if (nsl <= 128) gtot = eigh_jacobi_lds<2>(G, rp, rlog, e_cs, conv, sweeps);
                 else if (nsl <= 256) gtot = eigh_jacobi_lds<4>(G, rp, rlog, e_cs, conv, sweeps);
                 else if (nsl <= 384) gtot = eigh_jacobi_lds<6>(G, rp, rlog, e_cs, conv, sweeps);
                 else gtot = eigh_jacobi_lds<EIGH_MAXIT>(G, rp, rlog, e_cs, conv, sweeps);
-                for (int i = lane; i < r; i += 64) e_y[i] = G[tri_idx(i, i, rp)];
+                for (int i = lane; i < r; i += 64) e_y[i] = G[adj_idx(i, i, rp)];
             } else {
                 double *Gc = Gg0, *Gn = Gg1;
-                eigh_gram(Lm, n, r, rp, Gc);
+                eigh_gram<false>(Lm, n, r, rp, Gc);
                 __syncthreads();
                 EPH(1);
                 gtot = eigh_jacobi_global(Gc, Gn, rp, rlog, e_cs, conv, sweeps);
@@ -645,7 +668,8 @@ __global__ __launch_bounds__(64, GPMPC_EIGH_WPE) void joint_eigh_kernel(const Ei
                 e_vec[i] = zt;
             }
             __syncthreads();
-            eigh_replay(e_vec, rlog, gtot, rp);
+            if (rp <= a.lds_cap) eigh_replay<true>(e_vec, rlog, gtot, rp);
+            else eigh_replay<false>(e_vec, rlog, gtot, rp);
             __syncthreads();
         }
         EPH(3);
@@ -699,7 +723,8 @@ __global__ __launch_bounds__(64, GPMPC_EIGH_WPE) void joint_eigh_kernel(const Ei
                 __syncthreads();
                 for (int i = lane; i < rp; i += 64) e_vec[i] = (i == j) ? 1.0 : 0.0;
                 __syncthreads();
-                eigh_replay(e_vec, rlog, gtot, rp);
+                if (rp <= a.lds_cap) eigh_replay<true>(e_vec, rlog, gtot, rp);
+                else eigh_replay<false>(e_vec, rlog, gtot, rp);
                 __syncthreads();
                 const int col = n - r + e_rank[j];
                 for (int t = lane; t < n; t += 64) {

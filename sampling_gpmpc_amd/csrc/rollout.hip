@@ -534,7 +534,7 @@ size_t gpmpc_rollout_workspace_bytes(const gpmpc_gp_desc_t* gp, int32_t mode, in
     size_t need = align_up((size_t)Ns * gp->g_ny * rp.chain_doubles * sizeof(double), 256) + 2048;   // >= the tuned path's need (its zero page included)
     // the tiled throughput kernel keeps the whole tile matrix of a wave's four chains in the workspace (whichever env /
     // size it ends up serving: the query does not know the env, so the larger of the two layouts is reported)
-    if (gp->T == 3 && hall_tasks == 3 && 3 * (H - 1) <= 192 && H >= 2) {
+    if (gp->T == 3 && (hall_tasks == 3 || hall_tasks == 1) && 3 * (H - 1) <= 192 && H >= 2) {
         const size_t tl = rollout_tiles_workspace_bytes(gp, Ns, H) + 256;
         need = tl > need ? tl : need;
     }

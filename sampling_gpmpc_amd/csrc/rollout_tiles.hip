@@ -1050,8 +1050,7 @@ static size_t tiles_lds_for(const gpmpc_gp_desc_t* gp, const gpmpc_env_desc_t* e
 }
 
 // n_h0 / n_v0 > 0: a seeded call (gpmpc_rollout_seeded without a kept factor state) - the seed points are conditioning-only
-// passes of the same step body; hall_tasks == 1 only there (the unseeded value-only rollout stays with the generic kernel's
-// one-row-per-point layout, three times fewer rows)
+// passes of the same step body; hall_tasks == 1: value-only points keep three row slots (see the kernel)
 bool rollout_tiles_eligible(const gpmpc_gp_desc_t* gp, const gpmpc_env_desc_t* env, int mode, int hall_tasks, int H, int64_t Ns,
                             int n_h0, int n_v0) {
     const int md = tiles_mode();
@@ -1062,7 +1061,7 @@ bool rollout_tiles_eligible(const gpmpc_gp_desc_t* gp, const gpmpc_env_desc_t* e
     const char* eg = std::getenv("GPMPC_DISABLE_GRID_ROOT");
     if (eg && eg[0] == '1') return false;
     if (mode != GPMPC_MODE_RECONDITIONED || gp->T != 3 || gp->D != 2 || gp->real_has_grad) return false;
-    if (!(hall_tasks == 3 || (hall_tasks == 1 && n_pre > 0))) return false;
+    if (!(hall_tasks == 3 || hall_tasks == 1)) return false;
     if (!plan_has_grid_root(gp->grid_n0, gp->grid_n1, gp->real_has_grad)) return false;
     if ((H < 2 && n_pre == 0) || H < 1 || tiles_nt(H, n_pre) == 0) return false;
     if (tiles_nt(H, n_pre) > 32 && !((env->env_id == GPMPC_ENV_PENDULUM1D && gp->grid_n0 == 4) || (env->env_id == GPMPC_ENV_CAR_RESIDUAL && gp->grid_n0 == 5)))

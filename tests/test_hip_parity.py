@@ -858,6 +858,14 @@ def test_value_only_appended_labels(sg):
                          use_model_without_derivatives=False, hall_tasks=1)
     assert sg._lib.load().gpmpc_debug_last_rollout_path() == 0
     X = res.X_traj.cpu().numpy()
+    try:                                                          # the tiled kernel's dead-row form of the same call
+        sg._lib.load().gpmpc_rollout_pin_kernel(_lib.KERNEL_TILES)
+        res_t = rollout_device(agent, u_ff, erv.reshape(-1)[per:], erv.shape[1] * per, H=H, mode=_lib.MODE_RECONDITIONED,
+                               use_model_without_derivatives=False, hall_tasks=1)
+        assert sg._lib.load().gpmpc_debug_last_rollout_path() == 3
+    finally:
+        sg._lib.load().gpmpc_rollout_pin_kernel(-1)
+    assert relerr(res_t.X_traj.cpu().numpy(), X) < 1e-9 and relerr(res_t.Y.cpu().numpy(), res.Y.cpu().numpy()) < 1e-7
     # oracle loop (forward_sampling_rollout of oracle/agent_oracle.py with the label masking inserted)
     K = np.array(p["optimizer"]["terminal_tightening"]["K"])
     x_equi = np.array(p["env"]["goal_state"])
