@@ -801,6 +801,7 @@ __global__ __launch_bounds__(NT, WPE) void joint_kernel(const JointArgs a) {
         }
         while (!rooted) {
             bool failed = false;
+            int c_fail = 0;                                       // columns walked when the attempt failed
 #ifdef GPMPC_PHASE_TIMERS
             ++jroot_attempts;
 #endif
@@ -836,6 +837,7 @@ __global__ __launch_bounds__(NT, WPE) void joint_kernel(const JointArgs a) {
                 __syncthreads();
                 if (s_flag) {
                     failed = true;                     // uniform
+                    c_fail = c0 + nb;
                 } else {
 #pragma unroll
                     for (int rs = 0; rs < RPT; ++rs) {
@@ -854,12 +856,26 @@ __global__ __launch_bounds__(NT, WPE) void joint_kernel(const JointArgs a) {
             if (!failed) {
                 rooted = true;
             } else {
-                if (level == 3) break;
-                // total jitter after retry i is jitter*10^i, accumulated incrementally like the library does
-                const double jn = gp.jitter * ((level == 0) ? 1.0 : (level == 1) ? 10.0 : 100.0);
-                const double jp = (level == 0) ? 0.0 : gp.jitter * ((level == 1) ? 1.0 : 10.0);
-                jit_total += (jn - jp);
-                ++level;
+                // A retry whose jitter does not change ONE diagonal entry of the columns walked so far (shipped car
+                // configuration: Dyn_gp_jitter 1e-20 against variances of 1e-4 .. 1: S_tt + 1e-18 == S_tt in FP64) repeats
+                // the failed attempt operation for operation and fails at the same pivot: it is counted, not run.
+                bool identical = true;
+                while (identical) {
+                    if (level == 3) break;
+                    // total jitter after retry i is jitter*10^i, accumulated incrementally like the library does
+                    const double jn = gp.jitter * ((level == 0) ? 1.0 : (level == 1) ? 10.0 : 100.0);
+                    const double jp = (level == 0) ? 0.0 : gp.jitter * ((level == 1) ? 1.0 : 10.0);
+                    const double jit_next = jit_total + (jn - jp);
+                    bool same = true;
+                    for (int t1 = tid; t1 < c_fail; t1 += nt) {
+                        const double d = Sm[(long)t1 * mT + t1];
+                        same = same && ((d + jit_next) == (d + jit_total));
+                    }
+                    identical = __syncthreads_and(same ? 1 : 0) != 0;
+                    jit_total = jit_next;
+                    ++level;
+                }
+                if (identical && level == 3) break;               // every remaining retry would have failed identically
             }
         }
         info_acc |= (level << 1);
