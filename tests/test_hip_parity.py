@@ -1171,6 +1171,19 @@ def test_value_only_seeded_rollout_on_the_tiled_kernel(sg):
         assert relerr(Xt, Xg) < 1e-9 and relerr(Yt, Yg) < 1e-7
     # value-only conditioning differs from conditioning on all tasks
     assert relerr(out[(_lib.KERNEL_TILES, 1, False)][0], out[(_lib.KERNEL_TILES, 3, False)][0]) > 1e-6
+    # a one-step horizon behind the seeds (prepare_dynamics_set with n_last = 2): nothing is appended by the rollout itself
+    one = {}
+    for kern in (_lib.KERNEL_TILES, _lib.KERNEL_GENERIC):
+        try:
+            lib.gpmpc_rollout_pin_kernel(kern)
+            res = rollout_device(agent, u_ff[:1], z[:1].reshape(-1), z.shape[1], H=1, mode=_lib.MODE_RECONDITIONED,
+                                 use_model_without_derivatives=False, hall_tasks=1, seeds=(Xs, Ys), value_seeds=(Xv, Yv))
+            assert lib.gpmpc_debug_last_rollout_path() == (3 if kern == _lib.KERNEL_TILES else 0)
+            one[kern] = (res.X_traj.cpu().numpy(), res.Y.cpu().numpy())
+        finally:
+            lib.gpmpc_rollout_pin_kernel(-1)
+    assert relerr(one[_lib.KERNEL_TILES][0], one[_lib.KERNEL_GENERIC][0]) < 1e-9
+    assert relerr(one[_lib.KERNEL_TILES][1], one[_lib.KERNEL_GENERIC][1]) < 1e-7
 
 
 def test_seeded_rollout_with_more_than_200_seed_slots(sg):
