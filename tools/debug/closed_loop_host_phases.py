@@ -1,0 +1,37 @@
+"""Wall-clock pieces of one SQP iteration of the facade (car closed loop as shipped, Ns=1024, H=40), synchronised after every
+piece: where the time between the joint draw and the iteration's wall clock goes."""
+import os, sys, time, warnings
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import numpy as np, torch
+import sampling_gpmpc_amd as sg
+from sampling_gpmpc_amd import workloads as wl
+
+Ns, H, iters = 1024, 40, 4
+p = wl.closed_loop_params("params_car_residual", Ns, H, 3, iters)
+p["common"]["use_cuda"] = True
+p["agent"]["base_sample_generator"] = "counter"
+agent = sg.Agent(p, sg.make_env(p))
+x0 = np.asarray(p["env"]["start"], dtype=np.float64)[: agent.nx]
+u_h = wl.synthetic_u_ff(agent.nu, H)
+x_h = np.tile(x0, (H, Ns))
+sync = torch.cuda.synchronize
+
+def timed(fn):
+    sync(); t0 = time.perf_counter(); r = fn(); sync(); return r, (time.perf_counter() - t0) * 1e3
+
+with warnings.catch_warnings():
+    warnings.simplefilter("ignore")
+    for step in range(3):
+        agent.mpc_iteration(step)
+        for k in range(iters):
+            _, t_train = timed(lambda: agent.train_hallucinated_dynGP(k))
+            bx, t_xhat = timed(lambda: agent.get_batch_x_hat(x_h, u_h))
+            (gv, yg, ug), t_dev = timed(lambda: agent.dyn_fg_jacobians_device(bx, k))
+            h, t_d2h = timed(lambda: sg._lib.to_host(agent._last_device_jacobians_flat))
+            xg = np.zeros(H); w = np.zeros(H)
+            pl, t_plin = timed(lambda: agent.pack_p_lin(x_h, u_h.reshape(H, 1, -1).repeat(Ns, 1) if u_h.ndim == 2 else u_h, xg, w))
+            n1 = gv.numel()
+            mean_next = h[:n1].reshape(gv.shape)[:, :, :, 0].mean(axis=0).T
+            x_h = np.tile(np.vstack([x0[None, :], mean_next[:-1]]), (1, Ns))
+            print(f"step {step} k={k}: train {t_train:6.2f}  x_hat {t_xhat:6.2f}  draw+jacobians+append {t_dev:7.2f}  D2H {h.nbytes / 1e6:5.1f} MB {t_d2h:6.2f}  "
+                  f"p_lin {pl.nbytes / 1e6:5.1f} MB {t_plin:6.2f} ms", flush=True)
