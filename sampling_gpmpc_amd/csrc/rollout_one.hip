@@ -269,6 +269,8 @@ __global__ __launch_bounds__(64, 1) void rollout_one_kernel(const RolloutArgs a)
     constexpr int kPt0 = N0 + N1;
     const int jpt = lane - kPt0;                                  // this lane's appended point (valid: 0 <= jpt < 32)
     const double Inat = (kq == jq) ? 1.0 : 0.0;
+    // 1.0 in the lanes of MFMA block b: one_solve masks a tile row's right-hand side to the row's own block with it
+    const double MK[4] = {(bm == 0) ? 1.0 : 0.0, (bm == 1) ? 1.0 : 0.0, (bm == 2) ? 1.0 : 0.0, (bm == 3) ? 1.0 : 0.0};
     // natural-map reads of the lane-map converters (doubles): unified tile 4 g + bm, row kq, column jq
     const int vr_rd = (4 * bm + kq) * kOneRS + jq;                // + 16 g RS (g = 0, 1), group 2: block 0 only
     const int hs_rd = (4 * (bm - NKT) + kq) * kOneRS + jq;        // + 16 g RS; blocks of real-data tiles are clamped to row 0
@@ -385,7 +387,7 @@ __global__ __launch_bounds__(64, 1) void rollout_one_kernel(const RolloutArgs a)
 
         // ---- forward substitution, left-looking over tile rows: ONE hand-scheduled statement (tools/gen_rollout_one.py:
         // solve_stmt) - row r + 1's independent MFMAs stand in the wait states of row r, absent rows are left inside it -----
-        one_solve<K>(P, Vu, RN, n_h);
+        one_solve<K>(P, Vu, RN, MK, n_h);
         ODBG(0, Vu[0]);
         ODBG(1, Vu[1]);
         ODBG(2, Vu[2]);

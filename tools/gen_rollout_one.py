@@ -92,8 +92,9 @@ def chain_stmt(items, neg, fresh=False):
 #   v[216 + 2 g : 217 + 2 g]   Vu[g], the solution of column group g (tied operands with a physical constraint: the DPP merge
 #                              writes HALVES of it under a bank mask, and inline asm cannot name half of a %operand)
 #   v[232:233] T   v[234:235] T2 (the rotated copy)   v[236:237] W   v[238:245] X0 .. X3: the accumulators of two tile rows
-SOLVE_VU, SOLVE_T, SOLVE_T2, SOLVE_W, SOLVE_X = 216, 232, 234, 236, 238
-SOLVE_CLOBBER = list(range(232, 246))
+#   v[246:247] RNm: the row's right-hand side masked to the row's own block (the start value of its second accumulator)
+SOLVE_VU, SOLVE_T, SOLVE_T2, SOLVE_W, SOLVE_X, SOLVE_RNM = 216, 232, 234, 236, 238, 246
+SOLVE_CLOBBER = list(range(232, 248))
 
 
 def vp(n):
@@ -123,21 +124,36 @@ def solve_stmt(f, m, K, member):
     accs = lambda r: (SOLVE_X + 4 * (r & 1), SOLVE_X + 4 * (r & 1) + 2)
     rn_op = lambda g: f"%{K + 1 + (g - m.gd[0])}"
     nh_op = f"%{K + 1 + (K - m.gd[0] + 1)}"
+    mk_op = lambda b: f"%{K + 1 + (K - m.gd[0] + 1) + 1 + b}"     # 1.0 in the lanes of block b, 0.0 elsewhere
+    RNM = SOLVE_RNM
+    # --variant rnfold: the right-hand side starts the row's second accumulator (masked to the row's block) instead of being
+    # added on the chain.  Measured (tools/ubench/one_solve_chain.hip, 22 rows): -3 cycles per row alone, +6 together with the
+    # post-merge MFMA below - not shipped.
+    FOLD = "rnfold" in VARIANT
 
     def ra_list(r):
-        return [(accs(r)[i & 1], areg("p", r, g), VU(g), i < 2) for i, g in enumerate(m.groups[r][:-1])]
+        # (accumulator, A panel, B register, start value: None = accumulate)
+        return [(accs(r)[i & 1], areg("p", r, g), VU(g), (vp(RNM) if (i == 1 and FOLD) else "0") if i < 2 else None)
+                for i, g in enumerate(m.groups[r][:-1])]
 
     def emit_ra(item):
-        acc, a, b, fresh = item
-        L.append(f"{MF} {vp(acc)}, {a}, {vp(b)}, {'0' if fresh else vp(acc)} neg:[1,0,0]")
+        acc, a, b, start = item
+        L.append(f"{MF} {vp(acc)}, {a}, {vp(b)}, {start if start is not None else vp(acc)} neg:[1,0,0]")
+
+    def emit_rnm(r):
+        """RNm of row r: rhs_r in the lanes of the row's own block only - the cross-block sum then adds it exactly once, and the
+        `+ rhs` add leaves the row's dependent chain (one FP64 multiply by a 0 / 1 mask, off the chain)"""
+        u = u_of(r)
+        L.append(f"v_mul_f64 {vp(RNM)}, {rn_op(u >> 2)}, {mk_op(u & 3)}")
 
     def rot(ctrl):
         L.append(f"v_mov_b32_dpp v{T2}, v{T} {ctrl} row_mask:0xf bank_mask:0xf bound_ctrl:1")
         L.append(f"v_mov_b32_dpp v{T2 + 1}, v{T + 1} {ctrl} row_mask:0xf bank_mask:0xf bound_ctrl:1")
         L.append(f"v_add_f64 {vp(T)}, {vp(T)}, {vp(T2)}")
 
-    def row(r, nxt):
-        """nxt: the independent MFMAs of row r + 1 (None: the padded form)"""
+    def row(r, nxt, head=True):
+        """nxt: the independent MFMAs of row r + 1 (None: the padded form); head: the statement in front ended on the merge
+        (VALU write of Vu[dep] -> MFMA read: two wait states).  Returns whether the NEXT row needs that head."""
         u = u_of(r)
         g, b = u >> 2, u & 3
         c0, c1 = accs(r)
@@ -145,15 +161,23 @@ def solve_stmt(f, m, K, member):
         n_ind = len(m.groups[r]) - 1
         dacc = accs(r)[n_ind & 1]                       # the accumulator the independent MFMAs did not write last
         q = list(nxt) if nxt is not None else []
+        # one MFMA of the next row is kept for BEHIND the merge, where the next row's dependent MFMA would wait for Vu[dep]
+        post = q.pop() if (len(q) >= 3 and "nopost" not in VARIANT) else None
+        keep = 1                                        # (one stays for behind the diagonal MFMA)
 
         def slot(pad):
             """an MFMA of the next row where a wait would stand (it counts as one state for a VALU -> DPP / MFMA read)"""
-            if len(q) > 1 and "noslots" not in VARIANT:  # (the last one stays for behind the diagonal MFMA)
+            if len(q) > keep and "noslots" not in VARIANT:
                 emit_ra(q.pop(0))
                 L.append("s_nop 0")
             else:
                 L.append(f"s_nop {pad}")
-        L.append("s_nop 1")                             # the merge in front wrote Vu[dep]: VALU write -> MFMA read
+        if nxt is not None and FOLD:
+            emit_rnm(r + 1)                             # (read by the next row's second MFMA, in a slot below)
+            if head:
+                L.append("s_nop 0")
+        elif head:
+            L.append("s_nop 1")                         # the merge in front wrote Vu[dep]: VALU write -> MFMA read
         L.append(f"{MF} {vp(dacc)}, {areg('p', r, dep)}, {vp(VU(dep))}, {vp(dacc)} neg:[1,0,0]")
         if q:
             emit_ra(q.pop(0))
@@ -168,7 +192,7 @@ def solve_stmt(f, m, K, member):
             rot("row_ror:8")
             slot(1)
             rot("row_ror:4")
-            if "nornadd" not in VARIANT:
+            if not FOLD:
                 L.append(f"v_add_f64 {vp(T)}, {vp(T)}, {rn_op(g)}")
             slot(1)
         L.append(f"{MF} {vp(W)}, {areg('gd', g, 0)}, {vp(T)}, 0")
@@ -181,10 +205,17 @@ def solve_stmt(f, m, K, member):
             L.append("s_nop 5")
         L.append(f"v_mov_b32_dpp v{VU(g)}, v{W} quad_perm:[0,1,2,3] row_mask:0xf bank_mask:0x{1 << b:x}")
         L.append(f"v_mov_b32_dpp v{VU(g) + 1}, v{W + 1} quad_perm:[0,1,2,3] row_mask:0xf bank_mask:0x{1 << b:x}")
+        if post is not None:
+            emit_ra(post)
+            L.append("s_nop 0")
+            return False
+        return True
 
     if R0 <= 0:
         L.append(f"s_cmp_eq_u32 {nh_op}, 0")
         L.append("s_cbranch_scc1 .Lone_end_%=")
+    if FOLD:
+        emit_rnm(0)
     L.append("s_nop 1")
     first = ra_list(0)
     for i, it in enumerate(first):
@@ -192,19 +223,20 @@ def solve_stmt(f, m, K, member):
         if i + 1 < len(first):
             L.append("s_nop 1")
     lasts = []
+    head = False                                        # (the prologue ends on MFMAs)
     for r in rows:
         if r + 1 in rows:
             if r + 1 >= R0:                             # row r + 1 may be absent this step
                 L.append(f"s_cmp_gt_u32 {nh_op}, {4 * (r + 1)}")
                 L.append(f"s_cbranch_scc0 .Lone_last{r}_%=")
-                lasts.append(r)
-            row(r, ra_list(r + 1))
+                lasts.append((r, head))
+            head = row(r, ra_list(r + 1), head)
         else:
-            row(r, None)
+            row(r, None, head)
     L.append("s_branch .Lone_end_%=")
-    for r in lasts:
+    for r, hd in lasts:
         L.append(f".Lone_last{r}_%=:")
-        row(r, None)
+        row(r, None, True)                              # (reached by a branch: padded whatever stood in front - 8 cycles per step)
         L.append("s_branch .Lone_end_%=")
     L.pop()                                             # the last of them falls through
     L.append(".Lone_end_%=:")
@@ -215,10 +247,11 @@ def solve_stmt(f, m, K, member):
             ins.append(f'"{{a[{n}:{n + 1}]}}"({mem})')
     outs = ", ".join(f'"+{{v[{VU(g)}:{VU(g) + 1}]}}"(Vu[{g}])' for g in range(K + 1))
     rn = ", ".join(f'"v"(RN[{g}])' for g in range(m.gd[0], K + 1))
+    mk = ", ".join(f'"v"(MK[{b}])' for b in range(4))
     clob = ", ".join(f'"v{n}"' for n in SOLVE_CLOBBER) + ', "scc"'
     body = "\n        ".join(f'"{x}\\n\\t"' for x in L[:-1]) + f'\n        "{L[-1]}"'
-    f.write(f"__device__ __forceinline__ void one_solve_{K}(OnePanels& P, double* Vu, const double* RN, int nh) {{\n")
-    f.write(f"    asm volatile({body}\n        : {outs}\n        : {rn}, \"s\"(nh),\n          {', '.join(ins)}\n        : {clob});\n}}\n")
+    f.write(f"__device__ __forceinline__ void one_solve_{K}(OnePanels& P, double* Vu, const double* RN, const double* MK, int nh) {{\n")
+    f.write(f"    asm volatile({body}\n        : {outs}\n        : {rn}, \"s\"(nh), {mk},\n          {', '.join(ins)}\n        : {clob});\n}}\n")
 
 
 def set_stmt(items, mask="mask"):
@@ -328,7 +361,7 @@ def emit(f):
     disp("one_set_row", "void", "OnePanels& P, unsigned long long mBase, unsigned long long mLast, const double* V", "P, mBase, mLast, V", range(NTR))
     for K in m.gd:
         solve_stmt(f, m, K, member)
-    disp("one_solve", "void", "OnePanels& P, double* Vu, const double* RN, int nh", "P, Vu, RN, nh", m.gd)
+    disp("one_solve", "void", "OnePanels& P, double* Vu, const double* RN, const double* MK, int nh", "P, Vu, RN, MK, nh", m.gd)
     disp("one_hset_row", "void", "unsigned long long mBase, unsigned long long mLast, const double* V", "mBase, mLast, V", range(NTR))
     disp("one_gdm", "double", "OnePanels& P, double acc", "P, acc", m.gd)
     disp("one_set_gd", "void", "OnePanels& P, unsigned long long mask, double v", "P, mask, v", m.gd)
