@@ -434,13 +434,14 @@ __global__ __launch_bounds__(64, 1) void rollout_one_kernel(const RolloutArgs a)
                 for (int c = 0; c < T; ++c) Sn[bq][c] = S[bq][c] + ((bq == c) ? gp.noise[bq] : 0.0);
             bool r_ok;
             one_chol3_pair(Sn, S, C, Rt, cinv, rinv, c_ok, r_ok);
-            if (!r_ok) info_acc |= root_small_fast_retry<T>(S, gp.jitter, Rt);
+            if (__builtin_expect(!r_ok, 0)) info_acc |= root_small_fast_retry<T>(S, gp.jitter, Rt);
         }
         double zt[T];
 #pragma unroll
         for (int c = 0; c < T; ++c) zt[c] = readlane_f64(zq[c], t);
         double y[T];
-#pragma unroll
+        bool clip = false;                                        // ONE branch for the three slots: a taken branch of a lone
+#pragma unroll                                                    // wave costs an instruction fetch (~30 cycles), the clip is rare
         for (int bq = 0; bq < T; ++bq) {
             double acc = 0.0;
 #pragma unroll
@@ -450,11 +451,18 @@ __global__ __launch_bounds__(64, 1) void rollout_one_kernel(const RolloutArgs a)
                 if (all_zero) yb = mu[bq];
             }
             const double dlt = yb - mu[bq];
-            if (dlt * dlt > a.beta * a.beta * var[bq]) {
-                const double sd = a.beta * sqrt(var[bq]);
-                yb = fmin(fmax(yb, mu[bq] - sd), mu[bq] + sd);
-            }
+            clip = clip || (dlt * dlt > a.beta * a.beta * var[bq]);
             y[bq] = yb;
+        }
+        if (__builtin_expect(clip, 0)) {
+#pragma unroll
+            for (int bq = 0; bq < T; ++bq) {
+                const double dlt = y[bq] - mu[bq];
+                if (dlt * dlt > a.beta * a.beta * var[bq]) {
+                    const double sd = a.beta * sqrt(var[bq]);
+                    y[bq] = fmin(fmax(y[bq], mu[bq] - sd), mu[bq] + sd);
+                }
+            }
         }
         if (lane == 0 && a.Y) {
 #pragma unroll
