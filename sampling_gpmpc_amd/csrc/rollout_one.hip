@@ -79,6 +79,17 @@ __device__ __forceinline__ void one_for(F&& f) {
         one_for<B + 1, E>(f);
     }
 }
+// f(integral_constant<i>) for the i in [B, E) that equals the (uniform) v, by bisection; nothing if v is outside
+template <int B, int E, class F>
+__device__ __forceinline__ void one_pick_row(int v, F&& f) {
+    if constexpr (E - B == 1) {
+        if (v == B) f(std::integral_constant<int, B>{});
+    } else if constexpr (E - B > 1) {
+        constexpr int M = (B + E) / 2;
+        if (v < M) one_pick_row<B, M>(v, f);
+        else one_pick_row<M, E>(v, f);
+    }
+}
 // D = A B (C = 0), operands in ordinary registers
 __device__ __forceinline__ double one_mfma_zero(double a, double b) {
     double d;
@@ -511,9 +522,10 @@ __global__ __launch_bounds__(64, 1) void rollout_one_kernel(const RolloutArgs a)
                 mBase = __ballot(nw);
                 mLast = __ballot(nw && bm < b);
             };
-            one_for<(R0 > 0 ? R0 : 0), (R0 + 4 < kOneNTR ? R0 + 4 : kOneNTR)>([&](auto rc) {
+            // (a binary decision over the <= 4 candidate rows: a compare chain takes a branch per row in front of the right one)
+            one_pick_row<(R0 > 0 ? R0 : 0), (R0 + 4 < kOneNTR ? R0 + 4 : kOneNTR)>(tn, [&](auto rc) {
                 constexpr int r = decltype(rc)::value;
-                if (tn == r) {                                    // uniform
+                {
                     unsigned long long mBase, mLast;
                     row_masks(r, (NKT + r) & 3, mBase, mLast);
                     one_hset_row<r>(mBase, mLast, Vu);
@@ -562,7 +574,7 @@ __global__ __launch_bounds__(64, 1) void rollout_one_kernel(const RolloutArgs a)
                 one_set_gd<K>(P, ~0ull, Gt);
             }
             if constexpr (K < KLAST) {
-                if (lo + 3 > 16) {                                // (uniform) rows wrapped into group K + 1: its first diagonal tile
+                if (__builtin_expect(lo + 3 > 16, 0)) {           // (uniform, once per epoch) rows wrapped into group K + 1: its first diagonal tile
                     const bool newK1 = rA < lo + 3 - 16;
                     const int rkD1 = 4 * bm + kq + 16 - lo;       // >= 1: all of its columns are new
                     const double mixD1 = new_entry(rA + 16 - lo, rkD1, 0.0);
