@@ -215,7 +215,9 @@ struct TilesLds {
     __host__ __device__ static constexpr int per_chain(int npt) { return npt * (XS + YS + 4) + SCRN + SXN; }
 };
 
-template <int N0, int N1, int ENV, int NT>
+// SEED: the call has conditioning-only passes and / or value-only points (gpmpc_rollout_seeded, hall_tasks = 1); the plain
+// rollout is compiled without their selects and branches (3 % at configs[2])
+template <int N0, int N1, int ENV, int NT, bool SEED>
 __global__ __launch_bounds__(64, 1) void rollout_tiles_kernel(const RolloutArgs a) {
     constexpr int D = 2, T = 3;
     constexpr int G_NY = (ENV == GPMPC_ENV_PENDULUM1D) ? 1 : 3;
@@ -253,8 +255,8 @@ __global__ __launch_bounds__(64, 1) void rollout_tiles_kernel(const RolloutArgs 
     // n_v0 observed like the rollout's own draws.  hall_tasks == 1 (value-only appended labels, reference src/agent.py:399-405):
     // a value-only point KEEPS its three row slots, the two derivative rows are dead - identity rows of the factor with a
     // zero right-hand side, which contribute nothing to any product - so that every index of the tile layout stays as it is
-    const int n_pre = a.n_h0 + a.n_v0;
-    const bool th1 = a.hall_tasks == 1;
+    const int n_pre = SEED ? a.n_h0 + a.n_v0 : 0;
+    const bool th1 = SEED && a.hall_tasks == 1;
     const int H = a.H, npt_cap = max(n_pre + H - 1, 1);
     const long blk = blockIdx.x;
     // chain -> (sample, output)
@@ -367,7 +369,7 @@ __global__ __launch_bounds__(64, 1) void rollout_tiles_kernel(const RolloutArgs 
     TPH_DECL;
 #pragma unroll 1
     for (int tt = -n_pre; tt < H; ++tt) {
-        const bool seeding = tt < 0;                              // uniform: condition on a given point, draw nothing
+        const bool seeding = SEED && tt < 0;                      // uniform: condition on a given point, draw nothing
         const int t = seeding ? 0 : tt;
         const bool seed_full = seeding && (tt + n_pre) < a.n_h0;
         const bool vo_new = th1 && !seed_full;                    // this pass's point is observed in its value only
@@ -1090,7 +1092,8 @@ template <int N0, int N1, int ENV, int NT>
 static int launch_tiles(RolloutArgs& args, int g_ny, hipStream_t st) {
     const size_t lds = tiles_lds_bytes<N0, N1>(g_ny, args.H, args.n_h0 + args.n_v0);
     const long nblk = (g_ny == 1) ? (args.Ns + 3) / 4 : args.Ns;
-    auto k = rollout_tiles_kernel<N0, N1, ENV, NT>;
+    const bool seed = (args.n_h0 + args.n_v0 > 0) || args.hall_tasks == 1;
+    auto k = seed ? rollout_tiles_kernel<N0, N1, ENV, NT, true> : rollout_tiles_kernel<N0, N1, ENV, NT, false>;
     GPMPC_HIP_CHECK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(k, dim3((unsigned)nblk), dim3(64), lds, st, args);
     GPMPC_HIP_CHECK(hipGetLastError());
