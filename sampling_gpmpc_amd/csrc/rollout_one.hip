@@ -384,16 +384,17 @@ __global__ __launch_bounds__(64, 1) void rollout_one_kernel(const RolloutArgs a)
         one_sync_lds();
         // the solution, one natural register per group: the real-data tiles now, the appended tiles as they are solved
         double Vu[K + 1], RN[K + 1];
+        // (all LDS reads are issued before the first value is used: ONE round trip - hipcc had put the select of tile 8 and its
+        // s_waitcnt in front of the other reads)
         Vu[0] = VRb[vr_rd];
         Vu[1] = VRb[vr_rd + 16 * kOneRS];
-        {
-            const double t8 = VRb[(32 + kq) * kOneRS + jq];
-            Vu[2] = (bm == 0) ? t8 : 0.0;
-        }
-#pragma unroll
-        for (int g = 3; g <= K; ++g) Vu[g] = 0.0;
+        double t8 = VRb[(32 + kq) * kOneRS + jq];
 #pragma unroll
         for (int g = KFIRST; g <= K; ++g) RN[g] = HSb[max(hs_rd + 16 * g * kOneRS, 0)];
+        asm volatile("" : "+v"(t8), "+v"(RN[K]));                 // t8 is not touched before the last read has been issued
+        Vu[2] = (bm == 0) ? t8 : 0.0;
+#pragma unroll
+        for (int g = 3; g <= K; ++g) Vu[g] = 0.0;
         OPH(0);
 
         // ---- forward substitution, left-looking over tile rows: ONE hand-scheduled statement (tools/gen_rollout_one.py:
@@ -457,13 +458,15 @@ __global__ __launch_bounds__(64, 1) void rollout_one_kernel(const RolloutArgs a)
             double acc = 0.0;
 #pragma unroll
             for (int c = 0; c <= bq; ++c) acc = fma(Rt[bq][c], zt[c], acc);
-            double yb = acc + mu[bq];
-            if (a.var_zero_thr >= 0.0) {                          // (uniform)
-                if (all_zero) yb = mu[bq];
-            }
+            const double yb = acc + mu[bq];
             const double dlt = yb - mu[bq];
             clip = clip || (dlt * dlt > a.beta * a.beta * var[bq]);
             y[bq] = yb;
+        }
+        if (__builtin_expect(all_zero, 0)) {                      // (uniform; only with a threshold >= 0) the mean, nothing to clip
+#pragma unroll
+            for (int bq = 0; bq < T; ++bq) y[bq] = mu[bq];
+            clip = false;
         }
         if (__builtin_expect(clip, 0)) {
 #pragma unroll
