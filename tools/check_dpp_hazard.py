@@ -5,10 +5,11 @@ not pad there (it neither sees into an asm statement nor pads its boundary beyon
 Rules (measured on MI355X: tools/ubench/mfma64_hazard2.hip, mfma64_chain.hip, mfma64_war.hip; an `s_nop N` is N + 1 wait
 states, every other instruction one - EXCEPT an independent FP64 MFMA standing between an MFMA and the reader of its result:
 tools/ubench/mfma64_fill.hip (round 4) shows that ONE such MFMA leaves nothing to pad for a VALU, a DPP or an MFMA SrcA/B reader
-(the reader then waits 16+ cycles behind the producer); it counts as MFMA_WS = 6 wait states for the rules M2-M4.  rollout_one.hip
-relies on it: the next tile row's independent MFMAs stand where the s_nop of the previous row would be):
+(the reader then waits 16+ cycles behind the producer); it counts as MFMA_WS = 6 wait states for the rules M2-M4 - and as ONE,
+like any instruction, for D1 / M1.  rollout_one.hip relies on it: the next tile row's independent MFMAs stand where the s_nop
+of the previous row would be):
 
-  D1  VALU write of a VGPR -> the same VGPR read through DPP (row_newbcast source)            2 wait states
+  D1  VALU write of a VGPR -> the same VGPR read through DPP (v_fmac_f64_dpp / v_mov_b32_dpp source)   2 wait states
   M1  VALU write of a VGPR -> MFMA reading it as SrcA / SrcB / SrcC                           2
   M2  MFMA D -> MFMA reading it as SrcC                                                        4
   M3  MFMA D -> MFMA reading it as SrcA / SrcB                                                 6
@@ -58,7 +59,7 @@ MFMA_WS = 6
 def check(path):
     counts = {"dpp": 0, "mfma": 0}
     problems, kernel = [], None
-    window = []          # preceding instructions, newest last: (wait states, kind, set of ('v'|'a', n) written)
+    window = []          # preceding instructions, newest last: (wait states, wait states for M2-M4, kind, set of ('v'|'a', n) written)
     for ln, raw in enumerate(open(path), 1):
         t = raw.strip()
         if re.match(r"^_Z\w+:", t):
@@ -76,16 +77,16 @@ def check(path):
 
         def scan(read, rule, need, kinds):
             ws = 0
-            for states, kind, written in reversed(window):
+            for states, mstates, kind, written in reversed(window):
                 if ws >= need:
                     return
                 if kind in kinds and (written & read):
                     problems.append((kernel, ln, code, rule, sorted(written & read)))
                     return
-                ws += states
+                ws += mstates if rule in ("M2", "M3", "M4") else states
 
         is_mfma = op.startswith("v_mfma")
-        if op == "v_fmac_f64_dpp" and "row_newbcast" in code:
+        if (op == "v_fmac_f64_dpp" and "row_newbcast" in code) or op == "v_mov_b32_dpp":
             counts["dpp"] += 1
             if len(tagged) > 1:
                 scan(tagged[1], "D1", 2, ("valu",))
@@ -102,13 +103,14 @@ def check(path):
                 scan(reads, "M4", 6, ("mfma",))
         if op == "s_nop":
             m = re.search(r"s_nop\s+(\d+)", code)
-            window.append((int(m.group(1)) + 1 if m else 1, "nop", set()))
+            n = int(m.group(1)) + 1 if m else 1
+            window.append((n, n, "nop", set()))
         elif is_mfma:
-            window.append((MFMA_WS, "mfma", tagged[0] if tagged else set()))
+            window.append((1, MFMA_WS, "mfma", tagged[0] if tagged else set()))
         elif op.startswith("v_") and tagged:
-            window.append((1, "valu", tagged[0]))         # VALU: the destination is the first operand
+            window.append((1, 1, "valu", tagged[0]))      # VALU: the destination is the first operand
         else:
-            window.append((1, "other", set()))
+            window.append((1, 1, "other", set()))
         window = window[-12:]
     return counts, problems
 
