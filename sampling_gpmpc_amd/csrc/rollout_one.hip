@@ -27,6 +27,11 @@
 //   * everything else (kernel entries, the grid-root product, the 3 x 3 roots, the sample) is the VALU code of
 //     rollout_fast.hip with lane == conditioning point; two small LDS buffers convert "lane = point" into the natural map.
 //   * the step loop is unrolled by EPOCH K = group of the incomplete tile: every register index is static.
+//   * a lone wave is ISSUE bound (profiles/r4_one_issue_counters.txt: its MFMAs and its VALU instructions never co-execute, 19 %
+//     of its cycles it has no instruction to issue): the forward substitution is one hand-scheduled statement per epoch
+//     (one_solve<K>: the next tile row's independent MFMAs stand in the wait states of the current one), rare paths (root
+//     retry, sampling clip, variance-is-zero, the wrap-group diagonal) are out of line, and every instruction off the step's
+//     spine counts (~6 cycles per VALU, ~17 per MFMA).
 //
 // (A first version grouped FOUR TILE ROWS per MFMA with the solution tiles replicated in all blocks: 1.5x the MFMAs, three
 // times the masked writes; tools/experiments/rollout_one_superrow/.)

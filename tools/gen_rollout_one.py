@@ -1,22 +1,23 @@
 #!/usr/bin/env python3
 """Generates sampling_gpmpc_amd/csrc/rollout_one_gen.inc: the register-pinned leaf operations of rollout_one.hip.
 
-rollout_one_kernel keeps a chain's whole factor in AGPRs as A operands of v_mfma_f64_4x4x4_4b_f64: a PANEL is one FP64
-register (an AGPR pair) holding a 16 x 4 block of L - rows 16 R .. 16 R + 15 (the four MFMA blocks = four tile rows of
-SUPER ROW R), columns 4 p .. 4 p + 3 - in the A-operand lane map (lane 16 k + 4 b + m holds L[16 R + 4 b + m][4 p + k]).
-Rows are appended three per step, i.e. a few LANES of a panel change per step: a VALU instruction cannot address half of a
-64-bit inline-asm operand, and a panel that hipcc is free to move gets copied around (measured: v_accvgpr_mov / read pairs
-on every use).  So every panel is a C++ double that is ONLY ever touched through asm operands with a PHYSICAL register
-constraint "{a[2n:2n+1]}": the register allocator then has one choice, the asm text names the halves (a<2n>, a<2n+1>), and
-a masked lane update is s_mov exec + two v_accvgpr_write_b32.
+rollout_one_kernel keeps a chain's whole factor in AGPRs as A operands of v_mfma_f64_4x4x4_4b_f64: a PANEL (r, g) is one FP64
+register (an AGPR pair) holding tile row r of the appended labels against the four column tiles of GROUP g (unified column
+tiles 4 g .. 4 g + 3, the NKT real-data tiles first; one tile per MFMA block) in the A-operand lane map: lane (kq, bm, jq)
+holds L[4 r + jq][4 (4 g + bm) + kq].  Rows are appended three per step, i.e. a few LANES of a panel change per step: a VALU
+instruction cannot address half of a 64-bit inline-asm operand, and a panel that hipcc is free to move gets copied around
+(measured: v_accvgpr_mov / read pairs on every use).  So every panel is a C++ double that is ONLY ever touched through asm
+operands with a PHYSICAL register constraint "{a[2n:2n+1]}": the register allocator then has one choice, the asm text names the
+halves (a<2n>, a<2n+1>), and a masked lane update is s_mov exec + two v_accvgpr_write_b32.
 
-Panel order (index n, registers a[2n:2n+1]) for super rows R = 0 .. NRES-1:
-    PR[R][kt], kt < NKT   real-data block (whitened: the grid root), NKT = ceil(N_r / 4) column tiles
-    PH[R][p],  p < 4 R    appended rows against earlier super rows
-    PC[R][q],  q < 3      inside the diagonal super block: column tile q, blocks b > q (zero elsewhere)
-    GD[R]                 the four diagonal tiles, inverted: block b holds (L_bb^-1)^T in the natural map
-MFMA hazards as in tools/gen_mfma_chains.py: every statement opens with s_nop 1 and closes with s_nop 5; accumulating
-MFMAs alternate between two accumulators.  The subtracting form uses the FP64 MFMA's neg modifier (neg:[1,0,0]: -A B + C).
+Panel order (class Map; index n, registers a[2n:2n+1]): for r = 0 .. NTR-1 the groups of row r (every group in front of the
+row's own tile; the own group is absent when the row's tile is the group's first block), then GD[g], g = NKT >> 2 .. : the four
+diagonal tiles of group g, inverted - block b holds (L_bb^-1)^T in the natural map.  122 panels for NKT = 9, NTR = 22.
+
+Statements: the Gram / generic chains open with s_nop 1 and close with s_nop 5 (hipcc pads nothing around inline asm); the
+forward substitution of a step is ONE statement per epoch (solve_stmt) whose wait states hold the next tile row's independent
+MFMAs; tools/check_dpp_hazard.py checks the ISA of the result.  The subtracting form uses the FP64 MFMA's neg modifier
+(neg:[1,0,0]: -A B + C).  --variant ... --out ...: schedule experiments of tools/ubench/one_solve_chain.hip.
 """
 import os
 import sys
