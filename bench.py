@@ -266,7 +266,9 @@ def extra_closed_loop(sg, _lib, wl, name="params_car_residual", Ns=1024, H=40, i
     eigendecomposition root): Ns = 8192 / 8 = 1024, H = 40, k = 0..3 and k = 0 of the next MPC step.  Also used for
     configs[1]'s mode-J points (pendulum, Ns = 1024, H = 30, k = 0 and k = 1; Cholesky root, jitter 1e-6).
     `ms_per_draw`: HIP events around the draw (min of 4); `wall_ms_per_iteration`: wall clock of the real SQP iteration of
-    the facade (train -> x_hat -> draw + Jacobians + D2H of the three arrays), synchronised at both ends."""
+    the facade (train -> x_hat -> draw + Jacobians + D2H of the three arrays), synchronised at both ends, after one throw-away
+    iteration on a second Agent (process-wide first-use allocations); k = 0 of MPC step 0 still contains the once-per-Agent
+    plan of the real data (plan_kernel + its host set-up, ~1.1 ms)."""
     import warnings
     p = wl.closed_loop_params(name, Ns, H, 2, iters)
     p["common"]["use_cuda"] = True
@@ -350,6 +352,14 @@ def extra_closed_loop(sg, _lib, wl, name="params_car_residual", Ns=1024, H=40, i
 
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
+        # one throw-away iteration on a second Agent: the process-wide one-time costs of the facade (pinned staging buffers of
+        # the caching host allocator, first-use device allocations) are not part of an SQP iteration's wall clock
+        warm = sg.Agent(p, sg.make_env(p))
+        warm.mpc_iteration(0)
+        warm.train_hallucinated_dynGP(0)
+        warm.dyn_fg_jacobians(warm.get_batch_x_hat(x_h, u_h), 0)
+        del warm
+        torch.cuda.synchronize()
         agent.mpc_iteration(0)
         for k in range(iters):
             x_h = iteration(0, k, x_h)

@@ -10,6 +10,12 @@ Ns, H, iters = 1024, 40, 4
 p = wl.closed_loop_params("params_car_residual", Ns, H, 3, iters)
 p["common"]["use_cuda"] = True
 p["agent"]["base_sample_generator"] = "counter"
+warm = sg.Agent(p, sg.make_env(p))                     # process-wide first-use costs (pinned staging, allocator) go to a throw-away Agent
+warm.mpc_iteration(0)
+warm.train_hallucinated_dynGP(0)
+_x0 = np.asarray(p["env"]["start"], dtype=np.float64)[: warm.nx]
+warm.dyn_fg_jacobians(warm.get_batch_x_hat(np.tile(_x0, (H, Ns)), wl.synthetic_u_ff(warm.nu, H)), 0)
+del warm
 agent = sg.Agent(p, sg.make_env(p))
 x0 = np.asarray(p["env"]["start"], dtype=np.float64)[: agent.nx]
 u_h = wl.synthetic_u_ff(agent.nu, H)
