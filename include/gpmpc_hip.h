@@ -46,7 +46,10 @@ extern "C" {
 /* info bits (per batch element) */
 #define GPMPC_INFO_TRAIN_CHOL_FAIL   0x0001 /* non-positive pivot while factorising K_oo + Sigma (A.5)      */
 #define GPMPC_INFO_ROOT_JITTER_MASK  0x000e /* (info >> 1) & 7 = highest retry level reached, 0 = none      */
-#define GPMPC_INFO_ROOT_FAIL         0x0010 /* all 3 jitter retries failed for THIS chain (-> eigh root)     */
+#define GPMPC_INFO_ROOT_FAIL         0x0010 /* all 3 jitter retries failed for THIS chain; after an eigh redraw of the
+                                             * batch under GPMPC_ROOT_AUTO: set for EVERY chain, with retry level 3 - the
+                                             * batch's outcome (chains stop their own attempts once another one has failed
+                                             * for good, so per-chain levels would be a matter of timing)               */
 #define GPMPC_INFO_VAR_CLAMPED       0x0020 /* a posterior variance was raised to the 1e-10 floor (A.8)     */
 #define GPMPC_INFO_NEG_1x1           0x0040 /* 1x1 covariance negative -> sqrt gives NaN (as gpytorch)      */
 #define GPMPC_INFO_ROOT_EIGH         0x0080 /* y was drawn with the eigendecomposition root (A.7 step 4)    */

@@ -60,6 +60,8 @@ struct JointArgs {
     int fc_cs;              // row stride = n_r + rows_cap
     int fc_cap;             // rows_cap
     int n_c;
+    int abandon_root;       // 1 (GPMPC_ROOT_AUTO): the eigh kernel redraws the WHOLE batch once a chain has failed every retry -
+                            // a chain that sees the flag stops its own Cholesky attempts (their result would be overwritten)
 };
 
 // Blocked left-looking step shared by the three phases.  For the column block whose pivot rows are
@@ -443,6 +445,7 @@ __global__ __launch_bounds__(NT, WPE) void joint_kernel(const JointArgs a) {
     __shared__ double blk[NB][NB + 1];
     __shared__ double dinv_s[NB];
     __shared__ int s_flag;
+    __shared__ int s_abandon;
     __shared__ int s_info;
     __shared__ __attribute__((aligned(16))) double colx[NB][D];   // input point / task / label of the block's NB pivot slots
     __shared__ int colt[NB];
@@ -799,6 +802,7 @@ __global__ __launch_bounds__(NT, WPE) void joint_kernel(const JointArgs a) {
             rooted = true;
             __syncthreads();
         }
+        bool abandoned = false;
         while (!rooted) {
             bool failed = false;
             int c_fail = 0;                                       // columns walked when the attempt failed
@@ -807,6 +811,12 @@ __global__ __launch_bounds__(NT, WPE) void joint_kernel(const JointArgs a) {
 #endif
             for (int c0 = 0; c0 < mT && !failed; c0 += NB) {
                 const int nb = min(NB, mT - c0);
+                // Another chain of the batch may have failed for good (any_fail): thread 0 reads the flag NOW - a volatile load,
+                // past the caches, whose latency hides behind the block's update - and publishes it with the block's own
+                // factorisation flag, behind the barrier that is there anyway.  (A separate __syncthreads_or poll cost 70 us
+                // per launch at k = 0: more than abandoning saves.)
+                int seen = 0;
+                if (a.abandon_root && tid == 0) seen = *(volatile int*)a.any_fail;
 #ifdef GPMPC_PHASE_TIMERS
                 ++jroot_blocks;
 #endif
@@ -834,7 +844,12 @@ __global__ __launch_bounds__(NT, WPE) void joint_kernel(const JointArgs a) {
                 }
                 __syncthreads();
                 if (tid < 64) block_factor<NB>(blk, dinv_s, nb, &s_flag);
+                if (tid == 0) s_abandon = seen;
                 __syncthreads();
+                if (s_abandon) {                       // uniform: the eigh kernel redraws the whole batch
+                    abandoned = true;
+                    break;
+                }
                 if (s_flag) {
                     failed = true;                     // uniform
                     c_fail = c0 + nb;
@@ -852,6 +867,10 @@ __global__ __launch_bounds__(NT, WPE) void joint_kernel(const JointArgs a) {
                     }
                 }
                 __syncthreads();
+            }
+            if (abandoned) {
+                level = 3;                                        // what the batch reports after the redraw (joint_eigh_kernel)
+                break;
             }
             if (!failed) {
                 rooted = true;
@@ -1110,6 +1129,17 @@ int gpmpc_joint_sample(const gpmpc_gp_desc_t* gp, const void* plan, const double
     hipStream_t st = (hipStream_t)stream;
     GPMPC_HIP_CHECK(hipMemsetAsync(a.any_fail, 0, sizeof(int), st));
     const int nrow = n_ho + 1 + mT - a.n_c;            // rows that are computed (the cached ones have no thread)
+    {
+        // Abandoning pays when the launch needs at least two rounds of the chip (the chains of later rounds skip their root
+        // phase): measured on the car's closed loop, Ns = 1024: k = 0 (1.5 rounds) +5 %, k = 1..3 and the 480-slot k = 0
+        // (3-6 rounds) -1.5 ... -4.5 %; Ns = 4096: -3 ... -7 % at every k.  GPMPC_JOINT_ABANDON=0 / 1 forces it off / on.
+        static const char* aenv = getenv("GPMPC_JOINT_ABANDON");
+        const int nt_ = (nrow <= 128) ? 128 : ((nrow <= 256) ? 256 : ((nrow <= 512) ? 512 : 1024));
+        const int wpe_ = (nrow > 128 && nrow <= 256 && n_ho >= 300) ? 2 : 4;
+        const double rounds = (double)Ns * gp->g_ny * nt_ / (256.0 * 256.0 * wpe_);
+        const bool on = aenv ? (atoi(aenv) != 0) : (rounds >= 2.0);
+        a.abandon_root = (root_mode == GPMPC_ROOT_AUTO && mT > 1 && on) ? 1 : 0;
+    }
     // one label row per thread and a workgroup just wide enough for the rows (more chains per CU when they are short:
     // iteration 0 of config 5 has 121 rows; iteration 0 of every later MPC step conditions on the previous step's
     // whole hallucinated set - the reference's reset-after-build quirk - i.e. 601 rows at config 5: 1024 threads)

@@ -743,7 +743,11 @@ __global__ __launch_bounds__(64, GPMPC_EIGH_WPE) void joint_eigh_kernel(const Ei
         }
 #endif
         if (lane == 0) {
-            a.info[chain] |= info;
+            // After a redraw that a failed chain caused (not a forced one) every chain reports the BATCH's outcome - all retries
+            // exhausted, root failed, eigendecomposition root - whatever its own Cholesky attempts had reached: chains that saw
+            // the flag stopped theirs (joint.hip: abandon_root), and which ones did is a matter of timing.
+            const int prev = a.info[chain];
+            a.info[chain] = a.force ? (prev | info) : ((prev & ~0x000E) | (3 << 1) | GPMPC_INFO_ROOT_FAIL | info);
             atomicAdd(&g_eigh_work[0], work);
             atomicAdd(&g_eigh_work[1], 1ull);
             atomicAdd(&g_eigh_work[2], (unsigned long long)r);

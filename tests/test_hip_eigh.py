@@ -185,6 +185,9 @@ def test_config5_shard_as_shipped(sg):
             assert np.isfinite(gp_val).all() and np.isfinite(y_grad).all() and np.isfinite(u_grad).all()
             assert (info & sg._lib.INFO_ROOT_EIGH).all() and not (info & sg._lib.INFO_EIGH_NOCONV).any()
             assert not (info & sg._lib.INFO_TRAIN_CHOL_FAIL).any()
+            # after a redraw every chain reports the BATCH's outcome (all retries exhausted, root failed, eigh root): chains
+            # that see another chain's failure abandon their own Cholesky attempts, and which ones do is a matter of timing
+            assert (info & sg._lib.INFO_ROOT_FAIL).all() and (((info >> 1) & 7) == 3).all()
             # a chain's draw does not depend on which other chains are in the launch
             np.testing.assert_array_equal(gp_val[:sub], sv)
             np.testing.assert_array_equal(y_grad[:sub], sy)
