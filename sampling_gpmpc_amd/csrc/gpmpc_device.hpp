@@ -471,6 +471,48 @@ __device__ __forceinline__ void chol3_pair_fast(const double (&A)[3][3], const d
     invB[0] = y0[1], invB[1] = y1[1], invB[2] = y2[1];
 }
 
+// chol3_pair_fast (gpmpc_device.hpp) with ONE Newton step behind v_rsq_f64 instead of two (the seed is good to 2^-26, one
+// step leaves 1.5 (2^-26)^2 = 3e-16 on 1 / sqrt(d)) and without the Heron correction of the pivots: 42 of the pair's ~95
+// FP64 instructions less on the step's spine (one wave per SIMD: ~7 cycles each).  Used by rollout_one.hip (in rollout_tiles.hip it changed nothing measurable: its phase G is 5 % of a step).
+#define GPMPC_ROW2L(stmt)                                          \
+    _Pragma("unroll") for (int m_ = 0; m_ < 2; ++m_) { stmt; }  \
+    __builtin_amdgcn_sched_barrier(0)
+__device__ __forceinline__ void chol3_pair_lean(const double (&A)[3][3], const double (&B)[3][3], double (&LA)[3][3],
+                                               double (&LB)[3][3], double (&invA)[3], double (&invB)[3], bool& okA, bool& okB) {
+    double s10[2] = {A[1][0], B[1][0]}, s20[2] = {A[2][0], B[2][0]}, s21[2] = {A[2][1], B[2][1]};
+    double s11[2] = {A[1][1], B[1][1]}, s22[2] = {A[2][2], B[2][2]};
+    double d0[2] = {A[0][0], B[0][0]}, d1[2], d2[2], y0[2], y1[2], y2[2], h[2], t[2], e[2];
+    double l10[2], l20[2], l21[2], n21[2], p2[2], r0[2], r1[2], r2[2];
+    __builtin_amdgcn_sched_barrier(0);
+#define GPMPC_NEWTON1(y)                                         \
+    GPMPC_ROW2L(t[m_] = h[m_] * y[m_]);                          \
+    GPMPC_ROW2L(e[m_] = fma(-t[m_], y[m_], 0.5));                \
+    GPMPC_ROW2L(y[m_] = fma(y[m_], e[m_], y[m_]))
+    GPMPC_ROW2L(y0[m_] = __builtin_amdgcn_rsq(d0[m_]); h[m_] = 0.5 * d0[m_]);
+    GPMPC_NEWTON1(y0);
+    // (the pivots themselves are d * y: y = 1 / sqrt(d) to 1.5 ulp after the Newton step, so sqrt(d) to ~2 ulp; the Heron
+    // correction of chol3_pair_fast - four instructions per pivot and matrix on the step's spine - bought the last ulp)
+    GPMPC_ROW2L(l10[m_] = s10[m_] * y0[m_]; l20[m_] = s20[m_] * y0[m_]; r0[m_] = d0[m_] * y0[m_]);
+    GPMPC_ROW2L(d1[m_] = fma(-l10[m_], l10[m_], s11[m_]); n21[m_] = fma(-l20[m_], l10[m_], s21[m_]));
+    GPMPC_ROW2L(y1[m_] = __builtin_amdgcn_rsq(d1[m_]); h[m_] = 0.5 * d1[m_]; p2[m_] = fma(-l20[m_], l20[m_], s22[m_]));
+    GPMPC_NEWTON1(y1);
+    GPMPC_ROW2L(l21[m_] = n21[m_] * y1[m_]; r1[m_] = d1[m_] * y1[m_]);
+    GPMPC_ROW2L(d2[m_] = fma(-l21[m_], l21[m_], p2[m_]));
+    GPMPC_ROW2L(y2[m_] = __builtin_amdgcn_rsq(d2[m_]); h[m_] = 0.5 * d2[m_]);
+    GPMPC_NEWTON1(y2);
+    GPMPC_ROW2L(r2[m_] = d2[m_] * y2[m_]);
+#undef GPMPC_NEWTON1
+    asm volatile("" ::"v"(r0[0]), "v"(r1[0]), "v"(r2[0]), "v"(r0[1]), "v"(r1[1]), "v"(r2[1]));
+    okA = (d0[0] > 0.0) && (d1[0] > 0.0) && (d2[0] > 0.0);
+    okB = (d0[1] > 0.0) && (d1[1] > 0.0) && (d2[1] > 0.0);
+    LA[0][0] = r0[0], LA[1][0] = l10[0], LA[2][0] = l20[0], LA[1][1] = r1[0], LA[2][1] = l21[0], LA[2][2] = r2[0];
+    LB[0][0] = r0[1], LB[1][0] = l10[1], LB[2][0] = l20[1], LB[1][1] = r1[1], LB[2][1] = l21[1], LB[2][2] = r2[1];
+    LA[0][1] = LA[0][2] = LA[1][2] = 0.0;
+    LB[0][1] = LB[0][2] = LB[1][2] = 0.0;
+    invA[0] = y0[0], invA[1] = y1[0], invA[2] = y2[0];
+    invB[0] = y0[1], invB[1] = y1[1], invB[2] = y2[1];
+}
+
 // the jitter-on-failure retries of root_small_fast (after a failed un-jittered attempt)
 template <int T>
 __device__ __forceinline__ int root_small_fast_retry(const double (&S)[T][T], double jitter, double (&R)[T][T]) {
