@@ -213,6 +213,9 @@ __global__ __launch_bounds__(64, 1) void rollout_one_kernel(const RolloutArgs a)
     constexpr int KFIRST = NKT >> 2, KLAST = (NKT + kOneNTR - 1) >> 2;       // groups that hold diagonal tiles: 2 .. 7
     static_assert(4 * NKT == NR && N0 + N1 <= 16, "panel map generated for N_r = 36");
     extern __shared__ __attribute__((aligned(16))) double smem[];
+#ifdef GPMPC_PHASE_TIMERS
+    const long long opk0_ = __builtin_readcyclecounter();         // kernel entry: prologue = [8], epilogue = [9]
+#endif
 
     const GpParams& gp = a.gp;
     const int lane = threadIdx.x;
@@ -271,6 +274,9 @@ __global__ __launch_bounds__(64, 1) void rollout_one_kernel(const RolloutArgs a)
     OnePanels P;
     one_init(P, Inat);
     OPH_DECL;
+#ifdef GPMPC_PHASE_TIMERS
+    if (blockIdx.x == 0 && threadIdx.x == 0) g_one_phase_cycles[8] = opht_ - opk0_;
+#endif
 
     auto step = [&](auto Kc) {
         constexpr int K = decltype(Kc)::value;                    // group of the incomplete tile (unified tile 9 + (n_h >> 2))
@@ -581,6 +587,9 @@ __global__ __launch_bounds__(64, 1) void rollout_one_kernel(const RolloutArgs a)
     }
     if (lane == 0) a.info[s] = info_acc;
     OPH_STORE;
+#ifdef GPMPC_PHASE_TIMERS
+    if (blockIdx.x == 0 && threadIdx.x == 0) g_one_phase_cycles[9] = __builtin_readcyclecounter() - opk0_;   // whole kernel
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------------------------

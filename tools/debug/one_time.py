@@ -18,6 +18,7 @@ for (ns, h) in CASES:
         tot = sum(out[:8])
         print("   total cycles", tot, "per step", tot // h)
         for n, v in zip(names, out[:8]): print(f"   {n:16s} {v:9d} {v // h:7d}/step {100.0 * v / max(tot, 1):5.1f}%%")
+        print(f"   prologue (kernel entry -> step loop) {out[8]} cycles, whole kernel of wave 0 {out[9]} cycles (the step loop {tot})")
 '''
 cases = [(1024, 30), (1024, 15), (2048, 30), (256, 30)]
 for mode in ("1", "0"):
