@@ -367,7 +367,8 @@ __global__ __launch_bounds__(64, 1) void rollout_one_kernel(const RolloutArgs a)
 
         // ---- forward substitution, left-looking over tile rows: ONE hand-scheduled statement (tools/gen_rollout_one.py:
         // solve_stmt) - row r + 1's independent MFMAs stand in the wait states of row r, absent rows are left inside it -----
-        one_solve<K>(P, Vu, RN, MK, n_h);
+        double S0, S1;                                            // the Gram product's two accumulators (it rides in the last row's wait states)
+        one_solve<K>(P, Vu, RN, MK, n_h, S0, S1);
         ODBG(0, Vu[0]);
         ODBG(1, Vu[1]);
         ODBG(2, Vu[2]);
@@ -378,8 +379,6 @@ __global__ __launch_bounds__(64, 1) void rollout_one_kernel(const RolloutArgs a)
         // ---- S' = sum_g Vu[g]^T Vu[g] (each block sums its own tiles), summed over the blocks; entry [k][j] in lane 16 k + j ---
         double mu[T], S[T][T];
         {
-            double S0, S1;
-            one_fchain<K + 1>(S0, S1, Vu, Vu);
             const double Stot = one_block_sum(S0 + S1);
             ODBG(6, Stot);
             const int cb[T] = {cb0, cb1, cb2};

@@ -94,7 +94,8 @@ def chain_stmt(items, neg, fresh=False):
 #                              writes HALVES of it under a bank mask, and inline asm cannot name half of a %operand)
 #   v[232:233] T   v[234:235] T2 (the rotated copy)   v[236:237] W   v[238:245] X0 .. X3: the accumulators of two tile rows
 #   v[246:247] RNm: the row's right-hand side masked to the row's own block (the start value of its second accumulator)
-SOLVE_VU, SOLVE_T, SOLVE_T2, SOLVE_W, SOLVE_X, SOLVE_RNM = 216, 232, 234, 236, 238, 246
+#   v[248:249], v[250:251] G0 / G1: the accumulators of the Gram product S' = sum_g Vu[g]^T Vu[g] (outputs of the statement)
+SOLVE_VU, SOLVE_T, SOLVE_T2, SOLVE_W, SOLVE_X, SOLVE_RNM, SOLVE_G = 216, 232, 234, 236, 238, 246, 248
 SOLVE_CLOBBER = list(range(232, 248))
 
 
@@ -123,9 +124,17 @@ def solve_stmt(f, m, K, member):
     VU = lambda g: SOLVE_VU + 2 * g
     T, T2, W = SOLVE_T, SOLVE_T2, SOLVE_W
     accs = lambda r: (SOLVE_X + 4 * (r & 1), SOLVE_X + 4 * (r & 1) + 2)
-    rn_op = lambda g: f"%{K + 1 + (g - m.gd[0])}"
-    nh_op = f"%{K + 1 + (K - m.gd[0] + 1)}"
-    mk_op = lambda b: f"%{K + 1 + (K - m.gd[0] + 1) + 1 + b}"     # 1.0 in the lanes of block b, 0.0 elsewhere
+    NOUT = K + 1 + 2                                    # Vu[0 .. K], S0, S1
+    rn_op = lambda g: f"%{NOUT + (g - m.gd[0])}"
+    nh_op = f"%{NOUT + (K - m.gd[0] + 1)}"
+    mk_op = lambda b: f"%{NOUT + (K - m.gd[0] + 1) + 1 + b}"      # 1.0 in the lanes of block b, 0.0 elsewhere
+    GRAM = "nogram" not in VARIANT
+
+    def gram_items(gs):
+        """S' += Vu[g]^T Vu[g] (a natural register used as the A operand acts as its transpose): the step's Gram product rides in
+        the wait states of the LAST tile row - which has no next row to hide behind - and behind its merge"""
+        return [("gram", f"{MF} {vp(SOLVE_G + 2 * (g & 1))}, {vp(VU(g))}, {vp(VU(g))}, {'0' if g < 2 else vp(SOLVE_G + 2 * (g & 1))}")
+                for g in gs]
     RNM = SOLVE_RNM
     # --variant rnfold: the right-hand side starts the row's second accumulator (masked to the row's block) instead of being
     # added on the chain.  Measured (tools/ubench/one_solve_chain.hip, 22 rows): -3 cycles per row alone, +6 together with the
@@ -138,6 +147,9 @@ def solve_stmt(f, m, K, member):
                 for i, g in enumerate(m.groups[r][:-1])]
 
     def emit_ra(item):
+        if item[0] == "gram":
+            L.append(item[1])
+            return
         acc, a, b, start = item
         L.append(f"{MF} {vp(acc)}, {a}, {vp(b)}, {start if start is not None else vp(acc)} neg:[1,0,0]")
 
@@ -153,10 +165,14 @@ def solve_stmt(f, m, K, member):
         L.append(f"v_add_f64 {vp(T)}, {vp(T)}, {vp(T2)}")
 
     def row(r, nxt, head=True):
-        """nxt: the independent MFMAs of row r + 1 (None: the padded form); head: the statement in front ended on the merge
+        """nxt: the independent MFMAs of row r + 1 (None: the step's last row - the Gram products of the groups in front of
+        the row's own stand in their place, the own group's follows the merge); head: the statement in front ended on the merge
         (VALU write of Vu[dep] -> MFMA read: two wait states).  Returns whether the NEXT row needs that head."""
         u = u_of(r)
         g, b = u >> 2, u & 3
+        last = nxt is None
+        if last and GRAM:
+            nxt = gram_items(range(0, g))
         c0, c1 = accs(r)
         dep = m.groups[r][-1]
         n_ind = len(m.groups[r]) - 1
@@ -173,7 +189,7 @@ def solve_stmt(f, m, K, member):
                 L.append("s_nop 0")
             else:
                 L.append(f"s_nop {pad}")
-        if nxt is not None and FOLD:
+        if not last and FOLD:
             emit_rnm(r + 1)                             # (read by the next row's second MFMA, in a slot below)
             if head:
                 L.append("s_nop 0")
@@ -209,12 +225,17 @@ def solve_stmt(f, m, K, member):
         if post is not None:
             emit_ra(post)
             L.append("s_nop 0")
-            return False
+            if not last:
+                return False
+        if last and GRAM:                               # the own group's Gram product: Vu[g] was merged two instructions ago
+            if post is None:
+                L.append("s_nop 1")
+            emit_ra(gram_items([g])[0])
         return True
 
     if R0 <= 0:
         L.append(f"s_cmp_eq_u32 {nh_op}, 0")
-        L.append("s_cbranch_scc1 .Lone_end_%=")
+        L.append("s_cbranch_scc1 .Lone_none_%=")
     if FOLD:
         emit_rnm(0)
     L.append("s_nop 1")
@@ -239,19 +260,31 @@ def solve_stmt(f, m, K, member):
         L.append(f".Lone_last{r}_%=:")
         row(r, None, True)                              # (reached by a branch: padded whatever stood in front - 8 cycles per step)
         L.append("s_branch .Lone_end_%=")
-    L.pop()                                             # the last of them falls through
+    if R0 <= 0:                                         # no appended row yet: the Gram product of the real-data tiles alone
+        L.append(".Lone_none_%=:")
+        if GRAM:
+            L.append("s_nop 1")
+            for i, it in enumerate(gram_items(range(0, K + 1))):
+                if i:
+                    L.append("s_nop 1")
+                emit_ra(it)
+    else:
+        L.pop()                                         # the last of them falls through
     L.append(".Lone_end_%=:")
+    if GRAM:
+        L.append("s_nop 5")                             # S0 / S1 are read by the compiler's code next
     seen, ins = set(), []
     for n, mem in used:
         if n not in seen:
             seen.add(n)
             ins.append(f'"{{a[{n}:{n + 1}]}}"({mem})')
     outs = ", ".join(f'"+{{v[{VU(g)}:{VU(g) + 1}]}}"(Vu[{g}])' for g in range(K + 1))
+    outs += f', "=&{{v[{SOLVE_G}:{SOLVE_G + 1}]}}"(S0), "=&{{v[{SOLVE_G + 2}:{SOLVE_G + 3}]}}"(S1)'
     rn = ", ".join(f'"v"(RN[{g}])' for g in range(m.gd[0], K + 1))
     mk = ", ".join(f'"v"(MK[{b}])' for b in range(4))
     clob = ", ".join(f'"v{n}"' for n in SOLVE_CLOBBER) + ', "scc"'
     body = "\n        ".join(f'"{x}\\n\\t"' for x in L[:-1]) + f'\n        "{L[-1]}"'
-    f.write(f"__device__ __forceinline__ void one_solve_{K}(OnePanels& P, double* Vu, const double* RN, const double* MK, int nh) {{\n")
+    f.write(f"__device__ __forceinline__ void one_solve_{K}(OnePanels& P, double* Vu, const double* RN, const double* MK, int nh, double& S0, double& S1) {{\n")
     f.write(f"    asm volatile({body}\n        : {outs}\n        : {rn}, \"s\"(nh), {mk},\n          {', '.join(ins)}\n        : {clob});\n}}\n")
 
 
@@ -362,7 +395,7 @@ def emit(f):
     disp("one_set_row", "void", "OnePanels& P, unsigned long long mBase, unsigned long long mLast, const double* V", "P, mBase, mLast, V", range(NTR))
     for K in m.gd:
         solve_stmt(f, m, K, member)
-    disp("one_solve", "void", "OnePanels& P, double* Vu, const double* RN, const double* MK, int nh", "P, Vu, RN, MK, nh", m.gd)
+    disp("one_solve", "void", "OnePanels& P, double* Vu, const double* RN, const double* MK, int nh, double& S0, double& S1", "P, Vu, RN, MK, nh, S0, S1", m.gd)
     disp("one_hset_row", "void", "unsigned long long mBase, unsigned long long mLast, const double* V", "mBase, mLast, V", range(NTR))
     disp("one_gdm", "double", "OnePanels& P, double acc", "P, acc", m.gd)
     disp("one_set_gd", "void", "OnePanels& P, unsigned long long mask, double v", "P, mask, v", m.gd)

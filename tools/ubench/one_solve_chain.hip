@@ -17,7 +17,9 @@ __global__ __launch_bounds__(64, 1) void k(const double* in, double* out, long l
     long long best = 1ll << 60;
     for (int rep = 0; rep < 3; ++rep) {
         const long long t0 = __builtin_readcyclecounter();
-        for (int it = 0; it < iters; ++it) one_solve<7>(P, Vu, RN, MK, nh);
+        double S0 = 0, S1 = 0;
+        for (int it = 0; it < iters; ++it) one_solve<7>(P, Vu, RN, MK, nh, S0, S1);
+        Vu[0] += 1e-300 * (S0 + S1);
         const long long t1 = __builtin_readcyclecounter();
         best = (t1 - t0 < best) ? t1 - t0 : best;
     }
