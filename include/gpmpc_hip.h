@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define GPMPC_ABI_VERSION 6
+#define GPMPC_ABI_VERSION 7
 
 #define GPMPC_MAX_NY 4   /* GP outputs            (reference agent.g_dim.ny : 1 pendulum1D, 3 car)          */
 #define GPMPC_MAX_D  4   /* GP input dimension    (g_nx + g_nu : 2 in all shipped configs)                 */
@@ -274,6 +274,22 @@ int    gpmpc_joint_sample(const gpmpc_gp_desc_t* gp, const void* plan, const dou
                           int32_t root_mode, int32_t* info,
                           void* ws, size_t ws_bytes, void* stream,
                           void* factor_cache, int32_t cache_rows, int32_t n_cached);
+
+/*
+ * The two paths of gpmpc_joint_sample (ABI 7).  GPMPC_JOINT_VALU: one launch, one label row per thread, blocked left-looking
+ * factorisation on the vector pipe (every size).  GPMPC_JOINT_MFMA: three launches on the same stream - the factor phase extends
+ * the factor by the rows of the new hallucinated slots, joint_test_mfma_kernel forms V^T = L^-1 K_o*, the mean and
+ * S = K** - V^T V on the FP64 matrix pipe with the whole test block in registers, the tail draws - instantiated for
+ * n_r <= 64 real slots, n_r + n_ho <= 416 conditioning slots and m*T + 1 <= 128; taken from 48 hallucinated slots on
+ * (GPMPC_JOINT_MFMA_FROM).  Results of the two paths agree to rounding, not bit for bit: a caller that compares launches bit
+ * for bit (cache on / off, sample shards against the whole batch) pins the path.  gpmpc_joint_pin_path(GPMPC_JOINT_AUTO) releases
+ * the pin; a pinned GPMPC_JOINT_MFMA falls back to the VALU path for sizes it is not instantiated for.
+ */
+#define GPMPC_JOINT_AUTO 0
+#define GPMPC_JOINT_VALU 1
+#define GPMPC_JOINT_MFMA 2
+int    gpmpc_joint_pin_path(int32_t path);
+int    gpmpc_joint_last_path(void);          /* GPMPC_JOINT_VALU / GPMPC_JOINT_MFMA: what the last gpmpc_joint_sample ran; 0 before */
 
 /*
  * gpmpc_assemble_jacobians - full-state value and Jacobians from the GP sample.

@@ -12,9 +12,17 @@ from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 REPO = os.path.dirname(os.path.dirname(HERE))
-SOURCES = ["capi.hip", "rollout.hip", "rollout_fast.hip", "rollout_tiles.hip", "rollout_one.hip", "rollout_indep.hip", "joint.hip", "assemble.hip"]
-HEADERS = ["gpmpc_device.hpp", "gpmpc_host.hpp", "rollout_args.hpp", "joint_eigh.hpp",
+SOURCES = ["capi.hip", "rollout.hip", "rollout_fast.hip", "rollout_tiles.hip", "rollout_one.hip", "rollout_indep.hip", "joint.hip",
+           "joint_mfma.hip", "assemble.hip"]
+# everything a source may include: the generated statement files (.inc) count like headers - editing a generator's OUTPUT
+# rebuilds the kernels that include it; tests/test_generated_sources.py checks that the committed .inc files are what the
+# generators (tools/gen_rollout_one.py, tools/gen_mfma_chains.py) produce
+HEADERS = ["gpmpc_device.hpp", "gpmpc_host.hpp", "rollout_args.hpp", "joint_args.hpp", "joint_eigh.hpp",
+           "rollout_one_gen.inc", "rollout_tiles_mfma.inc", "joint_mfma_gen.inc",
            os.path.join(REPO, "include", "gpmpc_hip.h")]
+GENERATED = {"rollout_one_gen.inc": os.path.join(REPO, "tools", "gen_rollout_one.py"),
+             "rollout_tiles_mfma.inc": os.path.join(REPO, "tools", "gen_mfma_chains.py"),
+             "joint_mfma_gen.inc": os.path.join(REPO, "tools", "gen_joint_mfma.py")}
 OUT = os.path.join(os.path.dirname(HERE), "libgpmpc_hip.so")
 OBJDIR = os.path.join(HERE, "build")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
@@ -37,7 +45,8 @@ EXTRA_FLAGS = {"rollout_fast.hip": os.environ.get("GPMPC_FAST_FLAGS", "-mllvm -d
                "rollout_tiles.hip": os.environ.get("GPMPC_TILES_FLAGS", "").split(),
                # rollout_one.hip: without machine-LICM no SGPR is spilled (28 otherwise: v_readlane / v_writelane pairs in the step)
                "rollout_one.hip": os.environ.get("GPMPC_ONE_FLAGS", "-mllvm -disable-machine-licm").split(),
-               "rollout_indep.hip": os.environ.get("GPMPC_INDEP_FLAGS", "").split()}
+               "rollout_indep.hip": os.environ.get("GPMPC_INDEP_FLAGS", "").split(),
+               "joint_mfma.hip": os.environ.get("GPMPC_JOINT_MFMA_FLAGS", "").split()}
 
 
 STAMP = os.path.join(OBJDIR, "flags.stamp")
@@ -61,8 +70,20 @@ def is_default_build():
                 or os.environ.get("GPMPC_FAST_FLAGS") is not None)
 
 
+def clean_objdir():
+    """Only objects and the flags stamp belong in csrc/build/: -save-temps leftovers (.hipi, .bc, .s, .out) of experiment
+    builds would travel to the GPU box with every snapshot."""
+    if not os.path.isdir(OBJDIR):
+        return
+    for name in os.listdir(OBJDIR):
+        p = os.path.join(OBJDIR, name)
+        if os.path.isfile(p) and not (name.endswith(".o") and "-hip-amdgcn" not in name) and name != "flags.stamp":
+            os.remove(p)
+
+
 def build(force=False, verbose=False):
     os.makedirs(OBJDIR, exist_ok=True)
+    clean_objdir()
     digest = flags_digest()
     try:
         with open(STAMP) as f:

@@ -22,47 +22,11 @@
 //     (joint_eigh.hpp, launched right behind this kernel) redraws the whole batch with the eigendecomposition root.
 #include <type_traits>
 #include "gpmpc_host.hpp"
+#include "joint_args.hpp"
 #include "joint_eigh.hpp"
 
 namespace gpmpc {
 
-struct JointArgs {
-    GpParams gp;
-    const double* plan;
-    const double* X_r;
-    long Ns;
-    int n_h;
-    const double* X_h;
-    const double* Y_h;
-    const int* h_slots;
-    int n_ho;
-    int m;
-    const double* X_s;
-    const double* z;
-    double var_zero_thr, beta;
-    int apply_clip;
-    double* mean;
-    double* var;
-    double* y;
-    double* covar;
-    int* info;
-    double* ws;
-    long ws_chain_stride;   // doubles
-    int ld;                 // rows of M (padded)
-    double* Sall;           // [chains][mT*mT] posterior covariance, column-major, both triangles written
-    int* any_fail;          // set when a chain's jitter chain failed (read by joint_eigh_kernel)
-    // factor cache (caller-owned, persists between calls): per chain the hallucinated rows of the factor, row-major
-    // [rows_cap][fc_cs] (columns: real slots, then hallucinated slots; the diagonal blocks as block_factor left them) and
-    // 1/diag [rows_cap].  The first n_c rows (any count: the column blocks restart at slot n_c) are valid on entry and are
-    // not recomputed.
-    double* fcache;
-    long fc_stride;         // doubles per chain
-    int fc_cs;              // row stride = n_r + rows_cap
-    int fc_cap;             // rows_cap
-    int n_c;
-    int abandon_root;       // 1 (GPMPC_ROOT_AUTO): the eigh kernel redraws the WHOLE batch once a chain has failed every retry -
-                            // a chain that sees the flag stops its own Cholesky attempts (their result would be overwritten)
-};
 
 // Blocked left-looking step shared by the three phases.  For the column block whose pivot rows are
 // prow0..prow0+nb-1 and for every row this thread owns (row = tid + rs*256, row >= rlo):
@@ -461,17 +425,18 @@ __global__ __launch_bounds__(NT, WPE) void joint_kernel(const JointArgs a) {
     const int n_ho = a.n_ho, m = a.m, mT = m * T;
     const int n_o = n_r + n_ho;
     const int ld = a.ld;
-    const int wrow = n_ho, trow0 = n_ho + 1, nrow = n_ho + 1 + mT;
-    const long nchains = a.Ns * gp.g_ny;
+    // JOINT_PHASE_FACTOR: the hallucinated rows only (no w row, no test rows: joint_test_mfma_kernel forms them)
+    const bool ph_factor = a.phase != JOINT_PHASE_TAIL, ph_test = a.phase == JOINT_PHASE_ALL, ph_tail = a.phase != JOINT_PHASE_FACTOR;
+    const int wrow = n_ho, trow0 = n_ho + 1, nrow = ph_test ? n_ho + 1 + mT : n_ho;
 
     double* M = a.ws + (long)blockIdx.x * a.ws_chain_stride;     // [n_o][ld]   column-major, thread == row
     double* Rm = M + (long)n_o * ld;                              // [mT][mT]    factor attempts
     double* muv = Rm + (long)mT * mT;                             // [mT]
     double* yv = muv + mT;                                        // [mT]   mean + R z
 
-    for (long chain = blockIdx.x; chain < nchains; chain += gridDim.x) {
+    for (long chain = a.chain0 + blockIdx.x; chain < a.chain1; chain += gridDim.x) {
         double* Sm = a.Sall + chain * (long)mT * mT;             // [mT][mT]    column-major, lower part valid
-        double* fc = a.fcache ? a.fcache + chain * a.fc_stride : nullptr;      // cached factor rows of this chain
+        double* fc = a.fcache ? a.fcache + (chain - a.fc_chain_base) * a.fc_stride : nullptr;      // cached factor rows of this chain
         double* fdinv = fc ? fc + (long)a.fc_cap * a.fc_cs : nullptr;
         const int n_c = fc ? a.n_c : 0, CS = a.fc_cs;             // rows < n_c: valid in the cache, not recomputed
         const int rb = n_c;                                       // thread 0 owns row rb: the workgroup spans the rows that are computed
@@ -488,7 +453,7 @@ __global__ __launch_bounds__(NT, WPE) void joint_kernel(const JointArgs a) {
         for (int d = 0; d < D; ++d) il2[d] = gp.inv_l2[o][d];
         const double os = gp.os[o];
         int info_acc = 0;
-        if (tid == 0) s_info = 0;
+        if (tid == 0) s_info = (a.phase == JOINT_PHASE_TAIL && a.info_in) ? a.info[chain] : 0;
         __syncthreads();
 #ifdef GPMPC_PHASE_TIMERS
         long long jph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -530,7 +495,7 @@ __global__ __launch_bounds__(NT, WPE) void joint_kernel(const JointArgs a) {
 
         // ---- real columns: M[row, :n_r] = L_rr^-1 k_r(row)  (w row = w_r) ------------------------------------------
         // the same blocked substitution as below, against the plan's factor L_rr (row-major) instead of rows of M
-        {
+        if (ph_factor) {
             const double* Lrr = plan_L(a.plan, gp, o);
             for (int cb = 0; cb < n_r; cb += NB) {
                 const int nb = min(NB, n_r - cb);
@@ -589,7 +554,7 @@ __global__ __launch_bounds__(NT, WPE) void joint_kernel(const JointArgs a) {
         // ---- hallucinated columns, NB at a time -------------------------------------------------------------------
         // (the blocks are NB wide from slot 0 and again from slot n_c: a block never straddles the cached / new boundary,
         // so n_c needs no alignment - the cache holds plain factor entries, any partition can read them)
-        for (int c0 = 0, nb = 0; c0 < n_ho; c0 += nb) {
+        for (int c0 = 0, nb = 0; c0 < n_ho && ph_factor; c0 += nb) {
             const bool cached = c0 < n_c;                     // uniform: the block's pivot rows and its factorised diagonal block are in the cache
             nb = min(NB, (cached ? n_c : n_ho) - c0);
             if (tid < NB) {                                   // descriptors of the block's pivot slots, shared by all rows
@@ -693,8 +658,15 @@ __global__ __launch_bounds__(NT, WPE) void joint_kernel(const JointArgs a) {
         }
 
         JPH(4);
+        if (!ph_tail) {                                           // JOINT_PHASE_FACTOR: the chain's rows are in M and in the cache
+            if (info_acc) atomicOr(&s_info, info_acc);
+            __syncthreads();
+            if (tid == 0) a.info[chain] = s_info;
+            __syncthreads();
+            continue;
+        }
         // ---- posterior mean; covariance S = K** - V V^T (same blocked update, no factor step) ---------------------
-        {   // mu = V^T w.  A dot product per test row: the w row (n_o entries) goes through LDS in chunks, every test-row
+        if (ph_test) {   // mu = V^T w.  A dot product per test row: the w row (n_o entries) goes through LDS in chunks, every test-row
             // thread streams its own row with MU_U loads in flight.  (It used to be the blocked update with the w row as the
             // only pivot: NB DPP FMAs per conditioning slot for one useful column - 159 k of 2.7 M cycles per chain at k = 3.)
             // Same operations in the same order as that update: acc = fma(-V[t][k], w[k], acc), k ascending; mu = -acc.
@@ -741,7 +713,7 @@ __global__ __launch_bounds__(NT, WPE) void joint_kernel(const JointArgs a) {
         // kernel entries only are formed here and V V^T comes off them on the matrix pipe (k = 3: 8.07 against 8.35 ms)
         // (the 128-thread kernel only ever sees <= 7 hallucinated slots: it keeps the VALU form and its register allocation)
         const bool s_mfma = NT >= 256 && n_o >= GPMPC_JOINT_S_MFMA_MIN;
-        for (int c0 = 0; c0 < mT; c0 += NB) {
+        for (int c0 = 0; c0 < mT && ph_test; c0 += NB) {
             const int nb = min(NB, mT - c0);
             double acc[RPT][NB];
 #pragma unroll
@@ -785,8 +757,12 @@ __global__ __launch_bounds__(NT, WPE) void joint_kernel(const JointArgs a) {
             }
         }
         __syncthreads();
+        if (!ph_test) {                                           // JOINT_PHASE_TAIL: S is in Sm, the mean in a.mean
+            for (int t1 = tid; t1 < mT; t1 += nt) muv[t1] = a.mean[chain * (long)mT + t1];
+            __syncthreads();
+        }
         if constexpr (NT >= 256) {
-            if (s_mfma) {                                         // K** is in Sm: subtract V V^T, all waves of the workgroup
+            if (s_mfma && ph_test) {                              // K** is in Sm: subtract V V^T, all waves of the workgroup
                 syrk_lower_mfma<NT, (WPE >= 4) ? 4 : 8, (WPE < 4)>(M + trow0, ld, n_o, mT, Sm);
                 __syncthreads();
             }
@@ -993,11 +969,34 @@ static long joint_grid(long nchains) {
     return nchains < cap ? nchains : cap;
 }
 
-// workspace layout (doubles): [joint slots | S of every chain | eigh slots | flags]
+// workspace layout (doubles): [joint slots | S of every chain | eigh slots | flags | temporary factor cache]
+// The temporary factor cache serves the matrix-pipe path of a call WITHOUT a caller-owned cache (or with one that is too small
+// for this call's rows): joint_test_mfma_kernel reads the hallucinated rows of the factor row-major, 16-byte aligned - the
+// layout of the factor cache - so the factor phase fills tc_slots cache entries inside the workspace and the call proceeds in
+// batches of tc_slots chains.
 struct JointWs {
     long grid, stride, s_off, egrid, estride, e_off, f_off, total;
+    long tc_off, tc_slots, tc_stride;
+    int tc_rows, tc_cs;
     int ld;
 };
+
+static int fc_row_stride(int n_r, int rows) { return (n_r + rows + 1) & ~1; }
+
+// the launch sizes from which the matrix-pipe path (factor phase + joint_test_mfma_kernel + tail) is taken
+static int joint_mfma_from() {
+    static const char* env = getenv("GPMPC_JOINT_MFMA_FROM");     // hallucinated slots from which it is used (0: never)
+    return env ? atoi(env) : 48;
+}
+static int g_joint_path_pin = 0;          // gpmpc_joint_pin_path: 0 auto, 1 VALU path, 2 matrix-pipe path where instantiated
+static int g_joint_last_path = 0;
+static bool joint_use_mfma(int n_r, int n_ho, int m, int T) {
+    if (!joint_mfma_eligible(n_r, n_ho, m, T)) return false;
+    if (g_joint_path_pin == 1) return false;
+    if (g_joint_path_pin == 2) return true;
+    const int from = joint_mfma_from();
+    return from > 0 && n_ho >= from;
+}
 
 static long eigh_grid(long nchains) {
     static const char* env = getenv("GPMPC_EIGH_SLOTS_PER_CU");       // experiment knob (tools/eigh_sweep.sh)
@@ -1017,6 +1016,16 @@ static JointWs joint_ws_layout(int n_r, int n_ho, int m, int T, long nchains) {
     w.e_off = w.s_off + nchains * mT * mT;
     w.f_off = w.e_off + (mT > 1 ? w.egrid * w.estride : 0);
     w.total = w.f_off + 32;
+    w.tc_off = w.tc_slots = w.tc_stride = 0;
+    w.tc_rows = w.tc_cs = 0;
+    if (joint_mfma_eligible(n_r, n_ho, m, T)) {       // (pin-independent: the workspace serves either path)
+        w.tc_rows = (n_ho + 1) & ~1;
+        w.tc_cs = fc_row_stride(n_r, w.tc_rows);
+        w.tc_stride = (long)w.tc_rows * (w.tc_cs + 1);
+        w.tc_slots = nchains < 1024 ? nchains : 1024;
+        w.tc_off = (w.total + 1) & ~1L;
+        w.total = w.tc_off + w.tc_slots * w.tc_stride;
+    }
     return w;
 }
 
@@ -1045,6 +1054,15 @@ int gpmpc_debug_read_eigh_phases(long long* out /*[host] 8*/) {
     return GPMPC_OK;
 }
 
+// which joint path gpmpc_joint_sample takes: 0 = by size (GPMPC_JOINT_MFMA_FROM), 1 = the one-launch VALU path, 2 = the
+// matrix-pipe path wherever it is instantiated (else the VALU path)
+int gpmpc_joint_pin_path(int32_t path) {
+    if (path < 0 || path > 2) return fail(GPMPC_E_ARG, "gpmpc_joint_pin_path: 0 (auto), 1 (VALU) or 2 (matrix pipe)");
+    g_joint_path_pin = path;
+    return GPMPC_OK;
+}
+int gpmpc_joint_last_path(void) { return g_joint_last_path; }
+
 // occupancy of the eigh kernel as the runtime computes it (blocks of one wave per CU) for an m*T-slot covariance
 int gpmpc_debug_eigh_occupancy(int mT, size_t extra_lds) {
     const int np = (mT + 1) & ~1;
@@ -1058,7 +1076,7 @@ int gpmpc_debug_eigh_occupancy(int mT, size_t extra_lds) {
 // bytes of the caller-owned factor cache of gpmpc_joint_sample for up to cache_rows hallucinated label rows per chain
 size_t gpmpc_joint_cache_bytes(const gpmpc_gp_desc_t* gp, int64_t Ns, int32_t cache_rows) {
     if (check_gp(gp) != GPMPC_OK || cache_rows < 16 || Ns < 1) return 0;
-    const size_t cs = (size_t)observed_real_slots(gp) + cache_rows;
+    const size_t cs = (size_t)fc_row_stride(observed_real_slots(gp), cache_rows);
     return align_up((size_t)Ns * gp->g_ny * cache_rows * (cs + 1) * sizeof(double), 256);
 }
 
@@ -1111,7 +1129,6 @@ int gpmpc_joint_sample(const gpmpc_gp_desc_t* gp, const void* plan, const double
     const JointWs w = joint_ws_layout(a.gp.n_r, n_ho, m, gp->T, Ns * gp->g_ny);
     a.ws_chain_stride = w.stride;
     a.ld = w.ld;
-    const long grid = w.grid;
     if (ws_bytes < (size_t)w.total * sizeof(double))
         return fail(GPMPC_E_WORKSPACE, "gpmpc_joint_sample: workspace too small");
     a.Sall = (double*)ws + w.s_off;
@@ -1121,7 +1138,7 @@ int gpmpc_joint_sample(const gpmpc_gp_desc_t* gp, const void* plan, const double
             return fail(GPMPC_E_ARG, "gpmpc_joint_sample: factor cache: rows >= 16, 0 <= n_cached <= min(n_ho, rows)");
         a.fcache = (double*)factor_cache;
         a.fc_cap = cache_rows;
-        a.fc_cs = a.gp.n_r + cache_rows;
+        a.fc_cs = fc_row_stride(a.gp.n_r, cache_rows);
         a.fc_stride = (long)cache_rows * (a.fc_cs + 1);
         a.n_c = n_cached;
     } else {
@@ -1129,24 +1146,28 @@ int gpmpc_joint_sample(const gpmpc_gp_desc_t* gp, const void* plan, const double
         a.fc_cap = a.fc_cs = a.n_c = 0;
         a.fc_stride = 0;
     }
+    a.fc_chain_base = 0;
+    a.phase = JOINT_PHASE_ALL;
+    a.info_in = 0;
+    a.chain0 = 0;
+    a.chain1 = Ns * gp->g_ny;
     hipStream_t st = (hipStream_t)stream;
     GPMPC_HIP_CHECK(hipMemsetAsync(a.any_fail, 0, sizeof(int), st));
-    const int nrow = n_ho + 1 + mT - a.n_c;            // rows that are computed (the cached ones have no thread)
-    {
-        // Abandoning pays when the launch needs at least two rounds of the chip (the chains of later rounds skip their root
-        // phase): measured on the car's closed loop, Ns = 1024: k = 0 (1.5 rounds) +5 %, k = 1..3 and the 480-slot k = 0
-        // (3-6 rounds) -1.5 ... -4.5 %; Ns = 4096: -3 ... -7 % at every k.  GPMPC_JOINT_ABANDON=0 / 1 forces it off / on.
+    const long nchains = Ns * gp->g_ny;
+    // Abandoning pays when the launch needs at least two rounds of the chip (the chains of later rounds skip their root
+    // phase): measured on the car's closed loop, Ns = 1024: k = 0 (1.5 rounds) +5 %, k = 1..3 and the 480-slot k = 0
+    // (3-6 rounds) -1.5 ... -4.5 %; Ns = 4096: -3 ... -7 % at every k.  GPMPC_JOINT_ABANDON=0 / 1 forces it off / on.
+    auto abandon_for = [&](int nrow) -> int {
         static const char* aenv = getenv("GPMPC_JOINT_ABANDON");
         const int nt_ = (nrow <= 128) ? 128 : ((nrow <= 256) ? 256 : ((nrow <= 512) ? 512 : 1024));
         const int wpe_ = (nrow > 128 && nrow <= 256 && n_ho >= 300) ? 2 : 4;
-        const double rounds = (double)Ns * gp->g_ny * nt_ / (256.0 * 256.0 * wpe_);
+        const double rounds = (double)nchains * nt_ / (256.0 * 256.0 * wpe_);
         const bool on = aenv ? (atoi(aenv) != 0) : (rounds >= 2.0);
-        a.abandon_root = (root_mode == GPMPC_ROOT_AUTO && mT > 1 && on) ? 1 : 0;
-    }
+        return (root_mode == GPMPC_ROOT_AUTO && mT > 1 && on) ? 1 : 0;
+    };
     // one label row per thread and a workgroup just wide enough for the rows (more chains per CU when they are short:
     // iteration 0 of config 5 has 121 rows; iteration 0 of every later MPC step conditions on the previous step's
     // whole hallucinated set - the reference's reset-after-build quirk - i.e. 601 rows at config 5: 1024 threads)
-    const dim3 g((unsigned)grid);
     static const char* penv = getenv("GPMPC_JOINT_LDS_PAD");           // experiment knob: dynamic LDS bytes per workgroup (caps the chains per CU)
     const size_t lds_pad = penv ? (size_t)atol(penv) : 0;
     // long conditioning sets on the 256-thread workgroups: 32-column blocks at two waves per SIMD (256 VGPRs) - half the
@@ -1154,23 +1175,63 @@ int gpmpc_joint_sample(const gpmpc_gp_desc_t* gp, const void* plan, const double
     // serial work per block, so only from ~300 hallucinated slots on (k=3 scattered points 9.8 against 10.8 ms; k=2 7.2 / 7.0)
     static const char* wenv = getenv("GPMPC_JOINT_WIDE_FROM");        // experiment knob: hallucinated slots from which it is used
     const bool wide = n_ho >= (wenv ? atoi(wenv) : 300);
+    // launches joint_kernel for the chains [aa.chain0, aa.chain1) with `nrow` label rows per chain
+    auto launch = [&](const JointArgs& aa, int nrow) {
+        const long nch = aa.chain1 - aa.chain0;
+        const dim3 g((unsigned)(nch < w.grid ? nch : w.grid));
 #define GPMPC_JOINT_LAUNCH(TT)                                                                              \
     do {                                                                                                    \
-        if (nrow <= 128) hipLaunchKernelGGL((joint_kernel<TT, GPMPC_JOINT_NB, 1, 128, GPMPC_JOINT_WPE>), g, dim3(128), lds_pad, st, a);      \
-        else if (nrow <= 256 && wide) hipLaunchKernelGGL((joint_kernel<TT, GPMPC_JOINT_WIDE_NB, 1, 256, 2>), g, dim3(256), lds_pad, st, a); \
-        else if (nrow <= 256) hipLaunchKernelGGL((joint_kernel<TT, GPMPC_JOINT_NB, 1, 256, GPMPC_JOINT_WPE>), g, dim3(256), lds_pad, st, a); \
-        else if (nrow <= 512) hipLaunchKernelGGL((joint_kernel<TT, 16, 1, 512, GPMPC_JOINT_WPE>), g, dim3(512), 0, st, a); \
-        else if (nrow <= 1024) hipLaunchKernelGGL((joint_kernel<TT, 16, 1, 1024, 4>), g, dim3(1024), 0, st, a);            \
-        else hipLaunchKernelGGL((joint_kernel<TT, 16, 2, 1024, 4>), g, dim3(1024), 0, st, a);               \
+        if (nrow <= 128) hipLaunchKernelGGL((joint_kernel<TT, GPMPC_JOINT_NB, 1, 128, GPMPC_JOINT_WPE>), g, dim3(128), lds_pad, st, aa);      \
+        else if (nrow <= 256 && wide) hipLaunchKernelGGL((joint_kernel<TT, GPMPC_JOINT_WIDE_NB, 1, 256, 2>), g, dim3(256), lds_pad, st, aa); \
+        else if (nrow <= 256) hipLaunchKernelGGL((joint_kernel<TT, GPMPC_JOINT_NB, 1, 256, GPMPC_JOINT_WPE>), g, dim3(256), lds_pad, st, aa); \
+        else if (nrow <= 512) hipLaunchKernelGGL((joint_kernel<TT, 16, 1, 512, GPMPC_JOINT_WPE>), g, dim3(512), 0, st, aa); \
+        else if (nrow <= 1024) hipLaunchKernelGGL((joint_kernel<TT, 16, 1, 1024, 4>), g, dim3(1024), 0, st, aa);            \
+        else hipLaunchKernelGGL((joint_kernel<TT, 16, 2, 1024, 4>), g, dim3(1024), 0, st, aa);               \
     } while (0)
-    if (gp->T == 1) {
-        GPMPC_JOINT_LAUNCH(1);
-    } else if (gp->T == 3) {
-        GPMPC_JOINT_LAUNCH(3);
-    } else {
-        return fail(GPMPC_E_UNSUPPORTED, "joint: only T = 1 and T = 3 (D = 2) are instantiated");
-    }
+        if (gp->T == 1) GPMPC_JOINT_LAUNCH(1);
+        else GPMPC_JOINT_LAUNCH(3);
 #undef GPMPC_JOINT_LAUNCH
+    };
+    if (gp->T != 1 && gp->T != 3) return fail(GPMPC_E_UNSUPPORTED, "joint: only T = 1 and T = 3 (D = 2) are instantiated");
+    if (joint_use_mfma(a.gp.n_r, n_ho, m, gp->T)) {
+        // The matrix-pipe path: (i) the factor phase extends the factor by the rows of the new hallucinated slots (into the
+        // factor cache), (ii) joint_test_mfma_kernel forms the test rows, the mean and S, (iii) the tail draws.  Without a
+        // caller-owned cache that can take this call's rows the factor rows go to a temporary cache inside the workspace, one
+        // batch of chains at a time.
+        g_joint_last_path = 2;
+        const bool own = a.fcache && n_ho <= a.fc_cap && (a.fc_cap % 2) == 0;
+        JointArgs b = a;
+        if (!own) {
+            b.fcache = (double*)ws + w.tc_off;
+            b.fc_cap = w.tc_rows;
+            b.fc_cs = w.tc_cs;
+            b.fc_stride = w.tc_stride;
+            b.n_c = 0;
+        }
+        const long step = own ? nchains : w.tc_slots;
+        for (long c0 = 0; c0 < nchains; c0 += step) {
+            b.chain0 = c0;
+            b.chain1 = (c0 + step < nchains) ? c0 + step : nchains;
+            b.fc_chain_base = own ? 0 : c0;
+            b.info_in = 0;
+            if (n_ho > b.n_c) {
+                b.phase = JOINT_PHASE_FACTOR;
+                b.abandon_root = 0;
+                launch(b, n_ho - b.n_c);
+                GPMPC_HIP_CHECK(hipGetLastError());
+                b.info_in = 1;
+            }
+            if (int rc = joint_mfma_launch(b, st)) return rc;
+            b.phase = JOINT_PHASE_TAIL;
+            b.abandon_root = abandon_for(mT);
+            launch(b, mT);
+        }
+    } else {
+        g_joint_last_path = 1;
+        const int nrow = n_ho + 1 + mT - a.n_c;        // rows that are computed (the cached ones have no thread)
+        a.abandon_root = abandon_for(nrow);
+        launch(a, nrow);
+    }
     GPMPC_HIP_CHECK(hipGetLastError());
     // eigendecomposition root for the whole batch when a chain failed all jitter retries (or on request); the kernel
     // returns at once when the flag is clear

@@ -1,0 +1,67 @@
+// Kernel arguments shared by the translation units of gpmpc_joint_sample (joint.hip: factor extension, VALU test rows,
+// root + sample; joint_mfma.hip: the test rows on the FP64 matrix pipe).
+#pragma once
+#include "gpmpc_host.hpp"
+
+namespace gpmpc {
+
+// phases of joint_kernel (JointArgs::phase)
+enum : int {
+    JOINT_PHASE_ALL = 0,      // one launch: factor rows, w row, test rows, mean, S, root, sample (the VALU path)
+    JOINT_PHASE_FACTOR = 1,   // the hallucinated rows n_c .. n_ho - 1 of the factor only (into M and the factor cache)
+    JOINT_PHASE_TAIL = 2      // root + sample only: S is in Sall, the mean in `mean` (written by joint_test_mfma_kernel)
+};
+
+struct JointArgs {
+    GpParams gp;
+    const double* plan;
+    const double* X_r;
+    long Ns;
+    int n_h;
+    const double* X_h;
+    const double* Y_h;
+    const int* h_slots;
+    int n_ho;
+    int m;
+    const double* X_s;
+    const double* z;
+    double var_zero_thr, beta;
+    int apply_clip;
+    double* mean;
+    double* var;
+    double* y;
+    double* covar;
+    int* info;
+    double* ws;
+    long ws_chain_stride;   // doubles
+    int ld;                 // rows of M (padded)
+    double* Sall;           // [chains][mT*mT] posterior covariance, column-major, both triangles written
+    int* any_fail;          // set when a chain's jitter chain failed (read by joint_eigh_kernel)
+    // factor cache (caller-owned, persists between calls): per chain the hallucinated rows of the factor, row-major
+    // [rows_cap][fc_cs] (columns: real slots, then hallucinated slots; the diagonal blocks as block_factor left them) and
+    // 1/diag [rows_cap].  The first n_c rows (any count: the column blocks restart at slot n_c) are valid on entry and are
+    // not recomputed.  fc_cs is EVEN and so is rows_cap: every row starts on a 16-byte boundary (joint_test_mfma_kernel
+    // moves 16-byte pieces of the rows straight into LDS).
+    double* fcache;
+    long fc_stride;         // doubles per chain
+    int fc_cs;              // row stride = even(n_r + rows_cap)
+    int fc_cap;             // rows_cap
+    int n_c;
+    long fc_chain_base;     // the cache entry of chain c is fcache + (c - fc_chain_base) * fc_stride (a temporary cache inside
+                            // the workspace holds one batch of chains; the caller's cache all of them: 0)
+    int abandon_root;       // 1 (GPMPC_ROOT_AUTO): the eigh kernel redraws the WHOLE batch once a chain has failed every retry -
+                            // a chain that sees the flag stops its own Cholesky attempts (their result would be overwritten)
+    int phase;              // JOINT_PHASE_*
+    int info_in;            // JOINT_PHASE_TAIL: info[chain] already holds the factor phase's bits (OR into it)
+    long chain0, chain1;    // the chains of this launch: [chain0, chain1)
+};
+
+// joint_mfma.hip ---------------------------------------------------------------------------------------------------------
+// true when joint_test_mfma_kernel is instantiated for these sizes (n_r observed real slots, n_ho hallucinated slots, m test
+// points, T tasks)
+bool joint_mfma_eligible(int n_r, int n_ho, int m, int T);
+// launches joint_test_mfma_kernel for the chains [a.chain0, a.chain1): V^T = L^-1 K_o* (w column included), then
+// mean = V^T w into a.mean and S = K** - V^T V into a.Sall.  Needs a.fcache with every hallucinated row filled.
+int joint_mfma_launch(const JointArgs& a, hipStream_t st);
+
+}  // namespace gpmpc
