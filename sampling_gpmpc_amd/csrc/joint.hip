@@ -426,7 +426,10 @@ __global__ __launch_bounds__(NT, WPE) void joint_kernel(const JointArgs a) {
     const int n_o = n_r + n_ho;
     const int ld = a.ld;
     // JOINT_PHASE_FACTOR: the hallucinated rows only (no w row, no test rows: joint_test_mfma_kernel forms them)
-    const bool ph_factor = a.phase != JOINT_PHASE_TAIL, ph_test = a.phase == JOINT_PHASE_ALL, ph_tail = a.phase != JOINT_PHASE_FACTOR;
+    // JOINT_PHASE_CHOL: the new rows against the new columns only, starting from the Schur complement in Sall
+    const bool ph_chol = a.phase == JOINT_PHASE_CHOL;
+    const bool ph_factor = a.phase != JOINT_PHASE_TAIL, ph_test = a.phase == JOINT_PHASE_ALL,
+               ph_tail = a.phase == JOINT_PHASE_ALL || a.phase == JOINT_PHASE_TAIL;
     const int wrow = n_ho, trow0 = n_ho + 1, nrow = ph_test ? n_ho + 1 + mT : n_ho;
 
     double* M = a.ws + (long)blockIdx.x * a.ws_chain_stride;     // [n_o][ld]   column-major, thread == row
@@ -495,7 +498,7 @@ __global__ __launch_bounds__(NT, WPE) void joint_kernel(const JointArgs a) {
 
         // ---- real columns: M[row, :n_r] = L_rr^-1 k_r(row)  (w row = w_r) ------------------------------------------
         // the same blocked substitution as below, against the plan's factor L_rr (row-major) instead of rows of M
-        if (ph_factor) {
+        if (ph_factor && !ph_chol) {
             const double* Lrr = plan_L(a.plan, gp, o);
             for (int cb = 0; cb < n_r; cb += NB) {
                 const int nb = min(NB, n_r - cb);
@@ -554,7 +557,9 @@ __global__ __launch_bounds__(NT, WPE) void joint_kernel(const JointArgs a) {
         // ---- hallucinated columns, NB at a time -------------------------------------------------------------------
         // (the blocks are NB wide from slot 0 and again from slot n_c: a block never straddles the cached / new boundary,
         // so n_c needs no alignment - the cache holds plain factor entries, any partition can read them)
-        for (int c0 = 0, nb = 0; c0 < n_ho && ph_factor; c0 += nb) {
+        const int koff = ph_chol ? n_r + n_c : 0;                 // JOINT_PHASE_CHOL: the old columns are already eliminated
+        const int n_new = n_ho - n_c;
+        for (int c0 = ph_chol ? n_c : 0, nb = 0; c0 < n_ho && ph_factor; c0 += nb) {
             const bool cached = c0 < n_c;                     // uniform: the block's pivot rows and its factorised diagonal block are in the cache
             nb = min(NB, (cached ? n_c : n_ho) - c0);
             if (tid < NB) {                                   // descriptors of the block's pivot slots, shared by all rows
@@ -581,7 +586,13 @@ __global__ __launch_bounds__(NT, WPE) void joint_kernel(const JointArgs a) {
                 const int row = rb + tid + rs * nt;
 #pragma unroll
                 for (int q = 0; q < NB; ++q) acc[rs][q] = 0.0;
-                if (row >= max(c0, n_c) && row < nrow) {
+                if (ph_chol) {
+                    if (row >= c0 && row < nrow) {
+#pragma unroll
+                        for (int q = 0; q < NB; ++q)
+                            if (q < nb) acc[rs][q] = Sm[(long)(c0 + q - n_c) * n_new + (row - n_c)];
+                    }
+                } else if (row >= max(c0, n_c) && row < nrow) {
                     if (row == wrow) {
 #pragma unroll
                         for (int q = 0; q < NB; ++q)
@@ -604,7 +615,8 @@ __global__ __launch_bounds__(NT, WPE) void joint_kernel(const JointArgs a) {
                 }
             }
             JPH(1);
-            block_update<NB, RPT, KC, NT>(M + rb, ld, n_r + c0, cached ? fc + (long)c0 * CS : M + c0, cached ? CS : 1,
+            block_update<NB, RPT, KC, NT>(M + rb + (long)koff * ld, ld, n_r + c0 - koff,
+                                          cached ? fc + (long)c0 * CS : M + c0 + (long)koff * ld, cached ? CS : 1,
                                           cached ? 1 : ld, nb, cached ? 0 : c0 - rb, nrow - rb, acc, piv);
             __syncthreads();
             JPH(2);
@@ -991,7 +1003,7 @@ static int joint_mfma_from() {
 static int g_joint_path_pin = 0;          // gpmpc_joint_pin_path: 0 auto, 1 VALU path, 2 matrix-pipe path where instantiated
 static int g_joint_last_path = 0;
 static bool joint_use_mfma(int n_r, int n_ho, int m, int T) {
-    if (!joint_mfma_eligible(n_r, n_ho, m, T)) return false;
+    if (n_ho < 1 || !joint_mfma_eligible(n_r, n_ho, m * T + 1, T)) return false;
     if (g_joint_path_pin == 1) return false;
     if (g_joint_path_pin == 2) return true;
     const int from = joint_mfma_from();
@@ -1018,7 +1030,7 @@ static JointWs joint_ws_layout(int n_r, int n_ho, int m, int T, long nchains) {
     w.total = w.f_off + 32;
     w.tc_off = w.tc_slots = w.tc_stride = 0;
     w.tc_rows = w.tc_cs = 0;
-    if (joint_mfma_eligible(n_r, n_ho, m, T)) {       // (pin-independent: the workspace serves either path)
+    if (n_ho >= 1 && joint_mfma_eligible(n_r, n_ho, m * (int)T + 1, T)) {       // (pin-independent: the workspace serves either path)
         w.tc_rows = (n_ho + 1) & ~1;
         w.tc_cs = fc_row_stride(n_r, w.tc_rows);
         w.tc_stride = (long)w.tc_rows * (w.tc_cs + 1);
@@ -1151,6 +1163,7 @@ int gpmpc_joint_sample(const gpmpc_gp_desc_t* gp, const void* plan, const double
     a.info_in = 0;
     a.chain0 = 0;
     a.chain1 = Ns * gp->g_ny;
+    a.mfma_mode = JOINT_MFMA_TEST;
     hipStream_t st = (hipStream_t)stream;
     GPMPC_HIP_CHECK(hipMemsetAsync(a.any_fail, 0, sizeof(int), st));
     const long nchains = Ns * gp->g_ny;
@@ -1194,10 +1207,12 @@ int gpmpc_joint_sample(const gpmpc_gp_desc_t* gp, const void* plan, const double
     };
     if (gp->T != 1 && gp->T != 3) return fail(GPMPC_E_UNSUPPORTED, "joint: only T = 1 and T = 3 (D = 2) are instantiated");
     if (joint_use_mfma(a.gp.n_r, n_ho, m, gp->T)) {
-        // The matrix-pipe path: (i) the factor phase extends the factor by the rows of the new hallucinated slots (into the
-        // factor cache), (ii) joint_test_mfma_kernel forms the test rows, the mean and S, (iii) the tail draws.  Without a
-        // caller-owned cache that can take this call's rows the factor rows go to a temporary cache inside the workspace, one
-        // batch of chains at a time.
+        // The matrix-pipe path: (i) the factor is extended by the rows of the new hallucinated slots - their entries against the
+        // old columns and the Schur complement on the matrix pipe (joint_test_mfma_kernel, JOINT_MFMA_FACTOR), the Schur
+        // complement's blocked Cholesky by joint_kernel (JOINT_PHASE_CHOL); where that is not instantiated (more than 128 new
+        // rows, or more new rows than test slots) joint_kernel's factor phase forms the rows on the vector pipe -, (ii)
+        // joint_test_mfma_kernel forms the test rows, the mean and S, (iii) the tail draws.  Without a caller-owned cache that
+        // can take this call's rows the factor rows go to a temporary cache inside the workspace, one batch of chains at a time.
         g_joint_last_path = 2;
         const bool own = a.fcache && n_ho <= a.fc_cap && (a.fc_cap % 2) == 0;
         JointArgs b = a;
@@ -1208,19 +1223,30 @@ int gpmpc_joint_sample(const gpmpc_gp_desc_t* gp, const void* plan, const double
             b.fc_stride = w.tc_stride;
             b.n_c = 0;
         }
+        const int n_new = n_ho - b.n_c;
+        static const char* fenv = getenv("GPMPC_JOINT_MFMA_FACTOR");      // 0: the factor phase stays on the vector pipe
+        const bool mfma_factor = n_new > 0 && n_new <= mT && joint_mfma_eligible(a.gp.n_r, b.n_c, n_new, gp->T) &&
+                                 !(fenv && atoi(fenv) == 0);
         const long step = own ? nchains : w.tc_slots;
         for (long c0 = 0; c0 < nchains; c0 += step) {
             b.chain0 = c0;
             b.chain1 = (c0 + step < nchains) ? c0 + step : nchains;
             b.fc_chain_base = own ? 0 : c0;
             b.info_in = 0;
-            if (n_ho > b.n_c) {
-                b.phase = JOINT_PHASE_FACTOR;
-                b.abandon_root = 0;
-                launch(b, n_ho - b.n_c);
+            b.abandon_root = 0;
+            if (n_new > 0) {
+                if (mfma_factor) {
+                    b.mfma_mode = JOINT_MFMA_FACTOR;
+                    if (int rc = joint_mfma_launch(b, st)) return rc;
+                    b.phase = JOINT_PHASE_CHOL;
+                } else {
+                    b.phase = JOINT_PHASE_FACTOR;
+                }
+                launch(b, n_new);
                 GPMPC_HIP_CHECK(hipGetLastError());
                 b.info_in = 1;
             }
+            b.mfma_mode = JOINT_MFMA_TEST;
             if (int rc = joint_mfma_launch(b, st)) return rc;
             b.phase = JOINT_PHASE_TAIL;
             b.abandon_root = abandon_for(mT);

@@ -9,8 +9,12 @@ namespace gpmpc {
 enum : int {
     JOINT_PHASE_ALL = 0,      // one launch: factor rows, w row, test rows, mean, S, root, sample (the VALU path)
     JOINT_PHASE_FACTOR = 1,   // the hallucinated rows n_c .. n_ho - 1 of the factor only (into M and the factor cache)
-    JOINT_PHASE_TAIL = 2      // root + sample only: S is in Sall, the mean in `mean` (written by joint_test_mfma_kernel)
+    JOINT_PHASE_TAIL = 2,     // root + sample only: S is in Sall, the mean in `mean` (written by joint_test_mfma_kernel)
+    JOINT_PHASE_CHOL = 3      // the new hallucinated rows against the NEW columns only: blocked Cholesky of the Schur complement
+                              // joint_test_mfma_kernel (JOINT_MFMA_FACTOR) left in Sall (leading dimension n_ho - n_c); the rows'
+                              // entries against the old columns are already in the cache
 };
+enum : int { JOINT_MFMA_TEST = 0, JOINT_MFMA_FACTOR = 1 };
 
 struct JointArgs {
     GpParams gp;
@@ -54,12 +58,13 @@ struct JointArgs {
     int phase;              // JOINT_PHASE_*
     int info_in;            // JOINT_PHASE_TAIL: info[chain] already holds the factor phase's bits (OR into it)
     long chain0, chain1;    // the chains of this launch: [chain0, chain1)
+    int mfma_mode;          // joint_test_mfma_kernel: JOINT_MFMA_TEST / JOINT_MFMA_FACTOR
 };
 
 // joint_mfma.hip ---------------------------------------------------------------------------------------------------------
-// true when joint_test_mfma_kernel is instantiated for these sizes (n_r observed real slots, n_ho hallucinated slots, m test
-// points, T tasks)
-bool joint_mfma_eligible(int n_r, int n_ho, int m, int T);
+// true when joint_test_mfma_kernel is instantiated for these sizes: n_r observed real slots + n_hc hallucinated slots to condition
+// on, ncols columns (test mode: m T + 1; factor mode: the new hallucinated rows), T tasks
+bool joint_mfma_eligible(int n_r, int n_hc, int ncols, int T);
 // launches joint_test_mfma_kernel for the chains [a.chain0, a.chain1): V^T = L^-1 K_o* (w column included), then
 // mean = V^T w into a.mean and S = K** - V^T V into a.Sall.  Needs a.fcache with every hallucinated row filled.
 int joint_mfma_launch(const JointArgs& a, hipStream_t st);

@@ -85,3 +85,8 @@ for it in range(iters):
           f"  info {int(a[4].max())}/{int(b[4].max())} finite {bool(torch.isfinite(b[3]).all())}"
           + (f"  ms {a[6]:.3f} / {b[6]:.3f}" if a[6] is not None else ""), flush=True)
 print("worst mean/cov rel diff", worst)
+if os.environ.get("GPMPC_PHASE_TIMERS") == "1":
+    import ctypes as C
+    out = (C.c_longlong * 8)()
+    lib.gpmpc_debug_read_joint_mfma_phases(out)
+    print("joint_test_mfma_kernel phases (cycles, wave 0 of block 0, last launch): prologue %d entries %d solve %d gram %d" % tuple(out[:4]))
