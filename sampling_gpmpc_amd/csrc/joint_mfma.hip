@@ -51,17 +51,20 @@ constexpr int JM_THREADS = JM_NW * 64;
 constexpr int JM_KCH = 32;                        // conditioning slots per kernel-entry chunk
 constexpr int JM_COLS = JM_NCT * 16;
 
-constexpr int JM_SMEM_DOUBLES = JM_NT * 256 + JM_RING * 256 + JM_RT * 256 + 64 + JM_NT * 16 * 2 + JM_COLS * 2;
-constexpr int JM_SMEM_SHORTS = (JM_NT * 16 + 8) + (JM_NTD + 7) + 32 + 32 + (JM_COLS + 8) + (JM_NT * 16 + JM_COLS) / 2 + 2 * (4 * JM_NW + 4);
+constexpr int JM_STASH = 4;                       // tiles 22..25 of every wave go to LDS before the Gram phase (32 registers come free)
+constexpr int JM_SMEM_DOUBLES = JM_NT * 256 + (JM_NW * JM_STASH - JM_NT) * 256 + JM_RING * 256 + JM_RT * 256 + 64 + JM_NT * 16 * 2 + JM_COLS * 2 + JM_NT * 16;
+constexpr int JM_SMEM_SHORTS = (JM_NT * 16 + 8) + (JM_NTD + 7) + 32 + 32 + (JM_COLS + 8) + (JM_NT * 16 + 2 * JM_COLS) / 2 + 2 * (4 * JM_NW + 4);
 constexpr size_t JM_SMEM_BYTES = (size_t)JM_SMEM_DOUBLES * 8 + (size_t)JM_SMEM_SHORTS * 2 + 64;
 
-__device__ __attribute__((aligned(16))) double g_jm_zero[2] = {0.0, 0.0};
-__device__ long long g_jm_phase[8];
+__device__ __attribute__((aligned(16))) double g_jm_zero[4] = {0.0, 0.0, 0.0, 0.0};
+__device__ long long g_jm_phase[20];
 
 #ifdef GPMPC_PHASE_TIMERS
 #define JMPH(idx) do { const long long _n = __builtin_readcyclecounter(); jph[idx] += _n - jt; jt = _n; } while (0)
+#define JMPHS(idx) do { const long long _n = __builtin_readcyclecounter(); jphs[idx] += _n - jts; jts = _n; } while (0)
 #else
 #define JMPH(idx)
+#define JMPHS(idx)
 #endif
 
 __device__ __forceinline__ int jm_pi(int i) { return 4 * (i & 3) + (i >> 2); }
@@ -78,28 +81,37 @@ __device__ __forceinline__ jm_d4 jm_mfma(double a, double b, jm_d4 c) { return _
 // whatever hipcc schedules behind the statement may read the tile).
 #include "joint_mfma_gen.inc"
 
+// the lane id, formed HERE (volatile: hipcc neither hoists it out of a loop nor keeps - i.e. spills - an earlier copy)
+__device__ __forceinline__ int jm_lane_now() {
+    int ln;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(ln));
+    return ln;
+}
+
 __device__ __forceinline__ void jm_glds16(const double* src, double* lds_dst) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                      (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
 }
 
-// nd accumulators += a * b[.] (Gram products: independent chains back to back; the accumulators are read again as SrcC of the same
-// opcode only - no trailing wait states; jm_settle() stands in front of their first other reader)
-__device__ __forceinline__ void jm_gram_fma3(jm_d4& s0, jm_d4& s1, jm_d4& s2, double an, double b0, double b1, double b2) {
-    asm("s_nop 1\n\t"
-        "v_mfma_f64_16x16x4_f64 %0, %3, %4, %0\n\t"
-        "v_mfma_f64_16x16x4_f64 %1, %3, %5, %1\n\t"
-        "v_mfma_f64_16x16x4_f64 %2, %3, %6, %2"
-        : "+v"(s0), "+v"(s1), "+v"(s2)
-        : "v"(an), "v"(b0), "v"(b1), "v"(b2));
+// kern_entry (gpmpc_device.hpp) with per-LANE tasks: selects instead of q[a - 1] / inv_l2[a - 1] - a register array indexed by
+// a lane-dependent value lives in scratch memory (the entries and the Gram tiles spent most of their time in scratch loads)
+__device__ __forceinline__ double jm_kern_entry(double q0, double q1, double k, double il0, double il1, int a, int b) {
+    const double qa = (a == 1) ? q0 : q1, qb = (b == 1) ? q0 : q1;
+    if (a == 0) return (b == 0) ? k : k * qb;
+    if (b == 0) return -k * qa;
+    double v = -qa * qb;
+    if (a == b) v += (a == 1) ? il0 : il1;
+    return k * v;
 }
-__device__ __forceinline__ void jm_gram_fma2(jm_d4& s0, jm_d4& s1, double an, double b0, double b1) {
-    asm("s_nop 1\n\t"
-        "v_mfma_f64_16x16x4_f64 %0, %2, %3, %0\n\t"
-        "v_mfma_f64_16x16x4_f64 %1, %2, %4, %1"
-        : "+v"(s0), "+v"(s1)
-        : "v"(an), "v"(b0), "v"(b1));
+// exp(x), x <= 0 (one shared, small implementation: the library exp is inlined at every call site)
+__device__ __forceinline__ double jm_exp_neg(double x) {
+    const double xa[1] = {x};
+    double e[1];
+    expn_neg<1>(xa, e);
+    return e[0];
 }
+// (the Gram accumulators are read again as SrcC of the same opcode only - no wait states between the products; jm_settle() stands
+// in front of their first other reader)
 __device__ __forceinline__ void jm_settle(jm_d4& s0) {      // 18 wait states behind the MFMA that wrote s0 (store / VALU readers follow)
     asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 1" : "+v"(s0));
 }
@@ -113,24 +125,26 @@ template <int T>
 __global__ __launch_bounds__(JM_THREADS) void joint_test_mfma_kernel(const JointArgs a) {
     constexpr int D = 2;
     extern __shared__ __attribute__((aligned(16))) double jm_smem[];
-    double* linv = jm_smem;                       // [JM_NT][256]  inverted diagonal tiles, tile format
-    double* ring = linv + JM_NT * 256;            // [JM_RING][256] streamed tiles; second half = kernel-entry buffer; all = Gram exchange
+    double* linv = jm_smem;                       // [JM_NT][256]  inverted diagonal tiles, tile format; + 6 tiles: [JM_NW][JM_STASH][256] stash (Gram phase)
+    double* ring = linv + JM_NW * JM_STASH * 256;            // [JM_RING][256] streamed tiles; second half = kernel-entry buffer; all = Gram exchange
     double* realt = ring + JM_RING * 256;         // [JM_RT][256]  off-diagonal tiles with real rows
     double* yr = realt + JM_RT * 256;             // [64] L_rr w_r: the right-hand side that reproduces w_r on the real slots
     double* rptx = yr + 64;                       // [JM_NT * 16][2] input point of every slot run
     double* cptx = rptx + JM_NT * 16 * 2;         // [JM_COLS][2] input point of every column run
-    short* run_start = reinterpret_cast<short*>(cptx + JM_COLS * 2);     // [JM_NT * 16 + 8] first slot of every conditioning point's run
+    double* ylab = cptx + JM_COLS * 2;            // [JM_NT * 16] label of every hallucinated slot (test mode: the label column's entries)
+    short* run_start = reinterpret_cast<short*>(ylab + JM_NT * 16);     // [JM_NT * 16 + 8] first slot of every conditioning point's run
     unsigned short* stab = reinterpret_cast<unsigned short*>(run_start + JM_NT * 16 + 8);  // [JM_NTD + 7] streamed tile -> (k << 8) | j
     short* first_run = reinterpret_cast<short*>(stab + JM_NTD + 7);  // [32] run that contains slot 32 c
     short* starts_before = first_run + 32;                           // [32] runs that start before slot 32 c
     short* crun_start = starts_before + 32;                          // [JM_COLS + 8] first column of every column run
     signed char* stask = reinterpret_cast<signed char*>(crun_start + JM_COLS + 8);   // [JM_NT * 16] task of every slot
     signed char* ctask = stask + JM_NT * 16;                         // [JM_COLS] task of every column (-1: the label column)
-    int* wtot = reinterpret_cast<int*>(ctask + JM_COLS);             // [4][JM_NW]
+    unsigned char* crun_of = reinterpret_cast<unsigned char*>(ctask + JM_COLS);     // [JM_COLS] column run of every column
+    int* wtot = reinterpret_cast<int*>(crun_of + JM_COLS);           // [4][JM_NW]
     double* kbuf = ring + JM_CH * 256;            // [JM_KCH][JM_COLS]
 
     const GpParams& gp = a.gp;
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);       // (wv: an SGPR)
     const bool fmode = a.mfma_mode == JOINT_MFMA_FACTOR;
     const int n_r = gp.n_r, Tr = gp.real_has_grad ? T : 1;
     const int m = a.m, mT = m * T;
@@ -156,9 +170,12 @@ __global__ __launch_bounds__(JM_THREADS) void joint_test_mfma_kernel(const Joint
 #pragma unroll
     for (int d = 0; d < D; ++d) il2[d] = gp.inv_l2[o][d];
     const double os = gp.os[o];
+    const double noise0 = gp.noise[0], noise1 = gp.noise[T > 1 ? 1 : 0], noise2 = gp.noise[T > 2 ? 2 : 0];
 #ifdef GPMPC_PHASE_TIMERS
     long long jph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    long long jphs[3] = {0, 0, 0};                // inside the substitution: diagonal steps, hand-overs + first tiles, runs
     long long jt = __builtin_readcyclecounter();
+    long long jts = jt;
 #endif
 
     auto Lel = [&](int r, int c) -> double {      // factor entry (r, c), c <= r < n_o
@@ -180,49 +197,83 @@ __global__ __launch_bounds__(JM_THREADS) void joint_test_mfma_kernel(const Joint
     }
     __syncthreads();
 
-    // chunk c of the stream -> ring slots (c & 1) * 16 ..: wave w moves tiles 2 w, 2 w + 1 of the chunk
+    // chunk c of the stream -> ring slots (c & 1) * 16 ..: wave w moves tiles 2 w, 2 w + 1 of the chunk.  Lane (i, kk) names the 16-byte
+    // pieces (h, kk, i) of a tile: row 16 k + pi(i), columns 16 j + 4 kk + 2 h (+ 1).  Everything lane-dependent is formed ONCE (two
+    // registers); a tile adds a uniform offset.  (The first version formed the address per tile from spilled values: the reload's
+    // s_waitcnt vmcnt(0) stood right behind the first tile's loads and waited for them - 5 k cycles per hand-over.)
     auto issue_chunk = [&](int c) {
+        // (the lane-dependent part is RE-formed at every call from the lane id - six VALU instructions; kept in registers across the
+        // substitution, where 16 VGPRs are free, hipcc spills it and the reload is a round trip to scratch memory per hand-over)
+        const int ln = jm_lane_now();
+        const int dma_row = jm_pi(ln & 15);                     // row of the tile this lane reads
+        const double* dma_lane = fc + (long)(dma_row - n_r) * CS + 4 * (ln >> 4);
 #pragma unroll
         for (int u = 0; u < JM_CH / JM_NW; ++u) {
             const int q = c * JM_CH + wv * (JM_CH / JM_NW) + u;
-            if (q < ntd) {
+            if (q < ntd) {                        // (uniform)
                 const int kj = __builtin_amdgcn_readfirstlane((int)stab[q]);
                 const int k = kj >> 8, j = kj & 255;
-                const int r = 16 * k + jm_pi(lane & 15);
-                const bool ok = r < n_o;
-                const double* src = ok ? fc + (long)(r - n_r) * CS + 16 * j + 4 * (lane >> 4) : g_jm_zero;
-                double* dst = ring + (q & (JM_RING - 1)) * 256;
+                const long off = __builtin_amdgcn_readfirstlane(16 * k) * (long)CS + __builtin_amdgcn_readfirstlane(16 * j);
+                const double* src = (16 * k + dma_row < n_o) ? dma_lane + off : g_jm_zero;
+                double* dst = ring + __builtin_amdgcn_readfirstlane(q & (JM_RING - 1)) * 256;
                 jm_glds16(src, dst);
-                jm_glds16(ok ? src + 2 : g_jm_zero, dst + 128);
+                jm_glds16(src + 2, dst + 128);
             }
         }
     };
     issue_chunk(0);
 
     // ---- prologue: diagonal tiles (raw, row-major) into `linv`, real-row tiles, L_rr w_r, slot and column descriptors ---------
-    for (int e = tid; e < nt * 256; e += JM_THREADS) {
-        const int tj = e >> 8, i = (e >> 4) & 15, c = e & 15;
-        const int r = 16 * tj + i;
-        double v;
-        if (r < n_o) v = (c <= i) ? Lel(r, 16 * tj + c) : 0.0;
-        else v = (c == i) ? 1.0 : 0.0;
-        linv[e] = v;
+    // (every loop below has a compile-time trip count: its global loads are all in flight together - with run-time bounds hipcc
+    // waits for each load before it issues the next, and the prologue was ~25 serial round trips to L2 / HBM)
+    {
+        double v[JM_NT * 256 / JM_THREADS];
+#pragma unroll
+        for (int it = 0; it < JM_NT * 256 / JM_THREADS; ++it) {
+            const int e = tid + it * JM_THREADS;
+            const int tj = e >> 8, i = (e >> 4) & 15, c = e & 15;
+            const int r = 16 * tj + i;
+            v[it] = (c == i) ? 1.0 : 0.0;
+            if (r < n_o) v[it] = (c <= i) ? Lel(r, 16 * tj + c) : 0.0;
+        }
+#pragma unroll
+        for (int it = 0; it < JM_NT * 256 / JM_THREADS; ++it) {
+            const int e = tid + it * JM_THREADS;
+            if (e < nt * 256) linv[e] = v[it];
+        }
     }
     {
         const int nrt = kmin * (kmin - 1) / 2;
-        for (int e = tid; e < nrt * 256; e += JM_THREADS) {
+        double v[JM_RT * 256 / JM_THREADS];
+#pragma unroll
+        for (int it = 0; it < JM_RT * 256 / JM_THREADS; ++it) {
+            const int e = tid + it * JM_THREADS;
             const int ti = e >> 8, i = (e >> 4) & 15, c = e & 15;
             const int k = (ti < 1) ? 1 : ((ti < 3) ? 2 : 3);
             const int j = ti - k * (k - 1) / 2;
             const int r = 16 * k + i;
-            realt[ti * 256 + jm_off(i, c)] = (r < n_o) ? Lel(r, 16 * j + c) : 0.0;
+            v[it] = (e < nrt * 256 && r < n_o) ? Lel(r, 16 * j + c) : 0.0;
+        }
+#pragma unroll
+        for (int it = 0; it < JM_RT * 256 / JM_THREADS; ++it) {
+            const int e = tid + it * JM_THREADS;
+            const int ti = e >> 8, i = (e >> 4) & 15, c = e & 15;
+            if (e < nrt * 256) realt[ti * 256 + jm_off(i, c)] = v[it];
         }
     }
     if (!fmode) {                                 // y' = L_rr w_r, eight lanes per row
         const int row = tid >> 3, part = tid & 7;
         double acc = 0.0;
-        if (row < n_r)
-            for (int c = part; c <= row; c += 8) acc = fma(Lrr[(long)row * n_r + c], w_r[c], acc);
+        double lv[8], wv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int c = part + 8 * u;
+            const bool ok = row < n_r && c <= row;
+            lv[u] = ok ? Lrr[(long)row * n_r + c] : 0.0;
+            wv[u] = ok ? w_r[c] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc = fma(lv[u], wv[u], acc);
         acc += __shfl_xor(acc, 1, 64);
         acc += __shfl_xor(acc, 2, 64);
         acc += __shfl_xor(acc, 4, 64);
@@ -260,8 +311,12 @@ __global__ __launch_bounds__(JM_THREADS) void joint_test_mfma_kernel(const Joint
             if (idx < lim) {
                 pt[r] = (r < 2) ? slot_point(idx, task) : col_point(idx, task);
                 flag[r] = idx == 0 || pt[r] != ((r < 2) ? slot_point(idx - 1, tprev) : col_point(idx - 1, tprev));
-                if (r < 2) stask[idx] = (signed char)task;
-                else ctask[idx] = (signed char)task;
+                if (r < 2) {
+                    stask[idx] = (signed char)task;
+                    if (!fmode && idx >= n_r) ylab[idx] = Yh[a.h_slots[idx - n_r]];
+                } else {
+                    ctask[idx] = (signed char)task;
+                }
             }
             const unsigned long long bal = __ballot(flag[r]);
             excl_w[r] = __popcll(bal & ((1ull << lane) - 1ull));
@@ -291,6 +346,7 @@ __global__ __launch_bounds__(JM_THREADS) void joint_test_mfma_kernel(const Joint
                 first_run[sl / JM_KCH] = (short)(flag[r] ? excl : excl - 1);
             }
         }
+        if (tid < ncols) crun_of[tid] = (unsigned char)(off[2] + excl_w[2] - (flag[2] ? 0 : 1));
         if (flag[2]) {
             const int excl = off[2] + excl_w[2];
             crun_start[excl] = (short)tid;
@@ -325,6 +381,7 @@ __global__ __launch_bounds__(JM_THREADS) void joint_test_mfma_kernel(const Joint
             for (int p = 0; p < i; ++p) sacc = fma(Lt[i * 16 + p], x[p], sacc);
             const double ri = __shfl(rc, (lane & 48) | i, 64);
             x[i] = (i < c) ? 0.0 : ((i == c) ? ri : -sacc * ri);
+            asm volatile("" : "+v"(x[i]) : : "memory");      // row i's reads stay in row i (hoisted, the 120 LDS reads of a tile spill)
         }
         // every lane of the wave has read its tiles (they are this wave's alone): overwrite them in the tile format
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -342,15 +399,41 @@ __global__ __launch_bounds__(JM_THREADS) void joint_test_mfma_kernel(const Joint
         kbuf[row * JM_COLS + col] = 0.0;
     }
     __syncthreads();
+    // K_cc, the starting value of the Gram accumulators (test mode: K**; factor mode: K_nn + noise), goes to the chain's S buffer
+    // NOW, while registers are free: one lane per pair of column runs (one exponential for up to T x T entries), the lower
+    // triangle and its mirror from the same value.  The Gram phase - 208 registers of every lane hold X by then - only loads it.
+    {
+        const int ldK = fmode ? ncols : mT;
+        double* Kc = a.Sall + chain * (long)mT * mT;
+        const int nrun = fmode ? ncr : ncr - 1;   // (test mode: the last run is the label column)
+        for (int e = tid; e < nrun * nrun; e += JM_THREADS) {
+            const int ra = e / nrun, rb = e - ra * nrun;
+            if (rb > ra) continue;
+            const int a0 = crun_start[ra], a1 = crun_start[ra + 1], b0 = crun_start[rb], b1 = crun_start[rb + 1];
+            const double xa[D] = {cptx[2 * ra], cptx[2 * ra + 1]}, xb[D] = {cptx[2 * rb], cptx[2 * rb + 1]};
+            double qq[D];
+            const double kv = os * jm_exp_neg(-0.5 * kern_sqdist<D>(xa, xb, il2, qq));
+            for (int t1 = a0; t1 < a1; ++t1) {
+                const int ta = ctask[t1];
+                for (int t2 = b0; t2 < b1; ++t2) {
+                    if (t2 > t1) continue;
+                    double val = jm_kern_entry(qq[0], qq[1], kv, il2[0], il2[1], ta, ctask[t2]);
+                    if (fmode && t1 == t2) val += (ta == 0) ? noise0 : ((ta == 1) ? noise1 : noise2);
+                    Kc[(long)t1 * ldK + t2] = val;
+                    if (t1 != t2) Kc[(long)t2 * ldK + t1] = val;
+                }
+            }
+        }
+    }
     JMPH(0);
 
     // ---- kernel entries K_o* (and the label column) into the accumulators, JM_KCH slots at a time: one lane per (slot run,
     // column run) pair = one exponential for up to T x T entries -------------------------------------------------------------
     JmAcc A;
-    A.g0 = A.g1 = A.g2 = A.g3 = A.g4 = A.g5 = jm_d16(0.0);
-    A.g6 = jm_d8(0.0);
+    jm_acc_begin_a(A);                            // (the tiles' registers are taken from here on, not before: every tile that is read is set below)
+    constexpr int JM_CHUNKS_A = 10;
     const unsigned ncr_magic = 0xFFFFFFFFu / (unsigned)ncr + 1u;      // e / ncr = umulhi(e, magic) for e < 65536
-    for (int ch = 0; 2 * ch < nt; ++ch) {         // (a run-time loop: no C++ branch ever surrounds a statement that writes A)
+    for (int ch = 0; 2 * ch < nt && ch < JM_CHUNKS_A; ++ch) {     // tiles 0..19: the statements name those only - the other six are not live yet         // (a run-time loop: no C++ branch ever surrounds a statement that writes A)
         const int s0 = ch * JM_KCH;
         const int r0 = first_run[ch];
         const int r1 = starts_before[min(ch + 1, (n_o + JM_KCH - 1) / JM_KCH)];
@@ -364,14 +447,24 @@ __global__ __launch_bounds__(JM_THREADS) void joint_test_mfma_kernel(const Joint
                 const double xc[D] = {rptx[2 * (r0 + rr)], rptx[2 * (r0 + rr) + 1]};
                 const double xt[D] = {cptx[2 * cr], cptx[2 * cr + 1]};
                 double qq[D];
-                const double k = kern_scalar<D>(xc, xt, il2, os, qq);                     // r = x_slot - x_column
-                for (int sl = sl0; sl < sl1; ++sl) {
-                    const int ta = stask[sl];
-                    for (int c = ca; c < cb; ++c) kbuf[(sl - s0) * JM_COLS + c] = kern_entry<D>(qq, k, il2, ta, ctask[c]);
+                const double k = os * jm_exp_neg(-0.5 * kern_sqdist<D>(xc, xt, il2, qq)); // r = x_slot - x_column
+                if (T == 3 && sl1 - sl0 == 3 && sb - sa == 3 && cb - ca == 3) {
+                    // a whole point against a whole point (value + two derivatives each way): the 3 x 3 block at once - no task
+                    // look-ups, no branches (the general form below costs ten dependent LDS round trips per pair)
+                    const double kq0 = k * qq[0], kq1 = k * qq[1];
+                    double* row = kbuf + (sl0 - s0) * JM_COLS + ca;
+                    row[0] = k, row[1] = kq0, row[2] = kq1;
+                    row[JM_COLS] = -kq0, row[JM_COLS + 1] = k * (il2[0] - qq[0] * qq[0]), row[JM_COLS + 2] = -kq0 * qq[1];
+                    row[2 * JM_COLS] = -kq1, row[2 * JM_COLS + 1] = -kq1 * qq[0], row[2 * JM_COLS + 2] = k * (il2[1] - qq[1] * qq[1]);
+                } else {
+                    for (int sl = sl0; sl < sl1; ++sl) {
+                        const int ta = stask[sl];
+                        for (int c = ca; c < cb; ++c) kbuf[(sl - s0) * JM_COLS + c] = jm_kern_entry(qq[0], qq[1], k, il2[0], il2[1], ta, ctask[c]);
+                    }
                 }
             } else {                                                                      // the label column
                 for (int sl = sl0; sl < sl1; ++sl)
-                    kbuf[(sl - s0) * JM_COLS + ca] = (sl < n_r) ? yr[sl] : Yh[a.h_slots[sl - n_r]];
+                    kbuf[(sl - s0) * JM_COLS + ca] = (sl < n_r) ? yr[sl] : ylab[sl];
             }
         }
         if (n_o < s0 + JM_KCH) {                                                          // pad slots: zero rows
@@ -379,7 +472,56 @@ __global__ __launch_bounds__(JM_THREADS) void joint_test_mfma_kernel(const Joint
             for (int e = z0 + tid; e < JM_KCH * JM_COLS; e += JM_THREADS) kbuf[e] = 0.0;
         }
         __syncthreads();
+#pragma unroll 1
+        for (int u = 0; u < 2; ++u) {             // (tile 2 ch + 1 may lie beyond nt: it is written - with the buffer's stale rows - and never used)
+            double t[4];
 #pragma unroll
+            for (int v = 0; v < 4; ++v) t[v] = kbuf[(16 * u + 4 * (lane >> 4) + v) * JM_COLS + 16 * I0 + (lane & 15)];
+            jm_acc_set_a(A, 2 * ch + u, t[0], t[1], t[2], t[3]);
+        }
+        __syncthreads();
+    }
+    jm_acc_begin_b(A);
+    for (int ch = JM_CHUNKS_A; 2 * ch < nt; ++ch) {         // (a run-time loop: no C++ branch ever surrounds a statement that writes A)
+        const int s0 = ch * JM_KCH;
+        const int r0 = first_run[ch];
+        const int r1 = starts_before[min(ch + 1, (n_o + JM_KCH - 1) / JM_KCH)];
+        const int npairs = (r1 - r0) * ncr;
+        for (int e = tid; e < npairs; e += JM_THREADS) {
+            const int rr = (int)__umulhi((unsigned)e, ncr_magic), cr = e - rr * ncr;
+            const int sa = run_start[r0 + rr], sb = run_start[r0 + rr + 1];
+            const int ca = crun_start[cr], cb = crun_start[cr + 1];
+            const int sl0 = max(sa, s0), sl1 = min(sb, s0 + JM_KCH);
+            if (ctask[ca] >= 0) {
+                const double xc[D] = {rptx[2 * (r0 + rr)], rptx[2 * (r0 + rr) + 1]};
+                const double xt[D] = {cptx[2 * cr], cptx[2 * cr + 1]};
+                double qq[D];
+                const double k = os * jm_exp_neg(-0.5 * kern_sqdist<D>(xc, xt, il2, qq)); // r = x_slot - x_column
+                if (T == 3 && sl1 - sl0 == 3 && sb - sa == 3 && cb - ca == 3) {
+                    // a whole point against a whole point (value + two derivatives each way): the 3 x 3 block at once - no task
+                    // look-ups, no branches (the general form below costs ten dependent LDS round trips per pair)
+                    const double kq0 = k * qq[0], kq1 = k * qq[1];
+                    double* row = kbuf + (sl0 - s0) * JM_COLS + ca;
+                    row[0] = k, row[1] = kq0, row[2] = kq1;
+                    row[JM_COLS] = -kq0, row[JM_COLS + 1] = k * (il2[0] - qq[0] * qq[0]), row[JM_COLS + 2] = -kq0 * qq[1];
+                    row[2 * JM_COLS] = -kq1, row[2 * JM_COLS + 1] = -kq1 * qq[0], row[2 * JM_COLS + 2] = k * (il2[1] - qq[1] * qq[1]);
+                } else {
+                    for (int sl = sl0; sl < sl1; ++sl) {
+                        const int ta = stask[sl];
+                        for (int c = ca; c < cb; ++c) kbuf[(sl - s0) * JM_COLS + c] = jm_kern_entry(qq[0], qq[1], k, il2[0], il2[1], ta, ctask[c]);
+                    }
+                }
+            } else {                                                                      // the label column
+                for (int sl = sl0; sl < sl1; ++sl)
+                    kbuf[(sl - s0) * JM_COLS + ca] = (sl < n_r) ? yr[sl] : ylab[sl];
+            }
+        }
+        if (n_o < s0 + JM_KCH) {                                                          // pad slots: zero rows
+            const int z0 = (n_o - s0) * JM_COLS;
+            for (int e = z0 + tid; e < JM_KCH * JM_COLS; e += JM_THREADS) kbuf[e] = 0.0;
+        }
+        __syncthreads();
+#pragma unroll 1
         for (int u = 0; u < 2; ++u) {             // (tile 2 ch + 1 may lie beyond nt: it is written - with the buffer's stale rows - and never used)
             double t[4];
 #pragma unroll
@@ -391,132 +533,168 @@ __global__ __launch_bounds__(JM_THREADS) void joint_test_mfma_kernel(const Joint
     JMPH(1);
 
     // ---- right-looking block substitution ------------------------------------------------------------------------------------
-    // Run-time loops over the columns j and their tiles k > j; the statements pick their accumulator tile by a computed jump
-    // (joint_mfma_gen.inc): the schedule (which tiles exist, where a chunk of the stream ends) depends on n_o, the code does not.
-    // The next tile's A operand is requested from LDS before this tile's MFMAs are issued (unless it lies behind a chunk boundary).
+    // Run-time loops over the columns j and, per column, RUNS of tiles k > j whose factor tiles sit in consecutive slots of one chunk
+    // of the stream: a run is one statement (jm_acc_fma_run, joint_mfma_gen.inc) that picks its accumulator tiles by computed jumps
+    // and fetches every next tile's A operand in the shadow of the current tile's MFMAs (three rotating register sets).  Where the
+    // next tile opens a new chunk the statement fetches nothing: barrier (the chunk has landed: its loads were issued a chunk ago;
+    // the chunk before it is consumed), the loads of the chunk after it go out, and the tile's A operand is read (jm_sets_load).
     {
-        int seq = 0;                              // streamed tiles fetched so far
-        auto fetch = [&](int k, int j, jm_d2& a01, jm_d2& a23) {
-            const double* base;
-            if (k >= kmin) {
-                if ((seq & (JM_CH - 1)) == 0) {
-                    __syncthreads();              // chunk seq / 16 has landed (its loads were issued a chunk ago); the chunk before is consumed
-                    issue_chunk((seq >> 4) + 1);
-                }
-                base = ring + (seq & (JM_RING - 1)) * 256;
-                ++seq;
-            } else {
-                base = realt + (k * (k - 1) / 2 + j) * 256;
-            }
-            a01 = *reinterpret_cast<const jm_d2*>(base + lane * 2);
-            a23 = *reinterpret_cast<const jm_d2*>(base + 128 + lane * 2);
+        int seq = 0;                              // stream index of the next streamed tile
+#ifdef GPMPC_PHASE_TIMERS
+        jts = __builtin_readcyclecounter();
+#endif
+        const unsigned ring_b = (unsigned)(size_t)(__attribute__((address_space(3))) double*)ring;
+        const unsigned realt_b = (unsigned)(size_t)(__attribute__((address_space(3))) double*)realt;
+        auto streamed_now = [&](int k) { return k < kmin || (seq & (JM_CH - 1)) != 0; };        // tile k can be fetched without a hand-over
+        auto tile_addr = [&](int k, int j) -> unsigned {         // LDS byte address of tile (k, j)'s slot (takes the stream's next slot); uniform
+            if (k < kmin) return realt_b + (unsigned)(k * (k - 1) / 2 + j) * 2048u;
+            const unsigned ad = ring_b + (unsigned)(seq & (JM_RING - 1)) * 2048u;
+            ++seq;
+            return ad;
         };
+        JmSets S;
+        jm_sets_begin(S);
+        int set = 0;                              // the set that holds (or will take) the next tile's A operand
+        unsigned addr_p = realt_b;                // (any valid address: a run without a successor fetches it and drops it)
+        bool have = false;                        // set `set` holds the A operand of the next tile
         for (int j = 0; j < nt; ++j) {
             jm_d4 x;
             {
-                const jm_d2 d01 = *reinterpret_cast<const jm_d2*>(linv + j * 256 + lane * 2);
-                const jm_d2 d23 = *reinterpret_cast<const jm_d2*>(linv + j * 256 + 128 + lane * 2);
-                jm_acc_diag(A, j, d01.x, d01.y, d23.x, d23.y, x);     // X_j = Linv_jj acc_j
+                const int ln = jm_lane_now();      // (re-formed: see issue_chunk)
+                const jm_d2 d01 = *reinterpret_cast<const jm_d2*>(linv + j * 256 + ln * 2);
+                const jm_d2 d23 = *reinterpret_cast<const jm_d2*>(linv + j * 256 + 128 + ln * 2);
+                jm_acc_diag(A, S, j, d01.x, d01.y, d23.x, d23.y, x);  // X_j = Linv_jj acc_j
             }
             const jm_d4 xn = -x;
-            jm_d2 c01 = jm_d2{0.0, 0.0}, c23 = jm_d2{0.0, 0.0};
-            if (j + 1 < nt) fetch(j + 1, j, c01, c23);
-            for (int k = j + 1; k < nt; ++k) {
-                jm_d2 n01 = c01, n23 = c23;
-                const bool more = k + 1 < nt;
-                const bool ahead = more && !(k + 1 >= kmin && (seq & (JM_CH - 1)) == 0);
-                if (ahead) fetch(k + 1, j, n01, n23);
-                jm_acc_fma(A, k, c01.x, c01.y, c23.x, c23.y, xn[0], xn[1], xn[2], xn[3]);      // acc_k -= L_kj X_j
-                if (more && !ahead) fetch(k + 1, j, n01, n23);
-                c01 = n01, c23 = n23;
+            JMPHS(0);
+            int k = j + 1;
+            while (k < nt) {
+                if (!have) {
+                    if (k >= kmin && (seq & (JM_CH - 1)) == 0) {
+                        // every wave waits for ITS OWN pieces of the chunk, then the barrier: hipcc's __syncthreads carries no
+                        // vmcnt wait for the LDS-DMA loads (it only puts one in front of an LDS read it can see - behind the
+                        // barrier, where it covers this wave's pieces and nobody else's)
+                        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                        __syncthreads();
+                        issue_chunk((seq >> 4) + 1);
+                    }
+                    addr_p = tile_addr(k, j);
+                    jm_sets_load(S, set, addr_p);
+                    JMPHS(1);
+                }
+                // the run: tile k and the tiles behind it in this column, up to the end of the chunk
+                int n = 1;
+                if (k >= kmin) n = min(nt - k, JM_CH - ((seq - 1) & (JM_CH - 1)));
+                seq += n - 1;
+                // the tile behind the run: (k + n, j), or the first tile of the next column, or none
+                const bool same = k + n < nt;
+                const int kn = same ? k + n : j + 2, jn = same ? j : j + 1;
+                have = (same || j + 2 < nt) && streamed_now(kn);
+                const unsigned first = addr_p + 2048u;
+                unsigned tail = addr_p;
+                if (have) tail = addr_p = tile_addr(kn, jn);
+                jm_acc_fma_run(A, S, set, k, n, xn[0], xn[1], xn[2], xn[3], n > 1 ? first : tail, tail);      // acc_k -= L_kj X_j
+                set = (set + n) % 3;              // (the last iteration's fetch went there: the next tile, or a dummy that is overwritten)
+                k += n;
+                JMPHS(2);
             }
         }
     }
     __syncthreads();                              // every wave is done with the ring
     JMPH(2);
+    // tiles 22..25 of every wave's X go to LDS (the inverted diagonal tiles are no longer needed): the statements of the Gram phase
+    // name the tiles 0..21 only, 32 registers come free (with 208 registers pinned the phase spilled into scratch memory: one
+    // round trip to it costs as much as eight MFMAs)
+    double* stash = linv + wv * (JM_STASH * 256);
+#pragma unroll 1
+    for (int u = 0; u < JM_STASH; ++u) {
+        double t[4];
+        jm_acc_get(A, JM_NT - JM_STASH + u, t[0], t[1], t[2], t[3]);
+#pragma unroll
+        for (int v = 0; v < 4; ++v) stash[(u * 4 + v) * 64 + lane] = t[v];
+    }
+    // [t0 .. t3] = tile j of this wave's X (no branch around the statement: the register tiles and the stash are both read)
+    auto x_tile = [&](int j, double (&t)[4]) {
+        double r[4];
+        jm_acc_get_lo(A, min(j, JM_NT - JM_STASH - 1), r[0], r[1], r[2], r[3]);
+        const int su = max(j - (JM_NT - JM_STASH), 0);
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            const double l = stash[(su * 4 + v) * 64 + lane];
+            t[v] = (j < JM_NT - JM_STASH) ? r[v] : l;
+        }
+    };
 
     // ---- Gram: G_IJ = K_IJ - X_I^T X_J for J = I + d (mod 8), d = 0..4 (d = 4 counts for the tiles I < 4) ---------------------
     // test mode: K = K** and the label column / row of G is -mean; factor mode: K = K_nn + noise (the Schur complement)
     const int ldS = fmode ? ncols : mT;
     double* Sm = a.Sall + chain * (long)mT * mT;
     double* mean = a.mean + chain * (long)mT;
-    auto tile_init = [&](int I, int J, bool on) -> jm_d4 {
-        jm_d4 r = jm_d4{0.0, 0.0, 0.0, 0.0};
-        if (on) {
-            // register v, lane (kk, jj) = (row 16 I + 4 v + kk, column 16 J + jj)
-            const int t2 = 16 * J + (lane & 15);
-            const int c2 = min(t2, ldS - 1);
-            int j2, b2;
-            if (fmode) {
-                const int hs = a.h_slots[a.n_c + c2];
-                j2 = hs / T, b2 = hs - j2 * T;
-            } else {
-                j2 = c2 / T, b2 = c2 - j2 * T;
-            }
-            const double* x2 = (fmode ? Xh : Xs) + (long)j2 * D;
-            for (int v = 0; v < 4; ++v) {
-                const int t1 = 16 * I + 4 * v + (lane >> 4);
-                const int c1 = min(t1, ldS - 1);
-                int j1, b1;
-                if (fmode) {
-                    const int hs = a.h_slots[a.n_c + c1];
-                    j1 = hs / T, b1 = hs - j1 * T;
-                } else {
-                    j1 = c1 / T, b1 = c1 - j1 * T;
-                }
-                const double* x1 = (fmode ? Xh : Xs) + (long)j1 * D;
-                double qq[D];
-                const double kv = kern_scalar<D>(x1, x2, il2, os, qq);
-                double val = kern_entry<D>(qq, kv, il2, b1, b2);
-                if (fmode && t1 == t2) val += gp.noise[b1];
-                r[v] = (t1 < ldS && t2 < ldS) ? val : 0.0;
-            }
-        }
-        return r;
-    };
-    auto tile_out = [&](int I, int J, int d, const jm_d4& sv) {
+    const unsigned ring_gb = (unsigned)(size_t)(__attribute__((address_space(3))) double*)ring;
+    double* tbuf = ring + wv * 272;               // [16][17] per wave, inside the exchange buffer: used between two barriers of its own
+    auto tile_init = [&](int I, int J) -> jm_d4 {            // register v, lane (kk, jj) = K_cc(row 16 I + 4 v + kk, column 16 J + jj)
+        jm_d4 r;
         const int t2 = 16 * J + (lane & 15);
 #pragma unroll
         for (int v = 0; v < 4; ++v) {
             const int t1 = 16 * I + 4 * v + (lane >> 4);
+            r[v] = (t1 < ldS && t2 < ldS) ? Sm[(long)t1 * ldS + t2] : 0.0;
+        }
+        return r;
+    };
+    auto tile_out = [&](int I, int J, int d, const jm_d4& sv) {
+        // the tile and its mirror image, both as 128-byte row segments: the mirror through a per-wave LDS transpose
+        const int jj = lane & 15, kk = lane >> 4;
+#pragma unroll
+        for (int v = 0; v < 4; ++v) tbuf[(4 * v + kk) * 17 + jj] = sv[v];
+        const int t2 = 16 * J + jj;
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            const int t1 = 16 * I + 4 * v + kk;
             const double val = sv[v];
-            const bool lower_ok = d > 0 || t1 >= t2;        // diagonal tiles: the lower part and its mirror (one writer per entry)
             if (t1 < ldS && t2 < ldS) {
-                if (lower_ok) {
-                    Sm[(long)t1 * ldS + t2] = val;
-                    if (t1 != t2) Sm[(long)t2 * ldS + t1] = val;
-                }
+                if (d > 0 || t1 >= t2) Sm[(long)t1 * ldS + t2] = val;      // diagonal tiles: the lower part here, its mirror below
             } else if (!fmode && t1 == mT && t2 < mT) {
-                if (lower_ok) mean[t2] = -val;
-            } else if (!fmode && t2 == mT && t1 < mT) {
-                if (d > 0) mean[t1] = -val;
+                mean[t2] = -val;                                            // the label row
+            }
+        }
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            const int r2 = 16 * J + 4 * v + kk, c2 = 16 * I + jj;           // entry (r2, c2) of S = entry (c2, r2) of the tile
+            const double val = tbuf[jj * 17 + 4 * v + kk];
+            if (r2 < ldS && c2 < ldS) {
+                if (d > 0 || c2 > r2) Sm[(long)r2 * ldS + c2] = val;
+            } else if (!fmode && r2 == mT && c2 < mT && d > 0) {
+                mean[c2] = -val;                                            // the label column of an off-diagonal tile
             }
         }
     };
-    auto gram_pass = [&](auto d0c, auto ndc) {
-        constexpr int d0 = decltype(d0c)::value, nd = decltype(ndc)::value;
-        static_assert(nd == 2 || nd == 3, "two or three accumulators per pass");
-        jm_d4 sacc[3];
-        bool on[3];
-        int Jt[3];
+#pragma unroll 1
+    for (int pass = 0; pass < 3; ++pass) {        // d = 0, 1 | 2, 3 | 4, (5: nobody's) - two accumulators: a third one spills
+        const int d0 = 2 * pass;
+        jm_d4 sacc[2];
+        bool on[2];
+        int Jt[2];
 #pragma unroll
-        for (int dd = 0; dd < nd; ++dd) {
+        for (int dd = 0; dd < 2; ++dd) {
             const int d = d0 + dd;
             Jt[dd] = (I0 + d) & (JM_NCT - 1);
-            on[dd] = I0 < ncta && Jt[dd] < ncta && (d < 4 || I0 < 4);
-            sacc[dd] = tile_init(I0, Jt[dd], on[dd]);
+            on[dd] = d <= 4 && I0 < ncta && Jt[dd] < ncta && (d < 4 || I0 < 4);     // (what is written out; every product is formed)
         }
+        sacc[0] = tile_init(I0, Jt[0]);
+        sacc[1] = tile_init(I0, Jt[1]);
+        JMPH(3);
         for (int j0 = 0; j0 < nt; j0 += 4) {
             __syncthreads();                      // the previous group's tiles have been read
-#pragma unroll
+#pragma unroll 1
             for (int u = 0; u < 4; ++u) {
                 const int j = min(j0 + u, nt - 1);
                 double t[4];
-                jm_acc_get(A, j, t[0], t[1], t[2], t[3]);
-                if (active) {
+                x_tile(j, t);
+                {
 #pragma unroll
                     for (int v = 0; v < 4; ++v) ring[((I0 * 4 + u) * 4 + v) * 64 + lane] = t[v];
-                    if (d0 == 0 && fmode && j0 + u < nt) {
+                    if (active && pass == 0 && fmode && j0 + u < nt) {
                         // X^T = the new rows' entries against the old columns: row n_c + column, 4 consecutive slots per lane
                         const int col = 16 * I0 + (lane & 15), sl = 16 * j + 4 * (lane >> 4);
                         if (col < ncols) {
@@ -534,37 +712,38 @@ __global__ __launch_bounds__(JM_THREADS) void joint_test_mfma_kernel(const Joint
                 }
             }
             __syncthreads();
-#pragma unroll
+            JMPH(4);
+#pragma unroll 1
             for (int u = 0; u < 4; ++u) {
                 const bool valid = j0 + u < nt;   // (a tile beyond nt: the last tile again, with a zero A operand)
                 double t[4];
-                jm_acc_get(A, min(j0 + u, nt - 1), t[0], t[1], t[2], t[3]);      // (again: 4 moves are cheaper than 8 live registers per tile)
-#pragma unroll
-                for (int v = 0; v < 4; ++v) {
-                    const double an = valid ? -t[v] : 0.0;
-                    double b[3];
-#pragma unroll
-                    for (int dd = 0; dd < nd; ++dd) {
-                        const double bv = (d0 + dd == 0) ? t[v] : ring[((Jt[dd] * 4 + u) * 4 + v) * 64 + lane];
-                        b[dd] = on[dd] ? bv : 0.0;
-                    }
-                    if constexpr (nd == 3) jm_gram_fma3(sacc[0], sacc[1], sacc[2], an, b[0], b[1], b[2]);
-                    else jm_gram_fma2(sacc[0], sacc[1], an, b[0], b[1]);
-                }
+                x_tile(min(j0 + u, nt - 1), t);   // (again: 4 moves are cheaper than 8 live registers per tile)
+                // (tiles nobody writes out - idle column tiles, the sixth distance - cost their MFMAs: no select, no mask; a wave's own
+                // tile comes through the ring like everybody else's)
+                const unsigned ad0 = ring_gb + (unsigned)(((Jt[0] * 4 + u) * 4) * 64 + lane) * 8u;
+                const unsigned ad1 = ring_gb + (unsigned)(((Jt[1] * 4 + u) * 4) * 64 + lane) * 8u;
+                jm_gram_step0(sacc[0], sacc[1], valid ? t[0] : 0.0, ad0, ad1);
+                jm_gram_step1(sacc[0], sacc[1], valid ? t[1] : 0.0, ad0 + 512u, ad1 + 512u);
+                jm_gram_step2(sacc[0], sacc[1], valid ? t[2] : 0.0, ad0 + 1024u, ad1 + 1024u);
+                jm_gram_step3(sacc[0], sacc[1], valid ? t[3] : 0.0, ad0 + 1536u, ad1 + 1536u);
             }
+            JMPH(5);
         }
+        __syncthreads();                          // every wave has read the last group's tiles: the ring takes the transposes
 #pragma unroll
-        for (int dd = 0; dd < nd; ++dd) {
+        for (int dd = 0; dd < 2; ++dd) {
             jm_settle(sacc[dd]);
             if (on[dd]) tile_out(I0, Jt[dd], d0 + dd, sacc[dd]);
         }
-    };
-    gram_pass(std::integral_constant<int, 0>{}, std::integral_constant<int, 3>{});
-    gram_pass(std::integral_constant<int, 3>{}, std::integral_constant<int, 2>{});
-    JMPH(3);
+        JMPH(6);
+    }
 #ifdef GPMPC_PHASE_TIMERS
-    if (blockIdx.x == 0 && tid == 0)
-        for (int i = 0; i < 8; ++i) g_jm_phase[i] = jph[i];
+    if (blockIdx.x == 0 && (tid == 0 || tid == JM_THREADS - 64))
+    {
+        jph[7] = jphs[0];                         // (slot 7 of the phase record: diagonal steps; the other two are recovered below)
+        for (int i = 0; i < 8; ++i) g_jm_phase[i + (tid ? 8 : 0)] = jph[i];
+        g_jm_phase[16 + (tid ? 2 : 0)] = jphs[1], g_jm_phase[17 + (tid ? 2 : 0)] = jphs[2];
+    }
 #endif
 }
 
@@ -589,7 +768,7 @@ int joint_mfma_launch(const JointArgs& a, hipStream_t st) {
 
 }  // namespace gpmpc
 
-extern "C" int gpmpc_debug_read_joint_mfma_phases(long long* out /*[host] 8*/) {
-    GPMPC_HIP_CHECK(hipMemcpyFromSymbol(out, HIP_SYMBOL(gpmpc::g_jm_phase), 8 * sizeof(long long)));
+extern "C" int gpmpc_debug_read_joint_mfma_phases(long long* out /*[host] 20*/) {
+    GPMPC_HIP_CHECK(hipMemcpyFromSymbol(out, HIP_SYMBOL(gpmpc::g_jm_phase), 20 * sizeof(long long)));
     return GPMPC_OK;
 }

@@ -71,15 +71,40 @@ def test_closed_loop_as_shipped_car_runs_the_eigh_root(sg):
     print("as shipped car closed loop: GP side per SQP iteration (ms):", [round(t, 2) for t in loop.solver.gp_ms])
 
 
+@pytest.mark.parametrize("path", ["valu", "mfma"])
 @pytest.mark.parametrize("pname,Ns,H,budget", [("params_pendulum1D_samples", 5, 30, None), ("params_car_residual", 4, 40, None),
                                                 ("params_car_residual", 5, 40, 0.5),        # room for 2 of 5 samples only
                                                 ("params_pendulum1D_samples", 7, 30, 0.3)])         # all samples while the set is small, then 3 of 7
-def test_joint_factor_cache_is_bit_exact_and_used(sg, pname, Ns, H, budget):
+def test_joint_factor_cache_is_bit_exact_and_used(sg, pname, Ns, H, budget, path):
     """The factor cache of gpmpc_joint_sample: between two resets the hallucinated set only grows, so the rows of the slots
     that were already there are reused (the reference re-factorises everything on every call).  Two MPC steps x four SQP
     iterations with and without the cache: bit-identical Jacobians; the cache is hit at k >= 1 and at k = 0 of the second
-    MPC step (the reset-after-build quirk conditions on the previous step's whole set), and dropped when the points change."""
+    MPC step (the reset-after-build quirk conditions on the previous step's whole set), and dropped when the points change.
+
+    ``path`` (ABI 7, gpmpc_joint_pin_path): on the one-launch VALU path every factor row is the same sequence of FMAs whatever
+    is cached - bit-identical, as before.  The matrix-pipe path extends the factor by TILES of new rows against old columns:
+    with and without the cache the same entries are summed in a different grouping, so the two runs agree to rounding, not bit
+    for bit (include/gpmpc_hip.h says so; a caller that needs bit-equality pins the VALU path) - asserted at 1e-8 on the
+    pendulum's Cholesky-root draws and at the north-star tolerance on the car, whose eigendecomposition-root samples move by
+    1e-5 under a one-ulp change of the covariance (tests/test_hip_eigh.py prints that figure)."""
     from sampling_gpmpc_amd.gp_model import JointFactorCache
+    lib = sg._lib.load()
+    lib.gpmpc_joint_pin_path(sg._lib.JOINT_VALU if path == "valu" else sg._lib.JOINT_MFMA)
+    try:
+        _factor_cache_case(sg, pname, Ns, H, budget, path)
+    finally:
+        lib.gpmpc_joint_pin_path(sg._lib.JOINT_AUTO)
+
+
+def _factor_cache_case(sg, pname, Ns, H, budget, path):
+    from sampling_gpmpc_amd.gp_model import JointFactorCache
+
+    def same(u, v):
+        if path == "valu":
+            np.testing.assert_array_equal(u, v)
+        else:
+            tol = 1e-8 if "pendulum" in pname else 1e-4
+            np.testing.assert_allclose(u, v, rtol=tol, atol=tol * max(float(np.abs(v).max()), 1e-300))
     iters = 4
     p = closed_loop_params(pname, Ns, H, 2, iters)
     agent, _ = make_agents(sg, p)
@@ -107,7 +132,7 @@ def test_joint_factor_cache_is_bit_exact_and_used(sg, pname, Ns, H, budget):
                     a.train_hallucinated_dynGP(k)
                     outs.append(a.dyn_fg_jacobians(a.get_batch_x_hat(x_h, u_h), k))
                 for u, v in zip(*outs):
-                    np.testing.assert_array_equal(u, v)
+                    same(u, v)
                 hits.append(agent.model_i_call.n_cached_rows)
                 cached_samples.append(agent._ws_cache["joint_factor_cache"].n_samples)
                 assert plain.model_i_call.n_cached_rows == 0
@@ -140,7 +165,7 @@ def test_joint_factor_cache_is_bit_exact_and_used(sg, pname, Ns, H, budget):
             outs.append(a.dyn_fg_jacobians(a.get_batch_x_hat(x_h, u_h), iters - 1))
         assert agent.model_i_call.n_cached_rows == 0
         for u, v in zip(*outs):
-            np.testing.assert_array_equal(u, v)
+            same(u, v)
         # ... and with GPMPC_VERIFY_FACTOR_CACHE=1 the cache compares the points themselves: an in-place edit nobody announced
         # is caught too
         import sampling_gpmpc_amd.gp_model as gm
@@ -155,6 +180,6 @@ def test_joint_factor_cache_is_bit_exact_and_used(sg, pname, Ns, H, budget):
                 outs.append(a.dyn_fg_jacobians(a.get_batch_x_hat(x_h, u_h), iters - 1))
             assert agent.model_i_call.n_cached_rows == 0
             for u, v in zip(*outs):
-                np.testing.assert_array_equal(u, v)
+                same(u, v)
         finally:
             gm._VERIFY_CACHE = old_flag

@@ -444,6 +444,29 @@ def test_joint_draw_against_reference_golden(sg):
 ])
 def test_joint_draw_against_oracle(sg, pname, Ns, H, iters):
     """sample_gp / dyn_fg_jacobians over several SQP iterations vs the oracle (mean, variance, covariance, samples)."""
+    _joint_draw_against_oracle(sg, pname, Ns, H, iters)
+
+
+@pytest.mark.parametrize("pname,Ns,H,iters,cache", [
+    ("params_car_residual", 8, 40, 4, True),          # the closed loop's shape: 45 + 360 conditioning slots = 26 tiles at k = 3, 121 columns
+    ("params_car_residual", 5, 40, 3, False),         # no caller-owned cache: the factor rows go through the workspace's temporary one
+    ("params_pendulum1D_samples", 16, 30, 4, True),   # 36 real slots, 91 columns = 6 of the 8 column tiles
+    ("params_car_residual", 8, 12, 3, True),          # 37 columns: 3 column tiles, a ragged last slot tile at every k
+])
+def test_joint_draw_matrix_pipe_against_oracle(sg, pname, Ns, H, iters, cache):
+    """The same comparison with the matrix-pipe path pinned (ABI 7: gpmpc_joint_pin_path): factor extension and test rows by
+    joint_test_mfma_kernel (FP64 MFMA, X blocks in registers, L tiles streamed HBM -> LDS), Cholesky of the Schur complement
+    and root + sample by joint_kernel's phases - against the oracle, which factorises everything from scratch in one piece
+    (reference src/agent.py:629-641 per src/solver.py:84-94).  The path that ran is asserted."""
+    lib = sg._lib.load()
+    lib.gpmpc_joint_pin_path(sg._lib.JOINT_MFMA)
+    try:
+        _joint_draw_against_oracle(sg, pname, Ns, H, iters, expect_path=sg._lib.JOINT_MFMA, cache=cache)
+    finally:
+        lib.gpmpc_joint_pin_path(sg._lib.JOINT_AUTO)
+
+
+def _joint_draw_against_oracle(sg, pname, Ns, H, iters, expect_path=None, cache=True):
     p = load_params(pname)
     p["agent"]["num_dyn_samples"], p["optimizer"]["H"] = Ns, H
     p["agent"]["true_dyn_as_sample"] = False
@@ -462,7 +485,14 @@ def test_joint_draw_against_oracle(sg, pname, Ns, H, iters):
         oagent.train_hallucinated_dynGP(it)
         bx = agent.get_batch_x_hat_u_diff(x_h, u_h)
         obx = oagent.get_batch_x_hat_u_diff(x_h, u_h)
+        if not cache:
+            from sampling_gpmpc_amd.gp_model import JointFactorCache
+            off = JointFactorCache()
+            off.enabled = False
+            agent._ws_cache["joint_factor_cache"] = off
         gp_val, y_grad, u_grad = agent.dyn_fg_jacobians(bx, it)
+        if expect_path is not None and it >= 1:
+            assert sg._lib.load().gpmpc_joint_last_path() == expect_path, "the pinned joint path did not run"
         ogp_val, oy_grad, ou_grad = oagent.dyn_fg_jacobians(obx, it)
         post, opost = agent.model_i_call, oagent.model_i_call
         np.testing.assert_allclose(post.mean.cpu().numpy(), opost.mean.numpy(), rtol=1e-6, atol=1e-9)

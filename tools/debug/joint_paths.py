@@ -54,7 +54,12 @@ for it in range(iters):
             if c is not None:
                 c.rewind(held)
             post = agent.model_i(g_xu)
-            y = post._sample(z, clip=True, beta=p["agent"]["Dyn_gp_beta"], var_zero_thr=p["agent"]["Dyn_gp_variance_is_zero"])
+            try:
+                y = post._sample(z, clip=True, beta=p["agent"]["Dyn_gp_beta"], var_zero_thr=p["agent"]["Dyn_gp_variance_is_zero"])
+            except Exception as e:
+                bad = (post.last_info & _lib.INFO_TRAIN_CHOL_FAIL) != 0
+                print(f"k={it} path {path}: {type(e).__name__}; cached rows {post.n_cached_rows if hasattr(post, 'n_cached_rows') else '?'}; chains flagged {int(bad.sum())} of {bad.numel()}: {bad.nonzero()[:8].tolist()}", flush=True)
+                raise
             took = lib.gpmpc_joint_last_path()
             if c is not None:
                 c.rewind(held)
@@ -87,6 +92,9 @@ for it in range(iters):
 print("worst mean/cov rel diff", worst)
 if os.environ.get("GPMPC_PHASE_TIMERS") == "1":
     import ctypes as C
-    out = (C.c_longlong * 8)()
+    out = (C.c_longlong * 20)()
     lib.gpmpc_debug_read_joint_mfma_phases(out)
-    print("joint_test_mfma_kernel phases (cycles, wave 0 of block 0, last launch): prologue %d entries %d solve %d gram %d" % tuple(out[:4]))
+    for w, o in ((0, 0), (7, 8)):
+        print("joint_test_mfma_kernel phases (cycles, wave %d of block 0, last launch): prologue %d entries %d solve %d | gram: init %d publish %d products %d out %d"
+              % ((w,) + tuple(out[o:o + 7])))
+    print("  inside the substitution: wave 0: diagonal steps %d, hand-overs + first tiles %d, runs %d; wave 7: %d, %d, %d" % (out[7], out[16], out[17], out[15], out[18], out[19]))
