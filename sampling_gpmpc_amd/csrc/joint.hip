@@ -997,11 +997,11 @@ static int fc_row_stride(int n_r, int rows) { return (n_r + rows + 1) & ~1; }
 
 // the launch sizes from which the matrix-pipe path (factor phase + joint_test_mfma_kernel + tail) is taken
 static int joint_mfma_from() {
-    // hallucinated slots from which it is used (0: never).  Measured on the configs[4] shard (car, Ns = 1024, H = 40): k = 3 (360 slots)
-    // 7.7 against 8.7 ms, k = 2 (240) 5.8 / 5.9, k = 1 (120) 4.4 / 3.3 - the fixed per-chain phases of joint_test_mfma_kernel
-    // (descriptors, tile inversion, kernel entries with 48 free registers) only pay behind a long substitution
+    // hallucinated slots from which it is used (0: never).  Measured on the configs[4] shard (car, Ns = 1024, H = 40, scattered points):
+    // k = 3 (360 slots) 7.1 against 8.7 ms, k = 2 (240) 5.3 / 6.0, k = 1 (120) 4.0 / 3.4 - the fixed per-chain phases of
+    // joint_test_mfma_kernel (descriptors, tile inversion, kernel entries) only pay behind a long substitution
     static const char* env = getenv("GPMPC_JOINT_MFMA_FROM");
-    return env ? atoi(env) : 300;
+    return env ? atoi(env) : 200;
 }
 static int g_joint_path_pin = 0;          // gpmpc_joint_pin_path: 0 auto, 1 VALU path, 2 matrix-pipe path where instantiated
 static int g_joint_last_path = 0;

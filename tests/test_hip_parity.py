@@ -312,6 +312,7 @@ def test_rollout_sample_subset_invariance_full_size(sg):
     u_ff = synthetic_u_ff(1, H)
     X = forward_sampling_rollout(agent, u_ff)
     assert X.shape == (Ns, 2, H + 1) and np.isfinite(X).all()
+    assert _lib.load().gpmpc_debug_last_rollout_path() == 4, "configs[1] is rollout_one_kernel's launch (the bench's kernel)"
     erv = agent.epistimic_random_vector
     per_slab = Ns * 3
     z = erv.reshape(-1)[per_slab:]
