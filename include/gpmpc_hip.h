@@ -326,6 +326,21 @@ int     gpmpc_pack_plin_fb(int32_t nx, int32_t nu, int64_t Ns, int32_t H,
  * gpytorch raises / warns from host-side checks of its own, src/agent.py:629-641) */
 int     gpmpc_or_reduce_words(const int32_t* v, int64_t n, int32_t* out, void* stream);
 
+/*
+ * gpmpc_base_samples - the Agent's base samples ("epistimic_random_vector") from a counter-based stream (ABI 7).
+ * Replaces: reference src/agent.py:76-104 (random_vector_within_bounds: i.i.d. N(0,1) vectors of shape (g_ny, H, T), the whole
+ * vector redrawn until every entry lies in [-beta, beta]) for the sample-sharded runs: vector (j, i, s) is a pure function of
+ * (seed, MPC step j, SQP iteration i, GLOBAL sample id offset + s), so a rank generates exactly its own shard on its own GPU and
+ * the assembled run does not depend on the GPU count.  The reference's own stream (one torch.normal call per candidate on a global
+ * generator) stays available in the facade (base_sample_generator "reference").
+ *   out      [dev] (n_mpc, n_itrs, Ns, V) float64, V = g_ny * H * T
+ *   attempts [dev] (n_mpc, n_itrs, Ns) int32 or NULL: how many candidates were rejected before the kept one
+ * One wave per vector, the rejection loop inside the wave.  GPMPC_E_ARG when beta is so small that an attempt is accepted with
+ * probability < 1e-6.
+ */
+int     gpmpc_base_samples(uint64_t seed, int32_t n_mpc, int32_t n_itrs, int64_t offset, int64_t Ns, int32_t V, double beta,
+                           double* out, int32_t* attempts, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -78,6 +78,7 @@ SYMBOLS = {
     "gpmpc_pack_plin": (C.c_int, [_I32, _I32, _I64, _I32, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "gpmpc_pack_plin_fb": (C.c_int, [_I32, _I32, _I64, _I32, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "gpmpc_or_reduce_words": (C.c_int, [_P, _I64, _P, _P]),
+    "gpmpc_base_samples": (C.c_int, [C.c_uint64, _I32, _I32, _I64, _I64, _I32, _D, _P, _P, _P]),
 }
 
 _lib: Optional[C.CDLL] = None

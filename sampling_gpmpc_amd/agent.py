@@ -102,13 +102,21 @@ def _mix64(x: torch.Tensor) -> torch.Tensor:
     return x ^ _lsr(x, 31)
 
 
-def counter_base_samples(n_mpc, n_itrs, n_dyn, g_ny, H, T, beta, seed=123456, offset=0, device="cpu") -> torch.Tensor:
+def counter_base_samples(n_mpc, n_itrs, n_dyn, g_ny, H, T, beta, seed=123456, offset=0, device="cpu", _force_torch=False) -> torch.Tensor:
     """``(n_mpc, n_itrs, n_dyn, g_ny, H, T)`` truncated-normal vectors with the whole-vector rejection rule of reference
     ``src/agent.py:84-100``, each vector a pure function of (seed, j, i, offset + s): attempt ``a`` of a vector draws its
     ``V = g_ny H T`` entries from the hashed counters ``2 (a V + e)``, ``2 (a V + e) + 1`` (Box-Muller), and the first
     attempt with every entry in [-beta, beta] is kept.  Generated on ``device`` one (j, i) slab at a time."""
     V = g_ny * H * T
     dev = torch.device(device)
+    if dev.type == "cuda" and not _force_torch:
+        # one launch of gpmpc_base_samples (one wave per vector, the rejection loop inside it): bit-identical to the torch form
+        # below evaluated on the same device (tests/test_hip_parity.py), which costs ~15 launches per attempt and (j, i) slab
+        out = torch.empty(n_mpc, n_itrs, n_dyn, V, dtype=F64, device=dev)
+        with torch.cuda.device(dev):
+            _lib.check(_lib.load().gpmpc_base_samples(int(seed) & _M64, n_mpc, n_itrs, int(offset), n_dyn, V, float(beta), _lib.dptr(out), None,
+                                                      _lib.current_stream_ptr()), "gpmpc_base_samples")
+        return out.reshape(n_mpc, n_itrs, n_dyn, g_ny, H, T)
     out = torch.empty(n_mpc, n_itrs, n_dyn, V, dtype=F64, device=dev)
     sid = torch.arange(offset, offset + n_dyn, dtype=torch.int64, device=dev)
     e2 = 2 * torch.arange(V, dtype=torch.int64, device=dev)

@@ -1350,3 +1350,33 @@ def test_pinned_kernel_makes_shard_launches_bit_equal_to_the_full_launch(sg):
         np.testing.assert_array_equal(sub, X[1024:1536])
     finally:
         lib.gpmpc_rollout_pin_kernel(-1)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("Ns,g_ny,H,T,beta", [(1024, 1, 30, 3, 2.5), (4096, 3, 40, 3, 3.0), (32768, 3, 40, 1, 30.0)])
+def test_base_samples_kernel_against_the_torch_form(sg, Ns, g_ny, H, T, beta):
+    """gpmpc_base_samples (one launch, one wave per vector, the whole-vector rejection loop of reference src/agent.py:84-100 inside
+    the wave) against the same counter stream evaluated with torch ops on the same device: bit-identical, at two global-sample
+    offsets (a shard of a larger run is the slice of the whole run); inside the bounds; attempts counted."""
+    from sampling_gpmpc_amd.agent import counter_base_samples
+    n_mpc, n_itrs = 2, 3
+    for offset in (0, 777):
+        z = counter_base_samples(n_mpc, n_itrs, Ns, g_ny, H, T, beta, seed=4242, offset=offset, device="cuda")
+        zt = counter_base_samples(n_mpc, n_itrs, Ns, g_ny, H, T, beta, seed=4242, offset=offset, device="cuda", _force_torch=True)
+        assert z.shape == (n_mpc, n_itrs, Ns, g_ny, H, T) and z.is_cuda
+        assert torch.equal(z, zt), f"max |diff| {float((z - zt).abs().max()):.3e}"
+        assert float(z.abs().max()) <= beta
+    whole = counter_base_samples(n_mpc, n_itrs, Ns + 777, g_ny, H, T, beta, seed=4242, offset=0, device="cuda")
+    assert torch.equal(whole[:, :, 777:], z)
+    # the attempts the kernel reports are those of the rule: every earlier attempt has an entry outside the bounds
+    lib = sg._lib.load()
+    V = g_ny * H * T
+    out = torch.empty(n_mpc, n_itrs, 64, V, dtype=F64, device="cuda")
+    att = torch.zeros(n_mpc, n_itrs, 64, dtype=torch.int32, device="cuda")
+    sg._lib.check(lib.gpmpc_base_samples(4242, n_mpc, n_itrs, 0, 64, V, beta, sg._lib.dptr(out), sg._lib.dptr(att),
+                                         sg._lib.current_stream_ptr()), "gpmpc_base_samples")
+    torch.cuda.synchronize()
+    assert torch.equal(out.reshape(n_mpc, n_itrs, 64, g_ny, H, T), whole[:, :, :64])
+    if beta < 10:
+        assert int(att.max()) >= 1, "with these bounds some vector needs a second attempt"
+    print(f"Ns={Ns} V={V} beta={beta}: mean attempts {float(att.float().mean()) + 1:.2f}")
