@@ -194,7 +194,8 @@ class Agent(object):
     # generation number that changes whenever the tensors are replaced other than by appending points, and a flag "no NaN
     # label".  ``train_hallucinated_dynGP`` hands both to the model: the joint factor cache then vouches for its rows by
     # comparing two integers (no ``torch.equal`` + host sync per draw) and the observed-slot scan is skipped.  Assigning the
-    # attributes from outside starts a new generation; code that edits them IN PLACE calls ``invalidate_factor_cache()``.
+    # attributes from outside starts a new generation; an edit IN PLACE is noticed through the tensors' version counters
+    # (``_check_in_place_edits``; ``invalidate_factor_cache()`` announces one explicitly).
     @property
     def Hallcinated_X_train(self):
         return self._hall_X
@@ -203,6 +204,7 @@ class Agent(object):
     def Hallcinated_X_train(self, t):
         self._hall_X = t
         self._hall_gen = next(_HALL_GENERATION)
+        self._hall_seen = None
 
     @property
     def Hallcinated_Y_train(self):
@@ -213,17 +215,35 @@ class Agent(object):
         self._hall_Y = t
         self._hall_gen = next(_HALL_GENERATION)
         self._hall_all_observed = False                   # unknown labels: scan them
+        self._hall_seen = None
+
+    def _hall_versions(self):
+        """torch's in-place version counters of the hallucinated tensors (a view shares its base's counter)."""
+        return (self._hall_X._version, self._hall_Y._version)
+
+    def _check_in_place_edits(self):
+        """An in-place edit of ``Hallcinated_{X,Y}_train`` from outside - the reference's own idiom ``Hallcinated_X_train[rejected]
+        = ...`` - that nobody announced (``invalidate_factor_cache``): the tensors' version counters have moved since the Agent last
+        assigned them.  Then the factor rows of the cache and the "no NaN label" flag are no longer vouched for: new generation.
+        (No host sync: the counters are Python integers.)"""
+        seen = getattr(self, "_hall_seen", None)
+        now = self._hall_versions()
+        if seen is not None and seen != now:
+            self.invalidate_factor_cache()
+        self._hall_seen = now
 
     def invalidate_factor_cache(self):
         """after an in-place edit of the hallucinated tensors (``prepare_dynamics_set``'s survivor replacement does one)"""
         self._hall_gen = next(_HALL_GENERATION)
         self._hall_all_observed = False
+        self._hall_seen = self._hall_versions()
 
     def _reset_hallucinated(self):
         self._hall_X = torch.empty(self.ns, self.g_ny, 0, self.in_dim_x, dtype=F64, device=self.torch_device)
         self._hall_Y = torch.empty(self.ns, self.g_ny, 0, self.in_dim_y, dtype=F64, device=self.torch_device)
         self._hall_gen = next(_HALL_GENERATION)
         self._hall_all_observed = True
+        self._hall_seen = self._hall_versions()
 
     def random_vector_within_bounds(self):
         return random_vector_within_bounds(self.params, self.g_ny, self.in_dim_y, device=self.torch_device)
@@ -271,9 +291,16 @@ class Agent(object):
             newX, newY = newX[:, :, keep, :], newY[:, :, keep, :]
         # appended behind what is there: same generation (the factor rows of the earlier points stay valid); the labels are
         # draws (no NaN) unless the min-distance filter ran
+        self._check_in_place_edits()                      # (an unannounced edit of the old points must not ride along into the new tensors)
         self._hall_X = torch.cat([self._hall_X, newX], 2)
         self._hall_Y = torch.cat([self._hall_Y, newY], 2)
+        self._hall_seen = self._hall_versions()
         if min_distance >= 0.0:
+            self._hall_all_observed = False
+        # a draw that failed leaves NaN labels behind (negative 1 x 1 variance, an eigensolver that did not converge, a root that
+        # failed with the eigh root switched off): the observed-slot scan has to see them - gpytorch's mask policy drops such slots
+        call = self.model_i_call
+        if call is not None and (int(getattr(call, "last_bits", 0)) & (_lib.INFO_NEG_1x1 | _lib.INFO_EIGH_NOCONV | _lib.INFO_ROOT_FAIL)):
             self._hall_all_observed = False
 
     def get_batch_x_hat_u_diff(self, x_h, u_h):
@@ -332,6 +359,7 @@ class Agent(object):
             hx = torch.empty(self.ns, self.g_ny, 0, self.in_dim_x, dtype=F64, device=self.torch_device)
             hy = torch.empty(self.ns, self.g_ny, 0, 1, dtype=F64, device=self.torch_device)
         else:
+            self._check_in_place_edits()
             hx, hy = self.Hallcinated_X_train, self.Hallcinated_Y_train
         own = not use_model_without_derivatives
         self.model_i = HipGPModel(plan, hx, hy, self.batch_shape, self._ws_cache, dist_group=self.dist_group,

@@ -315,6 +315,7 @@ class HipPosterior:
             self._root = root
         bits = _or_reduce(info)
         self.last_info = info
+        self.last_bits = int(bits)
         self.used_eigh = bool(bits & _lib.INFO_ROOT_EIGH)
         if fbuf is not None:
             fcache.commit(mdl, n_ho, ok=not (bits & _lib.INFO_TRAIN_CHOL_FAIL), n_cached=n_c)

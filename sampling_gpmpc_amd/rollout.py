@@ -34,19 +34,46 @@ class RolloutResult:
 
 
 def pin_rollout_kernel_like(agent: Agent, *, H: int, Ns_launch: int, mode: int = _lib.MODE_RECONDITIONED,
-                            use_model_without_derivatives: bool = False) -> int:
+                            use_model_without_derivatives: bool = False, hall_tasks: Optional[int] = None) -> int:
     """Pin ``gpmpc_rollout``'s kernel to the one a launch of ``Ns_launch`` samples of this shape would take, and return it.
 
     The dispatcher picks by launch size, and the kernels sum in different orders: a sample's trajectory is bit-identical
     between two launches only if both ran the same kernel.  A sample-sharded run that must reproduce the single-GPU run of the
     same samples bit for bit calls this with the GLOBAL sample count before its shard-sized launches (at the price of the
-    kernel that is best for the shard size); ``_lib.load().gpmpc_rollout_pin_kernel(-1)`` restores the size heuristic."""
+    kernel that is best for the shard size).  ``hall_tasks``: the appended labels' task count of the launches to follow (a
+    value-only rollout, ``hall_tasks = 1``, may take another kernel than a ``T``-task one).  The pin is process-global and stays
+    until it is released: prefer ``with pinned_rollout_kernel_like(...)``, which restores what was pinned before."""
     lib = _lib.load()
     lib.gpmpc_rollout_pin_kernel(-1)
     plan = agent._plan(use_grad=not use_model_without_derivatives)
-    k = lib.gpmpc_rollout_kernel_for(plan.desc, agent.env_desc(), mode, plan.hyper.T, int(Ns_launch), int(H))
+    k = lib.gpmpc_rollout_kernel_for(plan.desc, agent.env_desc(), mode, plan.hyper.T if hall_tasks is None else int(hall_tasks),
+                                     int(Ns_launch), int(H))
     lib.gpmpc_rollout_pin_kernel(k)
+    global _PINNED_KERNEL
+    _PINNED_KERNEL = k
     return k
+
+
+_PINNED_KERNEL = -1          # what this module last pinned (gpmpc_rollout_pin_kernel has no getter for the pin itself)
+
+
+class pinned_rollout_kernel_like:
+    """``with pinned_rollout_kernel_like(agent, H=.., Ns_launch=..) as kernel: ...`` - the pin of ``pin_rollout_kernel_like`` for
+    the body only; the pin that was in force before (usually none) is restored on exit, also when the body raises."""
+
+    def __init__(self, agent: Agent, **kw):
+        self.agent, self.kw = agent, kw
+
+    def __enter__(self):
+        global _PINNED_KERNEL
+        self.prev = _PINNED_KERNEL
+        return pin_rollout_kernel_like(self.agent, **self.kw)
+
+    def __exit__(self, *exc):
+        global _PINNED_KERNEL
+        _lib.load().gpmpc_rollout_pin_kernel(self.prev)
+        _PINNED_KERNEL = self.prev
+        return False
 
 
 def rollout_device(agent: Agent, u_ff, z: torch.Tensor, z_step_stride: int, *, H: int, mode: int,

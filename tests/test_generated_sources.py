@@ -55,3 +55,13 @@ def test_joint_mfma_jump_tables_have_their_strides():
         pytest.skip("hipcc not available")
     r = subprocess.run([sys.executable, os.path.join(REPO, "tools", "check_joint_mfma_tables.py")], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout + r.stderr
+
+
+def test_hipcc_never_touches_the_pinned_agprs_of_rollout_one():
+    """rollout_one_kernel's factor panels live in AGPRs that hipcc only knows through physical-register asm constraints, with some
+    writes hidden under branches: the ISA hipcc emits with the build's flags must not name an AGPR outside the asm
+    statements, and must not spill inside the kernel (tools/check_one_agpr.py)."""
+    if not os.path.exists("/opt/rocm/bin/hipcc"):
+        pytest.skip("hipcc not available")
+    r = subprocess.run([sys.executable, os.path.join(REPO, "tools", "check_one_agpr.py")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr

@@ -158,7 +158,8 @@ def _factor_cache_case(sg, pname, Ns, H, budget, path):
         # is told (Agent.invalidate_factor_cache - prepare_dynamics_set calls it; assigning the attribute does it by itself) ...
         agent.Hallcinated_X_train[0, :, 0, :] += 1e-3
         plain.Hallcinated_X_train[0, :, 0, :] += 1e-3
-        agent.invalidate_factor_cache()
+        # (round 5: nobody has to announce the edit - the Agent compares the tensors' in-place version counters when it builds
+        # the next model; Agent.invalidate_factor_cache() remains for code that wants to say so)
         outs = []
         for a in (agent, plain):
             a.train_hallucinated_dynGP(iters)
