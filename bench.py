@@ -327,13 +327,18 @@ def extra_closed_loop(sg, _lib, wl, name="params_car_residual", Ns=1024, H=40, i
         flop_ref = wl.flop_mode_j(g_ny, T, n_r, H, n_ho // (T * H)) * Ns       # what the reference's call computes
         flop = flop_ref - wl.flop_mode_j_cached_rows(g_ny, n_r, n_c) * Ns      # what this call executes
         eigh = bool((info & _lib.INFO_ROOT_EIGH).all().item())
-        out.append({"mpc_step": step, "k": k, "n_o": int(n_r + n_ho),
+        mfma = raw.gpmpc_joint_last_path() == _lib.JOINT_MFMA     # the matrix-pipe path of gpmpc_joint_sample (ABI 7) ran
+        jk = ("joint_test_mfma_kernel<3> (factor extension) + joint_kernel<3,16,1,128,4> (Cholesky of the Schur complement) + "
+              "joint_test_mfma_kernel<3> (test rows, mean, S) + joint_kernel<3,16,1,128,4> (root + sample)") if mfma \
+            else "joint_kernel<3,NB,1,NT,W>"
+        out.append({"mpc_step": step, "k": k, "n_o": int(n_r + n_ho), "joint_path": "mfma" if mfma else "valu",
                     "cached_rows": n_c, "executed_flop_frac": flop / flop_ref, "ms_per_draw": ms_min,
                     "wall_ms_per_iteration": wall_ms,
                     "trajectory_steps_per_s": Ns * H / (ms_min * 1e-3),
                     "eigh_root": eigh, "finite": bool(np.isfinite(gp_val).all()),
-                    "roofline": roofline(flop, ms_min, "joint_kernel<3,NB,1,NT,W>" + (" + joint_eigh_kernel<3,2>" if eigh else ""),
+                    "roofline": roofline(flop, ms_min, jk + (" + joint_eigh_kernel<3,2>" if eigh else ""),
                                          8 * (2 * agent.nx + 2 * g_ny * T) * Ns * H,
+                                         bound=("fp64_mfma" if mfma else "fp64_valu"),
                                          note="joint draw incl. the facade's info reduction; FLOP = SURVEY 8d mode-J "
                                               "formula minus the factor rows served from the cache (`cached_rows`; "
                                               "`executed_flop_frac` of what the reference's call computes)"

@@ -456,7 +456,7 @@ __global__ __launch_bounds__(NT, WPE) void joint_kernel(const JointArgs a) {
         for (int d = 0; d < D; ++d) il2[d] = gp.inv_l2[o][d];
         const double os = gp.os[o];
         int info_acc = 0;
-        if (tid == 0) s_info = (a.phase == JOINT_PHASE_TAIL && a.info_in) ? a.info[chain] : 0;
+        if (tid == 0) s_info = a.info_in ? a.info[chain] : 0;     // (the bits of an earlier launch of the same call)
         __syncthreads();
 #ifdef GPMPC_PHASE_TIMERS
         long long jph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -1005,12 +1005,14 @@ static int joint_mfma_from() {
 }
 static int g_joint_path_pin = 0;          // gpmpc_joint_pin_path: 0 auto, 1 VALU path, 2 matrix-pipe path where instantiated
 static int g_joint_last_path = 0;
-static bool joint_use_mfma(int n_r, int n_ho, int m, int T) {
-    if (n_ho < 1 || !joint_mfma_eligible(n_r, n_ho, m * T + 1, T)) return false;
+static bool joint_mfma_wanted(int n_ho) {
     if (g_joint_path_pin == 1) return false;
     if (g_joint_path_pin == 2) return true;
     const int from = joint_mfma_from();
     return from > 0 && n_ho >= from;
+}
+static bool joint_use_mfma(int n_r, int n_ho, int m, int T) {
+    return n_ho >= 1 && joint_mfma_eligible(n_r, n_ho, m * T + 1, T) && joint_mfma_wanted(n_ho);
 }
 
 static long eigh_grid(long nchains) {
@@ -1256,6 +1258,9 @@ int gpmpc_joint_sample(const gpmpc_gp_desc_t* gp, const void* plan, const double
             launch(b, mT);
         }
     } else {
+        // (Measured and dropped: for conditioning sets beyond joint_test_mfma_kernel's 416 slots - k = 0 of the MPC steps after the first,
+        // 45 + 480 slots at configs[4] - the factor extension alone on the matrix pipe and the test rows here with every
+        // hallucinated row cached: 13.3 ms against 11.2 - the test rows' stream is the critical path of this kernel either way.)
         g_joint_last_path = 1;
         const int nrow = n_ho + 1 + mT - a.n_c;        // rows that are computed (the cached ones have no thread)
         a.abandon_root = abandon_for(nrow);
