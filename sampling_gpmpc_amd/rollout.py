@@ -320,13 +320,16 @@ class RolloutRunner:
     ``sampling_gpmpc_amd.distributed``): every buffer lives in HBM before the first launch."""
 
     def __init__(self, agent: Agent, u_ff, z: torch.Tensor, z_step_stride: int, H: int, mode: int,
-                 use_model_without_derivatives: bool, x0=None, want_samples: bool = False):
+                 use_model_without_derivatives: bool, x0=None, want_samples: bool = False,
+                 hall_tasks: Optional[int] = None):
         self.lib = _lib.load()
         dev = _lib.require_hip_device(agent.torch_device)
         p = agent.params
         self.agent, self.H, self.mode = agent, H, mode
         self.plan = agent._plan(use_grad=not use_model_without_derivatives)
         T = self.plan.hyper.T
+        # labels observed at an appended point: all T (the sample_gp path) or the value only (src/agent.py:402)
+        ht = T if hall_tasks is None else int(hall_tasks)
         self.Ns = agent.ns
         self.u_ff = torch.as_tensor(np.asarray(u_ff), dtype=F64).reshape(H, agent.nu).to(dev).contiguous()
         x0 = p["env"]["start"] if x0 is None else x0
@@ -337,12 +340,12 @@ class RolloutRunner:
         self.Y = torch.empty(self.Ns, agent.g_ny, H, T, dtype=F64, device=dev) if want_samples else None
         self.Xi = torch.empty(self.Ns, H, agent.in_dim_x, dtype=F64, device=dev) if want_samples else None
         self.info = torch.zeros(self.Ns, dtype=torch.int32, device=dev)
-        nbytes = self.lib.gpmpc_rollout_workspace_bytes(self.plan.desc, mode, T, self.Ns, H)
+        nbytes = self.lib.gpmpc_rollout_workspace_bytes(self.plan.desc, mode, ht, self.Ns, H)
         self.ws = torch.empty((nbytes + 7) // 8, dtype=F64, device=dev)
         self.env = agent.env_desc()
         self.beta = float(p["agent"]["Dyn_gp_beta"])
         self.var_zero = float(p["agent"]["Dyn_gp_variance_is_zero"])
-        self._args = (self.plan.desc, self.env, _lib.dptr(self.plan.buf), _lib.dptr(self.plan.X_r), mode, T,
+        self._args = (self.plan.desc, self.env, _lib.dptr(self.plan.buf), _lib.dptr(self.plan.X_r), mode, ht,
                       self.var_zero, self.beta, self.Ns, H, _lib.dptr(self.x0), 0, _lib.dptr(self.u_ff),
                       self.z.data_ptr(), self.z_step_stride, _lib.dptr(self.X_traj), _lib.dptr(self.Y),
                       _lib.dptr(self.Xi), _lib.dptr(self.info), _lib.dptr(self.ws), self.ws.numel() * 8)

@@ -1,10 +1,20 @@
-"""Time mode J (joint-horizon draw per SQP iteration, BASELINE config 5 shape) through Agent.dyn_fg_jacobians."""
+"""Time mode J (joint-horizon draw per SQP iteration, BASELINE config 5 shape) through Agent.dyn_fg_jacobians.
+
+    python tools/bench_joint.py [--car-only] [--cholesky-branch] [--sustained] [--path valu|mfma] [--only-k K]
+
+--path pins gpmpc_joint_sample's path for the whole run (default: the dispatcher's choice); --only-k times the draw of SQP
+iteration K only (the counter passes of tools/profile_joint_r5.sh: the last five draws of the run are that iteration's).
+"""
 import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import warnings
 import torch, numpy as np
 import sampling_gpmpc_amd as sg
 from tests.helpers import load_params
+
+ONLY_K = int(sys.argv[sys.argv.index("--only-k") + 1]) if "--only-k" in sys.argv else None
+PATH = sys.argv[sys.argv.index("--path") + 1] if "--path" in sys.argv else "auto"
+
 
 def run(pname, Ns, H, iters, jitter=None):
     p = load_params(pname)
@@ -17,6 +27,7 @@ def run(pname, Ns, H, iters, jitter=None):
         p["agent"]["Dyn_gp_jitter"] = jitter
     torch.manual_seed(3)
     agent = sg.Agent(p, sg.make_env(p))
+    sg._lib.load().gpmpc_joint_pin_path({"auto": sg._lib.JOINT_AUTO, "valu": sg._lib.JOINT_VALU, "mfma": sg._lib.JOINT_MFMA}[PATH])
     nx, nu = agent.nx, agent.nu
     g = torch.Generator().manual_seed(5)
     x0 = np.array(p["env"]["start"], dtype=np.float64)
@@ -47,7 +58,7 @@ def run(pname, Ns, H, iters, jitter=None):
                 while time.perf_counter() < t_end:
                     rewind(); agent.sample_gp(g_xu, base_samples=z)
                 torch.cuda.synchronize()
-            for rep in range(4):
+            for rep in range(4 if ONLY_K in (None, it) else 0):
                 rewind()
                 ev[0].record(); agent.sample_gp(g_xu, base_samples=z); ev[1].record(); torch.cuda.synchronize()
                 if rep:
@@ -70,7 +81,7 @@ def run(pname, Ns, H, iters, jitter=None):
             print("   eigh phases(cycles, chain 0 or 1000):", {n: out[i] for i, n in enumerate(names)},
                   f"=> {cyc} cycles in {out[5] * 10} ns: shader clock {cyc / max(out[5], 1) / 10:.2f} GHz")
         print(f"{pname:26s} Ns={Ns} H={H} k={it}: n_o={agent.model_i.plan.n_r + n_h*3:4d} m*T={H*3} cached rows {agent.model_i_call.n_cached_rows}: sample_gp {1e3*(t1-t0):8.2f} ms (best of 3) "
-              f"({Ns*H/(t1-t0)/1e6:7.2f} M traj-steps/s), max jitter level {lvl}, eigh root={eigh}, finite={bool(torch.isfinite(y).all())}", flush=True)
+              f"({Ns*H/(t1-t0)/1e6:7.2f} M traj-steps/s), path {sg._lib.load().gpmpc_joint_last_path()}, max jitter level {lvl}, eigh root={eigh}, finite={bool(torch.isfinite(y).all())}", flush=True)
 
 if __name__ == "__main__":
     if "--car-only" not in sys.argv:
