@@ -184,17 +184,26 @@ __device__ __forceinline__ void eigh_gram(const double* __restrict__ Lm, int n, 
             const double* pa = Lm + (long)(va ? ca : 0) * n;
             const double* pb = Lm + (long)(vb ? cb : 0) * n;
             double4_e acc = {0.0, 0.0, 0.0, 0.0};
-            for (int k0 = 0; k0 < n; k0 += 16) {
-                double av[4], bv[4];
+            // four 16-row steps per batch: their 32 loads are in flight together (one step at a time, every step waited for its own
+            // eight loads: at the closed loop's ranks - one tile pair - this phase was eight serial round trips to L2)
+            for (int k0 = 0; k0 < n; k0 += 64) {
+                double av[4][4], bv[4][4];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int row = k0 + 4 * u + kr;
-                    const bool vr = row < n;
-                    av[u] = (va && vr) ? pa[row] : 0.0;
-                    bv[u] = (vb && vr) ? pb[row] : 0.0;
-                }
+                for (int b = 0; b < 4; ++b)
 #pragma unroll
-                for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u], bv[u], acc, 0, 0, 0);
+                    for (int u = 0; u < 4; ++u) {
+                        const int row = k0 + 16 * b + 4 * u + kr;
+                        const int rc = min(row, n - 1);
+                        const double la = pa[rc], lb = pb[rc];           // (unconditional, clamped: no branch around a load)
+                        av[b][u] = (va && row < n) ? la : 0.0;
+                        bv[b][u] = (vb && row < n) ? lb : 0.0;
+                    }
+#pragma unroll
+                for (int b = 0; b < 4; ++b)
+                    if (k0 + 16 * b < n) {                               // uniform
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[b][u], bv[b][u], acc, 0, 0, 0);
+                    }
             }
 #pragma unroll
             for (int v = 0; v < 4; ++v) {                        // D: col = lane & 15, row = (lane >> 4) + 4 v

@@ -57,12 +57,16 @@ constexpr int JM_SMEM_SHORTS = (JM_NT * 16 + 8) + (JM_NTD + 7) + 32 + 32 + (JM_C
 constexpr size_t JM_SMEM_BYTES = (size_t)JM_SMEM_DOUBLES * 8 + (size_t)JM_SMEM_SHORTS * 2 + 64;
 
 __device__ __attribute__((aligned(16))) double g_jm_zero[4] = {0.0, 0.0, 0.0, 0.0};
-__device__ long long g_jm_phase[20];
+__device__ long long g_jm_phase[40];          // [20..27]: inside the prologue, [28..31]: inside the kernel entries (wave 0)
 
 #ifdef GPMPC_PHASE_TIMERS
 #define JMPH(idx) do { const long long _n = __builtin_readcyclecounter(); jph[idx] += _n - jt; jt = _n; } while (0)
 #define JMPHS(idx) do { const long long _n = __builtin_readcyclecounter(); jphs[idx] += _n - jts; jts = _n; } while (0)
+#define JMPHP(idx) do { const long long _n = __builtin_readcyclecounter(); jpp[idx] += _n - jtp; jtp = _n; } while (0)
+#define JMPHE(idx) do { const long long _n = __builtin_readcyclecounter(); jpe[idx] += _n - jtp; jtp = _n; } while (0)
 #else
+#define JMPHP(idx)
+#define JMPHE(idx)
 #define JMPH(idx)
 #define JMPHS(idx)
 #endif
@@ -173,9 +177,12 @@ __global__ __launch_bounds__(JM_THREADS) void joint_test_mfma_kernel(const Joint
     const double noise0 = gp.noise[0], noise1 = gp.noise[T > 1 ? 1 : 0], noise2 = gp.noise[T > 2 ? 2 : 0];
 #ifdef GPMPC_PHASE_TIMERS
     long long jph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    long long jphs[3] = {0, 0, 0};                // inside the substitution: diagonal steps, hand-overs + first tiles, runs
+    long long jphs[6] = {0, 0, 0, 0, 0, 0};       // inside the substitution: diagonal steps, hand-overs + first tiles, runs; of the hand-overs: own DMA wait, barrier, requests
     long long jt = __builtin_readcyclecounter();
     long long jts = jt;
+    long long jpp[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    long long jpe[4] = {0, 0, 0, 0};
+    long long jtp = jt;
 #endif
 
     auto Lel = [&](int r, int c) -> double {      // factor entry (r, c), c <= r < n_o
@@ -184,62 +191,80 @@ __global__ __launch_bounds__(JM_THREADS) void joint_test_mfma_kernel(const Joint
 
     // ---- table of the STREAMED tiles (k, j), k >= max(j + 1, kmin): rows that are all hallucinated slots, in consumption order
     // (column by column); the few tiles with real rows (k < kmin) sit in `realt` ------------------------------------------------
-    int ntd = 0;
-    {
-        int sbase = 0;
-        for (int jj = 0; jj < nt; ++jj) {
-            const int k0 = max(jj + 1, kmin);
-            if (jj == tid)
-                for (int k = k0; k < nt; ++k) stab[sbase + k - k0] = (unsigned short)((k << 8) | jj);
-            sbase += max(0, nt - k0);
-        }
-        ntd = sbase;
+    // (closed form of the start of column jj's tiles: the columns j' < kmin - 1 have nt - kmin streamed tiles each, column j' >= kmin - 1
+    // has nt - 1 - j'; one thread per (column, tile) - the first version let thread jj write column jj's entries one by one: 18 k cycles)
+    auto stab_base = [&](int jj) -> int {
+        const int c = min(jj, kmin - 1), n = jj - c;             // n columns j' = kmin - 1 .. jj - 1
+        return c * max(0, nt - kmin) + n * (nt - 1) - (n * (2 * (kmin - 1) + n - 1)) / 2;
+    };
+    const int ntd = stab_base(nt);
+    for (int e = tid; e < nt * 32; e += JM_THREADS) {
+        const int jj = e >> 5, k = max(jj + 1, kmin) + (e & 31);
+        if (k < nt) stab[stab_base(jj) + (e & 31)] = (unsigned short)((k << 8) | jj);
     }
     __syncthreads();
 
-    // chunk c of the stream -> ring slots (c & 1) * 16 ..: wave w moves tiles 2 w, 2 w + 1 of the chunk.  Lane (i, kk) names the 16-byte
-    // pieces (h, kk, i) of a tile: row 16 k + pi(i), columns 16 j + 4 kk + 2 h (+ 1).  Everything lane-dependent is formed ONCE (two
+    // chunk c of the stream -> ring slots (c & 1) * 16 ..: the waves 0..3 - one per SIMD - move four tiles each.  Lane (i, kk) names the
+    // 16-byte pieces (h, kk, i) of a tile: row 16 k + pi(i), columns 16 j + 4 kk + 2 h (+ 1).  Everything lane-dependent is formed ONCE (two
     // registers); a tile adds a uniform offset.  (The first version formed the address per tile from spilled values: the reload's
     // s_waitcnt vmcnt(0) stood right behind the first tile's loads and waited for them - 5 k cycles per hand-over.)
+    // Why four waves and not all eight: the requests cost a wave 0.8-1.6 k cycles per hand-over (table look-up, addresses, zero-page
+    // select), all eight waves paid them at the same moment - right behind the barrier - and the matrix pipe stood still meanwhile
+    // (35 k cycles per chain on the slowest wave).  Now the other wave of every SIMD starts its products at once and has the pipe to
+    // itself while its partner requests.
     auto issue_chunk = [&](int c) {
+        if (wv >= 4) return;                      // (uniform)
         // (the lane-dependent part is RE-formed at every call from the lane id - six VALU instructions; kept in registers across the
         // substitution, where 16 VGPRs are free, hipcc spills it and the reload is a round trip to scratch memory per hand-over)
         const int ln = jm_lane_now();
         const int dma_row = jm_pi(ln & 15);                     // row of the tile this lane reads
         const double* dma_lane = fc + (long)(dma_row - n_r) * CS + 4 * (ln >> 4);
+        const int q0 = c * JM_CH + wv * 4;
+        // the wave's four table entries with one LDS read (8-byte aligned: q0 is a multiple of four; entries beyond ntd are not used)
+        const unsigned long long kj4 = *reinterpret_cast<const unsigned long long*>(stab + q0);
+        const unsigned kj_lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)kj4);
+        const unsigned kj_hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(kj4 >> 32));
 #pragma unroll
-        for (int u = 0; u < JM_CH / JM_NW; ++u) {
-            const int q = c * JM_CH + wv * (JM_CH / JM_NW) + u;
+        for (int u = 0; u < 4; ++u) {
+            const int q = q0 + u;
             if (q < ntd) {                        // (uniform)
-                const int kj = __builtin_amdgcn_readfirstlane((int)stab[q]);
+                const int kj = (int)(((u < 2 ? kj_lo : kj_hi) >> (16 * (u & 1))) & 0xffffu);
                 const int k = kj >> 8, j = kj & 255;
-                const long off = __builtin_amdgcn_readfirstlane(16 * k) * (long)CS + __builtin_amdgcn_readfirstlane(16 * j);
+                const long off = (long)(16 * k) * CS + 16 * j;
                 const double* src = (16 * k + dma_row < n_o) ? dma_lane + off : g_jm_zero;
-                double* dst = ring + __builtin_amdgcn_readfirstlane(q & (JM_RING - 1)) * 256;
+                double* dst = ring + (q & (JM_RING - 1)) * 256;
                 jm_glds16(src, dst);
                 jm_glds16(src + 2, dst + 128);
             }
         }
     };
     issue_chunk(0);
+    JMPHP(0);
 
     // ---- prologue: diagonal tiles (raw, row-major) into `linv`, real-row tiles, L_rr w_r, slot and column descriptors ---------
     // (every loop below has a compile-time trip count: its global loads are all in flight together - with run-time bounds hipcc
     // waits for each load before it issues the next, and the prologue was ~25 serial round trips to L2 / HBM)
+    // (and every load is UNCONDITIONAL - a clamped address, the value selected afterwards: a load under a lane condition is a branch
+    // around it, and hipcc waits for it before the next one)
+    auto Lptr = [&](int r, int c) -> const double* {      // &L(r, c) for any r, c >= 0: clamped into the factor
+        const int rr = min(r, n_o - 1), cc = min(c, rr);
+        return (rr < n_r) ? Lrr + (long)rr * n_r + cc : fc + (long)(rr - n_r) * CS + cc;
+    };
     {
         double v[JM_NT * 256 / JM_THREADS];
 #pragma unroll
         for (int it = 0; it < JM_NT * 256 / JM_THREADS; ++it) {
             const int e = tid + it * JM_THREADS;
             const int tj = e >> 8, i = (e >> 4) & 15, c = e & 15;
-            const int r = 16 * tj + i;
-            v[it] = (c == i) ? 1.0 : 0.0;
-            if (r < n_o) v[it] = (c <= i) ? Lel(r, 16 * tj + c) : 0.0;
+            v[it] = *Lptr(16 * tj + i, 16 * tj + c);
         }
 #pragma unroll
         for (int it = 0; it < JM_NT * 256 / JM_THREADS; ++it) {
             const int e = tid + it * JM_THREADS;
-            if (e < nt * 256) linv[e] = v[it];
+            const int tj = e >> 8, i = (e >> 4) & 15, c = e & 15;
+            const int r = 16 * tj + i;
+            const double val = (r < n_o) ? ((c <= i) ? v[it] : 0.0) : ((c == i) ? 1.0 : 0.0);
+            if (e < nt * 256) linv[e] = val;
         }
     }
     {
@@ -251,16 +276,17 @@ __global__ __launch_bounds__(JM_THREADS) void joint_test_mfma_kernel(const Joint
             const int ti = e >> 8, i = (e >> 4) & 15, c = e & 15;
             const int k = (ti < 1) ? 1 : ((ti < 3) ? 2 : 3);
             const int j = ti - k * (k - 1) / 2;
-            const int r = 16 * k + i;
-            v[it] = (e < nrt * 256 && r < n_o) ? Lel(r, 16 * j + c) : 0.0;
+            v[it] = *Lptr(16 * k + i, 16 * j + c);
         }
 #pragma unroll
         for (int it = 0; it < JM_RT * 256 / JM_THREADS; ++it) {
             const int e = tid + it * JM_THREADS;
             const int ti = e >> 8, i = (e >> 4) & 15, c = e & 15;
-            if (e < nrt * 256) realt[ti * 256 + jm_off(i, c)] = v[it];
+            const int k = (ti < 1) ? 1 : ((ti < 3) ? 2 : 3);
+            if (e < nrt * 256) realt[ti * 256 + jm_off(i, c)] = (16 * k + i < n_o) ? v[it] : 0.0;
         }
     }
+    JMPHP(1);
     if (!fmode) {                                 // y' = L_rr w_r, eight lanes per row
         const int row = tid >> 3, part = tid & 7;
         double acc = 0.0;
@@ -279,6 +305,7 @@ __global__ __launch_bounds__(JM_THREADS) void joint_test_mfma_kernel(const Joint
         acc += __shfl_xor(acc, 4, 64);
         if (row < n_r && part == 0) yr[row] = acc;
     }
+    JMPHP(2);
     {   // runs of slots that share their input point (two slots per thread: tid, tid + 512), and the same for the columns
         static_assert(JM_NT * 16 <= 2 * JM_THREADS && JM_COLS <= JM_THREADS, "two slots, one column per thread");
         auto slot_point = [&](int sl, int& task) -> int {        // point id (real points first) and task of conditioning slot sl
@@ -365,6 +392,7 @@ __global__ __launch_bounds__(JM_THREADS) void joint_test_mfma_kernel(const Joint
         }
     }
     __syncthreads();
+    JMPHP(3);
     const int ncr = wtot[3 * JM_NW];              // column runs
     // invert the diagonal tiles in place: lane (tq, c) of wave w forms column c of the inverse of tile 32 pass + 4 w + tq
     for (int pass = 0; pass * 4 * JM_NW < nt; ++pass) {
@@ -392,6 +420,7 @@ __global__ __launch_bounds__(JM_THREADS) void joint_test_mfma_kernel(const Joint
             for (int i = 0; i < 16; ++i) Lw[jm_off(i, c)] = x[i];
         }
     }
+    JMPHP(4);
     // pad columns of the kernel-entry buffer: zero once (no entry is ever written there)
     for (int e = tid; e < JM_KCH * (JM_COLS - ncols); e += JM_THREADS) {
         const int w = JM_COLS - ncols;
@@ -399,6 +428,7 @@ __global__ __launch_bounds__(JM_THREADS) void joint_test_mfma_kernel(const Joint
         kbuf[row * JM_COLS + col] = 0.0;
     }
     __syncthreads();
+    JMPHP(5);
     // K_cc, the starting value of the Gram accumulators (test mode: K**; factor mode: K_nn + noise), goes to the chain's S buffer
     // NOW, while registers are free: one lane per pair of column runs (one exponential for up to T x T entries), the lower
     // triangle and its mirror from the same value.  The Gram phase - 208 registers of every lane hold X by then - only loads it.
@@ -406,13 +436,32 @@ __global__ __launch_bounds__(JM_THREADS) void joint_test_mfma_kernel(const Joint
         const int ldK = fmode ? ncols : mT;
         double* Kc = a.Sall + chain * (long)mT * mT;
         const int nrun = fmode ? ncr : ncr - 1;   // (test mode: the last run is the label column)
-        for (int e = tid; e < nrun * nrun; e += JM_THREADS) {
-            const int ra = e / nrun, rb = e - ra * nrun;
-            if (rb > ra) continue;
+        // pair e of the lower triangle (rb <= ra), row by row: ra = the largest r with r (r + 1) / 2 <= e
+        for (int e = tid; e < nrun * (nrun + 1) / 2; e += JM_THREADS) {
+            int ra = (int)((__builtin_sqrtf(8.0f * (float)e + 1.0f) - 1.0f) * 0.5f);
+            ra += ((ra + 1) * (ra + 2) / 2 <= e) ? 1 : 0;
+            ra -= (ra * (ra + 1) / 2 > e) ? 1 : 0;
+            const int rb = e - ra * (ra + 1) / 2;
             const int a0 = crun_start[ra], a1 = crun_start[ra + 1], b0 = crun_start[rb], b1 = crun_start[rb + 1];
             const double xa[D] = {cptx[2 * ra], cptx[2 * ra + 1]}, xb[D] = {cptx[2 * rb], cptx[2 * rb + 1]};
             double qq[D];
             const double kv = os * jm_exp_neg(-0.5 * kern_sqdist<D>(xa, xb, il2, qq));
+            if (T == 3 && a1 - a0 == 3 && b1 - b0 == 3) {
+                // a whole point against a whole point: the 3 x 3 block (rows: the tasks of run ra) and its mirror, no look-ups
+                const double kq0 = kv * qq[0], kq1 = kv * qq[1];
+                double blk[3][3] = {{kv, kq0, kq1},
+                                    {-kq0, kv * (il2[0] - qq[0] * qq[0]), -kq0 * qq[1]},
+                                    {-kq1, -kq1 * qq[0], kv * (il2[1] - qq[1] * qq[1])}};
+                if (fmode && ra == rb) blk[0][0] += noise0, blk[1][1] += noise1, blk[2][2] += noise2;
+#pragma unroll
+                for (int i = 0; i < 3; ++i)
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) {
+                        Kc[(long)(a0 + i) * ldK + b0 + j] = blk[i][j];
+                        if (ra != rb) Kc[(long)(b0 + j) * ldK + a0 + i] = blk[i][j];
+                    }
+                continue;
+            }
             for (int t1 = a0; t1 < a1; ++t1) {
                 const int ta = ctask[t1];
                 for (int t2 = b0; t2 < b1; ++t2) {
@@ -425,53 +474,69 @@ __global__ __launch_bounds__(JM_THREADS) void joint_test_mfma_kernel(const Joint
             }
         }
     }
+    JMPHP(6);
     JMPH(0);
 
     // ---- kernel entries K_o* (and the label column) into the accumulators, JM_KCH slots at a time: one lane per (slot run,
     // column run) pair = one exponential for up to T x T entries -------------------------------------------------------------
-    JmAcc A;
-    jm_acc_begin_a(A);                            // (the tiles' registers are taken from here on, not before: every tile that is read is set below)
-    constexpr int JM_CHUNKS_A = 10;
-    const unsigned ncr_magic = 0xFFFFFFFFu / (unsigned)ncr + 1u;      // e / ncr = umulhi(e, magic) for e < 65536
-    for (int ch = 0; 2 * ch < nt && ch < JM_CHUNKS_A; ++ch) {     // tiles 0..19: the statements name those only - the other six are not live yet         // (a run-time loop: no C++ branch ever surrounds a statement that writes A)
+    const int nck = fmode ? ncr : ncr - 1;       // column runs of kernel entries (test mode: the last run is the label column)
+    const unsigned nck_magic = 0xFFFFFFFFu / (unsigned)nck + 1u;      // e / nck = umulhi(e, magic) for e < 65536
+    // kernel entries of the slots 32 ch .. 32 ch + 31 against every column into kbuf: one lane per (slot run, column run) pair
+    auto fill_chunk = [&](int ch) {
         const int s0 = ch * JM_KCH;
         const int r0 = first_run[ch];
         const int r1 = starts_before[min(ch + 1, (n_o + JM_KCH - 1) / JM_KCH)];
-        const int npairs = (r1 - r0) * ncr;
+        const int npairs = (r1 - r0) * nck;
         for (int e = tid; e < npairs; e += JM_THREADS) {
-            const int rr = (int)__umulhi((unsigned)e, ncr_magic), cr = e - rr * ncr;
+            const int rr = (int)__umulhi((unsigned)e, nck_magic), cr = e - rr * nck;
             const int sa = run_start[r0 + rr], sb = run_start[r0 + rr + 1];
             const int ca = crun_start[cr], cb = crun_start[cr + 1];
-            const int sl0 = max(sa, s0), sl1 = min(sb, s0 + JM_KCH);
-            if (ctask[ca] >= 0) {
-                const double xc[D] = {rptx[2 * (r0 + rr)], rptx[2 * (r0 + rr) + 1]};
-                const double xt[D] = {cptx[2 * cr], cptx[2 * cr + 1]};
-                double qq[D];
-                const double k = os * jm_exp_neg(-0.5 * kern_sqdist<D>(xc, xt, il2, qq)); // r = x_slot - x_column
-                if (T == 3 && sl1 - sl0 == 3 && sb - sa == 3 && cb - ca == 3) {
-                    // a whole point against a whole point (value + two derivatives each way): the 3 x 3 block at once - no task
-                    // look-ups, no branches (the general form below costs ten dependent LDS round trips per pair)
-                    const double kq0 = k * qq[0], kq1 = k * qq[1];
-                    double* row = kbuf + (sl0 - s0) * JM_COLS + ca;
-                    row[0] = k, row[1] = kq0, row[2] = kq1;
-                    row[JM_COLS] = -kq0, row[JM_COLS + 1] = k * (il2[0] - qq[0] * qq[0]), row[JM_COLS + 2] = -kq0 * qq[1];
-                    row[2 * JM_COLS] = -kq1, row[2 * JM_COLS + 1] = -kq1 * qq[0], row[2 * JM_COLS + 2] = k * (il2[1] - qq[1] * qq[1]);
-                } else {
-                    for (int sl = sl0; sl < sl1; ++sl) {
-                        const int ta = stask[sl];
-                        for (int c = ca; c < cb; ++c) kbuf[(sl - s0) * JM_COLS + c] = jm_kern_entry(qq[0], qq[1], k, il2[0], il2[1], ta, ctask[c]);
-                    }
+            const double xc[D] = {rptx[2 * (r0 + rr)], rptx[2 * (r0 + rr) + 1]};
+            const double xt[D] = {cptx[2 * cr], cptx[2 * cr + 1]};
+            double qq[D];
+            const double k = os * jm_exp_neg(-0.5 * kern_sqdist<D>(xc, xt, il2, qq)); // r = x_slot - x_column
+            const int ns = sb - sa;
+            if (T == 3 && cb - ca == 3 && (ns == 3 || (ns == 1 && stask[sa] == 0))) {
+                // a whole point (value + two derivatives) or a value-only slot against a whole point: the rows of the 3 x 3
+                // block, no task look-ups, no loops - also for a point the chunk boundary cuts (its rows outside the chunk are
+                // not stored).  (The general form below costs ten dependent LDS round trips per pair, and ONE lane that takes
+                // it makes its whole wave walk it: the real slots and every boundary point did - 3-5 k cycles per chunk.)
+                const double kq0 = k * qq[0], kq1 = k * qq[1];
+                double* row = kbuf + (sa - s0) * JM_COLS + ca;
+                if (sa >= s0) row[0] = k, row[1] = kq0, row[2] = kq1;
+                if (ns == 3) {
+                    if (sa + 1 >= s0 && sa + 1 < s0 + JM_KCH)
+                        row[JM_COLS] = -kq0, row[JM_COLS + 1] = k * (il2[0] - qq[0] * qq[0]), row[JM_COLS + 2] = -kq0 * qq[1];
+                    if (sa + 2 < s0 + JM_KCH)
+                        row[2 * JM_COLS] = -kq1, row[2 * JM_COLS + 1] = -kq1 * qq[0], row[2 * JM_COLS + 2] = k * (il2[1] - qq[1] * qq[1]);
                 }
-            } else {                                                                      // the label column
-                for (int sl = sl0; sl < sl1; ++sl)
-                    kbuf[(sl - s0) * JM_COLS + ca] = (sl < n_r) ? yr[sl] : ylab[sl];
+            } else {
+                const int sl0 = max(sa, s0), sl1 = min(sb, s0 + JM_KCH);
+                for (int sl = sl0; sl < sl1; ++sl) {
+                    const int ta = stask[sl];
+                    for (int c = ca; c < cb; ++c) kbuf[(sl - s0) * JM_COLS + c] = jm_kern_entry(qq[0], qq[1], k, il2[0], il2[1], ta, ctask[c]);
+                }
             }
+        }
+        // the label column (test mode): one lane of the LAST wave per slot (as a column run of the pair loop it cost every wave
+        // that held one of its lanes a divergent walk over the run's slots)
+        if (!fmode && tid >= JM_THREADS - JM_KCH) {
+            const int sl = s0 + tid - (JM_THREADS - JM_KCH);
+            if (sl < n_o) kbuf[(sl - s0) * JM_COLS + mT] = (sl < n_r) ? yr[sl] : ylab[sl];
         }
         if (n_o < s0 + JM_KCH) {                                                          // pad slots: zero rows
             const int z0 = (n_o - s0) * JM_COLS;
             for (int e = z0 + tid; e < JM_KCH * JM_COLS; e += JM_THREADS) kbuf[e] = 0.0;
         }
+    };
+    JmAcc A;
+    jm_acc_begin_a(A);                            // (the tiles' registers are taken from here on, not before: every tile that is read is set below)
+    constexpr int JM_CHUNKS_A = 10;
+    for (int ch = 0; 2 * ch < nt && ch < JM_CHUNKS_A; ++ch) {     // tiles 0..19: the statements name those only - the other six are not live yet         // (a run-time loop: no C++ branch ever surrounds a statement that writes A)
+        fill_chunk(ch);
+        JMPHE(0);
         __syncthreads();
+        JMPHE(1);
 #pragma unroll 1
         for (int u = 0; u < 2; ++u) {             // (tile 2 ch + 1 may lie beyond nt: it is written - with the buffer's stale rows - and never used)
             double t[4];
@@ -479,47 +544,13 @@ __global__ __launch_bounds__(JM_THREADS) void joint_test_mfma_kernel(const Joint
             for (int v = 0; v < 4; ++v) t[v] = kbuf[(16 * u + 4 * (lane >> 4) + v) * JM_COLS + 16 * I0 + (lane & 15)];
             jm_acc_set_a(A, 2 * ch + u, t[0], t[1], t[2], t[3]);
         }
+        JMPHE(2);
         __syncthreads();
+        JMPHE(3);
     }
     jm_acc_begin_b(A);
     for (int ch = JM_CHUNKS_A; 2 * ch < nt; ++ch) {         // (a run-time loop: no C++ branch ever surrounds a statement that writes A)
-        const int s0 = ch * JM_KCH;
-        const int r0 = first_run[ch];
-        const int r1 = starts_before[min(ch + 1, (n_o + JM_KCH - 1) / JM_KCH)];
-        const int npairs = (r1 - r0) * ncr;
-        for (int e = tid; e < npairs; e += JM_THREADS) {
-            const int rr = (int)__umulhi((unsigned)e, ncr_magic), cr = e - rr * ncr;
-            const int sa = run_start[r0 + rr], sb = run_start[r0 + rr + 1];
-            const int ca = crun_start[cr], cb = crun_start[cr + 1];
-            const int sl0 = max(sa, s0), sl1 = min(sb, s0 + JM_KCH);
-            if (ctask[ca] >= 0) {
-                const double xc[D] = {rptx[2 * (r0 + rr)], rptx[2 * (r0 + rr) + 1]};
-                const double xt[D] = {cptx[2 * cr], cptx[2 * cr + 1]};
-                double qq[D];
-                const double k = os * jm_exp_neg(-0.5 * kern_sqdist<D>(xc, xt, il2, qq)); // r = x_slot - x_column
-                if (T == 3 && sl1 - sl0 == 3 && sb - sa == 3 && cb - ca == 3) {
-                    // a whole point against a whole point (value + two derivatives each way): the 3 x 3 block at once - no task
-                    // look-ups, no branches (the general form below costs ten dependent LDS round trips per pair)
-                    const double kq0 = k * qq[0], kq1 = k * qq[1];
-                    double* row = kbuf + (sl0 - s0) * JM_COLS + ca;
-                    row[0] = k, row[1] = kq0, row[2] = kq1;
-                    row[JM_COLS] = -kq0, row[JM_COLS + 1] = k * (il2[0] - qq[0] * qq[0]), row[JM_COLS + 2] = -kq0 * qq[1];
-                    row[2 * JM_COLS] = -kq1, row[2 * JM_COLS + 1] = -kq1 * qq[0], row[2 * JM_COLS + 2] = k * (il2[1] - qq[1] * qq[1]);
-                } else {
-                    for (int sl = sl0; sl < sl1; ++sl) {
-                        const int ta = stask[sl];
-                        for (int c = ca; c < cb; ++c) kbuf[(sl - s0) * JM_COLS + c] = jm_kern_entry(qq[0], qq[1], k, il2[0], il2[1], ta, ctask[c]);
-                    }
-                }
-            } else {                                                                      // the label column
-                for (int sl = sl0; sl < sl1; ++sl)
-                    kbuf[(sl - s0) * JM_COLS + ca] = (sl < n_r) ? yr[sl] : ylab[sl];
-            }
-        }
-        if (n_o < s0 + JM_KCH) {                                                          // pad slots: zero rows
-            const int z0 = (n_o - s0) * JM_COLS;
-            for (int e = z0 + tid; e < JM_KCH * JM_COLS; e += JM_THREADS) kbuf[e] = 0.0;
-        }
+        fill_chunk(ch);
         __syncthreads();
 #pragma unroll 1
         for (int u = 0; u < 2; ++u) {             // (tile 2 ch + 1 may lie beyond nt: it is written - with the buffer's stale rows - and never used)
@@ -574,9 +605,13 @@ __global__ __launch_bounds__(JM_THREADS) void joint_test_mfma_kernel(const Joint
                         // every wave waits for ITS OWN pieces of the chunk, then the barrier: hipcc's __syncthreads carries no
                         // vmcnt wait for the LDS-DMA loads (it only puts one in front of an LDS read it can see - behind the
                         // barrier, where it covers this wave's pieces and nobody else's)
+                        JMPHS(1);
                         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                        JMPHS(3);
                         __syncthreads();
+                        JMPHS(4);
                         issue_chunk((seq >> 4) + 1);
+                        JMPHS(5);
                     }
                     addr_p = tile_addr(k, j);
                     jm_sets_load(S, set, addr_p);
@@ -602,9 +637,30 @@ __global__ __launch_bounds__(JM_THREADS) void joint_test_mfma_kernel(const Joint
     }
     __syncthreads();                              // every wave is done with the ring
     JMPH(2);
+    // factor mode: X^T = the new rows' entries against the old columns goes to the cache (row n_c + column, 4 consecutive slots per lane)
+    const int nt_f = fmode ? nt : 0;              // (a run-time trip count, not a branch around the statement)
+#pragma unroll 1
+    for (int j = 0; j < nt_f; ++j) {
+        double t[4];
+        jm_acc_get(A, j, t[0], t[1], t[2], t[3]);
+        if (active) {
+            const int col = 16 * I0 + (lane & 15), sl = 16 * j + 4 * (lane >> 4);
+            if (col < ncols) {
+                double* dst = fc + (long)(a.n_c + col) * CS + sl;
+                if (sl + 3 < n_o) {
+                    *reinterpret_cast<jm_d2*>(dst) = jm_d2{t[0], t[1]};
+                    *reinterpret_cast<jm_d2*>(dst + 2) = jm_d2{t[2], t[3]};
+                } else {
+#pragma unroll
+                    for (int v = 0; v < 4; ++v)
+                        if (sl + v < n_o) dst[v] = t[v];
+                }
+            }
+        }
+    }
     // tiles 22..25 of every wave's X go to LDS (the inverted diagonal tiles are no longer needed): the statements of the Gram phase
-    // name the tiles 0..21 only, 32 registers come free (with 208 registers pinned the phase spilled into scratch memory: one
-    // round trip to it costs as much as eight MFMAs)
+    // name the tiles 0..21 only, 32 registers come free for the Gram accumulators; the four tiles come back into the registers of
+    // tiles 0..3 once those are done with (jm_gram_reload)
     double* stash = linv + wv * (JM_STASH * 256);
 #pragma unroll 1
     for (int u = 0; u < JM_STASH; ++u) {
@@ -613,38 +669,46 @@ __global__ __launch_bounds__(JM_THREADS) void joint_test_mfma_kernel(const Joint
 #pragma unroll
         for (int v = 0; v < 4; ++v) stash[(u * 4 + v) * 64 + lane] = t[v];
     }
-    // [t0 .. t3] = tile j of this wave's X (no branch around the statement: the register tiles and the stash are both read)
-    auto x_tile = [&](int j, double (&t)[4]) {
-        double r[4];
-        jm_acc_get_lo(A, min(j, JM_NT - JM_STASH - 1), r[0], r[1], r[2], r[3]);
-        const int su = max(j - (JM_NT - JM_STASH), 0);
-#pragma unroll
-        for (int v = 0; v < 4; ++v) {
-            const double l = stash[(su * 4 + v) * 64 + lane];
-            t[v] = (j < JM_NT - JM_STASH) ? r[v] : l;
-        }
-    };
 
-    // ---- Gram: G_IJ = K_IJ - X_I^T X_J for J = I + d (mod 8), d = 0..4 (d = 4 counts for the tiles I < 4) ---------------------
+    // ---- Gram: G_IJ = K_IJ - X_I^T X_J for J = I + d (mod 8), d = 0..4 (d = 4 counts for the tiles I < 4), ONE pass: five accumulators
+    // per wave start at -K_IJ, take + X_I^T X_J tile by tile and are negated on the way out.  Groups of four slot tiles: every wave
+    // publishes its four X tiles in the exchange buffer (the ring: 8 waves x 4 tiles x 2 KB), barrier, every wave forms its 4 x 5
+    // products (A operand: its own tile, in place in its registers; B operands: the published tiles).  (Rounds 1-4 of this kernel
+    // ran three passes of two accumulators - every tile published three times, two MFMAs per LDS round trip: 208 k cycles per chain.)
     // test mode: K = K** and the label column / row of G is -mean; factor mode: K = K_nn + noise (the Schur complement)
     const int ldS = fmode ? ncols : mT;
     double* Sm = a.Sall + chain * (long)mT * mT;
     double* mean = a.mean + chain * (long)mT;
-    const unsigned ring_gb = (unsigned)(size_t)(__attribute__((address_space(3))) double*)ring;
-    double* tbuf = ring + wv * 272;               // [16][17] per wave, inside the exchange buffer: used between two barriers of its own
-    auto tile_init = [&](int I, int J) -> jm_d4 {            // register v, lane (kk, jj) = K_cc(row 16 I + 4 v + kk, column 16 J + jj)
+    auto tile_init = [&](int I, int J) -> jm_d4 {            // register v, lane (kk, jj) = -K_cc(row 16 I + 4 v + kk, column 16 J + jj)
         jm_d4 r;
         const int t2 = 16 * J + (lane & 15);
+        double ld[4];
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {                         // (unconditional loads, clamped: all in flight together)
+            const int t1 = 16 * I + 4 * v + (lane >> 4);
+            ld[v] = Sm[(long)min(t1, ldS - 1) * ldS + min(t2, ldS - 1)];
+        }
 #pragma unroll
         for (int v = 0; v < 4; ++v) {
             const int t1 = 16 * I + 4 * v + (lane >> 4);
-            r[v] = (t1 < ldS && t2 < ldS) ? Sm[(long)t1 * ldS + t2] : 0.0;
+            r[v] = (t1 < ldS && t2 < ldS) ? -ld[v] : 0.0;
         }
         return r;
     };
-    auto tile_out = [&](int I, int J, int d, const jm_d4& sv) {
+    int Jt[5];
+    jm_d4 kinit[5];
+#pragma unroll
+    for (int d = 0; d < 5; ++d) {
+        Jt[d] = (I0 + d) & (JM_NCT - 1);
+        kinit[d] = tile_init(I0, Jt[d]);
+    }
+    const unsigned ring_gb = (unsigned)(size_t)(__attribute__((address_space(3))) double*)ring;
+    const unsigned stash_gb = (unsigned)(size_t)(__attribute__((address_space(3))) double*)linv + (unsigned)wv * (JM_STASH * 2048u);
+    double* tbuf = ring + wv * 272;               // [16][17] per wave, inside the exchange buffer: used between two barriers of its own
+    auto tile_out = [&](int I, int J, int d, const jm_d4& sn) {
         // the tile and its mirror image, both as 128-byte row segments: the mirror through a per-wave LDS transpose
         const int jj = lane & 15, kk = lane >> 4;
+        const jm_d4 sv = -sn;
 #pragma unroll
         for (int v = 0; v < 4; ++v) tbuf[(4 * v + kk) * 17 + jj] = sv[v];
         const int t2 = 16 * J + jj;
@@ -669,72 +733,38 @@ __global__ __launch_bounds__(JM_THREADS) void joint_test_mfma_kernel(const Joint
             }
         }
     };
-#pragma unroll 1
-    for (int pass = 0; pass < 3; ++pass) {        // d = 0, 1 | 2, 3 | 4, (5: nobody's) - two accumulators: a third one spills
-        const int d0 = 2 * pass;
-        jm_d4 sacc[2];
-        bool on[2];
-        int Jt[2];
+    {
+        bool on[5];
+        unsigned ab[5];
 #pragma unroll
-        for (int dd = 0; dd < 2; ++dd) {
-            const int d = d0 + dd;
-            Jt[dd] = (I0 + d) & (JM_NCT - 1);
-            on[dd] = d <= 4 && I0 < ncta && Jt[dd] < ncta && (d < 4 || I0 < 4);     // (what is written out; every product is formed)
+        for (int d = 0; d < 5; ++d) {
+            on[d] = I0 < ncta && Jt[d] < ncta && (d < 4 || I0 < 4);         // (what is written out; every product is formed)
+            ab[d] = ring_gb + (unsigned)Jt[d] * 8192u;
         }
-        sacc[0] = tile_init(I0, Jt[0]);
-        sacc[1] = tile_init(I0, Jt[1]);
+        JmGram Gm;
+        Gm.s0 = kinit[0], Gm.s1 = kinit[1], Gm.s2 = kinit[2], Gm.s3 = kinit[3], Gm.s4 = kinit[4];
+        jm_gram_begin(Gm);
         JMPH(3);
-        for (int j0 = 0; j0 < nt; j0 += 4) {
+        const unsigned pub = ring_gb + (unsigned)I0 * 8192u;
+        for (int g = 0; 4 * g < nt; ++g) {
             __syncthreads();                      // the previous group's tiles have been read
+            jm_gram_reload(A, Gm, stash_gb, __builtin_amdgcn_readfirstlane(g == 2 ? 1 : 0));
+            const int nu = min(4, nt - 4 * g);
 #pragma unroll 1
-            for (int u = 0; u < 4; ++u) {
-                const int j = min(j0 + u, nt - 1);
-                double t[4];
-                x_tile(j, t);
-                {
-#pragma unroll
-                    for (int v = 0; v < 4; ++v) ring[((I0 * 4 + u) * 4 + v) * 64 + lane] = t[v];
-                    if (active && pass == 0 && fmode && j0 + u < nt) {
-                        // X^T = the new rows' entries against the old columns: row n_c + column, 4 consecutive slots per lane
-                        const int col = 16 * I0 + (lane & 15), sl = 16 * j + 4 * (lane >> 4);
-                        if (col < ncols) {
-                            double* dst = fc + (long)(a.n_c + col) * CS + sl;
-                            if (sl + 3 < n_o) {
-                                *reinterpret_cast<jm_d2*>(dst) = jm_d2{t[0], t[1]};
-                                *reinterpret_cast<jm_d2*>(dst + 2) = jm_d2{t[2], t[3]};
-                            } else {
-#pragma unroll
-                                for (int v = 0; v < 4; ++v)
-                                    if (sl + v < n_o) dst[v] = t[v];
-                            }
-                        }
-                    }
-                }
-            }
+            for (int u = 0; u < nu; ++u) jm_gram_publish(A, Gm, 4 * g + u, pub);
             __syncthreads();
             JMPH(4);
 #pragma unroll 1
-            for (int u = 0; u < 4; ++u) {
-                const bool valid = j0 + u < nt;   // (a tile beyond nt: the last tile again, with a zero A operand)
-                double t[4];
-                x_tile(min(j0 + u, nt - 1), t);   // (again: 4 moves are cheaper than 8 live registers per tile)
-                // (tiles nobody writes out - idle column tiles, the sixth distance - cost their MFMAs: no select, no mask; a wave's own
-                // tile comes through the ring like everybody else's)
-                const unsigned ad0 = ring_gb + (unsigned)(((Jt[0] * 4 + u) * 4) * 64 + lane) * 8u;
-                const unsigned ad1 = ring_gb + (unsigned)(((Jt[1] * 4 + u) * 4) * 64 + lane) * 8u;
-                jm_gram_step0(sacc[0], sacc[1], valid ? t[0] : 0.0, ad0, ad1);
-                jm_gram_step1(sacc[0], sacc[1], valid ? t[1] : 0.0, ad0 + 512u, ad1 + 512u);
-                jm_gram_step2(sacc[0], sacc[1], valid ? t[2] : 0.0, ad0 + 1024u, ad1 + 1024u);
-                jm_gram_step3(sacc[0], sacc[1], valid ? t[3] : 0.0, ad0 + 1536u, ad1 + 1536u);
-            }
+            for (int u = 0; u < nu; ++u) jm_gram_tile(A, Gm, 4 * g + u, ab[0], ab[1], ab[2], ab[3], ab[4]);
             JMPH(5);
         }
         __syncthreads();                          // every wave has read the last group's tiles: the ring takes the transposes
-#pragma unroll
-        for (int dd = 0; dd < 2; ++dd) {
-            jm_settle(sacc[dd]);
-            if (on[dd]) tile_out(I0, Jt[dd], d0 + dd, sacc[dd]);
-        }
+        jm_settle(Gm.s4);                         // (the last MFMA issued wrote s4; the others are older)
+        if (on[0]) tile_out(I0, Jt[0], 0, Gm.s0);
+        if (on[1]) tile_out(I0, Jt[1], 1, Gm.s1);
+        if (on[2]) tile_out(I0, Jt[2], 2, Gm.s2);
+        if (on[3]) tile_out(I0, Jt[3], 3, Gm.s3);
+        if (on[4]) tile_out(I0, Jt[4], 4, Gm.s4);
         JMPH(6);
     }
 #ifdef GPMPC_PHASE_TIMERS
@@ -743,6 +773,11 @@ __global__ __launch_bounds__(JM_THREADS) void joint_test_mfma_kernel(const Joint
         jph[7] = jphs[0];                         // (slot 7 of the phase record: diagonal steps; the other two are recovered below)
         for (int i = 0; i < 8; ++i) g_jm_phase[i + (tid ? 8 : 0)] = jph[i];
         g_jm_phase[16 + (tid ? 2 : 0)] = jphs[1], g_jm_phase[17 + (tid ? 2 : 0)] = jphs[2];
+        if (tid == 0) {
+            for (int i = 0; i < 8; ++i) g_jm_phase[20 + i] = jpp[i];
+            for (int i = 0; i < 4; ++i) g_jm_phase[28 + i] = jpe[i];
+        }
+        for (int i = 0; i < 3; ++i) g_jm_phase[32 + i + (tid ? 3 : 0)] = jphs[3 + i];
     }
 #endif
 }
@@ -768,7 +803,7 @@ int joint_mfma_launch(const JointArgs& a, hipStream_t st) {
 
 }  // namespace gpmpc
 
-extern "C" int gpmpc_debug_read_joint_mfma_phases(long long* out /*[host] 20*/) {
-    GPMPC_HIP_CHECK(hipMemcpyFromSymbol(out, HIP_SYMBOL(gpmpc::g_jm_phase), 20 * sizeof(long long)));
+extern "C" int gpmpc_debug_read_joint_mfma_phases(long long* out /*[host] 40*/) {
+    GPMPC_HIP_CHECK(hipMemcpyFromSymbol(out, HIP_SYMBOL(gpmpc::g_jm_phase), 40 * sizeof(long long)));
     return GPMPC_OK;
 }
