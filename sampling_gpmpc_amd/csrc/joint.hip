@@ -988,6 +988,7 @@ static long joint_grid(long nchains) {
 // batches of tc_slots chains.
 struct JointWs {
     long grid, stride, s_off, egrid, estride, e_off, f_off, total;
+    long egrid_narrow, d_off;
     long tc_off, tc_slots, tc_stride;
     int tc_rows, tc_cs;
     int ld;
@@ -1031,8 +1032,14 @@ static JointWs joint_ws_layout(int n_r, int n_ho, int m, int T, long nchains) {
     w.egrid = eigh_grid(nchains);
     w.estride = eigh_slot_doubles((int)mT);
     w.e_off = w.s_off + nchains * mT * mT;
-    w.f_off = w.e_off + (mT > 1 ? w.egrid * w.estride : 0);
-    w.total = w.f_off + 32;
+    // (the narrow launch's slots - L for ranks <= 40, the log for ranks <= 32 - share the region: 4096 x 105 KB < 2560 x 1.15 MB at
+    // m T = 120)
+    w.egrid_narrow = nchains < 256L * 16 ? nchains : 256L * 16;
+    long eregion = mT > 1 ? w.egrid * w.estride : 0;
+    if (mT > 1 && w.egrid_narrow * eigh_narrow_slot_doubles((int)mT) > eregion) eregion = w.egrid_narrow * eigh_narrow_slot_doubles((int)mT);
+    w.f_off = w.e_off + eregion;
+    w.d_off = w.f_off + 32;                             // deferred chains' ids (ints)
+    w.total = w.d_off + (nchains + 1) / 2 + 1;
     w.tc_off = w.tc_slots = w.tc_stride = 0;
     w.tc_rows = w.tc_cs = 0;
     if (n_ho >= 1 && joint_mfma_eligible(n_r, n_ho, m * (int)T + 1, T)) {       // (pin-independent: the workspace serves either path)
@@ -1086,7 +1093,7 @@ int gpmpc_debug_eigh_occupancy(int mT, size_t extra_lds) {
     const int cap = np < EIGH_LDS_RANK ? np : EIGH_LDS_RANK;
     const size_t lds = (size_t)eigh_lds_doubles(mT, cap) * sizeof(double) + extra_lds;
     int nb = -1;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, joint_eigh_kernel<3, 2>, 64, lds) != hipSuccess) return -1;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, joint_eigh_kernel<3, 2, GPMPC_EIGH_WPE>, 64, lds) != hipSuccess) return -1;
     return nb;
 }
 
@@ -1170,7 +1177,7 @@ int gpmpc_joint_sample(const gpmpc_gp_desc_t* gp, const void* plan, const double
     a.chain1 = Ns * gp->g_ny;
     a.mfma_mode = JOINT_MFMA_TEST;
     hipStream_t st = (hipStream_t)stream;
-    GPMPC_HIP_CHECK(hipMemsetAsync(a.any_fail, 0, sizeof(int), st));
+    GPMPC_HIP_CHECK(hipMemsetAsync(a.any_fail, 0, 4 * sizeof(int), st));      // any_fail, deferred chains, max rank (joint_eigh_kernel)
     const long nchains = Ns * gp->g_ny;
     // Abandoning pays when the launch needs at least two rounds of the chip (the chains of later rounds skip their root
     // phase): measured on the car's closed loop, Ns = 1024: k = 0 (1.5 rounds) +5 %, k = 1..3 and the 480-slot k = 0
@@ -1292,15 +1299,56 @@ int gpmpc_joint_sample(const gpmpc_gp_desc_t* gp, const void* plan, const double
         const int np = (mT + 1) & ~1;
         e.lds_cap = global_G ? 0 : (np < EIGH_LDS_RANK ? np : EIGH_LDS_RANK);
         e.tol_mult = 16.0;
-        const size_t lds = (size_t)eigh_lds_doubles(mT, e.lds_cap) * sizeof(double);
-        const dim3 ge((unsigned)w.egrid), be(64);
-        if (gp->T == 1) {
-            if (mT <= 128) hipLaunchKernelGGL((joint_eigh_kernel<1, 2>), ge, be, lds, st, e);
-            else hipLaunchKernelGGL((joint_eigh_kernel<1, 4>), ge, be, lds, st, e);
-        } else {
-            if (mT <= 128) hipLaunchKernelGGL((joint_eigh_kernel<3, 2>), ge, be, lds, st, e);
-            else hipLaunchKernelGGL((joint_eigh_kernel<3, 4>), ge, be, lds, st, e);
+        e.gg_off = (long)mT * mT;
+        e.rlog_off = e.gg_off + 2 * eigh_packed(np);
+        e.pass = EIGH_PASS_ALL;
+        e.defer_rank = 0;
+        int* flags = a.any_fail;                        // [0] any_fail, [1] deferred chains, [2] max rank of this call; zeroed above
+        e.defer_count = flags + 1;
+        e.rank_hint = flags + 2;
+        e.defer_list = (int*)((double*)ws + w.d_off);
+        // Batches of low rank (the closed loop's points: 6..16 of 120) first run the NARROW form - LDS for ranks <= 32, 128
+        // registers: 16 chains resident per CU instead of 7 (the kernel is a chain of dependent LDS / L2 round trips per wave) - and
+        // the chains it defers (rank > 32) the full form, in a second launch over their list.  Which form a chain takes does not
+        // change its result.  The choice follows the largest rank of the LAST call whose counter has arrived (a heuristic for
+        // speed only): scattered points (ranks ~50) skip the narrow launch.
+        static int* hint_host = nullptr;
+        if (!hint_host) {
+            GPMPC_HIP_CHECK(hipHostMalloc((void**)&hint_host, sizeof(int), hipHostMallocDefault));
+            *hint_host = 0;
         }
+        static const char* nenv = getenv("GPMPC_EIGH_NARROW");            // 0 / 1: force the choice (A/B timing, tests)
+        const int last_rank = *(volatile int*)hint_host;
+        const bool narrow = !global_G && mT <= 128 && mT > EIGH_NARROW_RANK &&
+                            (nenv ? atoi(nenv) != 0 : last_rank <= EIGH_NARROW_RANK);
+        auto launch_eigh = [&](const EighArgs& ea, long grid, int wpe) {
+            const size_t lds = (size_t)eigh_lds_doubles(mT, ea.lds_cap) * sizeof(double);
+            const dim3 ge((unsigned)grid), be(64);
+            if (gp->T == 1) {
+                if (mT > 128) hipLaunchKernelGGL((joint_eigh_kernel<1, 4, GPMPC_EIGH_WPE>), ge, be, lds, st, ea);
+                else if (wpe == 4) hipLaunchKernelGGL((joint_eigh_kernel<1, 2, GPMPC_EIGH_NARROW_WPE>), ge, be, lds, st, ea);
+                else hipLaunchKernelGGL((joint_eigh_kernel<1, 2, GPMPC_EIGH_WPE>), ge, be, lds, st, ea);
+            } else {
+                if (mT > 128) hipLaunchKernelGGL((joint_eigh_kernel<3, 4, GPMPC_EIGH_WPE>), ge, be, lds, st, ea);
+                else if (wpe == 4) hipLaunchKernelGGL((joint_eigh_kernel<3, 2, GPMPC_EIGH_NARROW_WPE>), ge, be, lds, st, ea);
+                else hipLaunchKernelGGL((joint_eigh_kernel<3, 2, GPMPC_EIGH_WPE>), ge, be, lds, st, ea);
+            }
+        };
+        if (narrow) {
+            EighArgs en = e;
+            en.pass = EIGH_PASS_NARROW;
+            en.lds_cap = EIGH_NARROW_RANK;
+            en.defer_rank = EIGH_NARROW_RANK;
+            en.gg_off = 0;                              // (no chain of this launch takes the HBM/L2 form)
+            en.rlog_off = (long)mT * (EIGH_NARROW_RANK + EIGH_PB);
+            en.ws_slot_stride = eigh_narrow_slot_doubles((int)mT);
+            launch_eigh(en, w.egrid_narrow, 4);           // (4: "the narrow instantiation", whatever its occupancy)
+            GPMPC_HIP_CHECK(hipGetLastError());
+            e.pass = EIGH_PASS_DEFERRED;
+        }
+        launch_eigh(e, w.egrid, GPMPC_EIGH_WPE);
+        GPMPC_HIP_CHECK(hipGetLastError());
+        GPMPC_HIP_CHECK(hipMemcpyAsync(hint_host, e.rank_hint, sizeof(int), hipMemcpyDeviceToHost, st));
         GPMPC_HIP_CHECK(hipGetLastError());
     }
     return GPMPC_OK;

@@ -52,7 +52,19 @@ struct EighArgs {
     double* root;            // optional [chains][n][n] row-major
     int lds_cap;             // largest (even) rank whose packed Gram matrix fits the dynamic LDS
     double tol_mult;         // pivoted-Cholesky stop: residual diagonal <= tol_mult * eps * max prior variance
+    // slot layout (doubles from the slot's start): L [n][l_cols] column-major | 2 x packed G (ranks beyond the LDS cap) | rotation log
+    long gg_off, rlog_off;
+    // two-launch form for batches of low rank (the closed loop's points: ranks 6..16 of 120): EIGH_PASS_NARROW runs first with a
+    // small LDS cap - twice the chains resident per CU - and DEFERS a chain whose rank exceeds defer_rank (its id goes to
+    // defer_list, nothing of it is written); EIGH_PASS_DEFERRED then handles exactly the listed chains with the full cap.  A chain's
+    // result does not depend on which launch produced it: both take the LDS path of the same code for its rank.
+    int pass;                // EIGH_PASS_ALL / _NARROW / _DEFERRED
+    int defer_rank;
+    int* defer_list;         // [chains]
+    int* defer_count;
+    int* rank_hint;          // max rank seen (atomicMax): the host reads it - whenever it arrives - to pick the next call's form
 };
+enum : int { EIGH_PASS_ALL = 0, EIGH_PASS_NARROW = 1, EIGH_PASS_DEFERRED = 2 };
 
 __device__ long long g_eigh_phase[8];
 __device__ int g_eigh_stat[4];         // phase-timer builds: max rank, chains on the HBM/L2 path
@@ -74,6 +86,10 @@ constexpr int EIGH_MAX_SWEEPS = 16;
 constexpr double EIGH_TINY_ROT = 1e-8; // a sweep whose largest rotation tangent is below this is the last one
 constexpr int EIGH_LDS_RANK = 64;      // packed 64 x 64 Gram matrix = 16.6 KB of LDS per chain: ~7 chains per CU
 constexpr int EIGH_PB = 8;             // candidate pivots per pass of the pivoted Cholesky
+#ifndef GPMPC_EIGH_NARROW_WPE
+#define GPMPC_EIGH_NARROW_WPE 4        // waves per SIMD of the narrow launch
+#endif
+constexpr int EIGH_NARROW_RANK = 32;   // LDS rank cap of the narrow launch (EIGH_PASS_NARROW): 8.6 KB of LDS per chain at m T = 120
 #ifndef GPMPC_EIGH_PIVOT_THRESHOLD
 #define GPMPC_EIGH_PIVOT_THRESHOLD (1.0 / 16.0)
 #endif
@@ -96,6 +112,12 @@ __host__ __device__ inline long eigh_lds_doubles(int n, int cap) {
 __host__ __device__ inline long eigh_slot_doubles(int n) {
     const long np = (n + 1) & ~1;
     return (long)n * n + 2 * eigh_packed((int)np) + (long)(EIGH_MAX_SWEEPS / 2) * np * np + 8;
+}
+
+// slot of the narrow launch: L for ranks <= EIGH_NARROW_RANK + EIGH_PB (a chain is deferred at the top of the pass that finds it
+// beyond the cap), the rotation log for ranks <= EIGH_NARROW_RANK
+__host__ __device__ inline long eigh_narrow_slot_doubles(int n) {
+    return (long)n * (EIGH_NARROW_RANK + EIGH_PB) + (long)(EIGH_MAX_SWEEPS / 2) * EIGH_NARROW_RANK * EIGH_NARROW_RANK + 8;
 }
 
 // packed upper triangle, row a holds columns a..rp-1
@@ -173,7 +195,7 @@ __device__ __forceinline__ void rot_block(double cI, double sI, double cK, doubl
 }
 
 // ---- B. G = L^T L (packed upper triangle), FP64 MFMA: A[i][k] = L[k0+k][I*16+i], B[k][j] = L[k0+k][J*16+j] -----------
-template <bool ADJ, class GP>
+template <bool ADJ, int NB, class GP>
 __device__ __forceinline__ void eigh_gram(const double* __restrict__ Lm, int n, int r, int rp, GP G) {
     const int lane = threadIdx.x & 63;
     const int ntile = (rp + 15) / 16;
@@ -184,12 +206,12 @@ __device__ __forceinline__ void eigh_gram(const double* __restrict__ Lm, int n, 
             const double* pa = Lm + (long)(va ? ca : 0) * n;
             const double* pb = Lm + (long)(vb ? cb : 0) * n;
             double4_e acc = {0.0, 0.0, 0.0, 0.0};
-            // four 16-row steps per batch: their 32 loads are in flight together (one step at a time, every step waited for its own
+            // NB 16-row steps per batch: their 8 NB loads are in flight together (one step at a time, every step waited for its own
             // eight loads: at the closed loop's ranks - one tile pair - this phase was eight serial round trips to L2)
-            for (int k0 = 0; k0 < n; k0 += 64) {
-                double av[4][4], bv[4][4];
+            for (int k0 = 0; k0 < n; k0 += 16 * NB) {
+                double av[NB][4], bv[NB][4];
 #pragma unroll
-                for (int b = 0; b < 4; ++b)
+                for (int b = 0; b < NB; ++b)
 #pragma unroll
                     for (int u = 0; u < 4; ++u) {
                         const int row = k0 + 16 * b + 4 * u + kr;
@@ -199,7 +221,7 @@ __device__ __forceinline__ void eigh_gram(const double* __restrict__ Lm, int n, 
                         bv[b][u] = (vb && row < n) ? lb : 0.0;
                     }
 #pragma unroll
-                for (int b = 0; b < 4; ++b)
+                for (int b = 0; b < NB; ++b)
                     if (k0 + 16 * b < n) {                               // uniform
 #pragma unroll
                         for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[b][u], bv[b][u], acc, 0, 0, 0);
@@ -414,8 +436,8 @@ __device__ __forceinline__ void eigh_replay(double* e_vec, const double* __restr
     }
 }
 
-template <int T, int RPL>
-__global__ __launch_bounds__(64, GPMPC_EIGH_WPE) void joint_eigh_kernel(const EighArgs a) {
+template <int T, int RPL, int WPE>
+__global__ __launch_bounds__(64, WPE) void joint_eigh_kernel(const EighArgs a) {
     // dynamic LDS, sized by the launch (eigh_lds_doubles): packed Gram matrix + pad slot | rotations (c, s) | staging /
     // eigenvalues / raw sample | rotated base samples | ranks, candidates
     extern __shared__ __attribute__((aligned(16))) double e_dyn[];
@@ -430,11 +452,13 @@ __global__ __launch_bounds__(64, GPMPC_EIGH_WPE) void joint_eigh_kernel(const Ei
     const long nchains = a.Ns * gp.g_ny;
     double* Lm = a.ws + (long)blockIdx.x * a.ws_slot_stride;     // [n][n] column-major, r columns used
     const int np = (n + 1) & ~1;
-    double* Gg0 = Lm + (long)n * n;
+    double* Gg0 = Lm + a.gg_off;
     double* Gg1 = Gg0 + eigh_packed(np);
-    double* rlog = Gg1 + eigh_packed(np);
+    double* rlog = Lm + a.rlog_off;
+    const long nwork = (a.pass == EIGH_PASS_DEFERRED) ? (long)*a.defer_count : nchains;
 
-    for (long chain = blockIdx.x; chain < nchains; chain += gridDim.x) {
+    for (long item = blockIdx.x; item < nwork; item += gridDim.x) {
+        const long chain = (a.pass == EIGH_PASS_DEFERRED) ? (long)a.defer_list[item] : item;
         const int o = (int)(chain % gp.g_ny);
         const double* Sm = a.Sall + chain * (long)n * n;
         double kmax = gp.os[o];
@@ -468,7 +492,12 @@ __global__ __launch_bounds__(64, GPMPC_EIGH_WPE) void joint_eigh_kernel(const Ei
         }
         int r = 0;
         unsigned long long work = 0;                             // FLOP of this chain (see g_eigh_work)
+        bool deferred = false;
         while (r < n) {
+            if (a.pass == EIGH_PASS_NARROW && r > a.defer_rank) {      // (uniform) beyond this launch's LDS cap: the second launch's
+                deferred = true;
+                break;
+            }
             // candidates: repeated arg max; the row index rides in the low mantissa byte (ties -> lowest row)
             bool taken[RPL];
 #pragma unroll
@@ -617,6 +646,11 @@ __global__ __launch_bounds__(64, GPMPC_EIGH_WPE) void joint_eigh_kernel(const Ei
             }
         }
         EPH(0);
+        if (deferred) {
+            if (lane == 0) a.defer_list[atomicAdd(a.defer_count, 1)] = (int)chain;
+            continue;
+        }
+        if (lane == 0 && a.rank_hint) atomicMax(a.rank_hint, r);
 
         const int rp = (r + 1) & ~1;
         int info = GPMPC_INFO_ROOT_EIGH;
@@ -632,17 +666,17 @@ __global__ __launch_bounds__(64, GPMPC_EIGH_WPE) void joint_eigh_kernel(const Ei
             int sweeps;
             if (rp <= a.lds_cap) {
                 lds_double* G = (lds_double*)e_dyn;
-                eigh_gram<true>(Lm, n, r, rp, G);
+                eigh_gram<true, (WPE == GPMPC_EIGH_NARROW_WPE ? 2 : 4)>(Lm, n, r, rp, G);
                 EPH(1);
                 const int h = rp / 2, nsl = (h / 2) * h;
-                if (nsl <= 128) gtot = eigh_jacobi_lds<2>(G, rp, rlog, e_cs, conv, sweeps);
+                if (nsl <= 128 || WPE == GPMPC_EIGH_NARROW_WPE) gtot = eigh_jacobi_lds<2>(G, rp, rlog, e_cs, conv, sweeps);     // (the narrow launch: ranks <= 32, nsl <= 128)
                 else if (nsl <= 256) gtot = eigh_jacobi_lds<4>(G, rp, rlog, e_cs, conv, sweeps);
                 else if (nsl <= 384) gtot = eigh_jacobi_lds<6>(G, rp, rlog, e_cs, conv, sweeps);
                 else gtot = eigh_jacobi_lds<EIGH_MAXIT>(G, rp, rlog, e_cs, conv, sweeps);
                 for (int i = lane; i < r; i += 64) e_y[i] = G[adj_idx(i, i, rp)];
             } else {
                 double *Gc = Gg0, *Gn = Gg1;
-                eigh_gram<false>(Lm, n, r, rp, Gc);
+                eigh_gram<false, 4>(Lm, n, r, rp, Gc);
                 __syncthreads();
                 EPH(1);
                 gtot = eigh_jacobi_global(Gc, Gn, rp, rlog, e_cs, conv, sweeps);
