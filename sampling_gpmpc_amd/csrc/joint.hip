@@ -1004,6 +1004,7 @@ static int joint_mfma_from() {
     static const char* env = getenv("GPMPC_JOINT_MFMA_FROM");
     return env ? atoi(env) : 200;
 }
+static int g_eigh_narrow_force = -1;      // gpmpc_debug_eigh_narrow: -1 heuristic, 0 / 1 forced (tests)
 static int g_joint_path_pin = 0;          // gpmpc_joint_pin_path: 0 auto, 1 VALU path, 2 matrix-pipe path where instantiated
 static int g_joint_last_path = 0;
 static bool joint_mfma_wanted(int n_ho) {
@@ -1071,6 +1072,23 @@ int gpmpc_debug_read_eigh_work(unsigned long long* out /*[host] 4*/, int reset) 
         GPMPC_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_eigh_work), zero, sizeof(zero)));
     }
     return GPMPC_OK;
+}
+
+// tests: force the two-launch form of the eigendecomposition root off (0) / on (1), -1 = the rank heuristic; returns the previous value
+int gpmpc_debug_eigh_narrow(int mode) {
+    const int prev = g_eigh_narrow_force;
+    g_eigh_narrow_force = mode < 0 ? -1 : (mode ? 1 : 0);
+    return prev;
+}
+// chains the narrow launches have deferred to the full instantiation since the last reset
+long long gpmpc_debug_eigh_deferred(int reset) {
+    unsigned long long v = 0;
+    if (hipMemcpyFromSymbol(&v, HIP_SYMBOL(g_eigh_deferred), sizeof(v)) != hipSuccess) return -1;
+    if (reset) {
+        const unsigned long long zero = 0;
+        if (hipMemcpyToSymbol(HIP_SYMBOL(g_eigh_deferred), &zero, sizeof(zero)) != hipSuccess) return -1;
+    }
+    return (long long)v;
 }
 
 int gpmpc_debug_read_eigh_phases(long long* out /*[host] 8*/) {
@@ -1317,10 +1335,11 @@ int gpmpc_joint_sample(const gpmpc_gp_desc_t* gp, const void* plan, const double
             GPMPC_HIP_CHECK(hipHostMalloc((void**)&hint_host, sizeof(int), hipHostMallocDefault));
             *hint_host = 0;
         }
-        static const char* nenv = getenv("GPMPC_EIGH_NARROW");            // 0 / 1: force the choice (A/B timing, tests)
+        static const char* nenv = getenv("GPMPC_EIGH_NARROW");            // 0 / 1: force the choice (A/B timing)
+        const int forced = g_eigh_narrow_force >= 0 ? g_eigh_narrow_force : (nenv ? atoi(nenv) : -1);
         const int last_rank = *(volatile int*)hint_host;
         const bool narrow = !global_G && mT <= 128 && mT > EIGH_NARROW_RANK &&
-                            (nenv ? atoi(nenv) != 0 : last_rank <= EIGH_NARROW_RANK);
+                            (forced >= 0 ? forced != 0 : last_rank <= EIGH_NARROW_RANK);
         auto launch_eigh = [&](const EighArgs& ea, long grid, int wpe) {
             const size_t lds = (size_t)eigh_lds_doubles(mT, ea.lds_cap) * sizeof(double);
             const dim3 ge((unsigned)grid), be(64);

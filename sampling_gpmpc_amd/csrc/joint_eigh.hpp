@@ -73,6 +73,7 @@ __device__ int g_eigh_stat[4];         // phase-timer builds: max rank, chains o
 // pivot and remaining candidate) + Gram tiles (2048 per MFMA issued) + Jacobi (per round: rp/2 rotations of ~30 and
 // (rp/2)^2 two-sided 2x2 block updates of 24) + replay (6 per pair and round) + y = mean + L t (2 n r)
 __device__ unsigned long long g_eigh_work[4];
+__device__ unsigned long long g_eigh_deferred;      // chains the narrow launch handed to the second one (tests)
 #ifdef GPMPC_PHASE_TIMERS
 #define EPH(idx) do { const long long _n = __builtin_readcyclecounter(); eph[idx] += _n - et; et = _n; } while (0)
 #else
@@ -647,7 +648,10 @@ __global__ __launch_bounds__(64, WPE) void joint_eigh_kernel(const EighArgs a) {
         }
         EPH(0);
         if (deferred) {
-            if (lane == 0) a.defer_list[atomicAdd(a.defer_count, 1)] = (int)chain;
+            if (lane == 0) {
+                a.defer_list[atomicAdd(a.defer_count, 1)] = (int)chain;
+                atomicAdd(&g_eigh_deferred, 1ull);
+            }
             continue;
         }
         if (lane == 0 && a.rank_hint) atomicMax(a.rank_hint, r);

@@ -279,3 +279,62 @@ def test_eigh_root_against_50_digit_eigensolver(sg):
             assert int((lam > 1e-12 * lam.max()).sum()) <= 3          # rank 3: the second stage repeats the first
     print(f"kernel eigh root vs 50-digit max(Sigma, 0) on 6 x 6 rank-3 covariances: max |R R^T - P| / max|Sigma| = {worst:.2e}")
     assert worst < 1e-12
+
+
+def test_eigh_narrow_and_deferred_launches_give_the_same_bits(sg):
+    """Round 5: batches of low rank run a NARROW instantiation of the eigh kernel first (LDS for ranks <= 32, twice the chains per
+    CU); a chain beyond that rank is deferred to the full instantiation in a second launch.  Which launch handles a chain must not
+    show in its result: the same draws with the two-launch form forced off and on - on smooth points (ranks ~10: nothing
+    deferred), on scattered points (ranks ~50: everything deferred) and on a batch that mixes both."""
+    import ctypes as C
+    raw = sg._lib.load()
+    raw.gpmpc_debug_eigh_deferred.restype = C.c_longlong
+    Ns, H, iters = 48, 40, 2
+    p = _car(Ns, H, iters)
+    p["agent"]["base_sample_generator"] = "vectorized"
+    g = torch.Generator().manual_seed(17)
+    x0 = np.array(p["env"]["start"], dtype=np.float64)
+    smooth = np.tile(x0, (H, Ns)) + 0.02 * np.arange(H)[:, None]
+    rough = smooth + 0.05 * torch.randn(H, Ns * 4, generator=g, dtype=F64).numpy()
+    mixed = smooth.copy()
+    mixed[:, : (Ns // 2) * 4] = rough[:, : (Ns // 2) * 4]
+    u_s = np.zeros((H, Ns, 2))
+    u_r = 0.3 * torch.randn(H, Ns, 2, generator=g, dtype=F64).numpy()
+    u_m = u_s.copy()
+    u_m[:, : Ns // 2] = u_r[:, : Ns // 2]
+    try:
+        # (chains the narrow launch must defer: none on the smooth points, most on the scattered ones - a few of those stay below
+        # rank 32 -, some but not all of the mixed batch)
+        for name, x_h, u_h, lo, hi in (("smooth", smooth, u_s, 0, 0), ("rough", rough, u_r, 2 * Ns, 3 * Ns),
+                                       ("mixed", mixed, u_m, Ns, 3 * Ns - Ns)):
+            torch.manual_seed(5)
+            agent, _ = make_agents(sg, p)
+            agent.mpc_iteration(0)
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                for k in range(iters):
+                    agent.train_hallucinated_dynGP(k)
+                    bx = agent.get_batch_x_hat_u_diff(x_h, u_h)
+                    g_xu = agent.env_model.get_g_xu_hat(bx).contiguous()
+                    z = agent.epistimic_random_vector[agent.mpc_iter][k]
+                    cache = agent._ws_cache.get("joint_factor_cache")
+                    held = cache.n_valid if cache is not None else 0
+                    out = {}
+                    for mode in (0, 1):
+                        raw.gpmpc_debug_eigh_narrow(mode)
+                        raw.gpmpc_debug_eigh_deferred(1)
+                        if agent._ws_cache.get("joint_factor_cache") is not None:
+                            agent._ws_cache["joint_factor_cache"].rewind(held)
+                        y = agent.sample_gp(g_xu, base_samples=z).clone()
+                        torch.cuda.synchronize()
+                        out[mode] = (y, agent.model_i_call.last_info.clone(), int(raw.gpmpc_debug_eigh_deferred(0)))
+                    assert (out[0][1] & sg._lib.INFO_ROOT_EIGH).all()
+                    assert torch.equal(out[0][0], out[1][0]), f"{name} k={k}: the two-launch form changed a sample"
+                    assert torch.equal(out[0][1], out[1][1])
+                    assert out[0][2] == 0 and lo <= out[1][2] <= hi, (name, k, out[0][2], out[1][2])
+                    raw.gpmpc_debug_eigh_narrow(-1)
+                    if agent._ws_cache.get("joint_factor_cache") is not None:
+                        agent._ws_cache["joint_factor_cache"].rewind(held)
+                    agent.get_batch_gp_sensitivities(bx, k)
+    finally:
+        raw.gpmpc_debug_eigh_narrow(-1)
