@@ -57,6 +57,14 @@ constexpr int JM_SMEM_SHORTS = (JM_NT * 16 + 8) + (JM_NTD + 7) + 32 + 32 + (JM_C
 constexpr size_t JM_SMEM_BYTES = (size_t)JM_SMEM_DOUBLES * 8 + (size_t)JM_SMEM_SHORTS * 2 + 64;
 
 __device__ __attribute__((aligned(16))) double g_jm_zero[4] = {0.0, 0.0, 0.0, 0.0};
+// rows of a 16 x 16 identity, each followed by zeros: row i starts at g_jm_eye[i * 16] (the pad rows of the last diagonal tile)
+__device__ __attribute__((aligned(16))) double g_jm_eye[16 * 16] = {
+    1, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0,
+    0, 0, 0, 1, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0,
+    0, 0, 0, 0, 0, 0, 1, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1, 0, 0, 0, 0, 0, 0, 0,
+    0, 0, 0, 0, 0, 0, 0, 0, 0, 1, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1, 0, 0, 0, 0,
+    0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1, 0,
+    0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1};
 __device__ long long g_jm_phase[40];          // [20..27]: inside the prologue, [28..31]: inside the kernel entries (wave 0)
 
 #ifdef GPMPC_PHASE_TIMERS
@@ -250,21 +258,22 @@ __global__ __launch_bounds__(JM_THREADS) void joint_test_mfma_kernel(const Joint
         const int rr = min(r, n_o - 1), cc = min(c, rr);
         return (rr < n_r) ? Lrr + (long)rr * n_r + cc : fc + (long)(rr - n_r) * CS + cc;
     };
-    {
-        double v[JM_NT * 256 / JM_THREADS];
+    {   // the (at most four) diagonal tiles with real rows: through registers (the plan's rows are not 16-byte aligned)
+        constexpr int NV = 4 * 256 / JM_THREADS;
+        double v[NV];
 #pragma unroll
-        for (int it = 0; it < JM_NT * 256 / JM_THREADS; ++it) {
+        for (int it = 0; it < NV; ++it) {
             const int e = tid + it * JM_THREADS;
             const int tj = e >> 8, i = (e >> 4) & 15, c = e & 15;
             v[it] = *Lptr(16 * tj + i, 16 * tj + c);
         }
 #pragma unroll
-        for (int it = 0; it < JM_NT * 256 / JM_THREADS; ++it) {
+        for (int it = 0; it < NV; ++it) {
             const int e = tid + it * JM_THREADS;
             const int tj = e >> 8, i = (e >> 4) & 15, c = e & 15;
             const int r = 16 * tj + i;
             const double val = (r < n_o) ? ((c <= i) ? v[it] : 0.0) : ((c == i) ? 1.0 : 0.0);
-            if (e < nt * 256) linv[e] = val;
+            if (tj < kmin) linv[e] = val;
         }
     }
     {
@@ -394,6 +403,39 @@ __global__ __launch_bounds__(JM_THREADS) void joint_test_mfma_kernel(const Joint
     __syncthreads();
     JMPHP(3);
     const int ncr = wtot[3 * JM_NW];              // column runs
+    // The diagonal tiles whose rows are all hallucinated slots (tj >= kmin) go HBM -> LDS directly, row-major as the inversion reads
+    // them: lane l of a request moves the 16-byte piece (row 8 h + l / 8, columns 2 (l % 8), + 1) - the LDS side is lane-linear, a
+    // tile is two requests.  They are requested HERE - behind the last load of the prologue that anything waits for - and needed by the
+    // inversion, which stands behind K_cc (13 k cycles of exponentials and stores, no load anything waits for) (as register loads
+    // in front of the point-run scan they were a 16-19 k cycle stall: the first touch of 52 KB per chain by 256 workgroups that
+    // start together).  Pieces
+    // above the diagonal and pad rows come from an identity tile (the inversion reads the lower triangle and the diagonal only).
+    {
+        const int ln = jm_lane_now();
+        const int di = ln >> 3, dc = 2 * (ln & 7);
+#pragma unroll
+        for (int nq = 0; nq < (2 * JM_NT + JM_NW - 1) / JM_NW; ++nq) {
+            const int q = wv + JM_NW * nq, tj = kmin + (q >> 1), hh = q & 1;
+            if (tj < nt) {                        // (uniform)
+                const int i = 8 * hh + di, r = 16 * tj + i;
+                const double* src = (r < n_o && dc <= i) ? fc + (long)(r - n_r) * CS + 16 * tj + dc : g_jm_eye + i * 16 + dc;
+                jm_glds16(src, linv + tj * 256 + hh * 128);
+            }
+        }
+    }
+
+    JMPHP(4);
+    // pad columns of the kernel-entry buffer: zero once (no entry is ever written there)
+    for (int e = tid; e < JM_KCH * (JM_COLS - ncols); e += JM_THREADS) {
+        const int w = JM_COLS - ncols;
+        const int row = e / w, col = ncols + (e - row * w);
+        kbuf[row * JM_COLS + col] = 0.0;
+    }
+    __syncthreads();
+    JMPHP(5);
+    JMPHP(6);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's pieces of the diagonal tiles have landed
+    __syncthreads();
     // invert the diagonal tiles in place: lane (tq, c) of wave w forms column c of the inverse of tile 32 pass + 4 w + tq
     for (int pass = 0; pass * 4 * JM_NW < nt; ++pass) {
         const int tq = lane >> 4, c = lane & 15;
@@ -420,61 +462,7 @@ __global__ __launch_bounds__(JM_THREADS) void joint_test_mfma_kernel(const Joint
             for (int i = 0; i < 16; ++i) Lw[jm_off(i, c)] = x[i];
         }
     }
-    JMPHP(4);
-    // pad columns of the kernel-entry buffer: zero once (no entry is ever written there)
-    for (int e = tid; e < JM_KCH * (JM_COLS - ncols); e += JM_THREADS) {
-        const int w = JM_COLS - ncols;
-        const int row = e / w, col = ncols + (e - row * w);
-        kbuf[row * JM_COLS + col] = 0.0;
-    }
-    __syncthreads();
-    JMPHP(5);
-    // K_cc, the starting value of the Gram accumulators (test mode: K**; factor mode: K_nn + noise), goes to the chain's S buffer
-    // NOW, while registers are free: one lane per pair of column runs (one exponential for up to T x T entries), the lower
-    // triangle and its mirror from the same value.  The Gram phase - 208 registers of every lane hold X by then - only loads it.
-    {
-        const int ldK = fmode ? ncols : mT;
-        double* Kc = a.Sall + chain * (long)mT * mT;
-        const int nrun = fmode ? ncr : ncr - 1;   // (test mode: the last run is the label column)
-        // pair e of the lower triangle (rb <= ra), row by row: ra = the largest r with r (r + 1) / 2 <= e
-        for (int e = tid; e < nrun * (nrun + 1) / 2; e += JM_THREADS) {
-            int ra = (int)((__builtin_sqrtf(8.0f * (float)e + 1.0f) - 1.0f) * 0.5f);
-            ra += ((ra + 1) * (ra + 2) / 2 <= e) ? 1 : 0;
-            ra -= (ra * (ra + 1) / 2 > e) ? 1 : 0;
-            const int rb = e - ra * (ra + 1) / 2;
-            const int a0 = crun_start[ra], a1 = crun_start[ra + 1], b0 = crun_start[rb], b1 = crun_start[rb + 1];
-            const double xa[D] = {cptx[2 * ra], cptx[2 * ra + 1]}, xb[D] = {cptx[2 * rb], cptx[2 * rb + 1]};
-            double qq[D];
-            const double kv = os * jm_exp_neg(-0.5 * kern_sqdist<D>(xa, xb, il2, qq));
-            if (T == 3 && a1 - a0 == 3 && b1 - b0 == 3) {
-                // a whole point against a whole point: the 3 x 3 block (rows: the tasks of run ra) and its mirror, no look-ups
-                const double kq0 = kv * qq[0], kq1 = kv * qq[1];
-                double blk[3][3] = {{kv, kq0, kq1},
-                                    {-kq0, kv * (il2[0] - qq[0] * qq[0]), -kq0 * qq[1]},
-                                    {-kq1, -kq1 * qq[0], kv * (il2[1] - qq[1] * qq[1])}};
-                if (fmode && ra == rb) blk[0][0] += noise0, blk[1][1] += noise1, blk[2][2] += noise2;
-#pragma unroll
-                for (int i = 0; i < 3; ++i)
-#pragma unroll
-                    for (int j = 0; j < 3; ++j) {
-                        Kc[(long)(a0 + i) * ldK + b0 + j] = blk[i][j];
-                        if (ra != rb) Kc[(long)(b0 + j) * ldK + a0 + i] = blk[i][j];
-                    }
-                continue;
-            }
-            for (int t1 = a0; t1 < a1; ++t1) {
-                const int ta = ctask[t1];
-                for (int t2 = b0; t2 < b1; ++t2) {
-                    if (t2 > t1) continue;
-                    double val = jm_kern_entry(qq[0], qq[1], kv, il2[0], il2[1], ta, ctask[t2]);
-                    if (fmode && t1 == t2) val += (ta == 0) ? noise0 : ((ta == 1) ? noise1 : noise2);
-                    Kc[(long)t1 * ldK + t2] = val;
-                    if (t1 != t2) Kc[(long)t2 * ldK + t1] = val;
-                }
-            }
-        }
-    }
-    JMPHP(6);
+    JMPHP(7);
     JMPH(0);
 
     // ---- kernel entries K_o* (and the label column) into the accumulators, JM_KCH slots at a time: one lane per (slot run,
@@ -679,19 +667,27 @@ __global__ __launch_bounds__(JM_THREADS) void joint_test_mfma_kernel(const Joint
     const int ldS = fmode ? ncols : mT;
     double* Sm = a.Sall + chain * (long)mT * mT;
     double* mean = a.mean + chain * (long)mT;
-    auto tile_init = [&](int I, int J) -> jm_d4 {            // register v, lane (kk, jj) = -K_cc(row 16 I + 4 v + kk, column 16 J + jj)
+    // -K_cc tile (I, J) straight into the accumulators' registers: register v, lane (kk, jj) = -K_cc(row 16 I + 4 v + kk, column 16 J + jj)
+    // (test mode: K**; factor mode: K_nn + noise).  One exponential per ENTRY here - 20 per lane against 1.6 per thread when the
+    // prologue formed K_cc by 3 x 3 blocks into the chain's S buffer - but those 115 KB per chain went out to HBM and came back
+    // (0.7 GB per launch, written in the burst in which 256 workgroups also fetch their first tiles).
+    auto tile_init = [&](int I, int J) -> jm_d4 {
         jm_d4 r;
         const int t2 = 16 * J + (lane & 15);
-        double ld[4];
-#pragma unroll
-        for (int v = 0; v < 4; ++v) {                         // (unconditional loads, clamped: all in flight together)
-            const int t1 = 16 * I + 4 * v + (lane >> 4);
-            ld[v] = Sm[(long)min(t1, ldS - 1) * ldS + min(t2, ldS - 1)];
-        }
+        const int t2c = min(t2, ncols - 1);
+        const int rb = crun_of[t2c], tb = ctask[t2c];
+        const double xb[D] = {cptx[2 * rb], cptx[2 * rb + 1]};
 #pragma unroll
         for (int v = 0; v < 4; ++v) {
             const int t1 = 16 * I + 4 * v + (lane >> 4);
-            r[v] = (t1 < ldS && t2 < ldS) ? -ld[v] : 0.0;
+            const int t1c = min(t1, ncols - 1);
+            const int ra = crun_of[t1c], ta = ctask[t1c];
+            const double xa[D] = {cptx[2 * ra], cptx[2 * ra + 1]};
+            double qq[D];
+            const double kv = os * jm_exp_neg(-0.5 * kern_sqdist<D>(xa, xb, il2, qq));
+            double val = jm_kern_entry(qq[0], qq[1], kv, il2[0], il2[1], ta, tb);
+            if (fmode && t1 == t2) val += (ta == 0) ? noise0 : ((ta == 1) ? noise1 : noise2);
+            r[v] = (t1 < ldS && t2 < ldS) ? -val : 0.0;
         }
         return r;
     };

@@ -97,7 +97,7 @@ if os.environ.get("GPMPC_PHASE_TIMERS") == "1":
     for w, o in ((0, 0), (7, 8)):
         print("joint_test_mfma_kernel phases (cycles, wave %d of block 0, last launch): prologue %d entries %d solve %d | gram: init %d publish %d products %d out %d"
               % ((w,) + tuple(out[o:o + 7])))
-    print("  inside the prologue (wave 0): tables + first chunk %d, diagonal + real tiles %d, y' %d, point runs + barrier %d, inversion %d, pad + barrier %d, K_cc %d" % tuple(out[20:27]))
+    print("  inside the prologue (wave 0): tables + first chunk %d, real-row tiles %d, y' %d, point runs + barrier %d, diagonal-tile requests %d, pad + barrier %d, K_cc %d, wait + inversion %d" % tuple(out[20:28]))
     print("  inside the kernel entries (wave 0, the first 10 chunks): pairs %d, barrier %d, into the accumulators %d, barrier %d" % tuple(out[28:32]))
     print("  inside the substitution: wave 0: diagonal steps %d, hand-overs + first tiles %d, runs %d; wave 7: %d, %d, %d" % (out[7], out[16], out[17], out[15], out[18], out[19]))
     print("  hand-overs (the three parts that are NOT in the 'hand-overs + first tiles' figure above): wave 0: own pieces of the chunk %d, barrier %d, next chunk's requests %d; wave 7: %d, %d, %d" % tuple(out[32:38]))
