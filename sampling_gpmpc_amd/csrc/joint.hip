@@ -671,6 +671,10 @@ __global__ __launch_bounds__(NT, WPE) void joint_kernel(const JointArgs a) {
 
         JPH(4);
         if (!ph_tail) {                                           // JOINT_PHASE_FACTOR: the chain's rows are in M and in the cache
+#ifdef GPMPC_PHASE_TIMERS
+            if (blockIdx.x == 0 && tid == 0)                      // (slots 10..14: the last factor-only launch - FACTOR or CHOL)
+                for (int i = 0; i < 5; ++i) g_joint_phase[10 + i] = jph[i];
+#endif
             if (info_acc) atomicOr(&s_info, info_acc);
             __syncthreads();
             if (tid == 0) a.info[chain] = s_info;

@@ -101,3 +101,6 @@ if os.environ.get("GPMPC_PHASE_TIMERS") == "1":
     print("  inside the kernel entries (wave 0, the first 10 chunks): pairs %d, barrier %d, into the accumulators %d, barrier %d" % tuple(out[28:32]))
     print("  inside the substitution: wave 0: diagonal steps %d, hand-overs + first tiles %d, runs %d; wave 7: %d, %d, %d" % (out[7], out[16], out[17], out[15], out[18], out[19]))
     print("  hand-overs (the three parts that are NOT in the 'hand-overs + first tiles' figure above): wave 0: own pieces of the chunk %d, barrier %d, next chunk's requests %d; wave 7: %d, %d, %d" % tuple(out[32:38]))
+    jo = (C.c_longlong * 16)()
+    lib.gpmpc_debug_read_joint_phases(jo)
+    print("joint_kernel, the last factor-only launch (CHOL phase; cycles, block 0): real columns %d, block start (descriptors, S / kernel entries) %d, update %d, diagonal block %d, row solve + stores %d" % tuple(jo[10:15]))
