@@ -995,6 +995,7 @@ struct JointWs {
     long egrid_narrow, d_off;
     long tc_off, tc_slots, tc_stride;
     int tc_rows, tc_cs;
+    long xt_off, xt_slots;                              // X tiles of the TOP launch (split conditioning sets): xt_slots chains
     int ld;
 };
 
@@ -1019,6 +1020,13 @@ static bool joint_mfma_wanted(int n_ho) {
 }
 static bool joint_use_mfma(int n_r, int n_ho, int m, int T) {
     return n_ho >= 1 && joint_mfma_eligible(n_r, n_ho, m * T + 1, T) && joint_mfma_wanted(n_ho);
+}
+// conditioning sets beyond one launch of joint_test_mfma_kernel (the 45 + 480 slots of the k = 0 draw of MPC steps >= 1 at
+// configs[4]): the test rows in two launches (JOINT_MFMA_TEST_TOP / _BOTTOM); needs a caller-owned factor cache with every row
+static bool joint_use_mfma_split(int n_r, int n_ho, int m, int T) {
+    static const char* env = getenv("GPMPC_JOINT_MFMA_SPLIT");         // 0: such draws stay on the vector pipe (A/B timing)
+    if (env && atoi(env) == 0) return false;
+    return joint_mfma_split_eligible(n_r, n_ho, m * T + 1, T) && joint_mfma_wanted(n_ho);
 }
 
 static long eigh_grid(long nchains) {
@@ -1054,6 +1062,12 @@ static JointWs joint_ws_layout(int n_r, int n_ho, int m, int T, long nchains) {
         w.tc_slots = nchains < 1024 ? nchains : 1024;
         w.tc_off = (w.total + 1) & ~1L;
         w.total = w.tc_off + w.tc_slots * w.tc_stride;
+    }
+    w.xt_off = w.xt_slots = 0;
+    if (joint_mfma_split_eligible(n_r, n_ho, m * (int)T + 1, T)) {                // (pin-independent, as above)
+        w.xt_slots = nchains < 1024 ? nchains : 1024;
+        w.xt_off = (w.total + 1) & ~1L;
+        w.total = w.xt_off + w.xt_slots * JOINT_MFMA_XBUF_DOUBLES;
     }
     return w;
 }
@@ -1198,6 +1212,7 @@ int gpmpc_joint_sample(const gpmpc_gp_desc_t* gp, const void* plan, const double
     a.chain0 = 0;
     a.chain1 = Ns * gp->g_ny;
     a.mfma_mode = JOINT_MFMA_TEST;
+    a.xbuf = nullptr;
     hipStream_t st = (hipStream_t)stream;
     GPMPC_HIP_CHECK(hipMemsetAsync(a.any_fail, 0, 4 * sizeof(int), st));      // any_fail, deferred chains, max rank (joint_eigh_kernel)
     const long nchains = Ns * gp->g_ny;
@@ -1240,7 +1255,9 @@ int gpmpc_joint_sample(const gpmpc_gp_desc_t* gp, const void* plan, const double
 #undef GPMPC_JOINT_LAUNCH
     };
     if (gp->T != 1 && gp->T != 3) return fail(GPMPC_E_UNSUPPORTED, "joint: only T = 1 and T = 3 (D = 2) are instantiated");
-    if (joint_use_mfma(a.gp.n_r, n_ho, m, gp->T)) {
+    const bool split = !joint_use_mfma(a.gp.n_r, n_ho, m, gp->T) && joint_use_mfma_split(a.gp.n_r, n_ho, m, gp->T) &&
+                       a.fcache && n_ho <= a.fc_cap && (a.fc_cap % 2) == 0;
+    if (joint_use_mfma(a.gp.n_r, n_ho, m, gp->T) || split) {
         // The matrix-pipe path: (i) the factor is extended by the rows of the new hallucinated slots - their entries against the
         // old columns and the Schur complement on the matrix pipe (joint_test_mfma_kernel, JOINT_MFMA_FACTOR), the Schur
         // complement's blocked Cholesky by joint_kernel (JOINT_PHASE_CHOL); where that is not instantiated (more than 128 new
@@ -1261,7 +1278,7 @@ int gpmpc_joint_sample(const gpmpc_gp_desc_t* gp, const void* plan, const double
         static const char* fenv = getenv("GPMPC_JOINT_MFMA_FACTOR");      // 0: the factor phase stays on the vector pipe
         const bool mfma_factor = n_new > 0 && n_new <= mT && joint_mfma_eligible(a.gp.n_r, b.n_c, n_new, gp->T) &&
                                  !(fenv && atoi(fenv) == 0);
-        const long step = own ? nchains : w.tc_slots;
+        const long step = split ? w.xt_slots : (own ? nchains : w.tc_slots);
         for (long c0 = 0; c0 < nchains; c0 += step) {
             b.chain0 = c0;
             b.chain1 = (c0 + step < nchains) ? c0 + step : nchains;
@@ -1280,7 +1297,14 @@ int gpmpc_joint_sample(const gpmpc_gp_desc_t* gp, const void* plan, const double
                 GPMPC_HIP_CHECK(hipGetLastError());
                 b.info_in = 1;
             }
-            b.mfma_mode = JOINT_MFMA_TEST;
+            if (split) {
+                b.xbuf = (double*)ws + w.xt_off;
+                b.mfma_mode = JOINT_MFMA_TEST_TOP;
+                if (int rc = joint_mfma_launch(b, st)) return rc;
+                b.mfma_mode = JOINT_MFMA_TEST_BOTTOM;
+            } else {
+                b.mfma_mode = JOINT_MFMA_TEST;
+            }
             if (int rc = joint_mfma_launch(b, st)) return rc;
             b.phase = JOINT_PHASE_TAIL;
             b.abandon_root = abandon_for(mT);

@@ -14,7 +14,15 @@ enum : int {
                               // joint_test_mfma_kernel (JOINT_MFMA_FACTOR) left in Sall (leading dimension n_ho - n_c); the rows'
                               // entries against the old columns are already in the cache
 };
-enum : int { JOINT_MFMA_TEST = 0, JOINT_MFMA_FACTOR = 1 };
+// JOINT_MFMA_TEST_TOP / _BOTTOM: the test rows of a conditioning set of more than JOINT_MFMA_SPLIT slots in two launches - TOP is
+// the test mode over the first JOINT_MFMA_SPLIT slots (a leading block of the factor is the factor of the leading block); it leaves
+// the partial S and mean in their buffers and its X tiles in `xbuf`; BOTTOM conditions on the remaining slots: its right-hand side is
+// K_bottom - L_21 X_top (the factor's rows of the remaining slots against the first ones, streamed like every other tile), its Gram
+// phase starts from TOP's partial results.
+enum : int { JOINT_MFMA_TEST = 0, JOINT_MFMA_FACTOR = 1, JOINT_MFMA_TEST_TOP = 2, JOINT_MFMA_TEST_BOTTOM = 3 };
+constexpr int JOINT_MFMA_SPLIT = 416;           // conditioning slots of one launch of joint_test_mfma_kernel (26 tiles of 16)
+constexpr int JOINT_MFMA_BOTTOM_MAX = 128;      // slots of the BOTTOM launch at most (its stream table holds 26 x 8 + 28 tiles)
+constexpr long JOINT_MFMA_XBUF_DOUBLES = (long)(JOINT_MFMA_SPLIT / 16) * 8 * 256;   // TOP's X tiles of one chain: [tile][wave][4][64]
 
 struct JointArgs {
     GpParams gp;
@@ -58,13 +66,16 @@ struct JointArgs {
     int phase;              // JOINT_PHASE_*
     int info_in;            // JOINT_PHASE_TAIL: info[chain] already holds the factor phase's bits (OR into it)
     long chain0, chain1;    // the chains of this launch: [chain0, chain1)
-    int mfma_mode;          // joint_test_mfma_kernel: JOINT_MFMA_TEST / JOINT_MFMA_FACTOR
+    int mfma_mode;          // joint_test_mfma_kernel: JOINT_MFMA_TEST / _FACTOR / _TEST_TOP / _TEST_BOTTOM
+    double* xbuf;           // TOP writes, BOTTOM reads: X tiles of the chains [chain0, chain1), JOINT_MFMA_XBUF_DOUBLES each
 };
 
 // joint_mfma.hip ---------------------------------------------------------------------------------------------------------
 // true when joint_test_mfma_kernel is instantiated for these sizes: n_r observed real slots + n_hc hallucinated slots to condition
 // on, ncols columns (test mode: m T + 1; factor mode: the new hallucinated rows), T tasks
 bool joint_mfma_eligible(int n_r, int n_hc, int ncols, int T);
+// true when the test rows of this conditioning set run as TOP + BOTTOM launches (JOINT_MFMA_SPLIT < n_r + n_hc <= + _BOTTOM_MAX)
+bool joint_mfma_split_eligible(int n_r, int n_hc, int ncols, int T);
 // launches joint_test_mfma_kernel for the chains [a.chain0, a.chain1): V^T = L^-1 K_o* (w column included), then
 // mean = V^T w into a.mean and S = K** - V^T V into a.Sall.  Needs a.fcache with every hallucinated row filled.
 int joint_mfma_launch(const JointArgs& a, hipStream_t st);

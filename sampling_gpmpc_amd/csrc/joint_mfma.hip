@@ -158,13 +158,18 @@ __global__ __launch_bounds__(JM_THREADS) void joint_test_mfma_kernel(const Joint
     const GpParams& gp = a.gp;
     const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);       // (wv: an SGPR)
     const bool fmode = a.mfma_mode == JOINT_MFMA_FACTOR;
+    const bool top = a.mfma_mode == JOINT_MFMA_TEST_TOP, bottom = a.mfma_mode == JOINT_MFMA_TEST_BOTTOM;
     const int n_r = gp.n_r, Tr = gp.real_has_grad ? T : 1;
     const int m = a.m, mT = m * T;
     const int n_hc = fmode ? a.n_c : a.n_ho;      // hallucinated slots conditioned on
-    const int n_o = n_r + n_hc;
+    // the slots of THIS launch are the LOCAL slots 0 .. n_o - 1 = the problem's slots sb .. sb + n_o - 1 (sb > 0: the BOTTOM launch
+    // of a split conditioning set, whose first sb slots - nx tiles - the TOP launch has solved: their X tiles come from a.xbuf)
+    const int sb = bottom ? JOINT_MFMA_SPLIT : 0;
+    const int n_o = top ? JOINT_MFMA_SPLIT : n_r + n_hc - sb;
+    const int nx = sb >> 4;
     const int ncols = fmode ? a.n_ho - a.n_c : mT + 1;
     const int nt = (n_o + 15) >> 4;               // slot tiles
-    const int kmin = (n_r + 15) >> 4;             // tile rows < kmin hold real rows: staged through registers
+    const int kmin = bottom ? 0 : (n_r + 15) >> 4;   // tile rows < kmin hold real rows: staged through registers
     const int ncta = (ncols + 15) >> 4;           // column tiles in use
     const int I0 = wv;                            // this wave's column tile
     const bool active = I0 < ncta;
@@ -205,10 +210,23 @@ __global__ __launch_bounds__(JM_THREADS) void joint_test_mfma_kernel(const Joint
         const int c = min(jj, kmin - 1), n = jj - c;             // n columns j' = kmin - 1 .. jj - 1
         return c * max(0, nt - kmin) + n * (nt - 1) - (n * (2 * (kmin - 1) + n - 1)) / 2;
     };
-    const int ntd = stab_base(nt);
-    for (int e = tid; e < nt * 32; e += JM_THREADS) {
-        const int jj = e >> 5, k = max(jj + 1, kmin) + (e & 31);
-        if (k < nt) stab[stab_base(jj) + (e & 31)] = (unsigned short)((k << 8) | jj);
+    // BOTTOM: first the tiles against the nx solved columns (all nt tile rows of a column, column by column; bit 7 of the entry
+    // marks them), then the triangle of the launch's own tiles
+    const int ntd = bottom ? nx * nt + nt * (nt - 1) / 2 : stab_base(nt);
+    if (bottom) {
+        for (int e = tid; e < nx * nt; e += JM_THREADS) {
+            const int jx = e / nt, k = e - jx * nt;
+            stab[e] = (unsigned short)((k << 8) | 0x80 | jx);
+        }
+        for (int e = tid; e < nt * 32; e += JM_THREADS) {
+            const int jj = e >> 5, k = jj + 1 + (e & 31);
+            if (k < nt) stab[nx * nt + jj * (nt - 1) - (jj * (jj - 1)) / 2 + (e & 31)] = (unsigned short)((k << 8) | jj);
+        }
+    } else {
+        for (int e = tid; e < nt * 32; e += JM_THREADS) {
+            const int jj = e >> 5, k = max(jj + 1, kmin) + (e & 31);
+            if (k < nt) stab[stab_base(jj) + (e & 31)] = (unsigned short)((k << 8) | jj);
+        }
     }
     __syncthreads();
 
@@ -237,8 +255,8 @@ __global__ __launch_bounds__(JM_THREADS) void joint_test_mfma_kernel(const Joint
             const int q = q0 + u;
             if (q < ntd) {                        // (uniform)
                 const int kj = (int)(((u < 2 ? kj_lo : kj_hi) >> (16 * (u & 1))) & 0xffffu);
-                const int k = kj >> 8, j = kj & 255;
-                const long off = (long)(16 * k) * CS + 16 * j;
+                const int k = kj >> 8, j = kj & 127, ext = (kj >> 7) & 1;      // (ext: a column of the TOP launch's slots)
+                const long off = (long)(sb + 16 * k) * CS + (ext ? 0 : sb) + 16 * j;
                 const double* src = (16 * k + dma_row < n_o) ? dma_lane + off : g_jm_zero;
                 double* dst = ring + (q & (JM_RING - 1)) * 256;
                 jm_glds16(src, dst);
@@ -296,7 +314,7 @@ __global__ __launch_bounds__(JM_THREADS) void joint_test_mfma_kernel(const Joint
         }
     }
     JMPHP(1);
-    if (!fmode) {                                 // y' = L_rr w_r, eight lanes per row
+    if (!fmode && !bottom) {                      // y' = L_rr w_r, eight lanes per row
         const int row = tid >> 3, part = tid & 7;
         double acc = 0.0;
         double lv[8], wv[8];
@@ -318,11 +336,11 @@ __global__ __launch_bounds__(JM_THREADS) void joint_test_mfma_kernel(const Joint
     {   // runs of slots that share their input point (two slots per thread: tid, tid + 512), and the same for the columns
         static_assert(JM_NT * 16 <= 2 * JM_THREADS && JM_COLS <= JM_THREADS, "two slots, one column per thread");
         auto slot_point = [&](int sl, int& task) -> int {        // point id (real points first) and task of conditioning slot sl
-            if (sl < n_r) {
+            if (sb + sl < n_r) {
                 task = sl % Tr;
                 return sl / Tr;
             }
-            const int hs = a.h_slots[sl - n_r];
+            const int hs = a.h_slots[sb + sl - n_r];
             task = hs % T;
             return gp.N_r + hs / T;
         };
@@ -349,7 +367,7 @@ __global__ __launch_bounds__(JM_THREADS) void joint_test_mfma_kernel(const Joint
                 flag[r] = idx == 0 || pt[r] != ((r < 2) ? slot_point(idx - 1, tprev) : col_point(idx - 1, tprev));
                 if (r < 2) {
                     stask[idx] = (signed char)task;
-                    if (!fmode && idx >= n_r) ylab[idx] = Yh[a.h_slots[idx - n_r]];
+                    if (!fmode && sb + idx >= n_r) ylab[idx] = Yh[a.h_slots[sb + idx - n_r]];
                 } else {
                     ctask[idx] = (signed char)task;
                 }
@@ -374,7 +392,7 @@ __global__ __launch_bounds__(JM_THREADS) void joint_test_mfma_kernel(const Joint
             const int excl = off[r] + excl_w[r];
             if (flag[r]) {
                 run_start[excl] = (short)sl;
-                const double* xp = (sl < n_r) ? a.X_r + (long)pt[r] * D : Xh + (long)(pt[r] - gp.N_r) * D;
+                const double* xp = (sb + sl < n_r) ? a.X_r + (long)pt[r] * D : Xh + (long)(pt[r] - gp.N_r) * D;
                 rptx[2 * excl] = xp[0], rptx[2 * excl + 1] = xp[1];
             }
             if (sl < n_o && (sl & (JM_KCH - 1)) == 0) {
@@ -418,7 +436,7 @@ __global__ __launch_bounds__(JM_THREADS) void joint_test_mfma_kernel(const Joint
             const int q = wv + JM_NW * nq, tj = kmin + (q >> 1), hh = q & 1;
             if (tj < nt) {                        // (uniform)
                 const int i = 8 * hh + di, r = 16 * tj + i;
-                const double* src = (r < n_o && dc <= i) ? fc + (long)(r - n_r) * CS + 16 * tj + dc : g_jm_eye + i * 16 + dc;
+                const double* src = (r < n_o && dc <= i) ? fc + (long)(sb + r - n_r) * CS + sb + 16 * tj + dc : g_jm_eye + i * 16 + dc;
                 jm_glds16(src, linv + tj * 256 + hh * 128);
             }
         }
@@ -510,7 +528,7 @@ __global__ __launch_bounds__(JM_THREADS) void joint_test_mfma_kernel(const Joint
         // that held one of its lanes a divergent walk over the run's slots)
         if (!fmode && tid >= JM_THREADS - JM_KCH) {
             const int sl = s0 + tid - (JM_THREADS - JM_KCH);
-            if (sl < n_o) kbuf[(sl - s0) * JM_COLS + mT] = (sl < n_r) ? yr[sl] : ylab[sl];
+            if (sl < n_o) kbuf[(sl - s0) * JM_COLS + mT] = (sb + sl < n_r) ? yr[sl] : ylab[sl];
         }
         if (n_o < s0 + JM_KCH) {                                                          // pad slots: zero rows
             const int z0 = (n_o - s0) * JM_COLS;
@@ -576,17 +594,10 @@ __global__ __launch_bounds__(JM_THREADS) void joint_test_mfma_kernel(const Joint
         int set = 0;                              // the set that holds (or will take) the next tile's A operand
         unsigned addr_p = realt_b;                // (any valid address: a run without a successor fetches it and drops it)
         bool have = false;                        // set `set` holds the A operand of the next tile
-        for (int j = 0; j < nt; ++j) {
-            jm_d4 x;
-            {
-                const int ln = jm_lane_now();      // (re-formed: see issue_chunk)
-                const jm_d2 d01 = *reinterpret_cast<const jm_d2*>(linv + j * 256 + ln * 2);
-                const jm_d2 d23 = *reinterpret_cast<const jm_d2*>(linv + j * 256 + 128 + ln * 2);
-                jm_acc_diag(A, S, j, d01.x, d01.y, d23.x, d23.y, x);  // X_j = Linv_jj acc_j
-            }
-            const jm_d4 xn = -x;
-            JMPHS(0);
-            int k = j + 1;
+        // the runs of one column: tiles kfirst .. nt - 1 take -= L_kj X_j (xn = -X_j); (next_k, next_j) is the first tile of the column
+        // after this one (has_next: there is one) - the last run of the column fetches its A operand
+        auto do_column = [&](int jcur, int kfirst, const jm_d4& xn, int next_k, int next_j, bool has_next) {
+            int k = kfirst;
             while (k < nt) {
                 if (!have) {
                     if (k >= kmin && (seq & (JM_CH - 1)) == 0) {
@@ -601,7 +612,7 @@ __global__ __launch_bounds__(JM_THREADS) void joint_test_mfma_kernel(const Joint
                         issue_chunk((seq >> 4) + 1);
                         JMPHS(5);
                     }
-                    addr_p = tile_addr(k, j);
+                    addr_p = tile_addr(k, jcur);
                     jm_sets_load(S, set, addr_p);
                     JMPHS(1);
                 }
@@ -611,8 +622,8 @@ __global__ __launch_bounds__(JM_THREADS) void joint_test_mfma_kernel(const Joint
                 seq += n - 1;
                 // the tile behind the run: (k + n, j), or the first tile of the next column, or none
                 const bool same = k + n < nt;
-                const int kn = same ? k + n : j + 2, jn = same ? j : j + 1;
-                have = (same || j + 2 < nt) && streamed_now(kn);
+                const int kn = same ? k + n : next_k, jn = same ? jcur : next_j;
+                have = (same || has_next) && streamed_now(kn);
                 const unsigned first = addr_p + 2048u;
                 unsigned tail = addr_p;
                 if (have) tail = addr_p = tile_addr(kn, jn);
@@ -621,10 +632,65 @@ __global__ __launch_bounds__(JM_THREADS) void joint_test_mfma_kernel(const Joint
                 k += n;
                 JMPHS(2);
             }
+        };
+        // BOTTOM launch: the nx columns the TOP launch has solved.  X_j of this wave's 16 columns is a 2 KB register dump in a.xbuf;
+        // it comes HBM -> LDS into one of two wave-private slots (behind the launch's <= 8 inverted diagonal tiles), requested a
+        // column ahead - nothing of it lives in registers across a column (a VGPR the substitution carries is spilled).
+        {
+            const int nxr = bottom ? nx : 0;      // (a run-time trip count, not a branch around the statements)
+            double* xst = linv + 8 * 256 + wv * 512;
+            const double* xsrc = a.xbuf + (chain - a.chain0) * JOINT_MFMA_XBUF_DOUBLES + I0 * 256;
+            auto x_request = [&](int jx) {
+                if (jx < nxr) {                   // (uniform)
+                    const int ln = jm_lane_now();
+                    const double* src = xsrc + (long)jx * 2048 + ln * 2;
+                    double* dst = xst + (jx & 1) * 256;
+                    jm_glds16(src, dst);
+                    jm_glds16(src + 128, dst + 128);
+                }
+            };
+            x_request(0);
+            for (int jx = 0; jx < nxr; ++jx) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's X tile has landed
+                jm_d4 x;
+                {
+                    const int ln = jm_lane_now();
+                    const double* xs = xst + (jx & 1) * 256 + ln;
+                    x[0] = xs[0], x[1] = xs[64], x[2] = xs[128], x[3] = xs[192];
+                }
+                x_request(jx + 1);
+                const jm_d4 xn = -x;
+                JMPHS(0);
+                do_column(jx, 0, xn, (jx + 1 < nxr) ? 0 : 1, (jx + 1 < nxr) ? jx + 1 : 0, (jx + 1 < nxr) || nt > 1);
+            }
+        }
+        for (int j = 0; j < nt; ++j) {
+            jm_d4 x;
+            {
+                const int ln = jm_lane_now();      // (re-formed: see issue_chunk)
+                const jm_d2 d01 = *reinterpret_cast<const jm_d2*>(linv + j * 256 + ln * 2);
+                const jm_d2 d23 = *reinterpret_cast<const jm_d2*>(linv + j * 256 + 128 + ln * 2);
+                jm_acc_diag(A, S, j, d01.x, d01.y, d23.x, d23.y, x);  // X_j = Linv_jj acc_j
+            }
+            const jm_d4 xn = -x;
+            JMPHS(0);
+            do_column(j, j + 1, xn, j + 2, j + 1, j + 2 < nt);
         }
     }
     __syncthreads();                              // every wave is done with the ring
     JMPH(2);
+    // TOP launch of a split conditioning set: the wave's X tiles go to a.xbuf as they lie in the registers ([tile][wave][4][64])
+    {
+        const int nt_x = top ? nt : 0;            // (a run-time trip count, not a branch around the statement)
+        double* xdst = a.xbuf + (chain - a.chain0) * JOINT_MFMA_XBUF_DOUBLES + I0 * 256;
+#pragma unroll 1
+        for (int j = 0; j < nt_x; ++j) {
+            double t[4];
+            jm_acc_get(A, j, t[0], t[1], t[2], t[3]);
+#pragma unroll
+            for (int v = 0; v < 4; ++v) xdst[(long)j * 2048 + v * 64 + lane] = t[v];
+        }
+    }
     // factor mode: X^T = the new rows' entries against the old columns goes to the cache (row n_c + column, 4 consecutive slots per lane)
     const int nt_f = fmode ? nt : 0;              // (a run-time trip count, not a branch around the statement)
 #pragma unroll 1
@@ -691,12 +757,31 @@ __global__ __launch_bounds__(JM_THREADS) void joint_test_mfma_kernel(const Joint
         }
         return r;
     };
+    // BOTTOM launch: the accumulators continue from the TOP launch's results: -S_top, and +mean_top on the label row / column
+    auto tile_cont = [&](int I, int J) -> jm_d4 {
+        jm_d4 r;
+        const int t2 = 16 * J + (lane & 15);
+        double ls[4], lm[4];
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {                         // (unconditional loads, clamped)
+            const int t1 = 16 * I + 4 * v + (lane >> 4);
+            ls[v] = Sm[(long)min(t1, ldS - 1) * ldS + min(t2, ldS - 1)];
+            lm[v] = mean[min((t1 == mT) ? t2 : t1, mT - 1)];
+        }
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            const int t1 = 16 * I + 4 * v + (lane >> 4);
+            const bool lab = (t1 == mT && t2 < mT) || (t2 == mT && t1 < mT);
+            r[v] = (t1 < ldS && t2 < ldS) ? -ls[v] : (lab ? lm[v] : 0.0);
+        }
+        return r;
+    };
     int Jt[5];
     jm_d4 kinit[5];
 #pragma unroll
     for (int d = 0; d < 5; ++d) {
         Jt[d] = (I0 + d) & (JM_NCT - 1);
-        kinit[d] = tile_init(I0, Jt[d]);
+        kinit[d] = bottom ? tile_cont(I0, Jt[d]) : tile_init(I0, Jt[d]);
     }
     const unsigned ring_gb = (unsigned)(size_t)(__attribute__((address_space(3))) double*)ring;
     const unsigned stash_gb = (unsigned)(size_t)(__attribute__((address_space(3))) double*)linv + (unsigned)wv * (JM_STASH * 2048u);
@@ -781,6 +866,12 @@ __global__ __launch_bounds__(JM_THREADS) void joint_test_mfma_kernel(const Joint
 bool joint_mfma_eligible(int n_r, int n_hc, int ncols, int T) {
     const int n_o = n_r + n_hc;
     return (T == 1 || T == 3) && n_r >= 1 && n_r <= 64 && n_hc >= 0 && (n_o + 15) / 16 <= JM_NT && ncols >= 1 && ncols <= JM_COLS;
+}
+
+bool joint_mfma_split_eligible(int n_r, int n_hc, int ncols, int T) {
+    const int n_o = n_r + n_hc;
+    return (T == 1 || T == 3) && n_r >= 1 && n_r <= 64 && n_o > JOINT_MFMA_SPLIT && n_o <= JOINT_MFMA_SPLIT + JOINT_MFMA_BOTTOM_MAX &&
+           ncols >= 1 && ncols <= JM_COLS;
 }
 
 int joint_mfma_launch(const JointArgs& a, hipStream_t st) {

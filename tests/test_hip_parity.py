@@ -453,6 +453,9 @@ def test_joint_draw_against_oracle(sg, pname, Ns, H, iters):
     ("params_car_residual", 5, 40, 3, False),         # no caller-owned cache: the factor rows go through the workspace's temporary one
     ("params_pendulum1D_samples", 16, 30, 4, True),   # 36 real slots, 91 columns = 6 of the 8 column tiles
     ("params_car_residual", 8, 12, 3, True),          # 37 columns: 3 column tiles, a ragged last slot tile at every k
+    # conditioning sets beyond one launch (416 slots): the test rows as TOP + BOTTOM launches (round 5c)
+    ("params_car_residual", 4, 40, 5, True),          # k = 4: 45 + 480 slots = 26 + 7 tiles (the k = 0 draw of MPC steps >= 1 at configs[4])
+    ("params_pendulum1D_samples", 6, 30, 6, True),    # k = 5: 36 + 450 = 486 slots, a ragged fifth bottom tile; 91 columns
 ])
 def test_joint_draw_matrix_pipe_against_oracle(sg, pname, Ns, H, iters, cache):
     """The same comparison with the matrix-pipe path pinned (ABI 7: gpmpc_joint_pin_path): factor extension and test rows by
