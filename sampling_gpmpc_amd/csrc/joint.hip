@@ -1065,7 +1065,7 @@ static JointWs joint_ws_layout(int n_r, int n_ho, int m, int T, long nchains) {
     }
     w.xt_off = w.xt_slots = 0;
     if (joint_mfma_split_eligible(n_r, n_ho, m * (int)T + 1, T)) {                // (pin-independent, as above)
-        w.xt_slots = nchains < 1024 ? nchains : 1024;
+        w.xt_slots = nchains < 3072 ? nchains : 3072;          // 416 KB per chain: 1.3 GB at most
         w.xt_off = (w.total + 1) & ~1L;
         w.total = w.xt_off + w.xt_slots * JOINT_MFMA_XBUF_DOUBLES;
     }
