@@ -4,7 +4,8 @@ import numpy as np, torch
 import sampling_gpmpc_amd as sg
 from sampling_gpmpc_amd import _lib
 from tests.helpers import load_params
-Ns, H, iters = int(sys.argv[1]), 40, 3
+Ns, H = int(sys.argv[1]), 40
+iters = int(sys.argv[2]) if len(sys.argv) > 2 else 3      # 5: the last draw conditions on 45 + 480 slots (TOP + BOTTOM launches)
 p = load_params("params_car_residual")
 p["common"]["use_cuda"] = True
 p["agent"]["num_dyn_samples"], p["optimizer"]["H"] = Ns, H
