@@ -277,10 +277,12 @@ int    gpmpc_joint_sample(const gpmpc_gp_desc_t* gp, const void* plan, const dou
 
 /*
  * The two paths of gpmpc_joint_sample (ABI 7).  GPMPC_JOINT_VALU: one launch, one label row per thread, blocked left-looking
- * factorisation on the vector pipe (every size).  GPMPC_JOINT_MFMA: three launches on the same stream - the factor phase extends
- * the factor by the rows of the new hallucinated slots, joint_test_mfma_kernel forms V^T = L^-1 K_o*, the mean and
- * S = K** - V^T V on the FP64 matrix pipe with the whole test block in registers, the tail draws - instantiated for
- * n_r <= 64 real slots, n_r + n_ho <= 416 conditioning slots and m*T + 1 <= 128; taken from 48 hallucinated slots on
+ * factorisation on the vector pipe (every size).  GPMPC_JOINT_MFMA: four launches on the same stream - joint_test_mfma_kernel
+ * extends the factor by the rows of the new hallucinated slots (their entries against the old columns, the Schur complement),
+ * joint_kernel factorises the Schur complement, joint_test_mfma_kernel forms V^T = L^-1 K_o*, the mean and S = K** - V^T V on the
+ * FP64 matrix pipe with the whole test block in registers, the tail draws - instantiated for n_r <= 64 real slots,
+ * n_r + n_ho <= 416 conditioning slots (<= 544 with the test rows in two launches; that form needs the caller's factor cache) and
+ * m*T + 1 <= 128; taken from 100 hallucinated slots on
  * (GPMPC_JOINT_MFMA_FROM).  Results of the two paths agree to rounding, not bit for bit: a caller that compares launches bit
  * for bit (cache on / off, sample shards against the whole batch) pins the path.  gpmpc_joint_pin_path(GPMPC_JOINT_AUTO) releases
  * the pin; a pinned GPMPC_JOINT_MFMA falls back to the VALU path for sizes it is not instantiated for.

@@ -1003,11 +1003,12 @@ static int fc_row_stride(int n_r, int rows) { return (n_r + rows + 1) & ~1; }
 
 // the launch sizes from which the matrix-pipe path (factor phase + joint_test_mfma_kernel + tail) is taken
 static int joint_mfma_from() {
-    // hallucinated slots from which it is used (0: never).  Measured on the configs[4] shard (car, Ns = 1024, H = 40, scattered points):
-    // k = 3 (360 slots) 7.1 against 8.7 ms, k = 2 (240) 5.3 / 6.0, k = 1 (120) 4.0 / 3.4 - the fixed per-chain phases of
-    // joint_test_mfma_kernel (descriptors, tile inversion, kernel entries) only pay behind a long substitution
+    // hallucinated slots from which it is used (0: never).  configs[4] shard (car, Ns = 1024, H = 40, closed-loop points), VALU path
+    // against this one: k = 3 (360 slots) 7.15 / 4.53 ms, k = 2 (240) 4.45 / 3.15, k = 1 (120) 2.16 / 2.12 (Ns = 4096: 7.68 / 7.49) - the
+    // fixed per-chain phases of joint_test_mfma_kernel (descriptors, tile inversion, kernel entries) only pay behind a
+    // substitution of some length; below ~100 slots the one-launch VALU form wins
     static const char* env = getenv("GPMPC_JOINT_MFMA_FROM");
-    return env ? atoi(env) : 200;
+    return env ? atoi(env) : 100;
 }
 static int g_eigh_narrow_force = -1;      // gpmpc_debug_eigh_narrow: -1 heuristic, 0 / 1 forced (tests)
 static int g_joint_path_pin = 0;          // gpmpc_joint_pin_path: 0 auto, 1 VALU path, 2 matrix-pipe path where instantiated

@@ -23,9 +23,13 @@
 // (0.66 MB per chain at n_o = 405 instead of the 5.7 MB the VALU update re-reads), a 32-tile ring, 16 tiles per barrier.
 // The inverted diagonal tiles are made once per chain in the prologue (one inverse column per lane, four tiles per wave).
 // Kernel entries: one lane per (conditioning POINT, test point) pair - one exponential for up to T x T entries - through a
-// 32-slot LDS buffer into the accumulators.  Afterwards the Gram products X_I^T X_J run on the same registers (A operand = the
-// wave's own X, negated; B = wave J's X through LDS), accumulators starting at K** so that the running value shrinks towards S
-// as in the sequential form.
+// 32-slot LDS buffer into the accumulators.  Afterwards the Gram products X_I^T X_J run on the same registers in ONE pass: five
+// accumulator tiles per wave start at -K** (formed in place), the A operand is the wave's own X read where it lies, the B
+// operands are the other waves' tiles through LDS; the result is negated on the way out (the running value shrinks towards S as
+// in the sequential form).
+// The same kernel extends the factor (JOINT_MFMA_FACTOR: columns = the new hallucinated rows, out = their entries against the
+// old columns + the Schur complement) and handles conditioning sets of more than 26 tiles in two launches (JOINT_MFMA_TEST_TOP /
+// _BOTTOM, joint_args.hpp).  DESIGN.md 4.4c has the measurements, the register discipline and the MFMA source-read hazard.
 #include <type_traits>
 
 #include "joint_args.hpp"
@@ -56,6 +60,10 @@ constexpr int JM_SMEM_DOUBLES = JM_NT * 256 + (JM_NW * JM_STASH - JM_NT) * 256 +
 constexpr int JM_SMEM_SHORTS = (JM_NT * 16 + 8) + (JM_NTD + 7) + 32 + 32 + (JM_COLS + 8) + (JM_NT * 16 + 2 * JM_COLS) / 2 + 2 * (4 * JM_NW + 4);
 constexpr size_t JM_SMEM_BYTES = (size_t)JM_SMEM_DOUBLES * 8 + (size_t)JM_SMEM_SHORTS * 2 + 64;
 
+static_assert(JM_NTD + 7 >= (JOINT_MFMA_SPLIT / 16) * (JOINT_MFMA_BOTTOM_MAX / 16) + (JOINT_MFMA_BOTTOM_MAX / 16) * (JOINT_MFMA_BOTTOM_MAX / 16 - 1) / 2,
+              "the stream table holds the BOTTOM launch's tiles");
+static_assert(JOINT_MFMA_SPLIT == JM_NT * 16 && (8 + 2 * JM_NW) * 256 <= JM_NW * JM_STASH * 256,
+              "TOP fills every tile; BOTTOM's <= 8 inverted diagonal tiles and the waves' X slots share the linv region");
 __device__ __attribute__((aligned(16))) double g_jm_zero[4] = {0.0, 0.0, 0.0, 0.0};
 // rows of a 16 x 16 identity, each followed by zeros: row i starts at g_jm_eye[i * 16] (the pad rows of the last diagonal tile)
 __device__ __attribute__((aligned(16))) double g_jm_eye[16 * 16] = {
