@@ -174,6 +174,14 @@ class Agent(object):
         self.debug_keep_root = False   # tests: keep the eigendecomposition root of the last joint draw (model_i_call.root)
         self._plans = {}          # T -> RealDataPlan (real block factorised once per label layout)
         self._ws_cache = {}
+        # The hallucinated set grows by H points per SQP iteration and is reset once per MPC step - AFTER the model of iteration 0 has
+        # been built (reference src/agent.py:261-272): a joint draw conditions on at most max_sqp_iter * H points.  The joint
+        # workspace and the factor cache are sized for that once (multi-GiB device allocations cost 0.3-0.9 s each on this
+        # driver: growing them at every iteration of the first MPC step made it four of them, `tools/debug/first_call_costs.py`).
+        try:
+            self._ws_cache["joint_points_hint"] = int(params["optimizer"]["SEMPC"]["max_sqp_iter"]) * int(params["optimizer"]["H"])
+        except (KeyError, TypeError, ValueError):
+            pass
         self._reset_hallucinated()
 
         X, Y = env_model.initial_training_data()

@@ -32,6 +32,7 @@ import os
 # edits Hallcinated_* in place without Agent.invalidate_factor_cache())
 _VERIFY_CACHE = os.environ.get("GPMPC_VERIFY_FACTOR_CACHE") == "1"
 
+JOINT_WS_HINT_MAX_BYTES = 32 << 30   # largest workspace allocated ahead of need (Agent's bound on the conditioning set)
 MAX_JOINT_ROWS = 2048            # gpmpc_joint_sample: n_ho + 1 + m*T label rows per chain (include/gpmpc_hip.h)
 MAX_JOINT_TEST_SLOTS = 256       # m*T
 
@@ -164,9 +165,12 @@ class JointFactorCache:
         hy = mdl.hyper
         key = (Ns, hy.g_ny, mdl.plan.n_r, hy.T, mdl.plan.version)
         if self.buf is None or key != self.key or n_ho > self.rows:
-            # the set grows by the same number of slots every SQP iteration: room for four of them where that fits
+            # the set grows by the same number of slots every SQP iteration: room for the Agent's bound on it (max_sqp_iter * H
+            # points) where there is one, else for four of them where that fits
             n_samp = Ns
-            for mult in (4.0, 2.0, 1.25):
+            hint = getattr(mdl, "_ws_cache", {}).get("joint_points_hint")
+            n_hint = int(hint) * hy.T if hint else 0
+            for mult in ((float(n_hint) / n_ho,) if n_hint >= n_ho else ()) + (4.0, 2.0, 1.25):
                 rows = min(MAX_JOINT_ROWS, max(256, -(-int(mult * n_ho) // 128) * 128))
                 nbytes = lib.gpmpc_joint_cache_bytes(mdl.plan.desc, Ns, rows)
                 if 0 < nbytes <= self.MAX_BYTES:
@@ -276,6 +280,15 @@ class HipPosterior:
                 f"{m * hy.T} that is at most {(MAX_JOINT_ROWS - 1 - m * hy.T) // max(m * hy.T, 1)} iterations after the "
                 f"reset (the reference's max_sqp_iter of 150 is not reachable: its cost grows with the cube of the rows).")
         ws_bytes = lib.gpmpc_joint_workspace_bytes(mdl.plan.desc, Ns, n_ho, m)
+        # (the Agent's bound on the conditioning set: one allocation for the closed loop's largest draw instead of one per SQP
+        # iteration of the first MPC step; ignored where it would not fit the entry point's limits or a 32 GiB budget)
+        hint = mdl._ws_cache.get("joint_points_hint")
+        if hint:
+            n_hint = int(hint) * hy.T
+            if n_ho < n_hint and n_hint + 1 + m * hy.T <= MAX_JOINT_ROWS:
+                hb = lib.gpmpc_joint_workspace_bytes(mdl.plan.desc, Ns, n_hint, m)
+                if ws_bytes < hb <= JOINT_WS_HINT_MAX_BYTES:
+                    ws_bytes = hb
         ws = mdl._workspace(ws_bytes)
         fcache = mdl._ws_cache.setdefault("joint_factor_cache", JointFactorCache())
         fbuf, frows, n_c = fcache.prepare(mdl, Ns, n_ho)

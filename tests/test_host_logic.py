@@ -270,6 +270,12 @@ def test_joint_factor_cache_bookkeeping():
     assert c.prepare(mk(5), Ns, 15)[2] == 0             # reset: fewer slots than cached
     c.rewind(12)
     assert c.n_valid == 12 and c.prepare(mk(20), Ns, 60)[2] == 12
+    # the Agent's bound on the conditioning set (max_sqp_iter * H points) sizes the buffer once: no regrowth up to it
+    ch = JointFactorCache()
+    mh = mk(10)
+    mh._ws_cache = {"joint_points_hint": 160}
+    bufh, rows_h, _ = ch.prepare(mh, Ns, 30)
+    assert rows_h == 512 and ch.prepare(mk(20), Ns, 60)[0] is bufh and ch.prepare(mk(40), Ns, 120)[0] is bufh
     c.commit(mk(20), 60, ok=False)
     assert c.n_valid == 0 and c.prepare(mk(20), Ns, 60)[2] == 0      # a failed factorisation is not kept
     c.commit(mk(20), 60, ok=True)
