@@ -55,6 +55,9 @@ def make_agents(sg, p, erv=None):
         agent = sg.Agent(small, env)
         agent.params = pg
         agent.epistimic_random_vector = torch.as_tensor(erv, dtype=F64).to(agent.torch_device)
+        # (the constructor sized the joint buffers for the tiny config: a factor cache that regrows mid-loop restarts from zero
+        # cached rows, and the matrix-pipe path's results depend on the cache state to rounding - INTEGRATION.md)
+        agent._ws_cache["joint_points_hint"] = int(pg["optimizer"]["SEMPC"]["max_sqp_iter"]) * int(pg["optimizer"]["H"])
     oenv = ao.make_oracle_env(p)
     oagent = ao.OracleAgent(p, oenv, torch.as_tensor(erv, dtype=F64).cpu())
     return agent, oagent
