@@ -622,16 +622,18 @@ static int rollout_impl(const gpmpc_gp_desc_t* gp, const gpmpc_env_desc_t* env, 
     args.state_stride = state ? state_sample_doubles(gp->g_ny, observed_real_slots(gp), state_slots, state_points, gp->D) : 0;
     args.resume = resume;
     args.max_points = rp.max_points;
-    if (mode == GPMPC_MODE_RECONDITIONED && !rp.fac_lds && !state) {
-        const size_t need = (size_t)Ns * gp->g_ny * rp.chain_doubles * sizeof(double);
-        if (!ws || ws_bytes < need) return fail(GPMPC_E_WORKSPACE, "gpmpc_rollout: workspace too small");
-    }
     hipStream_t st = (hipStream_t)stream;
     // seed points without a kept factor state are conditioning-only passes of the tiled kernel's step body; a kept / resumed
     // state is the generic kernel's own factor layout
     int kernel = GPMPC_KERNEL_GENERIC;
     if (!seeded) kernel = select_rollout_kernel(gp, env, mode, hall_tasks, H, Ns);
     else if (!state && rollout_tiles_eligible(gp, env, mode, hall_tasks, H, Ns, n_h0, n_v0)) kernel = GPMPC_KERNEL_TILES;
+    // the generic kernel's factor lives in the workspace (the tiled / fast kernels check their own needs in their launchers; the
+    // one-chain-per-wave MFMA kernel keeps the factor in registers and needs none)
+    if (kernel == GPMPC_KERNEL_GENERIC && mode == GPMPC_MODE_RECONDITIONED && !rp.fac_lds && !state) {
+        const size_t need = (size_t)Ns * gp->g_ny * rp.chain_doubles * sizeof(double);
+        if (!ws || ws_bytes < need) return fail(GPMPC_E_WORKSPACE, "gpmpc_rollout: workspace too small");
+    }
     g_last_rollout_path = kernel;
     if (kernel == GPMPC_KERNEL_ONE) return rollout_one_launch(gp, env, args, st);
     if (kernel == GPMPC_KERNEL_TILES) return rollout_tiles_launch(gp, env, args, ws, ws_bytes, st);

@@ -5,9 +5,10 @@ not pad there (it neither sees into an asm statement nor pads its boundary beyon
 Rules (measured on MI355X: tools/ubench/mfma64_hazard2.hip, mfma64_chain.hip, mfma64_war.hip; an `s_nop N` is N + 1 wait
 states, every other instruction one - EXCEPT an independent FP64 MFMA standing between an MFMA and the reader of its result:
 tools/ubench/mfma64_fill.hip (round 4) shows that ONE such MFMA leaves nothing to pad for a VALU, a DPP or an MFMA SrcA/B reader
-(the reader then waits 16+ cycles behind the producer); it counts as MFMA_WS = 6 wait states for the rules M2-M4 - and as ONE,
-like any instruction, for D1 / M1.  rollout_one.hip relies on it: the next tile row's independent MFMAs stand where the s_nop
-of the previous row would be):
+(the reader then waits 16+ cycles behind the producer); IN rollout_one.hip ONLY it counts as 6 wait states for the rules M2-M4
+(the next tile row's independent MFMAs stand where the s_nop of the previous row would be; `gpmpc_selftest` and the parity tests
+run that kernel against the oracle on the part at hand) - everywhere else, and for D1 / M1, an MFMA is ONE wait state like any
+instruction:
 
   D1  VALU write of a VGPR -> the same VGPR read through DPP (v_fmac_f64_dpp / v_mov_b32_dpp source)   2 wait states
   M1  VALU write of a VGPR -> MFMA reading it as SrcA / SrcB / SrcC                           2
@@ -53,10 +54,13 @@ def regs(tok):
 
 
 TOK = r"-?[va]\[\d+:\d+\]|-?[va]\d+"
-MFMA_WS = 6
+MFMA_WS_RELAXED = 6         # rollout_one.hip only (its solve statements are scheduled on the mfma64_fill.hip measurement)
+RELAXED_FILES = ("rollout_one",)
 
 
-def check(path):
+def check(path, mfma_ws=None):
+    if mfma_ws is None:     # STRICT by default: an MFMA is one wait state like any instruction; relaxed only for the named files
+        mfma_ws = MFMA_WS_RELAXED if os.path.basename(path).startswith(RELAXED_FILES) else 1
     counts = {"dpp": 0, "mfma": 0}
     problems, kernel = [], None
     window = []          # preceding instructions, newest last: (wait states, wait states for M2-M4, kind, set of ('v'|'a', n) written)
@@ -106,7 +110,7 @@ def check(path):
             n = int(m.group(1)) + 1 if m else 1
             window.append((n, n, "nop", set()))
         elif is_mfma:
-            window.append((1, MFMA_WS, "mfma", tagged[0] if tagged else set()))
+            window.append((1, mfma_ws, "mfma", tagged[0] if tagged else set()))
         elif op.startswith("v_") and tagged:
             window.append((1, 1, "valu", tagged[0]))      # VALU: the destination is the first operand
         else:
