@@ -873,25 +873,26 @@ __global__ __launch_bounds__(JM_THREADS) void joint_test_mfma_kernel(const Joint
 
 bool joint_mfma_eligible(int n_r, int n_hc, int ncols, int T) {
     const int n_o = n_r + n_hc;
-    return (T == 1 || T == 3) && n_r >= 1 && n_r <= 64 && n_hc >= 0 && (n_o + 15) / 16 <= JM_NT && ncols >= 1 && ncols <= JM_COLS;
+    // (T = 3 only: a value-only model - T = 1 - never has hallucinated data behind the reference's call surface, src/agent.py:221-226;
+    // the kernel is written for both, but no test reaches the T = 1 form: it is not instantiated)
+    return T == 3 && n_r >= 1 && n_r <= 64 && n_hc >= 0 && (n_o + 15) / 16 <= JM_NT && ncols >= 1 && ncols <= JM_COLS;
 }
 
 bool joint_mfma_split_eligible(int n_r, int n_hc, int ncols, int T) {
     const int n_o = n_r + n_hc;
-    return (T == 1 || T == 3) && n_r >= 1 && n_r <= 64 && n_o > JOINT_MFMA_SPLIT && n_o <= JOINT_MFMA_SPLIT + JOINT_MFMA_BOTTOM_MAX &&
+    return T == 3 && n_r >= 1 && n_r <= 64 && n_o > JOINT_MFMA_SPLIT && n_o <= JOINT_MFMA_SPLIT + JOINT_MFMA_BOTTOM_MAX &&
            ncols >= 1 && ncols <= JM_COLS;
 }
 
 int joint_mfma_launch(const JointArgs& a, hipStream_t st) {
     static bool attr_done = false;
+    if (a.gp.T != 3) return fail(GPMPC_E_UNSUPPORTED, "joint_test_mfma_kernel is instantiated for T = 3");
     if (!attr_done) {
-        GPMPC_HIP_CHECK(hipFuncSetAttribute((const void*)joint_test_mfma_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)JM_SMEM_BYTES));
         GPMPC_HIP_CHECK(hipFuncSetAttribute((const void*)joint_test_mfma_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)JM_SMEM_BYTES));
         attr_done = true;
     }
     const dim3 g((unsigned)(a.chain1 - a.chain0)), b(JM_THREADS);
-    if (a.gp.T == 1) hipLaunchKernelGGL((joint_test_mfma_kernel<1>), g, b, JM_SMEM_BYTES, st, a);
-    else hipLaunchKernelGGL((joint_test_mfma_kernel<3>), g, b, JM_SMEM_BYTES, st, a);
+    hipLaunchKernelGGL((joint_test_mfma_kernel<3>), g, b, JM_SMEM_BYTES, st, a);
     GPMPC_HIP_CHECK(hipGetLastError());
     return GPMPC_OK;
 }

@@ -7,6 +7,7 @@ RTOL_TRAJ = 1e-6 (two orders tighter) and print the observed maximum error, whic
 conditioning of K, ~1e5 pendulum / ~1e7 car).
 """
 import os
+import warnings
 
 import numpy as np
 import pytest
@@ -1386,3 +1387,4 @@ def test_base_samples_kernel_against_the_torch_form(sg, Ns, g_ny, H, T, beta):
     if beta < 10:
         assert int(att.max()) >= 1, "with these bounds some vector needs a second attempt"
     print(f"Ns={Ns} V={V} beta={beta}: mean attempts {float(att.float().mean()) + 1:.2f}")
+
