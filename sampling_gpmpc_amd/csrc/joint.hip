@@ -1277,7 +1277,10 @@ int gpmpc_joint_sample(const gpmpc_gp_desc_t* gp, const void* plan, const double
         }
         const int n_new = n_ho - b.n_c;
         static const char* fenv = getenv("GPMPC_JOINT_MFMA_FACTOR");      // 0: the factor phase stays on the vector pipe
-        const bool mfma_factor = n_new > 0 && n_new <= mT && joint_mfma_eligible(a.gp.n_r, b.n_c, n_new, gp->T) &&
+        // (with nothing cached - the second SQP iteration - the new rows only meet the real columns: joint_kernel's factor phase does
+        // rows and Cholesky in one launch, 1.98 against 2.15 ms per draw at configs[4], k = 1; from 120 cached slots on the matrix pipe
+        // wins: 3.2 against 3.9 ms at k = 2)
+        const bool mfma_factor = n_new > 0 && n_new <= mT && b.n_c > 0 && joint_mfma_eligible(a.gp.n_r, b.n_c, n_new, gp->T) &&
                                  !(fenv && atoi(fenv) == 0);
         const long step = split ? w.xt_slots : (own ? nchains : w.tc_slots);
         for (long c0 = 0; c0 < nchains; c0 += step) {
