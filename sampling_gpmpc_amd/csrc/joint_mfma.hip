@@ -73,7 +73,7 @@ __device__ __attribute__((aligned(16))) double g_jm_eye[16 * 16] = {
     0, 0, 0, 0, 0, 0, 0, 0, 0, 1, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1, 0, 0, 0, 0,
     0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1, 0,
     0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1};
-__device__ long long g_jm_phase[40];          // [20..27]: inside the prologue, [28..31]: inside the kernel entries (wave 0)
+__device__ long long g_jm_phase[4][40];       // per launch mode (JOINT_MFMA_*): the last launch of that mode          // [20..27]: inside the prologue, [28..31]: inside the kernel entries (wave 0)
 
 #ifdef GPMPC_PHASE_TIMERS
 #define JMPH(idx) do { const long long _n = __builtin_readcyclecounter(); jph[idx] += _n - jt; jt = _n; } while (0)
@@ -681,45 +681,36 @@ __global__ __launch_bounds__(JM_THREADS) void joint_test_mfma_kernel(const Joint
                 jm_acc_diag(A, S, j, d01.x, d01.y, d23.x, d23.y, x);  // X_j = Linv_jj acc_j
             }
             const jm_d4 xn = -x;
+            // X_j is final: it leaves NOW where somebody else wants it - factor mode: X^T = the new rows' entries against the old
+            // columns, into the cache (row n_c + column, 4 consecutive slots per lane); TOP launch: the register dump for the BOTTOM
+            // launch.  (Written out in one loop behind the substitution these were 0.84 GB / 1.3 GB per launch in a burst of 256
+            // workgroups in lockstep: 35-40 k cycles per chain; here they trickle out under the products.)
+            if (fmode && active) {
+                const int ln = jm_lane_now();
+                const int col = 16 * I0 + (ln & 15), sl = 16 * j + 4 * (ln >> 4);
+                if (col < ncols) {
+                    double* dst = fc + (long)(a.n_c + col) * CS + sl;
+                    if (sl + 3 < n_o) {
+                        *reinterpret_cast<jm_d2*>(dst) = jm_d2{x[0], x[1]};
+                        *reinterpret_cast<jm_d2*>(dst + 2) = jm_d2{x[2], x[3]};
+                    } else {
+#pragma unroll
+                        for (int v = 0; v < 4; ++v)
+                            if (sl + v < n_o) dst[v] = x[v];
+                    }
+                }
+            }
+            if (top) {
+                double* xd = a.xbuf + (chain - a.chain0) * JOINT_MFMA_XBUF_DOUBLES + I0 * 256 + (long)j * 2048 + jm_lane_now();
+#pragma unroll
+                for (int v = 0; v < 4; ++v) xd[v * 64] = x[v];
+            }
             JMPHS(0);
             do_column(j, j + 1, xn, j + 2, j + 1, j + 2 < nt);
         }
     }
     __syncthreads();                              // every wave is done with the ring
     JMPH(2);
-    // TOP launch of a split conditioning set: the wave's X tiles go to a.xbuf as they lie in the registers ([tile][wave][4][64])
-    {
-        const int nt_x = top ? nt : 0;            // (a run-time trip count, not a branch around the statement)
-        double* xdst = a.xbuf + (chain - a.chain0) * JOINT_MFMA_XBUF_DOUBLES + I0 * 256;
-#pragma unroll 1
-        for (int j = 0; j < nt_x; ++j) {
-            double t[4];
-            jm_acc_get(A, j, t[0], t[1], t[2], t[3]);
-#pragma unroll
-            for (int v = 0; v < 4; ++v) xdst[(long)j * 2048 + v * 64 + lane] = t[v];
-        }
-    }
-    // factor mode: X^T = the new rows' entries against the old columns goes to the cache (row n_c + column, 4 consecutive slots per lane)
-    const int nt_f = fmode ? nt : 0;              // (a run-time trip count, not a branch around the statement)
-#pragma unroll 1
-    for (int j = 0; j < nt_f; ++j) {
-        double t[4];
-        jm_acc_get(A, j, t[0], t[1], t[2], t[3]);
-        if (active) {
-            const int col = 16 * I0 + (lane & 15), sl = 16 * j + 4 * (lane >> 4);
-            if (col < ncols) {
-                double* dst = fc + (long)(a.n_c + col) * CS + sl;
-                if (sl + 3 < n_o) {
-                    *reinterpret_cast<jm_d2*>(dst) = jm_d2{t[0], t[1]};
-                    *reinterpret_cast<jm_d2*>(dst + 2) = jm_d2{t[2], t[3]};
-                } else {
-#pragma unroll
-                    for (int v = 0; v < 4; ++v)
-                        if (sl + v < n_o) dst[v] = t[v];
-                }
-            }
-        }
-    }
     // tiles 22..25 of every wave's X go to LDS (the inverted diagonal tiles are no longer needed): the statements of the Gram phase
     // name the tiles 0..21 only, 32 registers come free for the Gram accumulators; the four tiles come back into the registers of
     // tiles 0..3 once those are done with (jm_gram_reload)
@@ -860,13 +851,13 @@ __global__ __launch_bounds__(JM_THREADS) void joint_test_mfma_kernel(const Joint
     if (blockIdx.x == 0 && (tid == 0 || tid == JM_THREADS - 64))
     {
         jph[7] = jphs[0];                         // (slot 7 of the phase record: diagonal steps; the other two are recovered below)
-        for (int i = 0; i < 8; ++i) g_jm_phase[i + (tid ? 8 : 0)] = jph[i];
-        g_jm_phase[16 + (tid ? 2 : 0)] = jphs[1], g_jm_phase[17 + (tid ? 2 : 0)] = jphs[2];
+        for (int i = 0; i < 8; ++i) g_jm_phase[a.mfma_mode][i + (tid ? 8 : 0)] = jph[i];
+        g_jm_phase[a.mfma_mode][16 + (tid ? 2 : 0)] = jphs[1], g_jm_phase[a.mfma_mode][17 + (tid ? 2 : 0)] = jphs[2];
         if (tid == 0) {
-            for (int i = 0; i < 8; ++i) g_jm_phase[20 + i] = jpp[i];
-            for (int i = 0; i < 4; ++i) g_jm_phase[28 + i] = jpe[i];
+            for (int i = 0; i < 8; ++i) g_jm_phase[a.mfma_mode][20 + i] = jpp[i];
+            for (int i = 0; i < 4; ++i) g_jm_phase[a.mfma_mode][28 + i] = jpe[i];
         }
-        for (int i = 0; i < 3; ++i) g_jm_phase[32 + i + (tid ? 3 : 0)] = jphs[3 + i];
+        for (int i = 0; i < 3; ++i) g_jm_phase[a.mfma_mode][32 + i + (tid ? 3 : 0)] = jphs[3 + i];
     }
 #endif
 }
@@ -899,7 +890,13 @@ int joint_mfma_launch(const JointArgs& a, hipStream_t st) {
 
 }  // namespace gpmpc
 
-extern "C" int gpmpc_debug_read_joint_mfma_phases(long long* out /*[host] 40*/) {
-    GPMPC_HIP_CHECK(hipMemcpyFromSymbol(out, HIP_SYMBOL(gpmpc::g_jm_phase), 40 * sizeof(long long)));
+extern "C" int gpmpc_debug_read_joint_mfma_phases(long long* out /*[host] 40*/) {      // the test-mode launch
+    GPMPC_HIP_CHECK(hipMemcpyFromSymbol(out, HIP_SYMBOL(gpmpc::g_jm_phase), 40 * sizeof(long long), 0));
+    return GPMPC_OK;
+}
+// the same record of the last launch of `mode` (JOINT_MFMA_TEST / _FACTOR / _TEST_TOP / _TEST_BOTTOM)
+extern "C" int gpmpc_debug_read_joint_mfma_phases_of(int mode, long long* out /*[host] 40*/) {
+    if (mode < 0 || mode > 3) return GPMPC_E_ARG;
+    GPMPC_HIP_CHECK(hipMemcpyFromSymbol(out, HIP_SYMBOL(gpmpc::g_jm_phase), 40 * sizeof(long long), (size_t)mode * 40 * sizeof(long long)));
     return GPMPC_OK;
 }

@@ -92,6 +92,12 @@ for it in range(iters):
 print("worst mean/cov rel diff", worst)
 if os.environ.get("GPMPC_PHASE_TIMERS") == "1":
     import ctypes as C
+    modes = {0: "test", 1: "factor", 2: "top", 3: "bottom"}
+    for md in ([1] if "--factor-phases" in sys.argv else []) + ([2, 3] if iters > 4 else []):
+        om = (C.c_longlong * 40)()
+        lib.gpmpc_debug_read_joint_mfma_phases_of(md, om)
+        print("joint_test_mfma_kernel, %s-mode launch (wave 0 / wave 7): prologue %d / %d entries %d / %d solve %d / %d | gram: init %d / %d publish %d / %d products %d / %d out %d / %d"
+              % ((modes[md],) + tuple(v for i in range(7) for v in (om[i], om[8 + i]))))
     out = (C.c_longlong * 40)()
     lib.gpmpc_debug_read_joint_mfma_phases(out)
     for w, o in ((0, 0), (7, 8)):
