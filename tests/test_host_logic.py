@@ -347,3 +347,20 @@ def test_host_thread_env_below_one_is_ignored(monkeypatch):
     got = ht.limit_host_threads()
     assert got is None or 1 <= got <= before
     assert torch.get_num_threads() >= 1
+
+
+def test_joint_workspace_covers_the_split_launches():
+    """gpmpc_joint_workspace_bytes (host logic, no GPU): between 417 and 544 conditioning slots the test rows of the matrix-pipe path
+    run as TOP + BOTTOM launches, whose X tiles (416 KB per chain, batches of <= 3072 chains) live in the workspace.  With 45 real
+    slots the form ends behind 499 hallucinated ones: the size drops by the X tiles there (at its lower end the temporary factor
+    cache of the one-launch form leaves as the X tiles come: no step to see)."""
+    from sampling_gpmpc_amd import _lib
+    lib = _lib.load()
+    desc = _lib.make_gp_desc(3, 2, 3, 45, False, [[2.0, 1.1]] * 3, [0.05] * 3, [2e-7] * 3, 1e-20)
+    m = 40
+    for Ns, chains in ((1024, 3072), (8, 24), (4096, 3072)):
+        xt = chains * 26 * 8 * 2048                   # chains of a batch x tiles x waves x 2 KB
+        b = {n: lib.gpmpc_joint_workspace_bytes(desc, Ns, n, m) for n in (498, 499, 500, 501)}
+        grow = b[499] - b[498]
+        assert grow > 0 and b[501] - b[500] > 0
+        assert abs((b[499] + grow - b[500]) - xt) < 0.1 * xt + (64 << 20), (Ns, b)      # (the per-chain slots grow in steps)
