@@ -210,6 +210,28 @@ __global__ __launch_bounds__(JM_THREADS) void joint_test_mfma_kernel(const Joint
         return (r < n_r) ? Lrr[(long)r * n_r + c] : fc[(long)(r - n_r) * CS + c];
     };
 
+    auto Lptr = [&](int r, int c) -> const double* {      // &L(r, c) for any r, c >= 0: clamped into the factor
+        const int rr = min(r, n_o - 1), cc = min(c, rr);
+        return (rr < n_r) ? Lrr + (long)rr * n_r + cc : fc + (long)(rr - n_r) * CS + cc;
+    };
+    // the (at most four) diagonal tiles with real rows and the off-diagonal tiles with real rows go through registers (the plan's rows
+    // are not 16-byte aligned): their loads are REQUESTED here, in front of the stream table, and stored behind it
+    constexpr int NVD = 4 * 256 / JM_THREADS, NVR = JM_RT * 256 / JM_THREADS;
+    double vd[NVD], vr[NVR];
+#pragma unroll
+    for (int it = 0; it < NVD; ++it) {
+        const int e = tid + it * JM_THREADS;
+        const int tj = e >> 8, i = (e >> 4) & 15, c = e & 15;
+        vd[it] = *Lptr(16 * tj + i, 16 * tj + c);
+    }
+#pragma unroll
+    for (int it = 0; it < NVR; ++it) {
+        const int e = tid + it * JM_THREADS;
+        const int ti = e >> 8, i = (e >> 4) & 15, c = e & 15;
+        const int k = (ti < 1) ? 1 : ((ti < 3) ? 2 : 3);
+        const int j = ti - k * (k - 1) / 2;
+        vr[it] = *Lptr(16 * k + i, 16 * j + c);
+    }
     // ---- table of the STREAMED tiles (k, j), k >= max(j + 1, kmin): rows that are all hallucinated slots, in consumption order
     // (column by column); the few tiles with real rows (k < kmin) sit in `realt` ------------------------------------------------
     // (closed form of the start of column jj's tiles: the columns j' < kmin - 1 have nt - kmin streamed tiles each, column j' >= kmin - 1
@@ -280,45 +302,22 @@ __global__ __launch_bounds__(JM_THREADS) void joint_test_mfma_kernel(const Joint
     // waits for each load before it issues the next, and the prologue was ~25 serial round trips to L2 / HBM)
     // (and every load is UNCONDITIONAL - a clamped address, the value selected afterwards: a load under a lane condition is a branch
     // around it, and hipcc waits for it before the next one)
-    auto Lptr = [&](int r, int c) -> const double* {      // &L(r, c) for any r, c >= 0: clamped into the factor
-        const int rr = min(r, n_o - 1), cc = min(c, rr);
-        return (rr < n_r) ? Lrr + (long)rr * n_r + cc : fc + (long)(rr - n_r) * CS + cc;
-    };
-    {   // the (at most four) diagonal tiles with real rows: through registers (the plan's rows are not 16-byte aligned)
-        constexpr int NV = 4 * 256 / JM_THREADS;
-        double v[NV];
+    {   // (the real-row tiles requested in front of the stream table)
 #pragma unroll
-        for (int it = 0; it < NV; ++it) {
-            const int e = tid + it * JM_THREADS;
-            const int tj = e >> 8, i = (e >> 4) & 15, c = e & 15;
-            v[it] = *Lptr(16 * tj + i, 16 * tj + c);
-        }
-#pragma unroll
-        for (int it = 0; it < NV; ++it) {
+        for (int it = 0; it < NVD; ++it) {
             const int e = tid + it * JM_THREADS;
             const int tj = e >> 8, i = (e >> 4) & 15, c = e & 15;
             const int r = 16 * tj + i;
-            const double val = (r < n_o) ? ((c <= i) ? v[it] : 0.0) : ((c == i) ? 1.0 : 0.0);
+            const double val = (r < n_o) ? ((c <= i) ? vd[it] : 0.0) : ((c == i) ? 1.0 : 0.0);
             if (tj < kmin) linv[e] = val;
         }
-    }
-    {
         const int nrt = kmin * (kmin - 1) / 2;
-        double v[JM_RT * 256 / JM_THREADS];
 #pragma unroll
-        for (int it = 0; it < JM_RT * 256 / JM_THREADS; ++it) {
+        for (int it = 0; it < NVR; ++it) {
             const int e = tid + it * JM_THREADS;
             const int ti = e >> 8, i = (e >> 4) & 15, c = e & 15;
             const int k = (ti < 1) ? 1 : ((ti < 3) ? 2 : 3);
-            const int j = ti - k * (k - 1) / 2;
-            v[it] = *Lptr(16 * k + i, 16 * j + c);
-        }
-#pragma unroll
-        for (int it = 0; it < JM_RT * 256 / JM_THREADS; ++it) {
-            const int e = tid + it * JM_THREADS;
-            const int ti = e >> 8, i = (e >> 4) & 15, c = e & 15;
-            const int k = (ti < 1) ? 1 : ((ti < 3) ? 2 : 3);
-            if (e < nrt * 256) realt[ti * 256 + jm_off(i, c)] = (16 * k + i < n_o) ? v[it] : 0.0;
+            if (e < nrt * 256) realt[ti * 256 + jm_off(i, c)] = (16 * k + i < n_o) ? vr[it] : 0.0;
         }
     }
     JMPHP(1);
