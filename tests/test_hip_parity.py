@@ -401,8 +401,20 @@ def test_mode_i_variants_against_oracle(sg, pname, Ns, H, feedback, x0):
     np.testing.assert_allclose(Y, Yo, rtol=1e-4, atol=1e-8)
 
 
-def test_joint_draw_against_reference_golden(sg):
-    """Mode J as the SQP loop drives it (two iterations; the second conditions on the first's 8 sampled points)."""
+@pytest.mark.parametrize("path", ["auto", "mfma"])
+def test_joint_draw_against_reference_golden(sg, path):
+    """Mode J as the SQP loop drives it (two iterations; the second conditions on the first's 8 sampled points) against the outputs of
+    the REFERENCE's own code (tests/golden/agent_e2e_J_pendulum1D.npz).  "auto": the dispatcher's choice (24 hallucinated slots: the VALU
+    path); "mfma": the matrix-pipe path pinned - its second iteration runs joint_test_mfma_kernel (factor extension + test rows)."""
+    lib = sg._lib.load()
+    lib.gpmpc_joint_pin_path(sg._lib.JOINT_MFMA if path == "mfma" else sg._lib.JOINT_AUTO)
+    try:
+        _joint_draw_against_reference_golden(sg, path)
+    finally:
+        lib.gpmpc_joint_pin_path(sg._lib.JOINT_AUTO)
+
+
+def _joint_draw_against_reference_golden(sg, path):
     d = np.load(os.path.join(GOLDEN, "agent_e2e_J_pendulum1D.npz"))
     p = load_params("params_pendulum1D_samples")
     Ns, H = int(d["Ns"]), int(d["H"])
@@ -418,6 +430,8 @@ def test_joint_draw_against_reference_golden(sg):
         bx = agent.get_batch_x_hat_u_diff(
             x_h, -(x_equi - x_h.reshape(H, Ns, -1)) @ K.T + np.tile(d["u_h"][:, None, :], (Ns, 1)))
         gp_val, y_grad, u_grad = agent.dyn_fg_jacobians(bx, it)
+        if it >= 1:
+            assert sg._lib.load().gpmpc_joint_last_path() == (sg._lib.JOINT_MFMA if path == "mfma" else sg._lib.JOINT_VALU)
         assert gp_val.dtype == np.float64 and gp_val.shape == (Ns, 2, H, 1)
         np.testing.assert_allclose(agent.model_i_call.mean.cpu().numpy(), d[f"mean_{it}"], rtol=1e-7, atol=1e-10)
         np.testing.assert_allclose(agent.model_i_call.variance.cpu().numpy(), d[f"var_{it}"], rtol=1e-5, atol=1e-12)
