@@ -23,9 +23,10 @@ gather has completed.  `gather` in the JSON reports the collective alone and wha
 
 Measurement order: W warmup steps -> K steps timed COLD (`cold.ms_per_step`: what a fresh process sees; the GPU has not
 reached its sustained clocks yet) -> `--prewarm` (default 2000, ~0.25 s) untimed steps -> W warmup steps -> EXACTLY K
-steps between two fences (barrier + synchronize): `value` / `ms_per_step`, max over ranks.  Prints ONE JSON line on rank
-0.  `roofline` is for the dominant kernel: algorithmic FP64 FLOP per launch divided by the launch
-duration measured with HIP events on the launch stream (one event pair per launch, in a pass of the same launches right
+steps between two fences (barrier + synchronize): `value` / `ms_per_step`, max over ranks.  Rank 0 prints ONE short JSON
+line on stdout (the contract line, < 4 KB, last thing printed; `legs` = {leg id: [ms, roofline frac, path]}) and, before it,
+the full objects of every leg as one JSON line on stderr (+ bench_extra.json).  `roofline` is for the dominant kernel:
+algorithmic FP64 FLOP per launch divided by the launch duration measured with HIP events on the launch stream (one event pair per launch, in a pass of the same launches right
 after the timed region).  `cpu_baseline` times the CPU oracle (the reference-faithful from-scratch algorithm, torch CPU
 FP64) on rank 0 at N = 1 on a bounded sample of the same workload, at the best of several thread counts.  `extra`
 (N = 1) carries BASELINE configs[2] (car, mode R) and configs[4]'s per-GPU shard (car closed loop AS SHIPPED, mode J,
@@ -221,7 +222,7 @@ def extra_car_rollout(sg, _lib, RolloutRunner, wl):
     bits = int(runner.info.max().item())
     ok = bool(torch.isfinite(runner.X_traj).all()) and not (bits & (_lib.INFO_TRAIN_CHOL_FAIL | _lib.INFO_ROOT_FAIL))
     flop = wl.flop_mode_r(3, 3, 45, 45, H) * Ns * H
-    return {"workload": "BASELINE configs[2]: params_car_residual, mode R (T=3), Ns=4096, H=40, 1 GPU",
+    return {"id": "carR_4096x40", "workload": "BASELINE configs[2]: params_car_residual, mode R (T=3), Ns=4096, H=40, 1 GPU",
             "value": Ns * H / (ms * 1e-3), "unit": "trajectory-steps/s", "ms_per_rollout": ms, "finite": ok,
             "kernel_path": int(_lib.load().gpmpc_debug_last_rollout_path()),
             "roofline": roofline(flop, ms, "rollout_tiles_kernel<5,9,car_residual,32> (four chains per wave, FP64 4x4x4 MFMA solve)"
@@ -251,7 +252,7 @@ def extra_pendulum_throughput(sg, _lib, RolloutRunner, wl):
     bits = int(runner.info.max().item())
     ok = bool(torch.isfinite(runner.X_traj).all()) and not (bits & (_lib.INFO_TRAIN_CHOL_FAIL | _lib.INFO_ROOT_FAIL))
     flop = wl.flop_mode_r(1, 3, 36, 36, H) * Ns * H
-    return {"workload": "BASELINE configs[1] workload at Ns=16384 (throughput point): params_pendulum1D_samples, mode R, H=30, 1 GPU",
+    return {"id": "penR_16384x30", "workload": "BASELINE configs[1] workload at Ns=16384 (throughput point): params_pendulum1D_samples, mode R, H=30, 1 GPU",
             "value": Ns * H / (ms * 1e-3), "unit": "trajectory-steps/s", "ms_per_rollout": ms, "finite": ok, "kernel_path": path,
             "roofline": roofline(flop, ms, "rollout_tiles_kernel<4,9,pendulum1D,32> (four chains per wave, FP64 4x4x4 MFMA solve)"
                                  if path == 3 else ("rollout_one_kernel<4,pendulum1D>" if path == 4 else "rollout_fast_kernel<3,36,1,pendulum1D>"),
@@ -259,7 +260,7 @@ def extra_pendulum_throughput(sg, _lib, RolloutRunner, wl):
                                  **({"bound": "fp64_mfma"} if path == 3 else {}))}
 
 
-def extra_closed_loop(sg, _lib, wl, name="params_car_residual", Ns=1024, H=40, iters=4, next_step=True, label=None):
+def extra_closed_loop(sg, _lib, wl, name="params_car_residual", Ns=1024, H=40, iters=4, next_step=True, label=None, tag="carJ_1024x40"):
     """Joint draws of the closed loop (mode J), per SQP iteration k (reference src/solver.py:84-94); linearisation points
     from the deterministic surrogate of SURVEY.md 8d (sample mean of the previous iteration's prediction).
     Default: BASELINE configs[4] on its per-GPU shard, AS SHIPPED (params_car_residual.yaml incl. Dyn_gp_jitter 1e-20 -> the
@@ -375,7 +376,7 @@ def extra_closed_loop(sg, _lib, wl, name="params_car_residual", Ns=1024, H=40, i
             # built (src/agent.py:261-272), so this draw conditions on all the iterations' points of the previous step
             agent.mpc_iteration(1)
             iteration(1, 0, x_h)
-    return {"workload": label or ("BASELINE configs[4] per-GPU shard as shipped: params_car_residual (Dyn_gp_jitter 1e-20), "
+    return {"id": tag, "workload": label or ("BASELINE configs[4] per-GPU shard as shipped: params_car_residual (Dyn_gp_jitter 1e-20), "
                                   "mode J, Ns=1024 (8192 / 8 GPUs), H=40, SQP iterations k=0..3 of MPC step 0 and k=0 of MPC "
                                   "step 1"), "iterations": out}
 
@@ -383,14 +384,14 @@ def extra_closed_loop(sg, _lib, wl, name="params_car_residual", Ns=1024, H=40, i
 def extra_car_joint_cfg3_size(sg, _lib, wl):
     """SURVEY 8d cfg3's size (car, Ns = 4096, H = 40) in mode J: the joint draw at SQP iterations k = 0..3 of one MPC step on
     ONE GPU (the closed loop of configs[4] with four times the per-GPU shard)."""
-    return extra_closed_loop(sg, _lib, wl, "params_car_residual", 4096, 40, 4, next_step=False,
+    return extra_closed_loop(sg, _lib, wl, "params_car_residual", 4096, 40, 4, next_step=False, tag="carJ_4096x40",
                              label="SURVEY 8d cfg3 size in mode J: params_car_residual as shipped, Ns=4096, H=40 on one GPU, "
                                    "joint draw at SQP iterations k=0..3")
 
 
 def extra_pendulum_joint(sg, _lib, wl):
     """SURVEY 8d cfg2, mode J: params_pendulum1D_samples as shipped (jitter 1e-6: Cholesky root), Ns=1024, H=30, k=0 and k=1."""
-    return extra_closed_loop(sg, _lib, wl, "params_pendulum1D_samples", 1024, 30, 2, next_step=False,
+    return extra_closed_loop(sg, _lib, wl, "params_pendulum1D_samples", 1024, 30, 2, next_step=False, tag="penJ_1024x30",
                              label="BASELINE configs[1] in mode J (SURVEY 8d cfg2): params_pendulum1D_samples, Ns=1024, H=30, "
                                    "joint draw at SQP iterations k=0 and k=1")
 
@@ -457,7 +458,7 @@ def sharded_closed_loop_leg(rank, world, dist, sg, _lib, wl, ns_per_gpu=1024, H=
                                 "gather_ms": gather_ms, "wall_ms_per_iteration": wall_ms, "finite": finite,
                                 "gathered_bytes": int(sum(a.nbytes for a in full)),
                                 "trajectory_steps_per_s": Ns * H / (wall_ms * 1e-3)})
-    return {"workload": "BASELINE configs[4] sharded over %d GPU(s): params_car_residual as shipped (Dyn_gp_jitter 1e-20), mode J, "
+    return {"id": "carJ_sharded", "workload": "BASELINE configs[4] sharded over %d GPU(s): params_car_residual as shipped (Dyn_gp_jitter 1e-20), mode J, "
                         "Ns=%d (%d per GPU), H=%d, SQP iterations k=0..%d of MPC steps 0 (cold: buffers grow) and 1 (steady)"
                         % (world, Ns, ns_per_gpu, H, iters - 1),
             "collective": "gather of the packed Jacobians (ns, nx, H, 1+nx+nu) f64 to rank 0 (RCCL) + one D2H copy",
@@ -563,6 +564,113 @@ def reachable_set_leg(a, rank, world, dist, sg, _lib, RolloutRunner, wl):
                 "finite": finite,
                 "roofline": reach_roofline(wl, a.reach_ns, kms)})
     return res
+
+
+HEADLINE_MAX_CHARS = 4096          # the contract line: printed LAST, shorter than this (tests/test_bench_contract.py)
+
+
+def _dedupe_strings(obj, legend, min_len=48):
+    """Every string of `min_len`+ characters below `obj` becomes a short id ("@3") into `legend` (id -> text): the same
+    note / kernel description is carried once however many legs repeat it."""
+    if isinstance(obj, dict):
+        return {k: _dedupe_strings(v, legend, min_len) for k, v in obj.items()}
+    if isinstance(obj, list):
+        return [_dedupe_strings(v, legend, min_len) for v in obj]
+    if isinstance(obj, str) and len(obj) >= min_len:
+        for k, v in legend.items():
+            if v == obj:
+                return k
+        k = "@%d" % len(legend)
+        legend[k] = obj
+        return k
+    return obj
+
+
+def _r4(x):
+    return float("%.5g" % x) if isinstance(x, float) else x
+
+
+def leg_summary(extra, reach):
+    """{short id: [ms, roofline frac]} of every informational leg - what the review reads first, kept on the headline line."""
+    legs = {}
+    for leg in extra or []:
+        if not isinstance(leg, dict) or "error" in leg:
+            legs["error:" + str(leg.get("workload"))[:40]] = None
+            continue
+        tag = leg.get("id", "leg")
+        if "iterations" in leg:
+            for it in leg["iterations"]:
+                ms = it.get("ms_per_draw", it.get("draw_ms"))
+                fr = it.get("roofline", {}).get("frac")
+                legs["%s.s%dk%d" % (tag, it["mpc_step"], it["k"])] = [_r4(ms), _r4(fr) if fr is not None else _r4(it.get("wall_ms_per_iteration"))]
+        else:
+            legs[tag] = [_r4(leg.get("ms_per_rollout")), _r4(leg.get("roofline", {}).get("frac")), leg.get("kernel_path")]
+    if reach and "roofline" in reach:
+        legs["carI_%dx40" % reach["Ns_per_gpu"]] = [_r4(reach["roofline"]["kernel_ms"]), _r4(reach["roofline"]["frac"]),
+                                                     _r4(reach["roofline"]["hbm_frac"])]
+    return legs
+
+
+def split_for_driver(out):
+    """(extras, headline): `headline` is the driver's contract line - every contract key, `roofline`, `cpu_baseline`, `gather`,
+    `cold`, and a compact `legs` table - below HEADLINE_MAX_CHARS; `extras` is everything else in full (notes deduplicated
+    into one legend): its own line on stderr BEFORE the headline, and bench_extra.json beside this script."""
+    head_keys = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                 "vs_baseline", "dtype", "data")
+    head = {k: out[k] for k in head_keys}
+    cfg = out["config"]
+    head["config"] = {"workload": "BASELINE configs[1]: params_pendulum1D_samples, mode R (T=3), Ns=%d per GPU, H=%d"
+                                  % (cfg["Ns_per_gpu"], cfg["H"]),
+                      "Ns_per_gpu": cfg["Ns_per_gpu"], "H": cfg["H"], "Ns_total": cfg["Ns_total"],
+                      "parallelism": "samples sharded over %d GPU(s), all-gather of X_traj per rollout" % out["n_gpus"],
+                      "device": cfg["device"], "cus": cfg["cus"]}
+    r = out["roofline"]
+    head["roofline"] = {k: r.get(k) for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel_ms",
+                                                   "flop_per_launch", "algorithmic_hbm_bytes_per_launch", "kernel_path",
+                                                   "mfma_busy", "kernel_ms_per_launch_event_pairs")}
+    head["roofline"]["kernel"] = r["kernel"].split(" (")[0]
+    c = out.get("cpu_baseline")
+    head["cpu_baseline"] = None if c is None else {"value": _r4(c["value"]), "unit": c["unit"], "cores": c["cores"], "kind": c["kind"],
+                                                   "sample": "%d rollouts of Ns=%d, full H, %.1f s of CPU work (oracle, torch CPU FP64)"
+                                                             % (c["_repeats"], c["_ns"], c["_dt"]),
+                                                   "host_cpus": c["host_cpus"]}
+    g = out.get("gather")
+    head["gather"] = None if g is None else {k: _r4(g[k]) for k in ("bytes_per_rank", "standalone_ms", "exposed_ms_per_step")}
+    head["cold"] = {"ms_per_step": _r4(out["cold"]["ms_per_step"]), "value": _r4(out["cold"]["value"])}
+    head["prewarm_steps"] = out["prewarm_steps"]
+    head["legs"] = leg_summary(out.get("extra"), out.get("reachable_set"))
+    head["legs_columns"] = "id: [ms, roofline frac (wall ms for sharded legs), path]; full objects: bench_extra line on stderr / bench_extra.json"
+    legend = {}
+    ext = {k: v for k, v in out.items() if k not in head_keys}
+    if ext.get("cpu_baseline"):
+        ext["cpu_baseline"] = {k: v for k, v in ext["cpu_baseline"].items() if not k.startswith("_")}
+    ext = _dedupe_strings(ext, legend)
+    extras = {"bench_extra": ext, "legend": legend}
+    if len(json.dumps(head)) >= HEADLINE_MAX_CHARS:              # never let the contract line grow past the window again
+        head.pop("legs_columns", None)
+        while len(json.dumps(head)) >= HEADLINE_MAX_CHARS and head["legs"]:
+            head["legs"].popitem()
+    return extras, head
+
+
+def emit(out):
+    """stdout carries exactly ONE JSON line, the short contract line (the form the driver parsed in rounds 1-4), printed last;
+    the extras object goes, as one JSON line of its own, to stderr BEFORE it and to bench_extra.json (GPMPC_BENCH_EXTRAS=stdout
+    puts it on stdout instead, still before the contract line)."""
+    extras, head = split_for_driver(out)
+    text = json.dumps(extras)
+    for d in (REPO, os.path.join(REPO, "gpurun_out")):
+        try:
+            if os.path.isdir(d):
+                with open(os.path.join(d, "bench_extra.json"), "w") as f:
+                    f.write(text + "\n")
+        except OSError:
+            pass
+    dst = sys.stdout if os.environ.get("GPMPC_BENCH_EXTRAS") == "stdout" else sys.stderr
+    dst.write(text + "\n")
+    dst.flush()
+    sys.stdout.write(json.dumps(head) + "\n")
+    sys.stdout.flush()
 
 
 def main():
@@ -756,7 +864,8 @@ def main():
                                              "of CPU work at the best of the probed thread counts (oracle: reference-faithful "
                                              "from-scratch batched Cholesky per step, torch CPU FP64; gpytorch itself is not "
                                              "installable on the box)" % (max(a.cpu_repeats, 1), a.cpu_sample, Ns, H, dt),
-                                   "thread_probe_steps_per_s": probe, "host_cpus": os.cpu_count()}
+                                   "thread_probe_steps_per_s": probe, "host_cpus": os.cpu_count(),
+                                   "_repeats": max(a.cpu_repeats, 1), "_ns": a.cpu_sample, "_dt": dt}
         else:
             out["cpu_baseline"] = None
         out["reachable_set"] = reach
@@ -776,7 +885,7 @@ def main():
                 except Exception as e:                            # noqa: BLE001 - never fatal for the bench line
                     extra.append({"workload": fn.__name__, "error": repr(e)[:300]})
             out["extra"] = extra
-        print(json.dumps(out), flush=True)
+        emit(out)
     if multi:
         dist.barrier()
         dist.destroy_process_group()
