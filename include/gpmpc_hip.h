@@ -251,7 +251,16 @@ int    gpmpc_rollout_seeded(const gpmpc_gp_desc_t* gp, const gpmpc_env_desc_t* e
  *           n_cached > 0 (<= n_ho) the first n_cached rows are taken from the cache - the CALLER vouches
  *           that h_slots[:n_cached] and their points X_h are the ones of the call that filled it (labels may differ:
  *           the factor does not depend on them) - and every call writes the rows it computed (n_ho <= cache_rows).
- *           Results are bit-identical with and without the cache.
+ *           cache_rows must be EVEN (>= 16) and the buffer 16-byte aligned (GPMPC_E_ARG otherwise; the matrix-pipe path
+ *           moves rows in 16-byte units).
+ *           Bit-identity: with the joint path PINNED (gpmpc_joint_pin_path(GPMPC_JOINT_VALU) or ..._MFMA) results are
+ *           bit-identical with and without the cache.  Under GPMPC_JOINT_AUTO the dispatcher takes the matrix-pipe path
+ *           from GPMPC_JOINT_MFMA_FROM (100) observed hallucinated slots on, and chains that HAVE cache room take its
+ *           factor extension while chains beyond the cache budget compute their rows on the VALU: a sample's low-order
+ *           bits then depend on which side of the budget it sits (1e-13 on a Cholesky root, up to 1e-5 on the
+ *           eigendecomposition root of params_car_residual.yaml).  Pin the path wherever
+ *           bit-reproducibility across batch sizes / GPU counts is claimed (make_sharded_agent(..., pin_joint_path=...)
+ *           of sampling_gpmpc_amd.distributed does it for a sharded run; the default leaves the dispatcher free).
  *           The cache may cover fewer chains than the batch: the host splits the batch into one call over the samples it
  *           has cache room for and one over the rest (factor_cache NULL); results are the same (a call's chains are
  *           independent), the caller applies the whole-batch eigh rule across the two calls (root_mode GPMPC_ROOT_EIGH).

@@ -1136,7 +1136,7 @@ int gpmpc_debug_eigh_occupancy(int mT, size_t extra_lds) {
 
 // bytes of the caller-owned factor cache of gpmpc_joint_sample for up to cache_rows hallucinated label rows per chain
 size_t gpmpc_joint_cache_bytes(const gpmpc_gp_desc_t* gp, int64_t Ns, int32_t cache_rows) {
-    if (check_gp(gp) != GPMPC_OK || cache_rows < 16 || Ns < 1) return 0;
+    if (check_gp(gp) != GPMPC_OK || cache_rows < 16 || (cache_rows & 1) || Ns < 1) return 0;
     const size_t cs = (size_t)fc_row_stride(observed_real_slots(gp), cache_rows);
     return align_up((size_t)Ns * gp->g_ny * cache_rows * (cs + 1) * sizeof(double), 256);
 }
@@ -1195,8 +1195,11 @@ int gpmpc_joint_sample(const gpmpc_gp_desc_t* gp, const void* plan, const double
     a.Sall = (double*)ws + w.s_off;
     a.any_fail = (int*)((double*)ws + w.f_off);
     if (factor_cache) {
-        if (cache_rows < 16 || n_cached < 0 || n_cached > n_ho || n_cached > cache_rows)
-            return fail(GPMPC_E_ARG, "gpmpc_joint_sample: factor cache: rows >= 16, 0 <= n_cached <= min(n_ho, rows)");
+        // an EVEN row count and a 16-byte aligned base: the matrix-pipe path moves cache rows in 16-byte units, and with an odd
+        // count it used to fall back to a temporary cache WITHOUT writing the caller's (the next call then read stale rows)
+        if (cache_rows < 16 || (cache_rows & 1) || n_cached < 0 || n_cached > n_ho || n_cached > cache_rows ||
+            (reinterpret_cast<uintptr_t>(factor_cache) & 15))
+            return fail(GPMPC_E_ARG, "gpmpc_joint_sample: factor cache: rows >= 16 and even, 16-byte aligned, 0 <= n_cached <= min(n_ho, rows)");
         a.fcache = (double*)factor_cache;
         a.fc_cap = cache_rows;
         a.fc_cs = fc_row_stride(a.gp.n_r, cache_rows);

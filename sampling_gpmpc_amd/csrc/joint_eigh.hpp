@@ -646,6 +646,10 @@ __global__ __launch_bounds__(64, WPE) void joint_eigh_kernel(const EighArgs a) {
                 ++r;
             }
         }
+        // a pass adds up to EIGH_PB pivots: a chain can leave the loop at full rank (r == n, or nothing left above tol) with
+        // r beyond this launch's LDS cap WITHOUT having passed the check at the top of a pass (EIGH_NARROW_RANK < m T <=
+        // EIGH_NARROW_RANK + EIGH_PB: T = 3 with H = 11..13).  It belongs to the second launch all the same
+        if (a.pass == EIGH_PASS_NARROW && r > a.defer_rank) deferred = true;
         EPH(0);
         if (deferred) {
             if (lane == 0) {

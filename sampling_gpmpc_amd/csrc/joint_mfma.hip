@@ -875,12 +875,10 @@ bool joint_mfma_split_eligible(int n_r, int n_hc, int ncols, int T) {
 }
 
 int joint_mfma_launch(const JointArgs& a, hipStream_t st) {
-    static bool attr_done = false;
     if (a.gp.T != 3) return fail(GPMPC_E_UNSUPPORTED, "joint_test_mfma_kernel is instantiated for T = 3");
-    if (!attr_done) {
-        GPMPC_HIP_CHECK(hipFuncSetAttribute((const void*)joint_test_mfma_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)JM_SMEM_BYTES));
-        attr_done = true;
-    }
+    // per launch, like every other launcher here: the attribute is per DEVICE (a process may drive several) and a static
+    // flag would not be thread safe
+    GPMPC_HIP_CHECK(hipFuncSetAttribute((const void*)joint_test_mfma_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)JM_SMEM_BYTES));
     const dim3 g((unsigned)(a.chain1 - a.chain0)), b(JM_THREADS);
     hipLaunchKernelGGL((joint_test_mfma_kernel<3>), g, b, JM_SMEM_BYTES, st, a);
     GPMPC_HIP_CHECK(hipGetLastError());

@@ -153,8 +153,14 @@ def sharded_forward_sampling_rollout(agent, u_ff, x0=None, group=None) -> torch.
 # ---------------------------------------------------------------------------------------------------------------------
 # closed loop (mode J): per-rank Agents over sample shards and the reference's cross-sample couplings
 # ---------------------------------------------------------------------------------------------------------------------
-def make_sharded_agent(agent_cls, params, env_model, group=None):
+def make_sharded_agent(agent_cls, params, env_model, group=None, pin_joint_path=None):
     """An ``Agent`` over this rank's contiguous shard of the ``num_dyn_samples`` GLOBAL samples.
+
+    ``pin_joint_path`` (``_lib.JOINT_VALU`` / ``_lib.JOINT_MFMA``; GPU only, process-wide): pins the kernel path of the joint
+    draw.  Under the default (``None``: the dispatcher chooses per call) a sample's low-order bits depend on the shard size
+    once the factor cache covers only a prefix of the shard's samples (include/gpmpc_hip.h, factor_cache): pin the path
+    when the sharded run has to reproduce the single-process run BIT for bit (it agrees to 1e-13 / 1e-5 - Cholesky / eigh
+    root - either way).
 
     ``agent.base_sample_generator: counter`` (the scalable way): the rank generates exactly its own shard from the
     counter-based stream keyed by global sample id - on its own device, no other shard is ever materialised, and sample
@@ -185,6 +191,8 @@ def make_sharded_agent(agent_cls, params, env_model, group=None):
         agent.epistimic_random_vector = erv.to(agent.torch_device)
     agent.dist_group = group if group is not None else dist.group.WORLD
     agent.shard, agent.ns_global = (lo, hi), Ns
+    if pin_joint_path is not None:
+        _lib.load().gpmpc_joint_pin_path(int(pin_joint_path))
     return agent
 
 

@@ -133,6 +133,7 @@ class JointFactorCache:
     at the previous call are reused.  The façade vouches for validity by comparing the current slot list and the points of
     the cached rows with a snapshot taken when they were written (the factor does not depend on the labels)."""
 
+    HINT_MAX_BYTES = 8 << 30     # budget of a cache sized ahead of need from the Agent's bound on the conditioning set
     MAX_BYTES = 24 << 30          # cache budget (the per-GPU shard of BASELINE configs[4] needs ~7 GB); a batch that needs
                                   # more caches the factor rows of a PREFIX of its samples (``n_samples``), the others recompute
 
@@ -168,12 +169,17 @@ class JointFactorCache:
             # the set grows by the same number of slots every SQP iteration: room for the Agent's bound on it (max_sqp_iter * H
             # points) where there is one, else for four of them where that fits
             n_samp = Ns
+            # The hint is honoured only when the set it describes is REACHABLE (it fits gpmpc_joint_sample's row limit: the
+            # shipped car's max_sqp_iter * H * T = 22500 does not) and within its own, smaller byte budget - it exists to
+            # avoid re-allocations, not to spend the cache budget ahead of need: otherwise the size follows the 4x rule, which
+            # is monotonic in Ns (same rule as HipPosterior's workspace hint below)
             hint = getattr(mdl, "_ws_cache", {}).get("joint_points_hint")
             n_hint = int(hint) * hy.T if hint else 0
-            for mult in ((float(n_hint) / n_ho,) if n_hint >= n_ho else ()) + (4.0, 2.0, 1.25):
+            hint_ok = n_hint >= n_ho and n_hint + 1 <= MAX_JOINT_ROWS
+            for i, mult in enumerate(((float(n_hint) / n_ho,) if hint_ok else ()) + (4.0, 2.0, 1.25)):
                 rows = min(MAX_JOINT_ROWS, max(256, -(-int(mult * n_ho) // 128) * 128))
                 nbytes = lib.gpmpc_joint_cache_bytes(mdl.plan.desc, Ns, rows)
-                if 0 < nbytes <= self.MAX_BYTES:
+                if 0 < nbytes <= (self.HINT_MAX_BYTES if (hint_ok and i == 0) else self.MAX_BYTES):
                     break
             if nbytes > self.MAX_BYTES:                                        # not for every sample: a prefix of them
                 per_sample = lib.gpmpc_joint_cache_bytes(mdl.plan.desc, 1, rows)

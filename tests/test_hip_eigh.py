@@ -167,6 +167,9 @@ def test_config5_shard_as_shipped(sg):
     ps = _car(sub, H, iters)
     small, osmall = make_agents(sg, ps, erv=erv[:, :, :sub])
     small.debug_keep_root = True
+    m0, msub = Ns // 2 - 8, 16                                      # a 16-sample window from the MIDDLE of the batch as well
+    mid, _ = make_agents(sg, _car(msub, H, iters), erv=erv[:, :, m0:m0 + msub])
+    raw = sg._lib.load()
     beta = p["agent"]["Dyn_gp_beta"]
     x0 = np.array(p["env"]["start"], dtype=np.float64)
     u_h = np.zeros((H, 2))
@@ -175,11 +178,18 @@ def test_config5_shard_as_shipped(sg):
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
         for k in range(iters):
-            for a in (agent, small, osmall):
+            for a in (agent, small, osmall, mid):
                 a.train_hallucinated_dynGP(k)
             xs = x_h.reshape(H, Ns, 4)[:, :sub].reshape(H, sub * 4)
+            xm = x_h.reshape(H, Ns, 4)[:, m0:m0 + msub].reshape(H, msub * 4)
             gp_val, y_grad, u_grad = agent.dyn_fg_jacobians(agent.get_batch_x_hat(x_h, u_h), k)
+            # the kernel path the dispatcher takes at the shipped shape: the matrix pipe from the second SQP iteration on
+            # (120 hallucinated slots >= GPMPC_JOINT_MFMA_FROM); a dispatcher change that silently drops it fails here
+            assert raw.gpmpc_joint_last_path() == (sg._lib.JOINT_MFMA if k >= 1 else sg._lib.JOINT_VALU), k
             sv, sy, su = small.dyn_fg_jacobians(small.get_batch_x_hat(xs, u_h), k)
+            mv, my, _ = mid.dyn_fg_jacobians(mid.get_batch_x_hat(xm, u_h), k)
+            np.testing.assert_array_equal(gp_val[m0:m0 + msub], mv)
+            np.testing.assert_array_equal(y_grad[m0:m0 + msub], my)
             osmall.dyn_fg_jacobians(osmall.get_batch_x_hat(xs, u_h), k)
             info = agent.model_i_call.last_info.cpu().numpy()
             assert np.isfinite(gp_val).all() and np.isfinite(y_grad).all() and np.isfinite(u_grad).all()

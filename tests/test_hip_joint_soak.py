@@ -1,0 +1,208 @@
+"""GPU: soaks of the matrix-pipe path of gpmpc_joint_sample (joint_test_mfma_kernel, csrc/joint_mfma.hip) at FULL WIDTH.
+
+The one bug class that kernel has had - an issued FP64 MFMA queued behind the SIMD's other wave reading SrcA / SrcB late
+ - produced ~10 % wrong chains at Ns >= 128, different ones run to run, and is invisible below 128 chains: the
+oracle cases of tests/test_hip_parity.py run 4-48 chains.  What guards it is here, in the GPU suite: the car closed loop AS
+SHIPPED (params_car_residual.yaml, Dyn_gp_jitter 1e-20; reference src/agent.py:629-641 per src/solver.py:84-94) at the per-GPU
+shard of BASELINE configs[4] (Ns = 1024, H = 40), the path PINNED and asserted:
+  (a) repeat determinism: every draw at k = 1..4 (k = 4: 45 + 480 slots, the TOP + BOTTOM pair of launches) four times from the
+      same factor-cache state - every chain's mean / variance / sample bit-equal to repetition 0 - and mean / variance within
+      1e-8 of the one-launch VALU path;
+  (b) workspace poisoning: the joint workspace NaN-filled in front of every draw - finite, bit-equal to the zero-filled run;
+  (c) subset invariance: Ns = 1024 against its first 8 samples alone, bit-equal.
+"""
+import warnings
+
+import numpy as np
+import pytest
+import torch
+
+from tests.helpers import load_params
+from tests.test_hip_parity import sg  # noqa: F401  (fixture)
+
+pytestmark = pytest.mark.gpu
+
+H = 40
+
+
+def _car_agent(sg, Ns, iters, erv=None):
+    p = load_params("params_car_residual")
+    p["common"]["use_cuda"] = True
+    p["agent"]["num_dyn_samples"], p["optimizer"]["H"] = Ns, H
+    p["agent"]["true_dyn_as_sample"] = False
+    p["agent"]["base_sample_generator"] = "vectorized"
+    p["common"]["num_MPC_itrs"], p["optimizer"]["SEMPC"]["max_sqp_iter"] = 1, iters
+    a = sg.Agent(p, sg.make_env(p))
+    if erv is not None:
+        a.epistimic_random_vector = erv
+    return a, p
+
+
+def _u_ff():
+    u_h = np.zeros((H, 2))
+    u_h[:, 0] = 0.05 * np.sin(2 * np.pi * np.arange(H) / H)
+    return u_h
+
+
+@pytest.fixture
+def pinned_mfma(sg):
+    lib = sg._lib.load()
+    lib.gpmpc_joint_pin_path(sg._lib.JOINT_MFMA)
+    yield lib
+    lib.gpmpc_joint_pin_path(sg._lib.JOINT_AUTO)
+
+
+def test_matrix_pipe_repeat_determinism_full_width(sg, pinned_mfma):
+    lib, Ns, iters, reps = pinned_mfma, 1024, 5, 4
+    torch.manual_seed(3)
+    agent, p = _car_agent(sg, Ns, iters)
+    g = torch.Generator().manual_seed(5)
+    x0 = np.array(p["env"]["start"], dtype=np.float64)
+    agent.mpc_iteration(0)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for k in range(iters):
+            # scattered linearisation points (every chain its own), as tools/debug/joint_fail_chains.py
+            x_h = np.tile(x0, (H, Ns)) + 0.05 * torch.randn(H, Ns * agent.nx, generator=g, dtype=torch.float64).numpy() \
+                + 0.02 * np.arange(H)[:, None]
+            u_h = 0.3 * torch.randn(H, Ns, agent.nu, generator=g, dtype=torch.float64).numpy()
+            agent.train_hallucinated_dynGP(k)
+            bx = agent.get_batch_x_hat_u_diff(x_h, u_h)
+            g_xu = agent.env_model.get_g_xu_hat(bx).contiguous()
+            z = agent.epistimic_random_vector[agent.mpc_iter][k]
+            cache = agent._ws_cache.get("joint_factor_cache")
+            held = cache.n_valid if cache is not None else 0
+
+            def draw(path):
+                lib.gpmpc_joint_pin_path(path)
+                c = agent._ws_cache.get("joint_factor_cache")
+                if c is not None:
+                    c.rewind(held)                                  # every repetition from the same cache state
+                post = agent.model_i(g_xu)
+                y, _ = post._run(z, True, 2.0, 1e-9, raise_chol_fail=False)
+                return post.mean.clone(), post.variance.clone(), y.clone(), post.last_info.clone()
+
+            if k >= 1:
+                truth = draw(sg._lib.JOINT_VALU)
+                assert lib.gpmpc_joint_last_path() == sg._lib.JOINT_VALU
+                assert not (truth[3] & sg._lib.INFO_TRAIN_CHOL_FAIL).any()
+                ref = None
+                for rep in range(reps):
+                    cur = draw(sg._lib.JOINT_MFMA)
+                    assert lib.gpmpc_joint_last_path() == sg._lib.JOINT_MFMA, "the pinned matrix-pipe path did not run"
+                    assert not (cur[3] & sg._lib.INFO_TRAIN_CHOL_FAIL).any()
+                    if ref is None:
+                        ref = cur
+                        for i, name in ((0, "mean"), (1, "variance")):
+                            e = float(((cur[i] - truth[i]).abs() / truth[i].abs().max()).max())
+                            assert e < 1e-8, f"k={k}: {name} of the matrix-pipe path is {e:.1e} from the VALU path"
+                    else:
+                        for i, name in ((0, "mean"), (1, "variance"), (2, "sample")):
+                            ndiff = int((cur[i] != ref[i]).flatten(1).any(-1).sum())
+                            assert ndiff == 0, f"k={k} repetition {rep}: {ndiff} samples whose {name} differs from repetition 0"
+            # continue the loop on the dispatcher's own choice, from the same cache state
+            lib.gpmpc_joint_pin_path(sg._lib.JOINT_MFMA)
+            c = agent._ws_cache.get("joint_factor_cache")
+            if c is not None:
+                c.rewind(held)
+            agent.get_batch_gp_sensitivities(bx, k)
+    assert agent.model_i.n_h == (iters - 1) * H                     # the last draw conditioned on 45 + 480 slots
+
+
+def test_matrix_pipe_workspace_poisoning(sg, pinned_mfma):
+    lib, Ns, iters = pinned_mfma, 128, 5
+    out = {}
+    for fill in (0.0, float("nan")):
+        torch.manual_seed(11)
+        agent, p = _car_agent(sg, Ns, iters)
+        x0 = np.array(p["env"]["start"], dtype=np.float64)
+        u_h, x_h, res = _u_ff(), np.tile(x0, (H, Ns)), []
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            for k in range(iters):
+                agent.train_hallucinated_dynGP(k)
+                ws = agent._ws_cache.get("joint")
+                if ws is not None:
+                    ws.fill_(fill)
+                gp_val, y_grad, _ = agent.dyn_fg_jacobians(agent.get_batch_x_hat(x_h, u_h), k)
+                if k >= 1:
+                    assert lib.gpmpc_joint_last_path() == sg._lib.JOINT_MFMA
+                res.append((gp_val.copy(), y_grad.copy()))
+                mean_next = gp_val[:, :, :, 0].mean(axis=0).T
+                x_h = np.tile(np.vstack([x0[None, :], mean_next[:-1]]), (1, Ns))
+        out[str(fill)] = res
+    for k in range(iters):
+        a, b = out["0.0"][k], out["nan"][k]
+        assert np.isfinite(b[0]).all() and np.isfinite(b[1]).all(), f"k={k}: NaN read from the workspace"
+        np.testing.assert_array_equal(a[0], b[0])
+        np.testing.assert_array_equal(a[1], b[1])
+
+
+def test_matrix_pipe_subset_invariance_full_width(sg, pinned_mfma):
+    lib, Ns, sub, iters = pinned_mfma, 1024, 8, 4
+    torch.manual_seed(11)
+    agent, p = _car_agent(sg, Ns, iters)
+    small, _ = _car_agent(sg, sub, iters, agent.epistimic_random_vector[:, :, :sub].clone())
+    x0 = np.array(p["env"]["start"], dtype=np.float64)
+    u_h, x_h = _u_ff(), np.tile(x0, (H, Ns))
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for k in range(iters):
+            agent.train_hallucinated_dynGP(k)
+            small.train_hallucinated_dynGP(k)
+            xs = x_h.reshape(H, Ns, 4)[:, :sub].reshape(H, sub * 4)
+            gv, yg, _ = agent.dyn_fg_jacobians(agent.get_batch_x_hat(x_h, u_h), k)
+            pa = lib.gpmpc_joint_last_path()
+            sv, sy, _ = small.dyn_fg_jacobians(small.get_batch_x_hat(xs, u_h), k)
+            ps = lib.gpmpc_joint_last_path()
+            if k >= 1:
+                assert pa == sg._lib.JOINT_MFMA and ps == sg._lib.JOINT_MFMA
+            assert torch.equal(agent.model_i_call.mean[:sub], small.model_i_call.mean), f"k={k}: mean depends on the batch"
+            assert torch.equal(agent.model_i_call.variance[:sub], small.model_i_call.variance), f"k={k}: variance depends on the batch"
+            np.testing.assert_array_equal(gv[:sub], sv)
+            np.testing.assert_array_equal(yg[:sub], sy)
+            mean_next = gv[:, :, :, 0].mean(axis=0).T
+            x_h = np.tile(np.vstack([x0[None, :], mean_next[:-1]]), (1, Ns))
+
+
+@pytest.mark.parametrize("Hs", [11, 12, 13])
+def test_eigh_root_full_rank_just_beyond_the_narrow_cap(sg, Hs):
+    """m T in 33..39 (T = 3, H = 11..13) with FULL-RANK covariances under a forced eigendecomposition root.  A pass of the
+    pivoted Cholesky adds up to 8 pivots, so such a chain reaches rank m T > 32 (the narrow launch's LDS cap) without ever
+    passing the deferral check at the top of a pass; it has to be handed to the second launch all the same (it used to take the
+    HBM Gram path with an aliased buffer).  Scattered, well separated test points make the covariance full rank; asserted:
+    R R^T == max(Sigma, 0), the draw reproduces mean + R z, and the chains WERE deferred."""
+    import ctypes as C
+    from tests.test_hip_eigh import _car
+    from tests.test_hip_parity import make_agents
+    Ns = 6
+    p = _car(Ns, Hs, 1, jitter=1e-9)
+    agent, _ = make_agents(sg, p)
+    g = torch.Generator().manual_seed(7)
+    x_h = np.tile(np.array(p["env"]["start"]), (Hs, Ns))
+    x_h = x_h + np.repeat(np.linspace(-0.9, 0.9, Hs)[:, None], Ns * 4, axis=1) * np.tile([0, 0, 1.0, 0], Ns)[None, :] \
+        + 0.05 * torch.randn(Hs, Ns * 4, generator=g, dtype=torch.float64).numpy()
+    u_h = 0.5 * torch.randn(Hs, Ns, 2, generator=g, dtype=torch.float64).numpy()
+    agent.train_hallucinated_dynGP(0)
+    gx = agent.env_model.get_g_xu_hat(agent.get_batch_x_hat_u_diff(x_h, u_h)).contiguous()
+    z = agent.epistimic_random_vector[0][0]
+    post = agent.model_i(gx)
+    raw = sg._lib.load()
+    raw.gpmpc_debug_eigh_deferred.restype = C.c_longlong
+    raw.gpmpc_debug_eigh_deferred(1)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        y, bits = post._run(z, clip=False, want_root=True, root_mode=sg._lib.ROOT_EIGH)
+    deferred = int(raw.gpmpc_debug_eigh_deferred(0))
+    assert bits & sg._lib.INFO_ROOT_EIGH and not bits & sg._lib.INFO_EIGH_NOCONV
+    R, S = post.root.cpu(), post.covariance_matrix.cpu()
+    rank = int((R.abs().amax(dim=-2) > 0).sum(dim=-1).max())
+    ev, U = torch.linalg.eigh(S)
+    Splus = (U * ev.clamp_min(0).unsqueeze(-2)) @ U.transpose(-1, -2)
+    err = float((R @ R.transpose(-1, -2) - Splus).abs().max())
+    print(f"H={Hs}: m T = {3 * Hs}, max rank {rank}, chains deferred to the second launch {deferred}, |RR^T - S+| {err:.1e}")
+    assert err < 1e-8 * float(S.abs().max())
+    zz = z.reshape(Ns, 3, -1, 1).cpu()
+    np.testing.assert_allclose((y.cpu() - post.mean.cpu()).reshape(Ns, 3, -1), (R @ zz).squeeze(-1), rtol=0, atol=1e-12)
+    if rank > 32:
+        assert deferred > 0, "a chain of rank > 32 stayed in the narrow launch"

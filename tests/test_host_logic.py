@@ -276,6 +276,14 @@ def test_joint_factor_cache_bookkeeping():
     mh._ws_cache = {"joint_points_hint": 160}
     bufh, rows_h, _ = ch.prepare(mh, Ns, 30)
     assert rows_h == 512 and ch.prepare(mk(20), Ns, 60)[0] is bufh and ch.prepare(mk(40), Ns, 120)[0] is bufh
+    # ... but only a REACHABLE bound (within gpmpc_joint_sample's 2048-row limit) is honoured: the shipped car's
+    # max_sqp_iter * H = 150 * 50 points is not, and the size then follows the 4x rule
+    cu = JointFactorCache()
+    mu = mk(10)
+    mu._ws_cache = {"joint_points_hint": 150 * 50}
+    assert cu.prepare(mu, Ns, 30)[1] == 256
+    # the entry points take an EVEN row count only (16-byte row units of the matrix-pipe path)
+    assert _lib.load().gpmpc_joint_cache_bytes(desc, Ns, 257) == 0 and _lib.load().gpmpc_joint_cache_bytes(desc, Ns, 256) > 0
     c.commit(mk(20), 60, ok=False)
     assert c.n_valid == 0 and c.prepare(mk(20), Ns, 60)[2] == 0      # a failed factorisation is not kept
     c.commit(mk(20), 60, ok=True)
