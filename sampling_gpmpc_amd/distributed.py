@@ -67,43 +67,73 @@ class OverlappedTubeGather:
     on the launch stream right after the rollout was enqueued) makes the side stream wait for it and enqueues the
     collective there; ``before_rollout(r)`` makes the launch stream wait for the gather that last read ``buffer(r)``.
     ``tube(r)`` is valid after ``wait(r)`` / ``finish()``.  Equal shards only (the bench shape); ragged shards use
-    ``all_gather_tube``."""
+    ``all_gather_tube``.
 
-    def __init__(self, ns_local: int, nx: int, H: int, group=None, device=None):
+    ``every`` = R > 1: the trajectories of R consecutive rollouts go into ONE buffer ``(R, ns, nx, H+1)`` and ONE collective
+    gathers them (``submit`` of the group's last rollout enqueues it; ``finish`` flushes a partial group).  A collective costs
+    the host ~25-40 us to enqueue (c10d + RCCL) whatever its size; at configs[1]'s 75 us rollouts that is a third of a step and,
+    with the event / stream-wait calls around it, the launch loop becomes host bound (round 5: 0.107 ms per step against 0.0755
+    without the gather).  One collective per R rollouts amortises it; every rollout's tube is still assembled on every rank -
+    ``tube(r)`` is then the strided view ``(world, ns, nx, H+1)`` of rollout r inside its group's gathered block."""
+
+    def __init__(self, ns_local: int, nx: int, H: int, group=None, device=None, every: int = 1):
         self.group = group
         self.world = dist.get_world_size(group)
+        self.every = R = max(int(every), 1)
+        self.ns = ns_local
         dev = torch.device("cuda", torch.cuda.current_device()) if device is None else device
-        self.X = [torch.empty(ns_local, nx, H + 1, dtype=torch.float64, device=dev) for _ in range(2)]
-        self.T = [torch.empty(self.world * ns_local, nx, H + 1, dtype=torch.float64, device=dev) for _ in range(2)]
+        self.X = [torch.empty(R, ns_local, nx, H + 1, dtype=torch.float64, device=dev) for _ in range(2)]
+        self.T = [torch.empty(self.world * R, ns_local, nx, H + 1, dtype=torch.float64, device=dev) for _ in range(2)]
         self.comm = torch.cuda.Stream(device=dev)
         self.rolled = [torch.cuda.Event() for _ in range(2)]
         self.gathered = [torch.cuda.Event() for _ in range(2)]
         self._pending = [False, False]
+        self._open = None                                    # group index with rollouts not yet submitted to a collective
+
+    def _slot(self, r: int):
+        g = r // self.every
+        return g & 1, r - g * self.every
 
     def buffer(self, r: int) -> torch.Tensor:
-        return self.X[r & 1]
+        b, j = self._slot(r)
+        return self.X[b][j]
 
     def tube(self, r: int) -> torch.Tensor:
-        return self.T[r & 1]
+        b, j = self._slot(r)
+        if self.every == 1:
+            return self.T[b].view(self.world * self.ns, *self.T[b].shape[2:])
+        return self.T[b].view(self.world, self.every, *self.T[b].shape[1:])[:, j]
 
     def before_rollout(self, r: int) -> None:
-        if self._pending[r & 1]:
-            torch.cuda.current_stream().wait_event(self.gathered[r & 1])
+        b, j = self._slot(r)
+        if j == 0 and self._pending[b]:                      # the group's buffer was last read by the gather two groups ago
+            torch.cuda.current_stream().wait_event(self.gathered[b])
 
-    def submit(self, r: int) -> None:
-        b = r & 1
+    def _gather(self, b: int) -> None:
         self.rolled[b].record()                              # on the launch stream
         with torch.cuda.stream(self.comm):
             self.comm.wait_event(self.rolled[b])
             dist.all_gather_into_tensor(self.T[b], self.X[b], group=self.group)
             self.gathered[b].record()
         self._pending[b] = True
+        self._open = None
+
+    def submit(self, r: int) -> None:
+        b, j = self._slot(r)
+        self._open = b
+        if j == self.every - 1:
+            self._gather(b)
 
     def wait(self, r: int) -> None:
-        if self._pending[r & 1]:
-            torch.cuda.current_stream().wait_event(self.gathered[r & 1])
+        b, _ = self._slot(r)
+        if self._open == b:                                  # a partial group: gather what is there
+            self._gather(b)
+        if self._pending[b]:
+            torch.cuda.current_stream().wait_event(self.gathered[b])
 
     def finish(self) -> None:
+        if self._open is not None:
+            self._gather(self._open)
         torch.cuda.current_stream().wait_stream(self.comm)
 
 
@@ -236,6 +266,9 @@ def replace_rejected_samples(X_local: torch.Tensor, Y_local: torch.Tensor, left_
     return Xg[lo:hi].contiguous(), Yg[lo:hi].contiguous()
 
 
+_GATHER_BUFFERS = {}
+
+
 def gather_jacobians(arrays, Ns: int, group=None, dst: int = 0):
     """Assemble the solver-side numpy arrays of ``dyn_fg_jacobians`` (``gp_val, y_grad, u_grad``, sample axis first)
     from the per-rank shards on rank ``dst`` (the closed loop moves the Jacobians to the solver's
@@ -254,20 +287,32 @@ def gather_jacobians(arrays, Ns: int, group=None, dst: int = 0):
             t = t.to(torch.device("cuda", torch.cuda.current_device()))
         ts.append(t)
     widths = [int(t.shape[-1]) for t in ts]
-    packed = torch.cat(ts, dim=-1).contiguous()                    # (ns_local, nx, H, 1 + nx + nu)
     sizes = [shard_range(Ns, r, world) for r in range(world)]
-    nloc, nmax = packed.shape[0], max(hi - lo for lo, hi in sizes)
+    nloc, nmax = ts[0].shape[0], max(hi - lo for lo, hi in sizes)
     if nloc != sizes[rank][1] - sizes[rank][0]:
         raise ValueError("local shard size does not match shard_range()")
-    if nloc < nmax:                                                # ragged shards: pad to the largest
-        pad = torch.zeros((nmax,) + tuple(packed.shape[1:]), dtype=packed.dtype, device=packed.device)
-        pad[:nloc] = packed
-        packed = pad
-    parts = [torch.empty_like(packed) for _ in range(world)] if rank == dst else None
+    # the send block (padded to the largest shard) and rank dst's receive blocks persist between calls: at configs[4]'s shard
+    # they are 9 MB / 73 MB, and a fresh device allocation of that size per SQP iteration costs more than the collective
+    shape = (nmax,) + tuple(ts[0].shape[1:-1]) + (sum(widths),)
+    key = (shape, world, rank == dst, ts[0].dtype, ts[0].device, id(group))
+    bufs = _GATHER_BUFFERS.get(key)
+    if bufs is None:
+        _GATHER_BUFFERS.clear()                                    # one shape at a time (a closed loop has one)
+        packed = torch.zeros(shape, dtype=ts[0].dtype, device=ts[0].device)
+        big = torch.empty((world,) + shape, dtype=ts[0].dtype, device=ts[0].device) if rank == dst else None
+        bufs = _GATHER_BUFFERS[key] = (packed, big)
+    packed, big = bufs
+    parts = [big[r] for r in range(world)] if rank == dst else None
+    c0 = 0
+    for t, w in zip(ts, widths):                                   # (ns_local, nx, H, 1 + nx + nu); pad rows stay zero
+        packed[:nloc, ..., c0:c0 + w].copy_(t)
+        c0 += w
     dist.gather(packed, parts, dst=dst, group=group)
     if rank != dst:
         return None
-    full = torch.cat([parts[r][: hi - lo] for r, (lo, hi) in enumerate(sizes)], dim=0)
+    # equal shards: the received blocks ARE the full array (no concatenation pass)
+    full = big.view((world * nmax,) + shape[1:]) if nmax * world == Ns else \
+        torch.cat([parts[r][: hi - lo] for r, (lo, hi) in enumerate(sizes)], dim=0)
     full = _lib.to_host(full)                                     # one D2H copy (pinned staging)
     assert full.shape[0] == Ns
     out, c0 = [], 0

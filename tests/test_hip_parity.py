@@ -697,21 +697,25 @@ def test_sharded_rollout_single_rank_rccl(sg):
         per = Ns * 3
         runners = [RolloutRunner(agent, u_ff * (1.0 + 0.1 * r), erv.reshape(-1)[per:], erv.shape[1] * per, H,
                                  sg._lib.MODE_RECONDITIONED, False) for r in range(5)]
-        pipe = OverlappedTubeGather(Ns, agent.nx, H)
-        tubes = []
-        for r, rn in enumerate(runners):
-            pipe.before_rollout(r)
-            rn.launch(out=pipe.buffer(r))
-            pipe.submit(r)
-            if r >= 1:                                           # consume tube r-1 while rollout r / gather r are in flight
-                pipe.wait(r - 1)
-                tubes.append(pipe.tube(r - 1).clone())
-        pipe.finish()
-        tubes.append(pipe.tube(len(runners) - 1).clone())
-        for r, rn in enumerate(runners):
-            ref = rn.launch().clone()
+        refs = []
+        for rn in runners:
+            refs.append(rn.launch().clone())
+        torch.cuda.synchronize()
+        for every in (1, 2, 3):                                  # one collective per rollout / per group of rollouts (last group partial)
+            pipe = OverlappedTubeGather(Ns, agent.nx, H, every=every)
+            tubes = []
+            for r, rn in enumerate(runners):
+                pipe.before_rollout(r)
+                rn.launch(out=pipe.buffer(r))
+                pipe.submit(r)
+                if r >= 1:                                       # consume tube r-1 while rollout r / gather r are in flight
+                    pipe.wait(r - 1)
+                    tubes.append(pipe.tube(r - 1).clone())
+            pipe.finish()
+            tubes.append(pipe.tube(len(runners) - 1).clone())
             torch.cuda.synchronize()
-            assert torch.equal(tubes[r], ref), r
+            for r in range(len(runners)):
+                assert torch.equal(tubes[r].reshape(refs[r].shape), refs[r]), (every, r)
     finally:
         dist.destroy_process_group()
     X = forward_sampling_rollout(agent, u_ff)
