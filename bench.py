@@ -440,8 +440,11 @@ def sharded_closed_loop_leg(rank, world, dist, sg, _lib, wl, ns_per_gpu=1024, H=
         for kw in range(2):
             warm.train_hallucinated_dynGP(kw)
             jw = warm.dyn_fg_jacobians_device(warm.get_batch_x_hat(xw, u_h), kw)
-        gather_jacobians(jw, Ns, dst=0)
-        del warm, jw
+        # (two gathers whose results are alive together: the loop below holds iteration k's arrays while iteration k + 1's are
+        # copied, i.e. TWO pinned staging blocks of the caching host allocator - a first-time pinned allocation costs ~25 ms)
+        w1 = gather_jacobians(jw, Ns, dst=0)
+        w2 = gather_jacobians(jw, Ns, dst=0)
+        del warm, jw, w1, w2
         torch.cuda.synchronize()
         for step in range(2):
             agent.mpc_iteration(step)

@@ -215,6 +215,25 @@ struct TilesLds {
     __host__ __device__ static constexpr int per_chain(int npt) { return npt * (XS + YS + 4) + SCRN + SXN; }
 };
 
+// GPMPC_TILES_PF: live KB of the NEXT solve's streamed tiles that are pulled into the XCD's L2 while the right-hand sides
+// (phase B, VALU + LDS only) are formed - see `prefetch` in the kernel.  0 disables it.
+// Measured (car Ns = 4096, H = 40; profiles/r6_car_prefetch_sweep.txt): 0 KB 1.643 ms, 8: 1.609, 12: 1.595, 16: 1.592, 20: 1.613, 32:
+// 1.700, 64: 1.99 - the XCD's 4 MB of L2 are shared by 128 waves (32 KB each, and the demand stream passes through it too):
+// beyond ~16 KB per wave the prefetched sectors are evicted before they are used and everything is fetched twice.
+#ifndef GPMPC_TILES_PF
+#define GPMPC_TILES_PF 12
+#endif
+// GPMPC_TILES_KEEP: live KB at the head of a wave's streamed tiles whose loads may stay in the XCD's L2 (sc1); the loads
+// beyond are streaming (sc1 + nt: evicted first).  A wave re-reads its streamed tiles once per step, in the same order: under
+// plain LRU a cyclic pass over more bytes than the wave's share of the L2 (4 MB / 128 waves) hits NOTHING - the tail evicts
+// the head just before it is wanted again.  With a non-temporal tail the head survives from step to step.  0: everything sc1.
+// MEASURED AND NOT KEPT (profiles/r6_car_prefetch_sweep.txt): every nt load is slower than the L2 miss it avoids for others - 1.84 /
+// 1.79 / 1.75 / 1.68 / 1.66 ms at 16 / 24 / 32 / 48 / 64 KB kept against 1.643 with no nt at all (all loads nt: 1.81): the stream
+// is served by the Infinity Cache (the in-flight factors, ~150 MB, fit its 256 MB), which nt loads do not allocate in.
+#ifndef GPMPC_TILES_KEEP
+#define GPMPC_TILES_KEEP 0
+#endif
+
 // SEED: the call has conditioning-only passes and / or value-only points (gpmpc_rollout_seeded, hall_tasks = 1); the plain
 // rollout is compiled without their selects and branches (3 % at configs[2])
 template <int N0, int N1, int ENV, int NT, bool SEED>
@@ -337,6 +356,16 @@ __global__ __launch_bounds__(64, 1) void rollout_tiles_kernel(const RolloutArgs 
     // a sample are never fetched - in lane order every line would carry 32 dead bytes and all of them would move
     const unsigned lane16 = live_m ? (unsigned)(bm * 16 + kq * 4 + jq) * 16u : 0x7ffff000u;
     const __amdgpu_buffer_rsrc_t wsr = __builtin_amdgcn_make_buffer_rsrc(wsu, 0, (int)(a.ws_chain_stride * 8), 0x00020000);
+    // L2 prefetch (see the step loop): lane i < 48 names 32-byte sector i % 24 of the live 768 bytes of pair i / 24 (the dead
+    // chain's quarter of a pair is never touched); lanes 48 .. 63 repeat lanes 0 .. 15 (same lines: no extra traffic)
+    const unsigned pf_voff = (unsigned)(((lane % 48) / 24) * 1024 + ((lane % 48) % 24) * 32);
+    const u32x4_v pf_rsrc = {(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(reinterpret_cast<uintptr_t>(wsu))),
+                             (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)((reinterpret_cast<uintptr_t>(wsu) >> 32) & 0xffffu)),
+                             (unsigned)__builtin_amdgcn_readfirstlane((int)(a.ws_chain_stride * 8)), 0x00020000u};
+    // landing slot: chain 0's S' exchange (32 doubles = 64 dwords) - written in phase F and read right behind it, dead from
+    // there to the next phase F; the solve in between opens with s_waitcnt vmcnt(0)
+    const unsigned pf_m0 = (unsigned)__builtin_amdgcn_readfirstlane(
+        (int)(unsigned)(size_t)(__attribute__((address_space(3))) double*)(smem + max(n_pre + a.H - 1, 1) * (L::XS + L::YS + 4) + L::SCRN + 32));
     auto tile_off = [](int e) -> int { return (e >> 1) * 1024 + (e & 1) * 8; };
     auto tile_load = [&](unsigned voff, int e) -> double {
         // sc1 (aux bit 4): served by L2.  A tile row is re-read after this wave has stored into it (rows arrive three at a
@@ -477,6 +506,28 @@ __global__ __launch_bounds__(64, 1) void rollout_tiles_kernel(const RolloutArgs 
         }
 
         TPH(0);
+        // ---- L2 prefetch of this step's streamed tiles ---------------------------------------------------------------------
+        // The solve below re-reads tile rows NRV .. nt-1 from the workspace (the wave's own stores of earlier steps; by now
+        // they sit in HBM / the Infinity Cache: 1024 waves x ~150 KB cycle through 32 MB of L2).  A lone wave cannot overlap
+        // that stream with its VALU phases through registers (no room for a ring that survives phases A-C) nor through LDS
+        // (full: the chains' point records) - but the XCD's L2 is a buffer nobody has to allocate: one dword per 32-byte
+        // sector of the first PF live KB is requested here, 4.2 k cycles of VALU / LDS work ahead of the first use, as LDS-DMA
+        // loads (`buffer_load_dword ... lds`: no destination register; all of them land in one 256-byte slot of LDS that is
+        // dead at this point of the step).  Inline asm on purpose: hipcc's wait insertion would put a vmcnt(0) in front of the next LDS read for
+        // a DMA it cannot prove disjoint.  The requests are older than every load of the solve, so the solve's counted waits
+        // are unaffected, and the `s_waitcnt vmcnt(0)` at its head (after phase B) finds them landed.
+        if constexpr (GPMPC_TILES_PF > 0) {
+            if (nfull >= NRV) {                                   // (uniform) regime (ii): rows NRV .. nt-1 stream
+                const int b0 = tri(NRV) * 512, b1 = tri(nt) * 512;      // byte range of the streamed tiles (pairs of 1024 B)
+                int nins = (b1 - b0 + 2047) >> 11;                // one instruction touches the 48 live sectors of two pairs
+                nins = min(nins, (GPMPC_TILES_PF * 1024 + 1535) / 1536);
+                int so = b0;
+#pragma unroll 1
+                for (int j = 0; j < nins; ++j, so += 2048)
+                    asm volatile("s_mov_b32 m0, %0\n\tbuffer_load_dword %1, %2, %3 offen lds"
+                                 :: "s"(pf_m0), "v"(pf_voff), "s"(pf_rsrc), "s"(so) : "m0", "memory");
+            }
+        }
         // ---- phase B: right-hand sides of the hallucinated rows, 16 points per pass; phase C: into tile registers ------
         double V[NT];
 #pragma unroll
@@ -598,12 +649,13 @@ __global__ __launch_bounds__(64, 1) void rollout_tiles_kernel(const RolloutArgs 
             double ring[RC];
             auto request = [&](auto loc, auto hic) {              // tile PAIRS of [lo & ~1, hi & ~1), clamped to the workspace
                 constexpr int lo = decltype(loc)::value & ~1, hi = (decltype(hic)::value < TOT ? decltype(hic)::value : TOT) & ~1;
-#pragma unroll
-                for (int e = lo; e < hi; e += 2) {
-                    const u32x4_v v = __builtin_amdgcn_raw_buffer_load_b128(wsr, lane16, (e >> 1) * 1024, 16);
+                static_for<lo / 2, hi / 2>([&](auto qc) {
+                    constexpr int e = 2 * decltype(qc)::value;
+                    constexpr int aux = (GPMPC_TILES_KEEP > 0 && (e - E0) * 384 >= GPMPC_TILES_KEEP * 1024) ? 18 : 16;
+                    const u32x4_v v = __builtin_amdgcn_raw_buffer_load_b128(wsr, lane16, (e >> 1) * 1024, aux);
                     ring[e % RC] = __builtin_bit_cast(double, u32x2_v{v.x, v.y});
                     ring[(e + 1) % RC] = __builtin_bit_cast(double, u32x2_v{v.z, v.w});
-                }
+                });
             };
             auto streamed_row = [&](auto rc) {
                 constexpr int r = decltype(rc)::value, base = tri(r), NCH = (r + 11) / 12;

@@ -64,7 +64,8 @@ def test_bench_line_contract():
 def test_bench_multi_gpu_path_with_one_rank():
     d = _run({"GPMPC_BENCH_FORCE_DIST": "1", "MASTER_PORT": "29547"}, args=("--no-extra", "--cpu-sample", "0"))
     g = d["gather"]
-    assert g is not None and g["overlapped_with_next_rollout"] and g["standalone_ms"] > 0 and g["bytes_per_rank"] == 1024 * 2 * 31 * 8
+    assert g is not None and g["every"] == 4 and g["standalone_ms"] > 0 and g["bytes_per_rank"] == 1024 * 2 * 31 * 8
+    assert d["_full"]["gather"]["overlapped_with_next_rollout"] and d["_full"]["gather"]["bytes_per_collective_per_rank"] == 4 * 1024 * 2 * 31 * 8
     assert d["value"] > 1e6
 
 
