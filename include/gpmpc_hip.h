@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define GPMPC_ABI_VERSION 7
+#define GPMPC_ABI_VERSION 8
 
 #define GPMPC_MAX_NY 4   /* GP outputs            (reference agent.g_dim.ny : 1 pendulum1D, 3 car)          */
 #define GPMPC_MAX_D  4   /* GP input dimension    (g_nx + g_nu : 2 in all shipped configs)                 */
@@ -332,6 +332,26 @@ int     gpmpc_pack_plin_fb(int32_t nx, int32_t nu, int64_t Ns, int32_t H,
                            const double* y_grad, const double* u_grad, const double* gp_val,
                            const double* x_h, const double* u_h, const double* xg, const double* w,
                            const double* tilde_eps, const double* K, double* p_lin, void* stream);
+
+/*
+ * gpmpc_build_x_hat (ABI 8) - batch_x_hat from the solver's iterate in one launch.
+ * Replaces: reference src/agent.py:480-501 (get_batch_x_hat_u_diff) / 503-527 (get_batch_x_hat): reshape, input broadcast and
+ * the nx-fold replication of the state row.
+ *   x_h [dev] (H, Ns*nx); u_h [dev] (H, nu) shared by the samples (u_per_sample 0) or (H, Ns, nu) (u_per_sample 1)
+ *   xu  [dev] (Ns, nx, H, nx+nu)   out
+ */
+int     gpmpc_build_x_hat(int32_t nx, int32_t nu, int64_t Ns, int32_t H, const double* x_h, const double* u_h,
+                          int32_t u_per_sample, double* xu, void* stream);
+
+/*
+ * gpmpc_assemble_jacobians_plin (ABI 8) - gpmpc_assemble_jacobians and gpmpc_pack_plin_fb in ONE launch: the three arrays
+ * (which may stay on the device) and the stage parameter vectors the reference's solver consumes (src/solver.py:98-131; x_hat_i
+ * is read from xu).  Arguments as the two entry points; u_h [dev] (H, nu) is the nominal input of the stage tail.
+ */
+int     gpmpc_assemble_jacobians_plin(const gpmpc_gp_desc_t* gp, const gpmpc_env_desc_t* env, int64_t Ns, int32_t H,
+                                      const double* xu, const double* y, double* gp_val, double* y_grad, double* u_grad,
+                                      const double* u_h, const double* xg, const double* w, const double* tilde_eps,
+                                      const double* K, double* p_lin, void* stream);
 /* bitwise OR of n int32 words ([dev], e.g. the per-chain info words of a launch) into out[0] ([dev], zeroed by the caller):
  * one launch and one word to read where the facade used a reduction per flag bit (nothing of the reference is replaced:
  * gpytorch raises / warns from host-side checks of its own, src/agent.py:629-641) */

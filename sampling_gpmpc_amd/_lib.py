@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libgpmpc_hip.so")
 
 MAX_NY, MAX_D, MAX_T, MAX_NX, MAX_NU = 4, 4, 5, 8, 4
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 ENV_PENDULUM1D, ENV_CAR_RESIDUAL = 0, 1
 MODE_INDEPENDENT, MODE_RECONDITIONED = 0, 1
@@ -77,6 +77,9 @@ SYMBOLS = {
     "gpmpc_plin_len": (_I64, [_I32, _I32, _I64]),
     "gpmpc_pack_plin": (C.c_int, [_I32, _I32, _I64, _I32, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "gpmpc_pack_plin_fb": (C.c_int, [_I32, _I32, _I64, _I32, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "gpmpc_build_x_hat": (C.c_int, [_I32, _I32, _I64, _I32, _P, _P, _I32, _P, _P]),
+    "gpmpc_assemble_jacobians_plin": (C.c_int, [C.POINTER(GpDesc), C.POINTER(EnvDesc), _I64, _I32, _P, _P, _P, _P, _P, _P, _P, _P, _P,
+                                                _P, _P, _P]),
     "gpmpc_or_reduce_words": (C.c_int, [_P, _I64, _P, _P]),
     "gpmpc_base_samples": (C.c_int, [C.c_uint64, _I32, _I32, _I64, _I64, _I32, _D, _P, _P, _P]),
 }

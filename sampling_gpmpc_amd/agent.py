@@ -506,6 +506,78 @@ class Agent(object):
                                           _lib.current_stream_ptr()), "gpmpc_pack_plin_fb")
         return _lib.to_host(p_lin)
 
+    def sqp_linearisation(self, x_h, u_h, sqp_iter, xg, w, K=None, u_nominal=None, train=True):
+        """One SQP iteration's GP side as the reference's solver consumes it (``src/solver.py:84-131``): ``train_hallucinated_dynGP``
+        -> batch_x_hat -> joint draw -> Jacobians -> stage parameter vectors ``p_lin`` (numpy ``(H, len)``, acados layout) with
+        the host <-> device traffic the loop actually needs: ONE upload of ``[x_h | u_h | u_nominal | xg | w]`` (pinned staging),
+        one launch for ``batch_x_hat`` (``gpmpc_build_x_hat``), the draw, ONE launch for the Jacobians AND ``p_lin``
+        (``gpmpc_assemble_jacobians_plin``), ONE download of ``p_lin``.  The three Jacobian arrays stay on the device
+        (``self._last_device_jacobians``; ``dyn_fg_jacobians`` remains the reference-shaped call that brings them to the host).
+
+        ``u_h``: ``(H, nu)`` shared by the samples (reference ``get_batch_x_hat``) or ``(H, Ns, nu)`` per sample (the feedback
+        form, ``get_batch_x_hat_u_diff``); ``u_nominal`` ``(H, nu)``: the inputs of the stage tail (default: ``u_h`` when it is
+        shared).  ``K``: feedback gain folded into ``A_i = y_grad + u_grad K`` (``src/solver.py:90``)."""
+        lib = _lib.load()
+        dev = _lib.require_hip_device(self.torch_device)
+        if train:
+            self.train_hallucinated_dynGP(sqp_iter)
+        H, ns, nx, nu = int(self.params["optimizer"]["H"]), self.ns, self.nx, self.nu
+        x_np = np.asarray(x_h, dtype=np.float64).reshape(-1)
+        u_np = np.asarray(u_h, dtype=np.float64)
+        per_sample = u_np.ndim == 3
+        un_np = (u_np if not per_sample else np.zeros((H, nu))) if u_nominal is None else np.asarray(u_nominal, dtype=np.float64)
+        u_np, un_np = u_np.reshape(-1), un_np.reshape(-1)[: H * nu]
+        xg_np, w_np = np.asarray(xg, dtype=np.float64).reshape(-1)[:H], np.asarray(w, dtype=np.float64).reshape(-1)[:H]
+        sizes = (x_np.size, u_np.size, un_np.size, H, H)
+        offs = np.concatenate([[0], np.cumsum(sizes)])
+        st = self._ws_cache.get("sqp_staging")
+        if st is None or st[0].numel() != offs[-1]:
+            st = (torch.empty(int(offs[-1]), dtype=F64, pin_memory=True), torch.empty(int(offs[-1]), dtype=F64, device=dev),
+                  torch.empty(ns, nx, H, nx + nu, dtype=F64, device=dev))
+            self._ws_cache["sqp_staging"] = st
+        hst, up, xu = st
+        hn = hst.numpy()
+        for a, o in zip((x_np, u_np, un_np, xg_np, w_np), offs[:-1]):
+            hn[o:o + a.size] = a
+        up.copy_(hst, non_blocking=True)
+        seg = [up[offs[i]:offs[i + 1]] for i in range(5)]
+        stream = _lib.current_stream_ptr()
+        _lib.check(lib.gpmpc_build_x_hat(nx, nu, ns, H, _lib.dptr(seg[0]), _lib.dptr(seg[1]), int(per_sample), _lib.dptr(xu), stream),
+                   "gpmpc_build_x_hat")
+        y = self.get_batch_gp_sensitivities(xu, sqp_iter).contiguous()
+        const = self._ws_cache.get("plin_const")
+        if const is None or const[0] != H:
+            te = torch.as_tensor(np.stack(self.tilde_eps_list)[:H], dtype=F64).to(dev).contiguous()
+            const = (H, te, {})
+            self._ws_cache["plin_const"] = const
+        te, Kc = const[1], const[2]
+        K_d = None
+        if K is not None:
+            key = np.asarray(K, dtype=np.float64).tobytes()
+            K_d = Kc.get(key)
+            if K_d is None:
+                K_d = torch.as_tensor(np.asarray(K), dtype=F64).to(dev).contiguous()
+                Kc.clear()
+                Kc[key] = K_d
+        n1, n2, n3 = ns * nx * H, ns * nx * H * nx, ns * nx * H * nu
+        n = lib.gpmpc_plin_len(nx, nu, ns)
+        out = self._ws_cache.get("sqp_out")
+        if out is None or out[0].numel() != n1 + n2 + n3 or out[1].shape != (H, n):
+            out = (torch.empty(n1 + n2 + n3, dtype=F64, device=dev), torch.empty(H, n, dtype=F64, device=dev))
+            self._ws_cache["sqp_out"] = out
+        flat, p_lin = out
+        gp_val = flat[:n1].view(ns, nx, H, 1)
+        y_grad = flat[n1:n1 + n2].view(ns, nx, H, nx)
+        u_grad = flat[n1 + n2:].view(ns, nx, H, nu)
+        plan = self.model_i.plan
+        _lib.check(lib.gpmpc_assemble_jacobians_plin(plan.desc, self.env_desc(), ns, H, _lib.dptr(xu), _lib.dptr(y), _lib.dptr(gp_val),
+                                                     _lib.dptr(y_grad), _lib.dptr(u_grad), _lib.dptr(seg[2]), _lib.dptr(seg[3]),
+                                                     _lib.dptr(seg[4]), _lib.dptr(te), _lib.dptr(K_d), _lib.dptr(p_lin), stream),
+                   "gpmpc_assemble_jacobians_plin")
+        self._last_device_jacobians_flat = flat
+        self._last_device_jacobians = (gp_val, y_grad, u_grad)
+        return _lib.to_host(p_lin)
+
     # ---------------------------------------------------------------------------------------------------------
     # forward sampling with rejection (reference src/agent.py:331-443)
     # ---------------------------------------------------------------------------------------------------------

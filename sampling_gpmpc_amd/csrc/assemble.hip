@@ -105,6 +105,99 @@ __global__ __launch_bounds__(256) void plin_kernel(int nx, int nu, long Ns, int 
     }
 }
 
+// batch_x_hat from the solver's iterate in ONE launch (reference src/agent.py:480-527: a reshape, a broadcast of the inputs and
+// an nx-fold replication of the state row - four torch ops and their temporaries):
+//   xu[s][r][h][0..nx) = x_h[h][s nx + c],  xu[s][r][h][nx..nx+nu) = u_h[h][(s)][j]   for every replica r < nx
+__global__ __launch_bounds__(256) void x_hat_kernel(int nx, int nu, long Ns, int H, const double* __restrict__ x_h,
+                                                    const double* __restrict__ u_h, int u_per_sample, double* __restrict__ xu) {
+    const int W = nx + nu;
+    const long total = Ns * nx * H * W;
+    for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(e % W);
+        const int h = (int)((e / W) % H);
+        const long s = e / ((long)W * H * nx);
+        xu[e] = (c < nx) ? x_h[(long)h * Ns * nx + s * nx + c]
+                         : (u_per_sample ? u_h[((long)h * Ns + s) * nu + (c - nx)] : u_h[(long)h * nu + (c - nx)]);
+    }
+}
+
+// gpmpc_assemble_jacobians + gpmpc_pack_plin_fb in ONE launch: thread (s, row, h) forms its row of [f | df/dx | df/du] as
+// jacobians_kernel does, writes it to the three arrays AND to its places in stage h's parameter vector (row `row` of A_i and
+// B_i, x_hat_i[row], f_i[row]); thread (0, 0, h) adds the stage's tail.  The reference's solver consumes only p_lin
+// (src/solver.py:98-131): with this form the three arrays never have to leave the device.
+template <int T>
+__global__ __launch_bounds__(256) void jacobians_plin_kernel(GpParams gp, EnvParams env, long Ns, int H,
+                                                             const double* __restrict__ xu, const double* __restrict__ y,
+                                                             double* __restrict__ gp_val, double* __restrict__ y_grad,
+                                                             double* __restrict__ u_grad, const double* __restrict__ u_h,
+                                                             const double* __restrict__ xg, const double* __restrict__ w,
+                                                             const double* __restrict__ tilde_eps, const double* __restrict__ Kfb,
+                                                             double* __restrict__ p_lin) {
+    constexpr int I1 = (T == 1) ? 0 : 1, I2 = (T == 1) ? 0 : 2;
+    const int nx = env.nx, nu = env.nu, W = 1 + nx + nu;
+    const long per = (long)nx * nx + (long)nx * nu + 2L * nx;
+    const long len = Ns * per + nu + 2 + (nx + nu + 1);
+    const long total = Ns * nx * H;
+    for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+        const int h = (int)(e % H);
+        const int row = (int)((e / H) % nx);
+        const long s = e / ((long)H * nx);
+        const double* xr = xu + ((s * nx + 0) * H + h) * (nx + nu);
+        double out[1 + GPMPC_MAX_NX + GPMPC_MAX_NU];
+        for (int c = 0; c < W; ++c) out[c] = 0.0;
+        if (env.env_id == GPMPC_ENV_PENDULUM1D) {
+            if (row == 0) {
+                out[0] = xr[0] + xr[1] * env.dt;
+                out[1] = 1.0;
+                out[2] = env.dt;
+            } else {
+                out[0] = xr[1];
+                out[2] = 1.0;
+                const double* yo = y + ((s * gp.g_ny + 0) * H + h) * T;
+                out[0] += yo[0];
+                out[1] += yo[I1];
+                out[3] += yo[I2];
+            }
+        } else {
+            out[0] = xr[row] + ((row == 3) ? xr[5] * env.dt : 0.0);
+            out[1 + row] = 1.0;
+            if (row == 3) out[6] = env.dt;
+            if (row < 3) {
+                const double* yo = y + ((s * gp.g_ny + row) * H + h) * T;
+                const double v = xr[3];
+                const double y0 = yo[0], y1 = yo[I1], y2 = yo[I2];
+                out[0] += v * y0;
+                out[3] += v * y1;
+                out[4] += y0;
+                out[5] += v * y2;
+            }
+        }
+        gp_val[e] = out[0];
+        for (int c = 0; c < nx; ++c) y_grad[e * nx + c] = out[1 + c];
+        for (int c = 0; c < nu; ++c) u_grad[e * nu + c] = out[1 + nx + c];
+        double* ps = p_lin + (long)h * len + s * per;
+        for (int b = 0; b < nx; ++b) {                            // A_i[row][b] (+ u_grad K under feedback, src/solver.py:90)
+            double v = out[1 + b];
+            if (Kfb) {
+                double acc = 0.0;
+                for (int j = 0; j < nu; ++j) acc += out[1 + nx + j] * Kfb[j * nx + b];
+                v += acc;
+            }
+            ps[row * nx + b] = v;
+        }
+        for (int b = 0; b < nu; ++b) ps[nx * nx + row * nu + b] = out[1 + nx + b];
+        ps[nx * nx + nx * nu + row] = xr[row];                    // x_hat_i[row] = x_h[h][s nx + row]
+        ps[nx * nx + nx * nu + nx + row] = out[0];                // f_i[row]
+        if (s == 0 && row == 0) {
+            double* pt = p_lin + (long)h * len + Ns * per;
+            for (int r = 0; r < nu; ++r) pt[r] = u_h[(long)h * nu + r];
+            pt[nu] = xg[h];
+            pt[nu + 1] = w[h];
+            for (int r = 0; r < nx + nu + 1; ++r) pt[nu + 2 + r] = tilde_eps[(long)h * (nx + nu + 1) + r];
+        }
+    }
+}
+
 static unsigned stream_grid(long total) {
     long g = (total + 255) / 256;
     if (g > 2048) g = 2048;            // ~8 workgroups per CU, grid-stride for the rest
@@ -135,6 +228,42 @@ int gpmpc_assemble_jacobians(const gpmpc_gp_desc_t* gp, const gpmpc_env_desc_t* 
     else if (gp->T == 3)
         hipLaunchKernelGGL(jacobians_kernel<3>, dim3(stream_grid(total)), dim3(256), 0, st, g, e, (long)Ns, H, xu, y,
                            gp_val, y_grad, u_grad);
+    else
+        return fail(GPMPC_E_UNSUPPORTED, "jacobians: only T = 1 and T = 3 are instantiated");
+    GPMPC_HIP_CHECK(hipGetLastError());
+    return GPMPC_OK;
+}
+
+int gpmpc_build_x_hat(int32_t nx, int32_t nu, int64_t Ns, int32_t H, const double* x_h, const double* u_h,
+                      int32_t u_per_sample, double* xu, void* stream) {
+    if (!x_h || !u_h || !xu) return fail(GPMPC_E_ARG, "gpmpc_build_x_hat: NULL pointer");
+    if (nx < 1 || nu < 1 || Ns < 1 || H < 1) return fail(GPMPC_E_ARG, "gpmpc_build_x_hat: bad sizes");
+    const long total = (long)Ns * nx * H * (nx + nu);
+    hipLaunchKernelGGL(x_hat_kernel, dim3(stream_grid(total)), dim3(256), 0, (hipStream_t)stream, nx, nu, (long)Ns, H, x_h, u_h,
+                       (int)u_per_sample, xu);
+    GPMPC_HIP_CHECK(hipGetLastError());
+    return GPMPC_OK;
+}
+
+int gpmpc_assemble_jacobians_plin(const gpmpc_gp_desc_t* gp, const gpmpc_env_desc_t* env, int64_t Ns, int32_t H,
+                                  const double* xu, const double* y, double* gp_val, double* y_grad, double* u_grad,
+                                  const double* u_h, const double* xg, const double* w, const double* tilde_eps, const double* K,
+                                  double* p_lin, void* stream) {
+    if (int rc = check_gp(gp)) return rc;
+    if (int rc = check_env(gp, env)) return rc;
+    if (!xu || !y || !gp_val || !y_grad || !u_grad || !u_h || !xg || !w || !tilde_eps || !p_lin)
+        return fail(GPMPC_E_ARG, "gpmpc_assemble_jacobians_plin: NULL pointer");
+    if (Ns < 1 || H < 1) return fail(GPMPC_E_ARG, "gpmpc_assemble_jacobians_plin: bad sizes");
+    GpParams g = make_gp_params(gp);
+    EnvParams e = make_env_params(env);
+    const long total = Ns * env->nx * H;
+    hipStream_t st = (hipStream_t)stream;
+    if (gp->T == 1)
+        hipLaunchKernelGGL(jacobians_plin_kernel<1>, dim3(stream_grid(total)), dim3(256), 0, st, g, e, (long)Ns, H, xu, y, gp_val,
+                           y_grad, u_grad, u_h, xg, w, tilde_eps, K, p_lin);
+    else if (gp->T == 3)
+        hipLaunchKernelGGL(jacobians_plin_kernel<3>, dim3(stream_grid(total)), dim3(256), 0, st, g, e, (long)Ns, H, xu, y, gp_val,
+                           y_grad, u_grad, u_h, xg, w, tilde_eps, K, p_lin);
     else
         return fail(GPMPC_E_UNSUPPORTED, "jacobians: only T = 1 and T = 3 are instantiated");
     GPMPC_HIP_CHECK(hipGetLastError());

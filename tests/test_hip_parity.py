@@ -630,6 +630,29 @@ def test_dyn_fg_jacobians_plumbing_golden(sg, tag, pname):
                                     x_h[stage, i * nx: nx * (i + 1)], gp_val[i, :, stage, :].reshape(-1)])
         p_lin = np.hstack([p_lin, u_h[stage], xg[stage], w[stage], agent.tilde_eps_list[stage]])
         np.testing.assert_array_equal(got[stage], p_lin)
+    # the fused SQP-iteration call (ABI 8: one upload, gpmpc_build_x_hat, the draw, gpmpc_assemble_jacobians_plin, one download):
+    # the same stage vectors, bit for bit, as the reference's literal loop over the reference-run golden arrays - with the
+    # per-sample inputs of the feedback form (src/solver.py:86-90, K folded into A_i) and with the shared inputs (:92-94)
+    K = np.arange(1, nu * nx + 1, dtype=np.float64).reshape(nu, nx) / 7.0
+    for per_sample, Kfb in ((True, None), (True, K), (False, None)):
+        u_in = d["u_diff"] if per_sample else u_h
+        got2 = agent.sqp_linearisation(x_h, u_in, 0, xg, w, K=Kfb, u_nominal=u_h, train=False)
+        gv, yg, ug = (t.cpu().numpy() for t in agent._last_device_jacobians)
+        bx = agent.get_batch_x_hat_u_diff(x_h, u_in) if per_sample else agent.get_batch_x_hat(x_h, u_in)
+        rv, ry, ru = agent.dyn_fg_jacobians(bx, 0)
+        for a, b in ((gv, rv), (yg, ry), (ug, ru)):
+            np.testing.assert_array_equal(a, b)
+        A = ry + (ru @ Kfb if Kfb is not None else 0.0)
+        for stage in range(H):
+            ref = np.empty(0)
+            for i in range(Ns):
+                ref = np.concatenate([ref, A[i, :, stage, :].reshape(-1), ru[i, :, stage, :].reshape(-1),
+                                      x_h[stage, i * nx: nx * (i + 1)], rv[i, :, stage, :].reshape(-1)])
+            ref = np.hstack([ref, u_h[stage], xg[stage], w[stage], agent.tilde_eps_list[stage]])
+            if Kfb is None:
+                np.testing.assert_array_equal(got2[stage], ref)
+            else:                                                # y_grad + u_grad K: the kernel sums nu products, numpy's matmul may pair them differently
+                np.testing.assert_allclose(got2[stage], ref, rtol=1e-15, atol=1e-15)
 
 
 def test_model_i_surface(sg):

@@ -39,5 +39,7 @@ with warnings.catch_warnings():
             n1 = gv.numel()
             mean_next = h[:n1].reshape(gv.shape)[:, :, :, 0].mean(axis=0).T
             x_h = np.tile(np.vstack([x0[None, :], mean_next[:-1]]), (1, Ns))
+            # the fused call of round 6 on a twin Agent in the same state would need a second factor cache; it is timed by
+            # tools/debug/closed_loop_fused_phases.py instead
             print(f"step {step} k={k}: train {t_train:6.2f}  x_hat {t_xhat:6.2f}  draw+jacobians+append {t_dev:7.2f}  D2H {h.nbytes / 1e6:5.1f} MB {t_d2h:6.2f}  "
                   f"p_lin {pl.nbytes / 1e6:5.1f} MB {t_plin:6.2f} ms", flush=True)
