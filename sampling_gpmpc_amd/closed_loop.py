@@ -61,17 +61,24 @@ class SurrogateSolver:
             x_old = self.x_h.copy()
             xs = self.x_h[:H]
             t0 = time.perf_counter()
-            player.train_hallucinated_dynGP(sqp_iter)
-            if fb:
-                u_fb = -(x_equi - xs.reshape(H, ns, -1)) @ K.T + np.tile(self.u_h[:, None, :], (ns, 1))
-                gp_val, y_grad, u_grad = player.dyn_fg_jacobians(player.get_batch_x_hat_u_diff(xs, u_fb), sqp_iter)
+            u_fb = (-(x_equi - xs.reshape(H, ns, -1)) @ K.T + np.tile(self.u_h[:, None, :], (ns, 1))) if fb else None
+            if self.pack and hasattr(player, "sqp_linearisation"):
+                # the HIP Agent's fused call (what a solver that consumes p_lin needs, src/solver.py:84-131): one upload, the
+                # draw, Jacobians + p_lin in one launch, one download; the three arrays stay on the device
+                self.p_lin = player.sqp_linearisation(xs, u_fb if fb else self.u_h, sqp_iter, xg, w, K=K, u_nominal=self.u_h)
+                self.gp_ms.append((time.perf_counter() - t0) * 1e3)
+                mean_next = player._last_device_jacobians[0][:, :, :, 0].mean(dim=0).T.cpu().numpy()
             else:
-                gp_val, y_grad, u_grad = player.dyn_fg_jacobians(player.get_batch_x_hat(xs, self.u_h), sqp_iter)
-            if self.pack:
-                self.p_lin = player.pack_p_lin(xs, self.u_h, xg, w, K=K)
-            self.gp_ms.append((time.perf_counter() - t0) * 1e3)
+                player.train_hallucinated_dynGP(sqp_iter)
+                if fb:
+                    gp_val, y_grad, u_grad = player.dyn_fg_jacobians(player.get_batch_x_hat_u_diff(xs, u_fb), sqp_iter)
+                else:
+                    gp_val, y_grad, u_grad = player.dyn_fg_jacobians(player.get_batch_x_hat(xs, self.u_h), sqp_iter)
+                if self.pack:
+                    self.p_lin = player.pack_p_lin(xs, self.u_h, xg, w, K=K)
+                self.gp_ms.append((time.perf_counter() - t0) * 1e3)
+                mean_next = gp_val[:, :, :, 0].mean(axis=0).T       # (H, nx)
             # surrogate QP step: stage j+1 is linearised where the sample mean of stage j's prediction lands
-            mean_next = gp_val[:, :, :, 0].mean(axis=0).T           # (H, nx)
             self.x_h[1:] = np.tile(mean_next, (1, ns))
             self.iterations = sqp_iter + 1
             x_diff = np.linalg.norm(self.x_h - x_old) / (np.linalg.norm(x_old) + 1e-6)

@@ -202,11 +202,49 @@ def real_gpytorch_pin():
             if best is None or err < best[0]:
                 best = (err, sem)
         report.append(f"{tag:14s} best match: {best[1]} ({best[0]:.3e})")
+    n_split = joint_car_split_capture(ref_agent, RefCar, "_gpytorch")
+    report.append(f"J_car_split    written: k = 0..3 of MPC step 0 and k = 0 of MPC step 1 (conditioning set {n_split} points), "
+                  f"mean / variance / samples of the reference's model_i_call")
     txt = "\n".join(report)
     print(txt)
     with open(f"{HERE}/gpytorch_pin_report.txt", "w") as f:
         f.write(txt + "\n")
     return 0
+
+
+def joint_car_split_capture(ref_agent, RefCar, suffix):
+    """Mode J as the closed loop runs it (src/solver.py:84-94): the car AS SHIPPED (Dyn_gp_jitter 1e-20 -> the eigendecomposition
+    root), H = 40, SQP iterations k = 0..3 of MPC step 0 and k = 0 of MPC step 1, whose draw conditions on 45 + 480 slots - the size
+    the HIP matrix-pipe path serves with its TOP + BOTTOM pair of launches (include/gpmpc_hip.h, ABI 7).  Driven through the
+    reference's own Agent; with ``suffix == "_gpytorch"`` the algebra behind it is the genuine library, else the import stub's
+    (the oracle).  Eigenvector signs are solver specific: consumers compare mean / variance and continue from these labels."""
+    p = load_params("params_car_residual")
+    Ns, H, iters = 4, 40, 4
+    p["common"]["use_cuda"] = False
+    p["agent"]["num_dyn_samples"], p["optimizer"]["H"] = Ns, H
+    p["agent"]["true_dyn_as_sample"] = False
+    p["common"]["num_MPC_itrs"], p["optimizer"]["SEMPC"]["max_sqp_iter"] = 2, iters
+    torch.manual_seed(123456)
+    agent = quiet(ref_agent.Agent, p, RefCar(p))
+    x0 = np.array(p["env"]["start"], dtype=np.float64)[: agent.nx]
+    u_h = np.stack([0.05 * np.sin(2 * np.pi * np.arange(H) / H), np.zeros(H)], axis=1)
+    x_h = np.tile(x0, (H, Ns))
+    rec = {"Ns": Ns, "H": H, "iters": iters, "u_h": u_h, "epistimic_random_vector": agent.epistimic_random_vector.clone().numpy()}
+    n_last = 0
+    for step, k in [(0, kk) for kk in range(iters)] + [(1, 0)]:
+        agent.mpc_iteration(step)
+        quiet(agent.train_hallucinated_dynGP, k)
+        n_last = int(agent.model_i.train_inputs[0].shape[-2])
+        gp_val, y_grad, u_grad = quiet(agent.dyn_fg_jacobians, agent.get_batch_x_hat(x_h, u_h), k)
+        post = agent.model_i_call
+        key = f"s{step}k{k}"
+        rec.update({f"x_h_{key}": x_h.copy(), f"mean_{key}": post.mean.detach().numpy().copy(),
+                    f"var_{key}": post.variance.detach().numpy().copy(), f"y_{key}": agent.model_i_samples.detach().numpy().copy(),
+                    f"gp_val_{key}": np.asarray(gp_val).copy(), f"n_train_{key}": n_last})
+        mean_next = np.asarray(gp_val)[:, :, :, 0].mean(axis=0).T
+        x_h = np.tile(np.vstack([x0[None, :], mean_next[:-1]]), (1, Ns))
+    np.savez(f"{HERE}/agent_e2e_J_car_split{suffix}.npz", **rec)
+    return n_last
 
 
 def fs_loop(agent, p, u_ff):
@@ -383,6 +421,9 @@ def main():
     from src.utils.reachable_set import get_reachable_set_ball as ref_ball            # noqa
     ref_agent.BatchMultitaskGPModelWithDerivatives_fromParams = OracleModelAdapter
     torch.set_default_dtype(torch.float64)
+    if "--only" in sys.argv and sys.argv[sys.argv.index("--only") + 1] == "joint_split":
+        print("agent_e2e_J_car_split.npz:", joint_car_split_capture(ref_agent, RefCar, ""), "points behind the last draw")
+        return
 
     # ---------------- configs -------------------------------------------------------------------------------
     hdr = ("# Configuration values for the GP-rollout hot path; key names and numeric values follow the\n"
@@ -540,6 +581,7 @@ def main():
     # ---------------- Agent.prepare_dynamics_set (src/agent.py:331-443) and the pinned-sample branches -------
     prepare_dynamics_set_fixture(ref_agent, RefPendulum1D)
     pinned_samples_fixture(ref_agent, RefPendulum1D, RefCar)
+    joint_car_split_capture(ref_agent, RefCar, "")
 
     # ---------------- extra/conditioning_gp.py executed as is -----------------------------------------------
     import matplotlib

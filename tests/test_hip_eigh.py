@@ -348,3 +348,28 @@ def test_eigh_narrow_and_deferred_launches_give_the_same_bits(sg):
                     agent.get_batch_gp_sensitivities(bx, k)
     finally:
         raw.gpmpc_debug_eigh_narrow(-1)
+
+
+@pytest.mark.parametrize("suffix", ["", "_gpytorch"])
+def test_joint_draws_of_the_closed_loop_against_reference_run(sg, suffix):
+    """agent_e2e_J_car_split.npz (committed): the reference's own Agent through these draws with the import stub's algebra.
+    The day gpytorch exists, ``tests/golden/make_goldens.py --real-gpytorch`` writes the closed-loop draws of the car as shipped
+    (k = 0..3 and the 45 + 480-slot k = 0 of the next MPC step: the matrix-pipe path's TOP + BOTTOM launches) from the REAL
+    ``model_i(x)``; this test then pins the HIP path - dispatcher's choice, path asserted - against them.  Skipped until then."""
+    path = os.path.join(os.path.dirname(__file__), "golden", f"agent_e2e_J_car_split{suffix}.npz")
+    if not os.path.exists(path):
+        pytest.skip("no real-gpytorch golden (run tests/golden/make_goldens.py --real-gpytorch where gpytorch is installed)")
+    from tests.test_oracle_golden import replay_joint_car_split
+    d = np.load(path)
+    p = _car(int(d["Ns"]), int(d["H"]), int(d["iters"]))
+    p["common"]["num_MPC_itrs"] = 2
+    agent, _ = make_agents(sg, p, erv=d["epistimic_random_vector"])
+    raw = sg._lib.load()
+
+    def check(step, k, post):
+        assert raw.gpmpc_joint_last_path() == (sg._lib.JOINT_MFMA if (k >= 1 or step >= 1) else sg._lib.JOINT_VALU)
+        assert (post.last_info & sg._lib.INFO_ROOT_EIGH).all()
+
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        replay_joint_car_split(agent, d, check=check)

@@ -156,6 +156,42 @@ def test_oracle_against_real_gpytorch_goldens_when_present(tag, pname):
     np.testing.assert_allclose(Y, d["Y"], rtol=1e-5, atol=1e-8)
 
 
+def replay_joint_car_split(agent, d, to_np=lambda t: t.detach().cpu().numpy(), check=None):
+    """Drives an Agent (oracle or HIP) through the closed-loop draws of agent_e2e_J_car_split_gpytorch.npz (car as shipped, k = 0..3 of
+    MPC step 0 and k = 0 of MPC step 1: 45 + 480 conditioning slots) from the reference's own linearisation points and labels."""
+    H, iters = int(d["H"]), int(d["iters"])
+    for step, k in [(0, kk) for kk in range(iters)] + [(1, 0)]:
+        key = f"s{step}k{k}"
+        agent.mpc_iteration(step)
+        agent.train_hallucinated_dynGP(k)
+        agent.dyn_fg_jacobians(agent.get_batch_x_hat(d[f"x_h_{key}"], d["u_h"]), k)
+        post = agent.model_i_call
+        np.testing.assert_allclose(to_np(post.mean), d[f"mean_{key}"], rtol=1e-6, atol=1e-9)
+        np.testing.assert_allclose(to_np(post.variance), d[f"var_{key}"], rtol=1e-4, atol=1e-12)
+        if check is not None:
+            check(step, k, post)
+        # continue from the REFERENCE's labels (eigenvector signs of the two roots differ): the appended points are the same
+        Y = torch.tensor(d[f"y_{key}"])
+        agent.Hallcinated_Y_train = torch.cat([agent.Hallcinated_Y_train[:, :, :-H].cpu(), Y], dim=2).to(agent.Hallcinated_Y_train.device)
+
+
+@pytest.mark.parametrize("suffix", ["", "_gpytorch"])
+def test_oracle_joint_draws_of_the_closed_loop_against_reference_run(suffix):
+    """agent_e2e_J_car_split.npz: the reference's own Agent driven through the closed loop's draws with the import stub's algebra
+    (pins everything around the algebra); ..._gpytorch.npz: the same with the GENUINE library, written by
+    ``make_goldens.py --real-gpytorch`` where gpytorch exists - skipped until then."""
+    path = os.path.join(GOLDEN, f"agent_e2e_J_car_split{suffix}.npz")
+    if not os.path.exists(path):
+        pytest.skip("no real-gpytorch golden (run tests/golden/make_goldens.py --real-gpytorch where gpytorch is installed)")
+    d = np.load(path)
+    p = load_params("params_car_residual")
+    p["agent"]["num_dyn_samples"], p["optimizer"]["H"] = int(d["Ns"]), int(d["H"])
+    p["agent"]["true_dyn_as_sample"] = False
+    p["common"]["num_MPC_itrs"], p["optimizer"]["SEMPC"]["max_sqp_iter"] = 2, int(d["iters"])
+    agent = ao.OracleAgent(p, ao.make_oracle_env(p), torch.tensor(d["epistimic_random_vector"]))
+    replay_joint_car_split(agent, d)
+
+
 def _pds_params(d):
     p = load_params("params_pendulum1D_samples")
     p["agent"]["num_dyn_samples"], p["optimizer"]["H"] = int(d["Ns"]), int(d["H"])
