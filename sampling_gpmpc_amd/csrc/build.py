@@ -13,7 +13,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 REPO = os.path.dirname(os.path.dirname(HERE))
 SOURCES = ["capi.hip", "rollout.hip", "rollout_fast.hip", "rollout_tiles.hip", "rollout_one.hip", "rollout_indep.hip", "joint.hip",
-           "joint_mfma.hip", "assemble.hip", "base_samples.hip"]
+           "joint_mfma.hip", "joint_chol.hip", "assemble.hip", "base_samples.hip"]
 # everything a source may include: the generated statement files (.inc) count like headers - editing a generator's OUTPUT
 # rebuilds the kernels that include it; tests/test_generated_sources.py checks that the committed .inc files are what the
 # generators (tools/gen_rollout_one.py, tools/gen_mfma_chains.py) produce

@@ -1010,6 +1010,7 @@ static int joint_mfma_from() {
     static const char* env = getenv("GPMPC_JOINT_MFMA_FROM");
     return env ? atoi(env) : 100;
 }
+static int g_chol_kernel_force = -1;      // gpmpc_debug_joint_chol_kernel: -1 default (on), 0 / 1 forced (tests, A/B timing)
 static int g_eigh_narrow_force = -1;      // gpmpc_debug_eigh_narrow: -1 heuristic, 0 / 1 forced (tests)
 static int g_joint_path_pin = 0;          // gpmpc_joint_pin_path: 0 auto, 1 VALU path, 2 matrix-pipe path where instantiated
 static int g_joint_last_path = 0;
@@ -1093,6 +1094,13 @@ int gpmpc_debug_read_eigh_work(unsigned long long* out /*[host] 4*/, int reset) 
     return GPMPC_OK;
 }
 
+// tests / A-B timing: 0 = the matrix-pipe path's Cholesky of the Schur complement by joint_kernel's CHOL phase, 1 = by
+// joint_chol_mfma_kernel, -1 = default (1); returns the previous value
+int gpmpc_debug_joint_chol_kernel(int mode) {
+    const int prev = g_chol_kernel_force;
+    g_chol_kernel_force = mode < 0 ? -1 : (mode ? 1 : 0);
+    return prev;
+}
 // tests: force the two-launch form of the eigendecomposition root off (0) / on (1), -1 = the rank heuristic; returns the previous value
 int gpmpc_debug_eigh_narrow(int mode) {
     const int prev = g_eigh_narrow_force;
@@ -1283,8 +1291,12 @@ int gpmpc_joint_sample(const gpmpc_gp_desc_t* gp, const void* plan, const double
         // (with nothing cached - the second SQP iteration - the new rows only meet the real columns: joint_kernel's factor phase does
         // rows and Cholesky in one launch, 1.98 against 2.15 ms per draw at configs[4], k = 1; from 120 cached slots on the matrix pipe
         // wins: 3.2 against 3.9 ms at k = 2)
-        const bool mfma_factor = n_new > 0 && n_new <= mT && b.n_c > 0 && joint_mfma_eligible(a.gp.n_r, b.n_c, n_new, gp->T) &&
-                                 !(fenv && atoi(fenv) == 0);
+        // (round 6: with the Schur complement's Cholesky on the matrix pipe too - joint_chol.hip - the factor extension wins with
+        // nothing cached as well: 1.91 against 2.03 ms at configs[4], k = 1; GPMPC_JOINT_MFMA_FACTOR_FIRST=0 keeps that draw's factor
+        // phase on the vector pipe)
+        static const char* f0env = getenv("GPMPC_JOINT_MFMA_FACTOR_FIRST");
+        const bool mfma_factor = n_new > 0 && n_new <= mT && (b.n_c > 0 || !(f0env && atoi(f0env) == 0)) &&
+                                 joint_mfma_eligible(a.gp.n_r, b.n_c, n_new, gp->T) && !(fenv && atoi(fenv) == 0);
         const long step = split ? w.xt_slots : (own ? nchains : w.tc_slots);
         for (long c0 = 0; c0 < nchains; c0 += step) {
             b.chain0 = c0;
@@ -1300,7 +1312,15 @@ int gpmpc_joint_sample(const gpmpc_gp_desc_t* gp, const void* plan, const double
                 } else {
                     b.phase = JOINT_PHASE_FACTOR;
                 }
-                launch(b, n_new);
+                // the Schur complement's Cholesky: one wave per chain on the matrix pipe (joint_chol.hip, round 6: 0.45 -> ~0.1 ms
+                // per draw at the configs[4] shard); GPMPC_JOINT_CHOL_KERNEL=0 / gpmpc_debug_joint_chol_kernel(0): joint_kernel's CHOL phase
+                static const char* cenv = getenv("GPMPC_JOINT_CHOL_KERNEL");
+                const int cforce = g_chol_kernel_force >= 0 ? g_chol_kernel_force : (cenv ? atoi(cenv) : 1);
+                if (mfma_factor && cforce != 0 && joint_chol_mfma_eligible(n_new)) {
+                    if (int rc = joint_chol_mfma_launch(b, st)) return rc;
+                } else {
+                    launch(b, n_new);
+                }
                 GPMPC_HIP_CHECK(hipGetLastError());
                 b.info_in = 1;
             }

@@ -80,4 +80,10 @@ bool joint_mfma_split_eligible(int n_r, int n_hc, int ncols, int T);
 // mean = V^T w into a.mean and S = K** - V^T V into a.Sall.  Needs a.fcache with every hallucinated row filled.
 int joint_mfma_launch(const JointArgs& a, hipStream_t st);
 
+// joint_chol.hip ---------------------------------------------------------------------------------------------------------
+// the Cholesky of the Schur complement JOINT_MFMA_FACTOR left in a.Sall (the new rows against the new columns: into the factor
+// cache, 1 / diag, the chain's info word) on the matrix pipe, one wave per chain; instantiated for 1..128 new rows
+bool joint_chol_mfma_eligible(int n_new);
+int joint_chol_mfma_launch(const JointArgs& a, hipStream_t st);
+
 }  // namespace gpmpc

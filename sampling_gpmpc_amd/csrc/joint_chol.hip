@@ -1,0 +1,289 @@
+// joint_chol_mfma_kernel: Cholesky of the Schur complement of the NEW hallucinated rows of a joint draw (mode "J") on the FP64
+// matrix pipe, one WAVE per (sample, output) chain, the whole matrix in registers (gfx950).
+//
+// Where it stands: the matrix-pipe path of gpmpc_joint_sample (joint.hip) extends the chain's factor by the rows of this SQP
+// iteration's points (reference src/agent.py:164-202 appends them, src/agent.py:241-250 / 640 re-factorises everything on the
+// next model_i(x) call): joint_test_mfma_kernel (JOINT_MFMA_FACTOR) forms the new rows' entries against the OLD columns and
+// leaves the Schur complement S = K_nn + noise - L_no L_no^T (n_new x n_new, n_new <= 128: one iteration's H T slots) in the
+// chain's S buffer; its Cholesky factor is the new rows' entries against the NEW columns.  joint_kernel's CHOL phase did that
+// with one label row per thread - 120 sequential pivots behind workgroup barriers, the matrix in LDS (one chain per CU):
+// 0.42-0.46 ms per draw at the configs[4] shard, 3-5 % of the FP64 peak's worth of a 1.8 GFLOP job, 10-15 % of every draw
+// from the third SQP iteration on (profiles/r5_closed_loop_trace.md).
+//
+// Here: S is held as UPPER-triangular 16 x 16 tiles A_kj (k <= j), four FP64 registers per tile in the D layout of
+// v_mfma_f64_16x16x4_f64 (register v, lane l: row 4 v + (l >> 4), column l & 15), 36 tiles = 288 registers, one wave per SIMD.
+// That layout is at once the instruction's B layout (K-slice v) and - read as the A operand - the TRANSPOSE of the tile
+// (A[i][k] of K-slice v sits in lane i + 16 k = the D-layout place of element [4 v + k][i]):
+//      nat(X, Y) := sum_v mfma(A = X.v, B = Y.v)  =  X^T Y          for two tiles in D layout, no conversion of either.
+// Left-looking blocked Cholesky S = R^T R over tile rows (R upper; the factor's rows are R's columns):
+//      acc_j = A_kj + sum_{p<k} nat(-R_pk, R_pj)                     j >= k
+//      R_kk = chol(acc_k)^T, V = R_kk^-1                             (the only step off the matrix pipe, see below)
+//      R_kj = R_kk^-T acc_j = nat(V, acc_j)                          j > k
+// 4 MFMAs per tile product, 448 per chain at eight tiles; a finished tile stays in registers only while a later row needs it
+// (<= 20 tiles alive, the next row's A tiles requested a step ahead: everything in the 256 VALU-addressable registers).  The diagonal tile goes through LDS into "lane = row" form: a
+// right-looking 16 x 16 Cholesky whose updates are v_fmac_f64_dpp row_newbcast (the pivot row's entry one DPP read away), and in
+// the same sweep W = L_kk^-1 by forward substitution on the identity (row-oriented, the finished rows broadcast the same way;
+// backward stable - a Neumann product on the matrix pipe would square the tile's condition); both back to D layout through LDS.  Results go to the factor cache transposed through LDS, 128 bytes
+// per row segment.  Values agree with the phase it replaces to rounding (the update sums in another order).
+#include <type_traits>
+
+#include "gpmpc_device.hpp"
+#include "joint_args.hpp"
+
+namespace gpmpc {
+
+typedef double jc_d4 __attribute__((ext_vector_type(4)));
+typedef double jc_d2 __attribute__((ext_vector_type(2)));
+typedef unsigned jc_u2 __attribute__((ext_vector_type(2)));
+
+constexpr int JC_LD = 18;                      // LDS row stride (doubles): rows 16-byte aligned, transposed reads conflict-free
+
+template <int B, int E, class F>
+__device__ __forceinline__ void jc_for(F&& f) {
+    if constexpr (B < E) {
+        f(std::integral_constant<int, B>{});
+        jc_for<B + 1, E>(f);
+    }
+}
+__device__ __forceinline__ void jc_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+__host__ __device__ constexpr int jc_idx(int k, int j, int ntl) { return k * ntl - k * (k - 1) / 2 + (j - k); }   // k <= j
+// X^T Y for two tiles in D layout, accumulated onto C
+__device__ __forceinline__ jc_d4 jc_nat(const jc_d4& X, const jc_d4& Y, jc_d4 C) {
+#pragma unroll
+    for (int v = 0; v < 4; ++v) C = __builtin_amdgcn_mfma_f64_16x16x4f64(X[v], Y[v], C, 0, 0, 0);
+    return C;
+}
+// acc -= m * src@lane J of the DPP row (src is read through DPP: it must not have been written in the two instructions before)
+template <int J, bool NOP = false>
+__device__ __forceinline__ void jc_fnma_bcast(double& acc, double src, double m) {
+    if constexpr (NOP)      // the first DPP read behind the VALU instructions that wrote the step's sources: two wait states
+        asm("s_nop 1\n\tv_fmac_f64_dpp %0, %1, -%2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(src), "v"(m), "n"(J));
+    else
+        asm("v_fmac_f64_dpp %0, %1, -%2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(src), "v"(m), "n"(J));
+}
+
+// acc -= m * acc@lane J of the DPP row (accumulator and broadcast source are the SAME register: as two asm operands hipcc copies it)
+template <int J, bool NOP = false>
+__device__ __forceinline__ void jc_fnma_self(double& acc, double m) {
+    if constexpr (NOP)
+        asm("s_nop 1\n\tv_fmac_f64_dpp %0, %0, -%1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(m), "n"(J));
+    else
+        asm("v_fmac_f64_dpp %0, %0, -%1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(m), "n"(J));
+}
+
+// GPMPC_PHASE_TIMERS: cycles of chain 0's wave per phase (loads | updates | diagonal tile | panel | stores), tools/debug/chol_phases.py
+__device__ long long g_jc_phase[8];
+#ifdef GPMPC_PHASE_TIMERS
+#define JCPH(i) do { const long long n_ = __builtin_readcyclecounter(); jph[i] += n_ - jt; jt = n_; } while (0)
+#else
+#define JCPH(i)
+#endif
+
+#ifndef GPMPC_JC_OCC8
+#define GPMPC_JC_OCC8 1                        // waves per SIMD of the eight-tile instance (2: 256 registers, ~45 of them spilled: no faster)
+#endif
+template <int NTL>
+__global__ __launch_bounds__(64, (NTL == 8) ? GPMPC_JC_OCC8 : 2) void joint_chol_mfma_kernel(const JointArgs a) {
+    constexpr int NTT = NTL * (NTL + 1) / 2;
+    constexpr int TS = 16 * JC_LD;                                // doubles of one tile buffer
+    __shared__ __attribute__((aligned(16))) double blk[TS];       // the diagonal tile: A_kk, then L_kk (lower, row-major)
+    __shared__ __attribute__((aligned(16))) double vt[NTL * TS];  // W = L_kk^-1 row-major; the output transposes of a column's tiles
+    const int lane = threadIdx.x, lr = lane >> 4, lc = lane & 15;
+    const int n_r = a.gp.n_r, n_c = a.n_c, n = a.n_ho - a.n_c, CS = a.fc_cs;
+    const long mT = (long)a.m * a.gp.T;
+    {
+        const long chain = a.chain0 + blockIdx.x;                 // one workgroup (= one wave) per chain
+        double* fc = a.fcache + (chain - a.fc_chain_base) * a.fc_stride;
+        double* fdinv = fc + (long)a.fc_cap * CS;
+        // the Schur complement (leading dimension n, both triangles) through a buffer descriptor: rows beyond n are beyond the
+        // buffer's end and read as zero without an address clamp; columns beyond n are masked on the value
+        const __amdgpu_buffer_rsrc_t Sr = __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(a.Sall + chain * mT * mT), 0, n * n * 8, 0x00020000);
+        unsigned vo[4];
+#pragma unroll
+        for (int v = 0; v < 4; ++v) vo[v] = (unsigned)(((4 * v + lr) * n + lc) * 8);
+        // the chain's cache entry through a descriptor too: a lane that has nothing to store names an offset beyond its end - the
+        // store is dropped without traffic and WITHOUT a branch (behind a store under an `if` hipcc's wait insertion cannot count the
+        // vector-memory operations in flight any more and turns every later wait for a load into s_waitcnt vmcnt(0))
+        const __amdgpu_buffer_rsrc_t Fr = __builtin_amdgcn_make_buffer_rsrc(fc, 0, (int)(a.fc_stride * 8), 0x00020000);
+        unsigned so[4];                                           // row 4 v + lr of a 16-row group, column lc
+#pragma unroll
+        for (int v = 0; v < 4; ++v) so[v] = (unsigned)((((long)(n_c + 4 * v + lr)) * CS + n_r + n_c + lc) * 8);
+        // tile (k, j), register v, this lane: element (16 k + 4 v + lr, 16 j + lc); the identity beyond n
+        // (the launcher picks NTL with 16 (NTL - 2) < n <= 16 NTL: only tile indices NTL - 2 and NTL - 1 can reach beyond n - every
+        // other tile needs no mask at all; hipcc hoists every lane mask of the unrolled kernel to its top and spills them)
+        auto load_tile = [&](auto kc, auto jcn) -> jc_d4 {
+            constexpr int k = decltype(kc)::value, j = decltype(jcn)::value;
+            jc_d4 t;
+#pragma unroll
+            for (int v = 0; v < 4; ++v)
+                t[v] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(Sr, vo[v], 128 * k * n + 128 * j, 0));
+            if constexpr (j >= NTL - 2) {
+                const bool cin = 16 * j + lc < n;
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    double val = cin ? t[v] : 0.0;
+                    if constexpr (k == j) val = (4 * v + lr == lc && !cin) ? 1.0 : val;      // the identity beyond n
+                    t[v] = val;
+                }
+            }
+            return t;
+        };
+        // Left-looking over tile rows: row k is R_kj = V_k (A_kj - sum_{p<k} R_pk^T R_pj), j >= k.  Alive at step k: the finished tiles
+        // R_pj with j >= k (column k's tiles leave for the cache at the end of the step) and the row in progress - at most
+        // (k + 1)(NTL - k) <= 20 tiles = 160 registers: two waves per SIMD, one's diagonal step (VALU / LDS) under the other's MFMAs.
+        jc_d4 U[NTT];
+        jc_d4 An[NTL];                                            // the A tiles of the next row (requested behind the panel products)
+        jc_for<0, NTL>([&](auto jcn) { An[decltype(jcn)::value] = load_tile(std::integral_constant<int, 0>{}, jcn); });
+        bool bad = false;
+#ifdef GPMPC_PHASE_TIMERS
+        long long jph[5] = {0, 0, 0, 0, 0};
+        long long jt = __builtin_readcyclecounter();
+#endif
+        jc_for<0, NTL>([&](auto kc) {
+            constexpr int k = decltype(kc)::value;
+            jc_d4 acc[NTL];
+            jc_for<k, NTL>([&](auto jcn) { acc[decltype(jcn)::value] = An[decltype(jcn)::value]; });
+            // the diagonal tile's products FIRST: the matrix pipe completes in order, so the VALU work on acc[k] below starts when ITS
+            // products are done and runs beside the products of the row's other tiles
+            jc_d4 Xn[k > 0 ? k : 1];
+            jc_for<0, k>([&](auto pc) {
+                constexpr int p = decltype(pc)::value;
+                Xn[p] = -U[jc_idx(p, k, NTL)];
+                acc[k] = jc_nat(Xn[p], U[jc_idx(p, k, NTL)], acc[k]);
+            });
+            jc_for<k + 1, NTL>([&](auto jcn) {
+                constexpr int j = decltype(jcn)::value;
+                jc_for<0, k>([&](auto pc) {
+                    constexpr int p = decltype(pc)::value;
+                    acc[j] = jc_nat(Xn[p], U[jc_idx(p, j, NTL)], acc[j]);
+                });
+            });
+            JCPH(1);
+            // ---- the diagonal tile in "lane = row" form (every DPP row of 16 lanes holds a copy and does the same work) ----------
+            jc_sync();                                            // the previous readers of blk / vt are done
+#pragma unroll
+            for (int v = 0; v < 4; ++v) blk[(4 * v + lr) * JC_LD + lc] = acc[k][v];
+            jc_sync();
+            double r[16];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const jc_d2 t = *reinterpret_cast<const jc_d2*>(&blk[lc * JC_LD + 2 * q]);
+                r[2 * q] = (2 * q <= lc) ? t.x : 0.0;
+                r[2 * q + 1] = (2 * q + 1 <= lc) ? t.y : 0.0;
+            }
+            // right-looking: after pivot j every later column takes its update at once - 15 - j INDEPENDENT DPP FMAs (lane i:
+            // A[i][q] -= L[i][j] L[q][j], L[q][j] = lane q's r[j]) instead of a chain of j dependent ones per pivot
+            // (a column of L leaves for LDS the moment it is final and a column of W' is born at its own pivot: 16 doubles alive
+            // between them, not 32)
+            double mydinv = 0.0;
+            double w[16];                                         // row lc of W' = D L^-1 (W'[i][:] = e_i - sum_k L[i][k] W[k][:])
+            jc_sync();                                            // every lane has read its row of blk
+            jc_for<0, 16>([&](auto jcn) {
+                constexpr int j = decltype(jcn)::value;
+                const double d = readlane_f64(r[j], j);
+                if (!(d > 0.0)) bad = true;
+                // v_rsq_f64 + ONE Newton step (3e-16 on 1 / sqrt, as rollout_one.hip) and sqrt = d / sqrt: six dependent operations on
+                // the serial spine of the tile instead of the twelve of sqrt_rsqrt_fast
+                double inv = __builtin_amdgcn_rsq(d);
+                inv = fma(inv, fma(-0.5 * d * inv, inv, 0.5), inv);
+                const double sd = d * inv;
+                const double lj = (lc > j) ? r[j] * inv : 0.0;    // L[i][j] below the diagonal, zero elsewhere
+                r[j] = (lc == j) ? sd : lj;
+                mydinv = (lc == j) ? inv : mydinv;
+                const double mj = lj * inv;                       // L[i][j] / L[j][j]: the multiplier of W'[j][:] for the rows below j
+                w[j] = (lc == j) ? 1.0 : 0.0;
+                if (lr == 0) blk[lc * JC_LD + j] = r[j];          // L_kk[lc][j] (zero above the diagonal)
+                // (r[j] and mj are VALU results of this step, w[] of the previous one: the first DPP read of each group carries the wait)
+                jc_for<j + 1, 16>([&](auto qc) {
+                    constexpr int q = decltype(qc)::value;
+                    jc_fnma_bcast<q, q == j + 1>(r[q], r[j], lj);
+                });
+                jc_for<0, j + 1>([&](auto cc) {
+                    constexpr int c = decltype(cc)::value;
+                    jc_fnma_self<j, c == 0>(w[c], mj);
+                });
+            });
+            if (lr == 0) {                                        // W = D^-1 W', row-major (above the diagonal: zero)
+#pragma unroll
+                for (int q = 0; q < 8; ++q)
+                    *reinterpret_cast<jc_d2*>(&vt[lc * JC_LD + 2 * q]) = jc_d2{w[2 * q] * mydinv, w[2 * q + 1] * mydinv};
+            }
+            // (1 / diag: an unconditional store as well; its slot sits behind the rows of the cache entry)
+            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(jc_u2, mydinv), Fr,
+                                                  (lr == 0 && 16 * k + lc < n) ? (unsigned)(((long)a.fc_cap * CS + n_c + 16 * k + lc) * 8) : 0x7ffff000u, 0, 0);
+            jc_sync();
+            jc_d4 V;
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                const int rr = 4 * v + lr;
+                V[v] = vt[lc * JC_LD + rr];                       // V[rr][lc] = W[lc][rr] (zero below the diagonal)
+                U[jc_idx(k, k, NTL)][v] = blk[lc * JC_LD + rr];   // R_kk[rr][lc] = L_kk[lc][rr] (zero below the diagonal)
+            }
+            JCPH(2);
+            // ---- the rest of the row on the matrix pipe; the next row's A tiles are requested behind it ------------------------
+            jc_for<k + 1, NTL>([&](auto jcn) {
+                constexpr int j = decltype(jcn)::value;
+                const jc_d4 zero = {0.0, 0.0, 0.0, 0.0};
+                U[jc_idx(k, j, NTL)] = jc_nat(V, acc[j], zero);
+            });
+            if constexpr (k + 1 < NTL)
+                jc_for<k + 1, NTL>([&](auto jcn) { An[decltype(jcn)::value] = load_tile(std::integral_constant<int, k + 1>{}, jcn); });
+            JCPH(3);
+            // ---- column k is final: the factor's rows are R's columns - its k + 1 tiles transposed through LDS (one buffer each, one
+            // hand-over for all of them), 16 doubles = 128 bytes per row segment -------------------------------------------------------
+            jc_sync();
+            jc_for<0, k + 1>([&](auto pc) {
+                constexpr int p = decltype(pc)::value;
+#pragma unroll
+                for (int v = 0; v < 4; ++v) vt[p * TS + (4 * v + lr) * JC_LD + lc] = U[jc_idx(p, k, NTL)][v];
+            });
+            jc_sync();
+            jc_for<0, k + 1>([&](auto pc) {
+                constexpr int p = decltype(pc)::value;            // tile (p, k): L[16 k + cc][16 p + rr] = R_pk[rr][cc]
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    const double val = vt[p * TS + lc * JC_LD + 4 * v + lr];
+                    bool ok = true;
+                    if constexpr (k >= NTL - 2) ok = 16 * k + 4 * v + lr < n;
+                    if constexpr (p == k) ok = ok && (lc <= 4 * v + lr);
+                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(jc_u2, val), Fr, ok ? so[v] : 0x7ffff000u,
+                                                          (16 * k * CS + 16 * p) * 8, 0);
+                }
+            });
+            JCPH(4);
+        });
+#ifdef GPMPC_PHASE_TIMERS
+        if (chain == a.chain0 && lane == 0)
+            for (int i = 0; i < 5; ++i) g_jc_phase[i] = jph[i];
+#endif
+        const bool any_bad = __builtin_amdgcn_ballot_w64(bad) != 0;
+        if (lane == 0) a.info[chain] = (a.info_in ? a.info[chain] : 0) | (any_bad ? GPMPC_INFO_TRAIN_CHOL_FAIL : 0);
+    }
+}
+
+bool joint_chol_mfma_eligible(int n_new) { return n_new >= 1 && n_new <= 128; }
+
+// the new hallucinated rows of the chains [a.chain0, a.chain1) against the new columns: Cholesky of the Schur complement in a.Sall
+int joint_chol_mfma_launch(const JointArgs& a, hipStream_t st) {
+    const int n = a.n_ho - a.n_c;
+    if (!joint_chol_mfma_eligible(n)) return fail(GPMPC_E_UNSUPPORTED, "joint_chol_mfma_kernel: 1..128 new rows");
+    const long nch = a.chain1 - a.chain0;
+    const dim3 g((unsigned)nch), b(64);
+    const int ntl = (n + 15) / 16;
+    if (ntl <= 2) hipLaunchKernelGGL(joint_chol_mfma_kernel<2>, g, b, 0, st, a);
+    else if (ntl <= 4) hipLaunchKernelGGL(joint_chol_mfma_kernel<4>, g, b, 0, st, a);
+    else if (ntl <= 6) hipLaunchKernelGGL(joint_chol_mfma_kernel<6>, g, b, 0, st, a);
+    else hipLaunchKernelGGL(joint_chol_mfma_kernel<8>, g, b, 0, st, a);
+    GPMPC_HIP_CHECK(hipGetLastError());
+    return GPMPC_OK;
+}
+
+}  // namespace gpmpc
+
+extern "C" int gpmpc_debug_read_joint_chol_phases(long long* out /*[host] 8*/) {
+    GPMPC_HIP_CHECK(hipMemcpyFromSymbol(out, HIP_SYMBOL(gpmpc::g_jc_phase), 8 * sizeof(long long)));
+    return GPMPC_OK;
+}
