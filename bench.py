@@ -268,121 +268,111 @@ def extra_closed_loop(sg, _lib, wl, name="params_car_residual", Ns=1024, H=40, i
     """Joint draws of the closed loop (mode J), per SQP iteration k (reference src/solver.py:84-94); linearisation points
     from the deterministic surrogate of SURVEY.md 8d (sample mean of the previous iteration's prediction).
     Default: BASELINE configs[4] on its per-GPU shard, AS SHIPPED (params_car_residual.yaml incl. Dyn_gp_jitter 1e-20 -> the
-    eigendecomposition root): Ns = 8192 / 8 = 1024, H = 40, k = 0..3 and k = 0 of the next MPC step.  Also used for
-    configs[1]'s mode-J points (pendulum, Ns = 1024, H = 30, k = 0 and k = 1; Cholesky root, jitter 1e-6).
-    `ms_per_draw`: HIP events around the draw (min of 4); `wall_ms_per_iteration`: wall clock of the real SQP iteration of
-    the facade (train -> x_hat -> draw + Jacobians + D2H of the three arrays), synchronised at both ends, after one throw-away
-    iteration on a second Agent (process-wide first-use allocations); k = 0 of MPC step 0 still contains the once-per-Agent
-    plan of the real data (plan_kernel + its host set-up, ~1.1 ms)."""
+    eigendecomposition root): Ns = 8192 / 8 = 1024, H = 40, k = 0..3 of MPC step 0 and of the steady-state MPC steps.  Also used
+    for configs[1]'s mode-J points (pendulum, Ns = 1024, H = 30, k = 0 and k = 1; Cholesky root, jitter 1e-6).
+
+    Every draw is timed ONCE, in the loop's own sequence (HIP events around Agent.sample_gp inside the real SQP iteration): from
+    round 6 a draw leaves its own X / S behind as the next call's new factor rows (gpmpc_joint_sample_pending), so a draw cannot
+    be repeated from a rewound cache without changing what it does.  `ms_per_draw`: the minimum over the repetitions of the same
+    (MPC step class, k) - two fresh Agents, and for the steady state the MPC steps 1 and 2 of each; `wall_ms_per_iteration`: wall
+    clock of the whole iteration through Agent.sqp_linearisation (train -> upload -> batch_x_hat -> draw -> Jacobians + p_lin ->
+    download of p_lin), same minimum.  MPC step 0's k = 0 contains the once-per-Agent plan of the real data (~1.1 ms wall)."""
+    import ctypes as C
     import warnings
-    p = wl.closed_loop_params(name, Ns, H, 2, iters)
+    n_steps = 3 if next_step else 1
+    p = wl.closed_loop_params(name, Ns, H, n_steps, iters)
     p["common"]["use_cuda"] = True
     p["agent"]["base_sample_generator"] = "counter"
-    agent = sg.Agent(p, sg.make_env(p))
-    g_ny, T = agent.g_ny, agent.in_dim_y
-    x0 = np.asarray(p["env"]["start"], dtype=np.float64)[: agent.nx]
-    u_h = wl.synthetic_u_ff(agent.nu, H)
-    x_h = np.tile(x0, (H, Ns))
-    out = []
-
-    def iteration(step, k, x_h):
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        agent.train_hallucinated_dynGP(k)                       # once per iteration: at k == 0 it resets the hallucinated set
-        torch.cuda.synchronize()
-        train_ms = (time.perf_counter() - t0) * 1e3
-        bx = agent.get_batch_x_hat(x_h, u_h)
-        g_xu = agent.env_model.get_g_xu_hat(bx).contiguous()
-        z = agent.epistimic_random_vector[step][k]
-        # the factor cache holds the rows of the slots the previous draw conditioned on; every timed draw starts from
-        # that state (not from the state the previous timed draw left: that would be all rows cached)
-        cache = agent._ws_cache.get("joint_factor_cache")
-        held = cache.n_valid if cache is not None else 0
-
-        def rewind():
-            c = agent._ws_cache.get("joint_factor_cache")       # created by the first draw that has hallucinated rows
-            if c is not None:
-                c.rewind(held)
-
-        def draw():
-            rewind()
-            agent.sample_gp(g_xu, base_samples=z)
-
-        for _ in range(3 if (k or step) else 40):               # the very first draw also brings the clocks up
-            draw()
-        torch.cuda.synchronize()
-        import ctypes as C
-        ework = (C.c_ulonglong * 4)()
-        raw = _lib.load()
-        raw.gpmpc_debug_read_eigh_work(ework, 1)                # reset the eigh kernel's work counters
-        ms, ms_min = time_launches(draw, 4)
-        torch.cuda.synchronize()
-        raw.gpmpc_debug_read_eigh_work(ework, 0)
-        n_draws = 4                                             # time_launches(draw, 4)
-        rewind()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()                                # the rest of the real iteration of the facade, wall clock
-        gp_val, _, _ = agent.dyn_fg_jacobians(agent.get_batch_x_hat(x_h, u_h), k)   # appends the draw to the hallucinated set
-        torch.cuda.synchronize()
-        wall_ms = train_ms + (time.perf_counter() - t0) * 1e3
-        info = agent.model_i_call.last_info
-        n_ho = int(agent.model_i.h_slots.numel())
-        n_c = int(agent.model_i_call.n_cached_rows)
-        n_r = int(agent.model_i.plan.n_r)
-        flop_ref = wl.flop_mode_j(g_ny, T, n_r, H, n_ho // (T * H)) * Ns       # what the reference's call computes
-        flop = flop_ref - wl.flop_mode_j_cached_rows(g_ny, n_r, n_c) * Ns      # what this call executes
-        eigh = bool((info & _lib.INFO_ROOT_EIGH).all().item())
-        mfma = raw.gpmpc_joint_last_path() == _lib.JOINT_MFMA     # the matrix-pipe path of gpmpc_joint_sample (ABI 7) ran
-        jk = ("joint_test_mfma_kernel<3> (factor extension) + joint_kernel<3,16,1,128,4> (Cholesky of the Schur complement) + "
-              "joint_test_mfma_kernel<3> (test rows, mean, S) + joint_kernel<3,16,1,128,4> (root + sample)") if mfma \
-            else "joint_kernel<3,NB,1,NT,W>"
-        out.append({"mpc_step": step, "k": k, "n_o": int(n_r + n_ho), "joint_path": "mfma" if mfma else "valu",
-                    "cached_rows": n_c, "executed_flop_frac": flop / flop_ref, "ms_per_draw": ms_min,
-                    "wall_ms_per_iteration": wall_ms,
-                    "trajectory_steps_per_s": Ns * H / (ms_min * 1e-3),
-                    "eigh_root": eigh, "finite": bool(np.isfinite(gp_val).all()),
-                    "roofline": roofline(flop, ms_min, jk + (" + joint_eigh_kernel<3,2>" if eigh else ""),
-                                         8 * (2 * agent.nx + 2 * g_ny * T) * Ns * H,
-                                         bound=("fp64_mfma" if mfma else "fp64_valu"),
-                                         note="joint draw incl. the facade's info reduction; FLOP = SURVEY 8d mode-J "
-                                              "formula minus the factor rows served from the cache (`cached_rows`; "
-                                              "`executed_flop_frac` of what the reference's call computes)"
-                                              + ("; the eigendecomposition root is counted separately: `eigh`" if eigh else ""),
-                                         **({"eigh": {"flop_per_launch": ework[0] / n_draws,
-                                                      "mean_rank": ework[2] / max(ework[1], 1),
-                                                      "mean_sweeps": ework[3] / max(ework[1], 1),
-                                                      "chains_per_launch": ework[1] / n_draws,
-                                                      "note": "work joint_eigh_kernel counted itself over the timed draws: pivoted-"
-                                                              "Cholesky passes + MFMA Gram tiles + Jacobi rounds actually run + "
-                                                              "replay + y = mean + L t (csrc/joint_eigh.hpp g_eigh_work); inside "
-                                                              "`ms_per_draw`, not inside `flop_per_launch` of this roofline object"}}
-                                            if eigh else {}))})
-        mean_next = gp_val[:, :, :, 0].mean(axis=0).T
-        return np.tile(np.vstack([x0[None, :], mean_next[:-1]]), (1, Ns))
-
+    raw = _lib.load()
+    ework = (C.c_ulonglong * 4)()
+    best = {}
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    xg, w = np.zeros(H), np.zeros(H)
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
-        # one throw-away iteration on a second Agent: the process-wide one-time costs of the facade (pinned staging buffers of
-        # the caching host allocator, first-use device allocations) are not part of an SQP iteration's wall clock
-        # (two iterations: the second one allocates the factor cache and is the first to launch the matrix-pipe kernels)
-        warm = sg.Agent(p, sg.make_env(p))
-        warm.mpc_iteration(0)
-        for kw in range(2):
-            warm.train_hallucinated_dynGP(kw)
-            warm.dyn_fg_jacobians(warm.get_batch_x_hat(x_h, u_h), kw)
-        del warm
-        torch.cuda.synchronize()
-        agent.mpc_iteration(0)
-        for k in range(iters):
-            x_h = iteration(0, k, x_h)
-        if next_step:
-            # iteration 0 of the NEXT MPC step: the reference resets the hallucinated set only after the model has been
-            # built (src/agent.py:261-272), so this draw conditions on all the iterations' points of the previous step
-            agent.mpc_iteration(1)
-            iteration(1, 0, x_h)
+        for rep in range(3):                                      # rep 0: throw-away (process-wide first-use costs: allocator, first launches)
+            agent = sg.Agent(p, sg.make_env(p))
+            g_ny, T = agent.g_ny, agent.in_dim_y
+            hbm_b = 8 * (2 * agent.nx + 2 * g_ny * T) * Ns * H
+            x0 = np.asarray(p["env"]["start"], dtype=np.float64)[: agent.nx]
+            u_h = wl.synthetic_u_ff(agent.nu, H)
+            x_h = np.tile(x0, (H, Ns))
+            inner = agent.sample_gp
+
+            def timed_draw(x_input, base_samples=None, _inner=inner):
+                e0.record()
+                y = _inner(x_input, base_samples=base_samples)
+                e1.record()
+                return y
+
+            agent.sample_gp = timed_draw
+            for step in range(n_steps if rep else min(n_steps, 2)):
+                agent.mpc_iteration(step)
+                for k in range(iters):
+                    raw.gpmpc_debug_read_eigh_work(ework, 1)      # reset the eigh kernel's work counters
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    agent.sqp_linearisation(x_h, u_h, k, xg, w)
+                    torch.cuda.synchronize()
+                    wall_ms = (time.perf_counter() - t0) * 1e3
+                    ms = e0.elapsed_time(e1)
+                    raw.gpmpc_debug_read_eigh_work(ework, 0)
+                    gp_val = agent._last_device_jacobians[0]
+                    mean_next = gp_val[:, :, :, 0].mean(dim=0).T.cpu().numpy()
+                    x_h = np.tile(np.vstack([x0[None, :], mean_next[:-1]]), (1, Ns))
+                    if rep == 0:
+                        continue
+                    post = agent.model_i_call
+                    info = post.last_info
+                    n_ho = int(agent.model_i.h_slots.numel())
+                    n_c = int(post.n_cached_rows)
+                    n_r = int(agent.model_i.plan.n_r)
+                    pend = bool(getattr(post, "used_pending", False))
+                    key = (min(step, 1), k)
+                    flop_ref = wl.flop_mode_j(g_ny, T, n_r, H, n_ho // (T * H)) * Ns       # what the reference's call computes
+                    n_skip = n_ho if pend else n_c                      # factor rows this call did not have to form against old columns
+                    flop = flop_ref - wl.flop_mode_j_cached_rows(g_ny, n_r, n_skip) * Ns \
+                        + (wl.flop_chol(g_ny, n_ho - n_c) * Ns if pend else 0.0)             # (+ the Cholesky of the pending block)
+                    eigh = bool((info & _lib.INFO_ROOT_EIGH).all().item())
+                    mfma = raw.gpmpc_joint_last_path() == _lib.JOINT_MFMA
+                    rec = {"mpc_step": min(step, 1), "k": k, "n_o": int(n_r + n_ho), "joint_path": "mfma" if mfma else "valu",
+                           "cached_rows": n_c, "pending_rows_used": pend, "executed_flop_frac": flop / flop_ref, "ms_per_draw": ms,
+                           "wall_ms_per_iteration": wall_ms, "trajectory_steps_per_s": Ns * H / (ms * 1e-3), "eigh_root": eigh,
+                           "finite": bool(torch.isfinite(gp_val).all().item()),
+                           "_flop": flop, "_eigh": (ework[0], ework[1], ework[2], ework[3])}
+                    old = best.get(key)
+                    if old is None or ms < old["ms_per_draw"]:
+                        rec["wall_ms_per_iteration"] = min(wall_ms, old["wall_ms_per_iteration"]) if old else wall_ms
+                        best[key] = rec
+                    else:
+                        old["wall_ms_per_iteration"] = min(wall_ms, old["wall_ms_per_iteration"])
+            del agent
+            torch.cuda.synchronize()
+    out = []
+    for key in sorted(best):
+        rec = best[key]
+        flop, ew = rec.pop("_flop"), rec.pop("_eigh")
+        mfma, eigh, pend = rec["joint_path"] == "mfma", rec["eigh_root"], rec["pending_rows_used"]
+        jk = (("joint_chol_mfma_kernel (pending rows: Cholesky of S + noise in place)" if pend else
+               "joint_test_mfma_kernel<3> (factor extension) + joint_chol_mfma_kernel") +
+              " + joint_test_mfma_kernel<3> (test rows, mean, S) + joint_kernel<3,16,1,128,4> (root + sample)") if mfma \
+            else "joint_kernel<3,NB,1,NT,W>"
+        rec["roofline"] = roofline(flop, rec["ms_per_draw"], jk + (" + joint_eigh_kernel<3,2>" if eigh else ""),
+                                   hbm_b,
+                                   bound=("fp64_mfma" if mfma else "fp64_valu"),
+                                   note="joint draw incl. the facade's info reduction, timed once in the loop's own sequence; FLOP = "
+                                        "SURVEY 8d mode-J formula minus the factor rows this call did not form (`cached_rows`, or all of "
+                                        "them with `pending_rows_used`; `executed_flop_frac` of what the reference's call computes)"
+                                        + ("; the eigendecomposition root is counted separately: `eigh`" if eigh else ""),
+                                   **({"eigh": {"flop_per_launch": float(ew[0]), "mean_rank": ew[2] / max(ew[1], 1),
+                                                "mean_sweeps": ew[3] / max(ew[1], 1), "chains_per_launch": float(ew[1]),
+                                                "note": "work joint_eigh_kernel counted itself over the draw (csrc/joint_eigh.hpp "
+                                                        "g_eigh_work); inside `ms_per_draw`, not inside `flop_per_launch`"}}
+                                      if eigh else {}))
+        out.append(rec)
     return {"id": tag, "workload": label or ("BASELINE configs[4] per-GPU shard as shipped: params_car_residual (Dyn_gp_jitter 1e-20), "
-                                  "mode J, Ns=1024 (8192 / 8 GPUs), H=40, SQP iterations k=0..3 of MPC step 0 and k=0 of MPC "
-                                  "step 1"), "iterations": out}
+                                             "mode J, Ns=1024 (8192 / 8 GPUs), H=40, SQP iterations k=0..3 of MPC step 0 "
+                                             "(mpc_step 0) and of the steady-state MPC steps (mpc_step 1)"), "iterations": out}
 
 
 def extra_car_joint_cfg3_size(sg, _lib, wl):

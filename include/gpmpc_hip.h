@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define GPMPC_ABI_VERSION 8
+#define GPMPC_ABI_VERSION 9
 
 #define GPMPC_MAX_NY 4   /* GP outputs            (reference agent.g_dim.ny : 1 pendulum1D, 3 car)          */
 #define GPMPC_MAX_D  4   /* GP input dimension    (g_nx + g_nu : 2 in all shipped configs)                 */
@@ -283,6 +283,34 @@ int    gpmpc_joint_sample(const gpmpc_gp_desc_t* gp, const void* plan, const dou
                           int32_t root_mode, int32_t* info,
                           void* ws, size_t ws_bytes, void* stream,
                           void* factor_cache, int32_t cache_rows, int32_t n_cached);
+
+/*
+ * gpmpc_joint_sample_pending (ABI 9) - gpmpc_joint_sample with PENDING ROWS of the factor cache.
+ * In the SQP loop the points a draw is made at are appended to the hallucinated set (reference src/agent.py:629-641, then
+ * :164-202): the next call's new slots ARE this call's test slots, and what this call computes for them - X = L^-1 K_o* and
+ * S = K** - X^T X - is the new rows' block of the factor against the old columns and their Schur complement (up to the likelihood
+ * noise of A.3 on its diagonal).  pending = bit mask:
+ *   GPMPC_PENDING_WRITE  this call may also write X^T into the cache rows n_ho .. n_ho + m*T - 1 and S into their diagonal block
+ *                        (matrix-pipe path, one test-mode launch, the caller's cache with room for the rows; T = 3, m*T <= 128);
+ *                        gpmpc_joint_pending_written() says whether it did;
+ *   GPMPC_PENDING_USE    the CALLER vouches that the rows n_cached .. n_ho - 1 of the cache were written that way by the previous
+ *                        call (same cache, h_slots[n_cached:] = all tasks of exactly that call's test points, in order, and
+ *                        h_slots[:n_cached] the set that call conditioned on): the factor extension is then the Cholesky of
+ *                        (S + noise) in place and nothing else.  A permission: where the path or the shapes do not allow it the
+ *                        rows are recomputed.
+ * Results agree with gpmpc_joint_sample to rounding (the new rows are the same sums in another order).
+ */
+#define GPMPC_PENDING_USE   1
+#define GPMPC_PENDING_WRITE 2
+int    gpmpc_joint_sample_pending(const gpmpc_gp_desc_t* gp, const void* plan, const double* X_r,
+                                  int64_t Ns, int32_t n_h, const double* X_h, const double* Y_h,
+                                  const int32_t* h_slots, int32_t n_ho, int32_t m,
+                                  const double* X_s, const double* z,
+                                  double var_zero_thr, double beta, int32_t apply_clip,
+                                  double* mean, double* var, double* y, double* covar, double* root,
+                                  int32_t root_mode, int32_t* info, void* ws, size_t ws_bytes, void* stream,
+                                  void* factor_cache, int32_t cache_rows, int32_t n_cached, int32_t pending);
+int    gpmpc_joint_pending_written(void);    /* 1: the last gpmpc_joint_sample[_pending] call wrote pending rows */
 
 /*
  * The two paths of gpmpc_joint_sample (ABI 7).  GPMPC_JOINT_VALU: one launch, one label row per thread, blocked left-looking

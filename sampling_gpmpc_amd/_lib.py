@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libgpmpc_hip.so")
 
 MAX_NY, MAX_D, MAX_T, MAX_NX, MAX_NU = 4, 4, 5, 8, 4
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 ENV_PENDULUM1D, ENV_CAR_RESIDUAL = 0, 1
 MODE_INDEPENDENT, MODE_RECONDITIONED = 0, 1
@@ -31,6 +31,7 @@ INFO_STATE_FULL = 0x0200
 
 ROOT_AUTO, ROOT_EIGH, ROOT_CHOLESKY = 0, 1, 2
 # gpmpc_rollout_pin_kernel / gpmpc_rollout_last_kernel (include/gpmpc_hip.h)
+PENDING_USE, PENDING_WRITE = 1, 2                      # gpmpc_joint_sample_pending
 JOINT_AUTO, JOINT_VALU, JOINT_MFMA = 0, 1, 2          # gpmpc_joint_pin_path / gpmpc_joint_last_path
 KERNEL_AUTO, KERNEL_GENERIC, KERNEL_FAST, KERNEL_INDEP, KERNEL_TILES, KERNEL_ONE = -1, 0, 1, 2, 3, 4
 
@@ -71,6 +72,9 @@ SYMBOLS = {
     "gpmpc_joint_cache_bytes": (_SZ, [C.POINTER(GpDesc), _I64, _I32]),
     "gpmpc_joint_sample": (C.c_int, [C.POINTER(GpDesc), _P, _P, _I64, _I32, _P, _P, _P, _I32, _I32, _P, _P,
                                      _D, _D, _I32, _P, _P, _P, _P, _P, _I32, _P, _P, _SZ, _P, _P, _I32, _I32]),
+    "gpmpc_joint_sample_pending": (C.c_int, [C.POINTER(GpDesc), _P, _P, _I64, _I32, _P, _P, _P, _I32, _I32, _P, _P,
+                                             _D, _D, _I32, _P, _P, _P, _P, _P, _I32, _P, _P, _SZ, _P, _P, _I32, _I32, _I32]),
+    "gpmpc_joint_pending_written": (C.c_int, []),
     "gpmpc_joint_pin_path": (C.c_int, [_I32]),
     "gpmpc_joint_last_path": (C.c_int, []),
     "gpmpc_assemble_jacobians": (C.c_int, [C.POINTER(GpDesc), C.POINTER(EnvDesc), _I64, _I32, _P, _P, _P, _P, _P, _P]),

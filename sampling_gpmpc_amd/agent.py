@@ -434,7 +434,14 @@ class Agent(object):
             else:
                 y[[slot], :, :, :] = self.model_i_call.mean[[slot], :, :, :]
         if not nothing_drawn:
+            n_before = int(self._hall_X.shape[2])
             self.update_hallucinated_Dyn_dataset(g_in, y)
+            # the points appended are the points the draw was made at (no min-distance filter dropped or masked any): the draw's
+            # own X / S are the new rows of the factor (gpmpc_joint_sample_pending) - said here, checked by JointFactorCache.pending_ok
+            if cfg["Dyn_gp_min_data_dist"] < 0.0 and int(self._hall_X.shape[2]) == n_before + int(g_in.shape[2]):
+                self._ws_cache["joint_pending_points"] = (self._hall_gen, int(self._hall_X.shape[2]), self.model_i_call)
+            else:
+                self._ws_cache.pop("joint_pending_points", None)
         return y
 
     def dyn_fg_jacobians_device(self, xu_hat, sqp_iter):

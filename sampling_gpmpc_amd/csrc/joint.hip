@@ -1155,12 +1155,27 @@ size_t gpmpc_joint_workspace_bytes(const gpmpc_gp_desc_t* gp, int64_t Ns, int32_
     return align_up((size_t)w.total * sizeof(double), 256);
 }
 
+static int g_joint_pending_written = 0;    // gpmpc_joint_pending_written
+
+int gpmpc_joint_pending_written(void) { return g_joint_pending_written; }
+
 int gpmpc_joint_sample(const gpmpc_gp_desc_t* gp, const void* plan, const double* X_r, int64_t Ns, int32_t n_h,
                        const double* X_h, const double* Y_h, const int32_t* h_slots, int32_t n_ho, int32_t m,
                        const double* X_s, const double* z, double var_zero_thr, double beta, int32_t apply_clip,
                        double* mean, double* var, double* y, double* covar, double* root, int32_t root_mode,
                        int32_t* info, void* ws, size_t ws_bytes, void* stream, void* factor_cache, int32_t cache_rows,
                        int32_t n_cached) {
+    return gpmpc_joint_sample_pending(gp, plan, X_r, Ns, n_h, X_h, Y_h, h_slots, n_ho, m, X_s, z, var_zero_thr, beta, apply_clip, mean,
+                                      var, y, covar, root, root_mode, info, ws, ws_bytes, stream, factor_cache, cache_rows, n_cached, 0);
+}
+
+int gpmpc_joint_sample_pending(const gpmpc_gp_desc_t* gp, const void* plan, const double* X_r, int64_t Ns, int32_t n_h,
+                               const double* X_h, const double* Y_h, const int32_t* h_slots, int32_t n_ho, int32_t m,
+                               const double* X_s, const double* z, double var_zero_thr, double beta, int32_t apply_clip,
+                               double* mean, double* var, double* y, double* covar, double* root, int32_t root_mode,
+                               int32_t* info, void* ws, size_t ws_bytes, void* stream, void* factor_cache, int32_t cache_rows,
+                               int32_t n_cached, int32_t pending) {
+    g_joint_pending_written = 0;
     if (int rc = check_gp(gp)) return rc;
     if (!plan || !X_r || !X_s || !z || !mean || !var || !y || !info || !ws)
         return fail(GPMPC_E_ARG, "gpmpc_joint_sample: NULL pointer");
@@ -1219,6 +1234,7 @@ int gpmpc_joint_sample(const gpmpc_gp_desc_t* gp, const void* plan, const double
         a.fc_stride = 0;
     }
     a.fc_chain_base = 0;
+    a.pend_write = a.pend_use = 0;
     a.phase = JOINT_PHASE_ALL;
     a.info_in = 0;
     a.chain0 = 0;
@@ -1297,6 +1313,12 @@ int gpmpc_joint_sample(const gpmpc_gp_desc_t* gp, const void* plan, const double
         static const char* f0env = getenv("GPMPC_JOINT_MFMA_FACTOR_FIRST");
         const bool mfma_factor = n_new > 0 && n_new <= mT && (b.n_c > 0 || !(f0env && atoi(f0env) == 0)) &&
                                  joint_mfma_eligible(a.gp.n_r, b.n_c, n_new, gp->T) && !(fenv && atoi(fenv) == 0);
+        // pending rows (see JointArgs): used when the caller says so and the shapes allow it; written by the one-launch test mode
+        // into the caller's cache when the rows fit
+        // (GPMPC_PENDING_USE is a permission: where the shapes do not allow it - or on the VALU path - the rows are recomputed)
+        const bool pend_use = (pending & GPMPC_PENDING_USE) && own && b.n_c > 0 && gp->T == 3 && joint_chol_mfma_eligible(n_new);
+        const bool pend_write = (pending & GPMPC_PENDING_WRITE) && own && !split && gp->T == 3 && n_ho + mT <= a.fc_cap &&
+                                joint_chol_mfma_eligible(mT);
         const long step = split ? w.xt_slots : (own ? nchains : w.tc_slots);
         for (long c0 = 0; c0 < nchains; c0 += step) {
             b.chain0 = c0;
@@ -1304,7 +1326,15 @@ int gpmpc_joint_sample(const gpmpc_gp_desc_t* gp, const void* plan, const double
             b.fc_chain_base = own ? 0 : c0;
             b.info_in = 0;
             b.abandon_root = 0;
-            if (n_new > 0) {
+            if (n_new > 0 && pend_use) {
+                // the caller vouches that the cache rows n_c .. n_ho - 1 hold the previous call's X^T and S (its test points are
+                // this call's new slots): the factor extension is the Cholesky of (S + noise) in place, nothing else
+                b.pend_use = 1;
+                if (int rc = joint_chol_mfma_launch(b, st)) return rc;
+                b.pend_use = 0;
+                GPMPC_HIP_CHECK(hipGetLastError());
+                b.info_in = 1;
+            } else if (n_new > 0) {
                 if (mfma_factor) {
                     b.mfma_mode = JOINT_MFMA_FACTOR;
                     if (int rc = joint_mfma_launch(b, st)) return rc;
@@ -1331,12 +1361,15 @@ int gpmpc_joint_sample(const gpmpc_gp_desc_t* gp, const void* plan, const double
                 b.mfma_mode = JOINT_MFMA_TEST_BOTTOM;
             } else {
                 b.mfma_mode = JOINT_MFMA_TEST;
+                b.pend_write = pend_write ? 1 : 0;
             }
             if (int rc = joint_mfma_launch(b, st)) return rc;
+            b.pend_write = 0;
             b.phase = JOINT_PHASE_TAIL;
             b.abandon_root = abandon_for(mT);
             launch(b, mT);
         }
+        g_joint_pending_written = pend_write ? 1 : 0;
     } else {
         // (Measured and dropped: for conditioning sets beyond joint_test_mfma_kernel's 416 slots - k = 0 of the MPC steps after the first,
         // 45 + 480 slots at configs[4] - the factor extension alone on the matrix pipe and the test rows here with every

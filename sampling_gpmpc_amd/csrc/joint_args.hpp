@@ -68,6 +68,13 @@ struct JointArgs {
     long chain0, chain1;    // the chains of this launch: [chain0, chain1)
     int mfma_mode;          // joint_test_mfma_kernel: JOINT_MFMA_TEST / _FACTOR / _TEST_TOP / _TEST_BOTTOM
     double* xbuf;           // TOP writes, BOTTOM reads: X tiles of the chains [chain0, chain1), JOINT_MFMA_XBUF_DOUBLES each
+    // PENDING ROWS (round 6).  In the SQP loop the points a draw is made at become the next call's new hallucinated points
+    // (reference src/agent.py:629-641 then :164-202), so the draw's own X = L^-1 K_o* IS the new rows' block against the old columns
+    // and its S = K** - X^T X the Schur complement (up to the likelihood noise on the diagonal).  pend_write: the test-mode launch
+    // also writes X^T into the cache rows n_ho .. n_ho + m T - 1 and S into their diagonal block.  pend_use: the caller vouches
+    // that the cache rows n_c .. n_ho - 1 hold exactly that from the previous call - the factor extension is then only the
+    // Cholesky of (block + noise), in place (joint_chol_mfma_kernel), no JOINT_MFMA_FACTOR launch.
+    int pend_write, pend_use;
 };
 
 // joint_mfma.hip ---------------------------------------------------------------------------------------------------------

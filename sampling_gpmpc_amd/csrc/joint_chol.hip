@@ -98,12 +98,18 @@ __global__ __launch_bounds__(64, (NTL == 8) ? GPMPC_JC_OCC8 : 2) void joint_chol
         const long chain = a.chain0 + blockIdx.x;                 // one workgroup (= one wave) per chain
         double* fc = a.fcache + (chain - a.fc_chain_base) * a.fc_stride;
         double* fdinv = fc + (long)a.fc_cap * CS;
-        // the Schur complement (leading dimension n, both triangles) through a buffer descriptor: rows beyond n are beyond the
-        // buffer's end and read as zero without an address clamp; columns beyond n are masked on the value
-        const __amdgpu_buffer_rsrc_t Sr = __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(a.Sall + chain * mT * mT), 0, n * n * 8, 0x00020000);
+        // the Schur complement (both triangles) through a buffer descriptor: rows beyond n are beyond the buffer's end and read as
+        // zero without an address clamp; columns beyond n are masked on the value.  It sits in the chain's S buffer (leading dimension
+        // n: JOINT_MFMA_FACTOR left it there) or - pend_use - in the diagonal block of the very cache rows this kernel writes (leading
+        // dimension CS: the previous call's test-mode launch left S = K** - X^T X there; the likelihood noise of the rows' tasks goes
+        // onto the diagonal here).  In place: a tile is read a whole step before the first store into its rows.
+        const bool pend = a.pend_use != 0;
+        const int ldS = pend ? CS : n;
+        const double* Sbase = pend ? fc + (long)n_c * CS + n_r + n_c : a.Sall + chain * mT * mT;
+        const __amdgpu_buffer_rsrc_t Sr = __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(Sbase), 0, ((n - 1) * ldS + n) * 8, 0x00020000);
         unsigned vo[4];
 #pragma unroll
-        for (int v = 0; v < 4; ++v) vo[v] = (unsigned)(((4 * v + lr) * n + lc) * 8);
+        for (int v = 0; v < 4; ++v) vo[v] = (unsigned)(((4 * v + lr) * ldS + lc) * 8);
         // the chain's cache entry through a descriptor too: a lane that has nothing to store names an offset beyond its end - the
         // store is dropped without traffic and WITHOUT a branch (behind a store under an `if` hipcc's wait insertion cannot count the
         // vector-memory operations in flight any more and turns every later wait for a load into s_waitcnt vmcnt(0))
@@ -119,7 +125,15 @@ __global__ __launch_bounds__(64, (NTL == 8) ? GPMPC_JC_OCC8 : 2) void joint_chol
             jc_d4 t;
 #pragma unroll
             for (int v = 0; v < 4; ++v)
-                t[v] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(Sr, vo[v], 128 * k * n + 128 * j, 0));
+                t[v] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(Sr, vo[v], 128 * k * ldS + 128 * j, 0));
+            if constexpr (k == j) {
+                if (pend) {                                       // (uniform) + noise of the row's task on the diagonal
+                    const int tk = a.h_slots[n_c + min(16 * k + lc, n - 1)] % 3;
+                    const double nz = (tk == 0) ? a.gp.noise[0] : ((tk == 1) ? a.gp.noise[1] : a.gp.noise[2]);
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) t[v] += (4 * v + lr == lc) ? nz : 0.0;
+                }
+            }
             if constexpr (j >= NTL - 2) {
                 const bool cin = 16 * j + lc < n;
 #pragma unroll

@@ -699,6 +699,21 @@ __global__ __launch_bounds__(JM_THREADS) void joint_test_mfma_kernel(const Joint
                     }
                 }
             }
+            if (a.pend_write && active) {                       // (uniform; test mode, one launch: the next call's new rows)
+                const int ln = jm_lane_now();
+                const int col = 16 * I0 + (ln & 15), sl = 16 * j + 4 * (ln >> 4);
+                if (col < mT) {
+                    double* dst = fc + (long)(a.n_ho + col) * CS + sl;
+                    if (sl + 3 < n_o) {
+                        *reinterpret_cast<jm_d2*>(dst) = jm_d2{x[0], x[1]};
+                        *reinterpret_cast<jm_d2*>(dst + 2) = jm_d2{x[2], x[3]};
+                    } else {
+#pragma unroll
+                        for (int v = 0; v < 4; ++v)
+                            if (sl + v < n_o) dst[v] = x[v];
+                    }
+                }
+            }
             if (top) {
                 double* xd = a.xbuf + (chain - a.chain0) * JOINT_MFMA_XBUF_DOUBLES + I0 * 256 + (long)j * 2048 + jm_lane_now();
 #pragma unroll
@@ -784,6 +799,8 @@ __global__ __launch_bounds__(JM_THREADS) void joint_test_mfma_kernel(const Joint
     const unsigned ring_gb = (unsigned)(size_t)(__attribute__((address_space(3))) double*)ring;
     const unsigned stash_gb = (unsigned)(size_t)(__attribute__((address_space(3))) double*)linv + (unsigned)wv * (JM_STASH * 2048u);
     double* tbuf = ring + wv * 272;               // [16][17] per wave, inside the exchange buffer: used between two barriers of its own
+    // pend_write: S also goes into the diagonal block of the cache rows the next call's new slots will occupy (both triangles)
+    double* pblk = fc + (long)a.n_ho * CS + n_r + a.n_ho;
     auto tile_out = [&](int I, int J, int d, const jm_d4& sn) {
         // the tile and its mirror image, both as 128-byte row segments: the mirror through a per-wave LDS transpose
         const int jj = lane & 15, kk = lane >> 4;
@@ -797,6 +814,7 @@ __global__ __launch_bounds__(JM_THREADS) void joint_test_mfma_kernel(const Joint
             const double val = sv[v];
             if (t1 < ldS && t2 < ldS) {
                 if (d > 0 || t1 >= t2) Sm[(long)t1 * ldS + t2] = val;      // diagonal tiles: the lower part here, its mirror below
+                if (a.pend_write && (d > 0 || t1 >= t2)) pblk[(long)t1 * CS + t2] = val;
             } else if (!fmode && t1 == mT && t2 < mT) {
                 mean[t2] = -val;                                            // the label row
             }
@@ -807,6 +825,7 @@ __global__ __launch_bounds__(JM_THREADS) void joint_test_mfma_kernel(const Joint
             const double val = tbuf[jj * 17 + 4 * v + kk];
             if (r2 < ldS && c2 < ldS) {
                 if (d > 0 || c2 > r2) Sm[(long)r2 * ldS + c2] = val;
+                if (a.pend_write && (d > 0 || c2 > r2)) pblk[(long)r2 * CS + c2] = val;
             } else if (!fmode && r2 == mT && c2 < mT && d > 0) {
                 mean[c2] = -val;                                            // the label column of an off-diagonal tile
             }

@@ -139,6 +139,7 @@ class JointFactorCache:
 
     def __init__(self):
         self.buf = None
+        self.pending = None           # the last call's pending rows (note_pending)
         self.rows = 0                 # capacity (label rows per chain)
         self.key = None               # (Ns, g_ny, n_r, T, plan version)
         self.slots = None             # int32 device tensor: the slots whose rows are valid
@@ -153,6 +154,7 @@ class JointFactorCache:
         self.slots = None
         self.n_pts = 0
         self.lineage = None
+        self.pending = None
 
     @property
     def X(self):
@@ -215,9 +217,37 @@ class JointFactorCache:
                     n_c = n_old
         return self.buf, self.rows, n_c
 
+    # -- pending rows (include/gpmpc_hip.h, gpmpc_joint_sample_pending) ------------------------------------------------------------
+    def pending_ok(self, mdl: "HipGPModel", n_ho: int, n_c: int) -> bool:
+        """May the call about to be made treat the cache rows ``n_c .. n_ho - 1`` as the previous call's pending rows?  Yes when
+        that call wrote them (``note_pending``) behind exactly the ``n_c`` slots that are cached now, and the hallucinated set has
+        since grown by exactly that call's test points with all their tasks observed - vouched for by the Agent (it appends the
+        points it drew at and says so: ``_ws_cache['joint_pending_points']``; same hallucinated-set generation), or, with
+        GPMPC_VERIFY_FACTOR_CACHE=1, by comparing the points themselves."""
+        p = self.pending
+        if p is None or n_c == 0 or n_c != p["n_ho"] or n_ho != n_c + p["m"] * p["T"] or mdl.n_h != p["n_pts"] + p["m"]:
+            return False
+        lin = getattr(mdl, "lineage", None)
+        tok = getattr(mdl, "_ws_cache", {}).get("joint_pending_points")
+        if lin is None or tok is None or tok[0] != lin[0] or tok[1] != mdl.n_h or tok[2] is not p["post"]:
+            return False
+        if p["gen"] != lin[0] or n_ho != mdl.n_h * mdl.hyper.T:
+            return False
+        if _VERIFY_CACHE and not bool(torch.equal(mdl.hall_X[:, :, p["n_pts"]:], p["post"]._x)):
+            return False
+        return True
+
+    def note_pending(self, mdl: "HipGPModel", post: "HipPosterior", n_ho: int, m: int, written: bool):
+        lin = getattr(mdl, "lineage", None)
+        self.pending = None
+        if written and lin is not None and self.slots is not None and int(self.slots.numel()) == n_ho:
+            self.pending = {"n_ho": n_ho, "m": m, "T": int(mdl.hyper.T), "n_pts": mdl.n_h, "gen": lin[0], "post": post}
+
     def rewind(self, n_slots: int):
         """Forget the rows beyond the first ``n_slots`` (benchmarks: put the cache back into the state it had before a
-        draw, so that repeated timed draws do the work of the first one)."""
+        draw, so that repeated timed draws do the work of the first one).  Pending rows (``pending_ok``) are forgotten too: a
+        draw that used them has factorised their diagonal block in place."""
+        self.pending = None
         if self.slots is not None:
             n = max(0, min(int(n_slots), int(self.slots.numel())))
             self.slots = self.slots[:n]
@@ -300,19 +330,30 @@ class HipPosterior:
         fbuf, frows, n_c = fcache.prepare(mdl, Ns, n_ho)
         n_cs = fcache.n_samples if fbuf is not None else Ns       # samples [0, n_cs) use the cache, the rest recompute
 
+        # pending rows: this call's test points become the next call's new slots in the SQP loop (the Agent appends them); the
+        # whole batch has to be in the cache, and a draw that only repeats (mean / covariance of the same call) changes nothing
+        whole = fbuf is not None and n_cs >= Ns
+        pend = 0
+        if whole and os.environ.get("GPMPC_JOINT_PENDING", "1") != "0":
+            pend = _lib.PENDING_WRITE | (_lib.PENDING_USE if fcache.pending_ok(mdl, n_ho, n_c) else 0)
+        self.used_pending = bool(pend & _lib.PENDING_USE)
+        fcache.pending = None                                      # consumed (or stale) either way
+
         def call(lo, hi, cache, mode):
             sl = lambda t: None if t is None else t[lo:hi]
-            _lib.check(lib.gpmpc_joint_sample(
+            _lib.check(lib.gpmpc_joint_sample_pending(
                 mdl.plan.desc, _lib.dptr(mdl.plan.buf), _lib.dptr(mdl.plan.X_r), hi - lo, mdl.n_h,
                 _lib.dptr(sl(mdl.hall_X)) if mdl.n_h else None, _lib.dptr(sl(mdl.hall_Y)) if mdl.n_h else None,
                 _lib.dptr(mdl.h_slots) if n_ho else None, n_ho, m, _lib.dptr(sl(self._x)), _lib.dptr(sl(z)),
                 float(var_zero_thr), float(beta), int(bool(clip)), _lib.dptr(sl(mean)), _lib.dptr(sl(var)), _lib.dptr(sl(y)),
                 _lib.dptr(sl(covar)), _lib.dptr(sl(root)), int(mode), _lib.dptr(sl(info)), _lib.dptr(ws), ws.numel() * 8,
                 _lib.current_stream_ptr(), _lib.dptr(fbuf) if cache else None, int(frows) if cache else 0,
-                int(n_c) if cache else 0), "gpmpc_joint_sample")
+                int(n_c) if cache else 0, int(pend) if cache else 0), "gpmpc_joint_sample")
 
+        self._pending_written = False
         if n_cs >= Ns:
             call(0, Ns, fbuf is not None, root_mode)
+            self._pending_written = bool(pend) and bool(lib.gpmpc_joint_pending_written())
         else:
             # The cache holds a prefix of the samples: two launches.  "One chain failed every retry => the WHOLE batch takes
             # the eigendecomposition root" (A.7 step 4) spans both: the part that did not fall back by itself is redrawn.
@@ -338,6 +379,7 @@ class HipPosterior:
         self.used_eigh = bool(bits & _lib.INFO_ROOT_EIGH)
         if fbuf is not None:
             fcache.commit(mdl, n_ho, ok=not (bits & _lib.INFO_TRAIN_CHOL_FAIL), n_cached=n_c)
+            fcache.note_pending(mdl, self, n_ho, m, self._pending_written and not (bits & _lib.INFO_TRAIN_CHOL_FAIL))
         if (bits & _lib.INFO_TRAIN_CHOL_FAIL) and raise_chol_fail:
             raise NotPSDError("Cholesky of the training covariance (real + hallucinated data) failed")
         if bits & _lib.INFO_VAR_CLAMPED:

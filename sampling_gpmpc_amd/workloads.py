@@ -82,6 +82,11 @@ def flop_mode_j_cached_rows(g_ny, n_real_obs, n_cached) -> float:
     return g_ny * ((n_real_obs + n_cached) ** 3 - n_real_obs ** 3) / 3
 
 
+def flop_chol(g_ny, n) -> float:
+    """FLOP of the Cholesky factorisation of an n x n block per sample (all outputs)."""
+    return g_ny * n ** 3 / 3
+
+
 def flop_mode_i(g_ny, N_r) -> float:
     return g_ny * (14 * N_r + N_r * N_r + 2 * N_r + 10)
 

@@ -206,3 +206,55 @@ def test_eigh_root_full_rank_just_beyond_the_narrow_cap(sg, Hs):
     np.testing.assert_allclose((y.cpu() - post.mean.cpu()).reshape(Ns, 3, -1), (R @ zz).squeeze(-1), rtol=0, atol=1e-12)
     if rank > 32:
         assert deferred > 0, "a chain of rank > 32 stayed in the narrow launch"
+
+
+@pytest.mark.parametrize("pname,Ns,Hh", [("params_car_residual", 64, 40), ("params_pendulum1D_samples", 24, 30)])
+def test_pending_rows_of_the_factor_cache(sg, pname, Ns, Hh, monkeypatch):
+    """gpmpc_joint_sample_pending (ABI 9): in the SQP loop a draw's test points become the next call's new hallucinated points
+    (reference src/agent.py:629-641 then :164-202), so the draw leaves X^T = the new rows against the old columns and S = their Schur
+    complement (before the likelihood noise) in the cache, and the next call only factorises (S + noise) in place.  Two MPC steps x four
+    SQP iterations with the matrix-pipe path pinned, pending rows on against off (GPMPC_JOINT_PENDING=0): the rows are USED from the
+    third iteration of a step on and at iteration 0 of the next step (the reset-after-build quirk), never right after the reset; mean /
+    variance agree to rounding, the samples to the tolerance of the configuration's root (Cholesky: 1e-8; the car's eigh root: 1e-4)."""
+    from tests.helpers import closed_loop_params
+    lib = sg._lib.load()
+    iters = 4
+    p = closed_loop_params(pname, Ns, Hh, 2, iters)
+    p["common"]["use_cuda"] = True
+    p["agent"]["base_sample_generator"] = "counter"
+    x0 = np.array(p["env"]["start"], dtype=np.float64)
+    runs = {}
+    lib.gpmpc_joint_pin_path(sg._lib.JOINT_MFMA)
+    try:
+        for mode in ("1", "0"):
+            monkeypatch.setenv("GPMPC_JOINT_PENDING", mode)
+            agent = sg.Agent(p, sg.make_env(p))
+            x0a = x0[: agent.nx]
+            u_h, x_h = np.zeros((Hh, agent.nu)), np.tile(x0a, (Hh, Ns))
+            rec = []
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                for step in range(2):
+                    agent.mpc_iteration(step)
+                    for k in range(iters):
+                        agent.train_hallucinated_dynGP(k)
+                        gv, yg, _ = agent.dyn_fg_jacobians(agent.get_batch_x_hat(x_h, u_h), k)
+                        post = agent.model_i_call
+                        rec.append((bool(post.used_pending), post.mean.clone(), post.variance.clone(), gv.copy(),
+                                    int(lib.gpmpc_joint_last_path())))
+                        assert not (post.last_info & sg._lib.INFO_TRAIN_CHOL_FAIL).any()
+                        mean_next = gv[:, :, :, 0].mean(axis=0).T
+                        x_h = np.tile(np.vstack([x0a[None, :], mean_next[:-1]]), (1, Ns))
+            runs[mode] = rec
+    finally:
+        lib.gpmpc_joint_pin_path(sg._lib.JOINT_AUTO)
+    used = [r[0] for r in runs["1"]]
+    print(f"{pname}: pending rows used per call {used}")
+    assert used == [False, False, True, True, True, False, True, True] and not any(r[0] for r in runs["0"])
+    tol_y = 1e-8 if "pendulum" in pname else 1e-4
+    for i, (a, b) in enumerate(zip(runs["1"], runs["0"])):
+        for j, name in ((1, "mean"), (2, "variance")):
+            e = float(((a[j] - b[j]).abs() / b[j].abs().max()).max())
+            assert e < 1e-9, f"call {i}: {name} with pending rows is {e:.1e} from the recomputed rows"
+        ey = float(np.abs(a[3] - b[3]).max() / np.abs(b[3]).max())
+        assert ey < tol_y, f"call {i}: samples {ey:.1e}"
