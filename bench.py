@@ -271,7 +271,8 @@ def extra_closed_loop(sg, _lib, wl, name="params_car_residual", Ns=1024, H=40, i
     eigendecomposition root): Ns = 8192 / 8 = 1024, H = 40, k = 0..3 of MPC step 0 and of the steady-state MPC steps.  Also used
     for configs[1]'s mode-J points (pendulum, Ns = 1024, H = 30, k = 0 and k = 1; Cholesky root, jitter 1e-6).
 
-    Every draw is timed ONCE, in the loop's own sequence (HIP events around Agent.sample_gp inside the real SQP iteration): from
+    Every draw is timed ONCE, in the loop's own sequence (HIP events around the gpmpc_joint_sample_pending call of the real SQP
+    iteration - its launches and the gaps between them, not the facade's Python around it; that is in `wall_ms_per_iteration`): from
     round 6 a draw leaves its own X / S behind as the next call's new factor rows (gpmpc_joint_sample_pending), so a draw cannot
     be repeated from a rewound cache without changing what it does.  `ms_per_draw`: the minimum over the repetitions of the same
     (MPC step class, k) - two fresh Agents, and for the steady state the MPC steps 1 and 2 of each; `wall_ms_per_iteration`: wall
@@ -297,15 +298,7 @@ def extra_closed_loop(sg, _lib, wl, name="params_car_residual", Ns=1024, H=40, i
             x0 = np.asarray(p["env"]["start"], dtype=np.float64)[: agent.nx]
             u_h = wl.synthetic_u_ff(agent.nu, H)
             x_h = np.tile(x0, (H, Ns))
-            inner = agent.sample_gp
-
-            def timed_draw(x_input, base_samples=None, _inner=inner):
-                e0.record()
-                y = _inner(x_input, base_samples=base_samples)
-                e1.record()
-                return y
-
-            agent.sample_gp = timed_draw
+            agent._ws_cache["joint_time_events"] = (e0, e1)       # recorded by HipPosterior around gpmpc_joint_sample_pending's launches
             for step in range(n_steps if rep else min(n_steps, 2)):
                 agent.mpc_iteration(step)
                 for k in range(iters):

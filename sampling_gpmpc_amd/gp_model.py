@@ -133,9 +133,9 @@ class JointFactorCache:
     at the previous call are reused.  The façade vouches for validity by comparing the current slot list and the points of
     the cached rows with a snapshot taken when they were written (the factor does not depend on the labels)."""
 
-    HINT_MAX_BYTES = 8 << 30     # budget of a cache sized ahead of need from the Agent's bound on the conditioning set
-    MAX_BYTES = 24 << 30          # cache budget (the per-GPU shard of BASELINE configs[4] needs ~7 GB); a batch that needs
-                                  # more caches the factor rows of a PREFIX of its samples (``n_samples``), the others recompute
+    MAX_BYTES = 64 << 30          # cache budget (the per-GPU shard of BASELINE configs[4] needs ~7 GB, configs[4] whole on one GPU -
+                                  # Ns = 8192 - 52 GB of the 288 GB); a batch that needs more caches the factor rows of a PREFIX of
+                                  # its samples (``n_samples``), the others recompute (and the draw leaves no pending rows)
 
     def __init__(self):
         self.buf = None
@@ -172,17 +172,22 @@ class JointFactorCache:
             # points) where there is one, else for four of them where that fits
             n_samp = Ns
             # The hint is honoured only when the set it describes is REACHABLE (it fits gpmpc_joint_sample's row limit: the
-            # shipped car's max_sqp_iter * H * T = 22500 does not) and within its own, smaller byte budget - it exists to
-            # avoid re-allocations, not to spend the cache budget ahead of need: otherwise the size follows the 4x rule, which
-            # is monotonic in Ns (same rule as HipPosterior's workspace hint below)
+            # shipped car's max_sqp_iter * H * T = 22500 does not - the size then follows the 4x rule, which is monotonic in Ns;
+            # same rule as HipPosterior's workspace hint below).  A reachable hint is honoured in full: when the rows do not fit the
+            # byte budget for every sample, a PREFIX of the samples is cached at that row count (a smaller row count would have to
+            # regrow - and start from zero cached rows - in the middle of the SQP loop)
             hint = getattr(mdl, "_ws_cache", {}).get("joint_points_hint")
             n_hint = int(hint) * hy.T if hint else 0
             hint_ok = n_hint >= n_ho and n_hint + 1 <= MAX_JOINT_ROWS
-            for i, mult in enumerate(((float(n_hint) / n_ho,) if hint_ok else ()) + (4.0, 2.0, 1.25)):
-                rows = min(MAX_JOINT_ROWS, max(256, -(-int(mult * n_ho) // 128) * 128))
+            if hint_ok:
+                rows = min(MAX_JOINT_ROWS, max(256, -(-n_hint // 128) * 128))
                 nbytes = lib.gpmpc_joint_cache_bytes(mdl.plan.desc, Ns, rows)
-                if 0 < nbytes <= (self.HINT_MAX_BYTES if (hint_ok and i == 0) else self.MAX_BYTES):
-                    break
+            else:
+                for mult in (4.0, 2.0, 1.25):
+                    rows = min(MAX_JOINT_ROWS, max(256, -(-int(mult * n_ho) // 128) * 128))
+                    nbytes = lib.gpmpc_joint_cache_bytes(mdl.plan.desc, Ns, rows)
+                    if 0 < nbytes <= self.MAX_BYTES:
+                        break
             if nbytes > self.MAX_BYTES:                                        # not for every sample: a prefix of them
                 per_sample = lib.gpmpc_joint_cache_bytes(mdl.plan.desc, 1, rows)
                 n_samp = int(self.MAX_BYTES // per_sample) if per_sample > 0 else 0
@@ -351,6 +356,9 @@ class HipPosterior:
                 int(n_c) if cache else 0, int(pend) if cache else 0), "gpmpc_joint_sample")
 
         self._pending_written = False
+        ev = mdl._ws_cache.get("joint_time_events")               # benchmarks: a pair of timing events around the entry point's launches
+        if ev is not None:
+            ev[0].record()
         if n_cs >= Ns:
             call(0, Ns, fbuf is not None, root_mode)
             self._pending_written = bool(pend) and bool(lib.gpmpc_joint_pending_written())
@@ -367,6 +375,8 @@ class HipPosterior:
                     else:
                         info[:n_cs] = 0
                         call(0, n_cs, True, _lib.ROOT_EIGH)
+        if ev is not None:
+            ev[1].record()
         self.n_cached_rows = n_c
         self._mean, self._var = mean, var
         if want_covar:

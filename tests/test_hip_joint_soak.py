@@ -251,10 +251,12 @@ def test_pending_rows_of_the_factor_cache(sg, pname, Ns, Hh, monkeypatch):
     used = [r[0] for r in runs["1"]]
     print(f"{pname}: pending rows used per call {used}")
     assert used == [False, False, True, True, True, False, True, True] and not any(r[0] for r in runs["0"])
-    tol_y = 1e-8 if "pendulum" in pname else 1e-4
+    # (the car's eigh-root samples move by ~1e-5 under a one-ulp change of the covariance, and the samples are the next iteration's
+    # labels and - through their mean - linearisation points: from the fourth call on the two runs are not fed the same inputs)
+    tol_y, tol_m = (1e-8, 1e-9) if "pendulum" in pname else (1e-4, 1e-6)
     for i, (a, b) in enumerate(zip(runs["1"], runs["0"])):
         for j, name in ((1, "mean"), (2, "variance")):
             e = float(((a[j] - b[j]).abs() / b[j].abs().max()).max())
-            assert e < 1e-9, f"call {i}: {name} with pending rows is {e:.1e} from the recomputed rows"
+            assert e < tol_m, f"call {i}: {name} with pending rows is {e:.1e} from the recomputed rows"
         ey = float(np.abs(a[3] - b[3]).max() / np.abs(b[3]).max())
         assert ey < tol_y, f"call {i}: samples {ey:.1e}"
