@@ -428,7 +428,7 @@ __global__ __launch_bounds__(NT, WPE) void joint_kernel(const JointArgs a) {
     // JOINT_PHASE_FACTOR: the hallucinated rows only (no w row, no test rows: joint_test_mfma_kernel forms them)
     // JOINT_PHASE_CHOL: the new rows against the new columns only, starting from the Schur complement in Sall
     const bool ph_chol = a.phase == JOINT_PHASE_CHOL;
-    const bool ph_factor = a.phase != JOINT_PHASE_TAIL, ph_test = a.phase == JOINT_PHASE_ALL,
+    const bool ph_factor = a.phase != JOINT_PHASE_TAIL, ph_test = a.phase == JOINT_PHASE_ALL || a.phase == JOINT_PHASE_HEAD,
                ph_tail = a.phase == JOINT_PHASE_ALL || a.phase == JOINT_PHASE_TAIL;
     const int wrow = n_ho, trow0 = n_ho + 1, nrow = ph_test ? n_ho + 1 + mT : n_ho;
 
@@ -670,7 +670,7 @@ __global__ __launch_bounds__(NT, WPE) void joint_kernel(const JointArgs a) {
         }
 
         JPH(4);
-        if (!ph_tail) {                                           // JOINT_PHASE_FACTOR: the chain's rows are in M and in the cache
+        if (!ph_tail && !ph_test) {                               // JOINT_PHASE_FACTOR: the chain's rows are in M and in the cache
 #ifdef GPMPC_PHASE_TIMERS
             if (blockIdx.x == 0 && tid == 0)                      // (slots 10..14: the last factor-only launch - FACTOR or CHOL)
                 for (int i = 0; i < 5; ++i) g_joint_phase[10 + i] = jph[i];
@@ -785,6 +785,14 @@ __global__ __launch_bounds__(NT, WPE) void joint_kernel(const JointArgs a) {
         }
 
         JPH(5);
+        if (a.phase == JOINT_PHASE_HEAD) {                        // the tail is joint_tail_mfma_kernel's: hand over the mean (S is in Sall)
+            for (int t1 = tid; t1 < mT; t1 += nt) a.mean[chain * (long)mT + t1] = muv[t1];
+            if (info_acc) atomicOr(&s_info, info_acc);
+            __syncthreads();
+            if (tid == 0) a.info[chain] = s_info;
+            __syncthreads();
+            continue;
+        }
         // ---- root: blocked Cholesky of S with the jitter-on-failure chain (A.7) -----------------------------------
         int level = 0;
         bool rooted = false;
@@ -1010,6 +1018,7 @@ static int joint_mfma_from() {
     static const char* env = getenv("GPMPC_JOINT_MFMA_FROM");
     return env ? atoi(env) : 100;
 }
+static int g_tail_kernel_force = -1;      // gpmpc_debug_joint_tail_kernel: -1 default (on), 0 / 1 forced
 static int g_chol_kernel_force = -1;      // gpmpc_debug_joint_chol_kernel: -1 default (on), 0 / 1 forced (tests, A/B timing)
 static int g_eigh_narrow_force = -1;      // gpmpc_debug_eigh_narrow: -1 heuristic, 0 / 1 forced (tests)
 static int g_joint_path_pin = 0;          // gpmpc_joint_pin_path: 0 auto, 1 VALU path, 2 matrix-pipe path where instantiated
@@ -1094,6 +1103,12 @@ int gpmpc_debug_read_eigh_work(unsigned long long* out /*[host] 4*/, int reset) 
     return GPMPC_OK;
 }
 
+// tests / A-B timing: 0 = joint_kernel's own tail, 1 = joint_tail_mfma_kernel, -1 = default (1); returns the previous value
+int gpmpc_debug_joint_tail_kernel(int mode) {
+    const int prev = g_tail_kernel_force;
+    g_tail_kernel_force = mode < 0 ? -1 : (mode ? 1 : 0);
+    return prev;
+}
 // tests / A-B timing: 0 = the matrix-pipe path's Cholesky of the Schur complement by joint_kernel's CHOL phase, 1 = by
 // joint_chol_mfma_kernel, -1 = default (1); returns the previous value
 int gpmpc_debug_joint_chol_kernel(int mode) {
@@ -1283,6 +1298,11 @@ int gpmpc_joint_sample_pending(const gpmpc_gp_desc_t* gp, const void* plan, cons
 #undef GPMPC_JOINT_LAUNCH
     };
     if (gp->T != 1 && gp->T != 3) return fail(GPMPC_E_UNSUPPORTED, "joint: only T = 1 and T = 3 (D = 2) are instantiated");
+    // the tail (root with the jitter chain, sample, post-processing) as joint_tail_mfma_kernel (joint_chol.hip, round 6) wherever it is
+    // instantiated: T = 3, 2 .. 128 test slots; GPMPC_JOINT_TAIL_KERNEL=0 / gpmpc_debug_joint_tail_kernel(0): joint_kernel's own tail
+    static const char* tenv = getenv("GPMPC_JOINT_TAIL_KERNEL");
+    const int tforce = g_tail_kernel_force >= 0 ? g_tail_kernel_force : (tenv ? atoi(tenv) : 1);
+    const bool tail_kernel = tforce != 0 && joint_tail_mfma_eligible(mT, gp->T);
     const bool split = !joint_use_mfma(a.gp.n_r, n_ho, m, gp->T) && joint_use_mfma_split(a.gp.n_r, n_ho, m, gp->T) &&
                        a.fcache && n_ho <= a.fc_cap && (a.fc_cap % 2) == 0;
     if (joint_use_mfma(a.gp.n_r, n_ho, m, gp->T) || split) {
@@ -1365,9 +1385,13 @@ int gpmpc_joint_sample_pending(const gpmpc_gp_desc_t* gp, const void* plan, cons
             }
             if (int rc = joint_mfma_launch(b, st)) return rc;
             b.pend_write = 0;
-            b.phase = JOINT_PHASE_TAIL;
-            b.abandon_root = abandon_for(mT);
-            launch(b, mT);
+            if (tail_kernel) {
+                if (int rc = joint_tail_mfma_launch(b, st)) return rc;
+            } else {
+                b.phase = JOINT_PHASE_TAIL;
+                b.abandon_root = abandon_for(mT);
+                launch(b, mT);
+            }
         }
         g_joint_pending_written = pend_write ? 1 : 0;
     } else {
@@ -1376,8 +1400,17 @@ int gpmpc_joint_sample_pending(const gpmpc_gp_desc_t* gp, const void* plan, cons
         // hallucinated row cached: 13.3 ms against 11.2 - the test rows' stream is the critical path of this kernel either way.)
         g_joint_last_path = 1;
         const int nrow = n_ho + 1 + mT - a.n_c;        // rows that are computed (the cached ones have no thread)
-        a.abandon_root = abandon_for(nrow);
-        launch(a, nrow);
+        if (tail_kernel) {                             // head (factor rows, test rows, mean, S) here, the tail one wave per chain
+            a.phase = JOINT_PHASE_HEAD;
+            a.abandon_root = 0;
+            launch(a, nrow);
+            GPMPC_HIP_CHECK(hipGetLastError());
+            a.info_in = 1;
+            if (int rc = joint_tail_mfma_launch(a, st)) return rc;
+        } else {
+            a.abandon_root = abandon_for(nrow);
+            launch(a, nrow);
+        }
     }
     GPMPC_HIP_CHECK(hipGetLastError());
     // eigendecomposition root for the whole batch when a chain failed all jitter retries (or on request); the kernel

@@ -10,6 +10,8 @@ enum : int {
     JOINT_PHASE_ALL = 0,      // one launch: factor rows, w row, test rows, mean, S, root, sample (the VALU path)
     JOINT_PHASE_FACTOR = 1,   // the hallucinated rows n_c .. n_ho - 1 of the factor only (into M and the factor cache)
     JOINT_PHASE_TAIL = 2,     // root + sample only: S is in Sall, the mean in `mean` (written by joint_test_mfma_kernel)
+    JOINT_PHASE_HEAD = 4,     // everything but the tail: factor rows, test rows, mean (into `mean`) and S (into Sall); the root and the
+                              // sample follow in joint_tail_mfma_kernel (joint_chol.hip)
     JOINT_PHASE_CHOL = 3      // the new hallucinated rows against the NEW columns only: blocked Cholesky of the Schur complement
                               // joint_test_mfma_kernel (JOINT_MFMA_FACTOR) left in Sall (leading dimension n_ho - n_c); the rows'
                               // entries against the old columns are already in the cache
@@ -92,5 +94,8 @@ int joint_mfma_launch(const JointArgs& a, hipStream_t st);
 // cache, 1 / diag, the chain's info word) on the matrix pipe, one wave per chain; instantiated for 1..128 new rows
 bool joint_chol_mfma_eligible(int n_new);
 int joint_chol_mfma_launch(const JointArgs& a, hipStream_t st);
+// the TAIL of a draw (root with the jitter chain, sample, post-processing; S in a.Sall, the mean in a.mean) one wave per chain
+bool joint_tail_mfma_eligible(int mT, int T);
+int joint_tail_mfma_launch(const JointArgs& a, hipStream_t st);
 
 }  // namespace gpmpc

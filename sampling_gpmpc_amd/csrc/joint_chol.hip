@@ -82,6 +82,68 @@ __device__ long long g_jc_phase[8];
 #define JCPH(i)
 #endif
 
+// The diagonal tile A (D layout, symmetric) -> R = chol(A)^T and V = R^-1 (both D layout), 1 / diag of the lane's row (lane & 15);
+// `bad` is set where a pivot is not positive.  blk / vt: two 16 x JC_LD LDS buffers of this wave.
+__device__ __forceinline__ void jc_diag_tile(double* blk, double* vt, const jc_d4& A, int lr, int lc, bool& bad, double& mydinv_out,
+                                             jc_d4& R, jc_d4& V) {
+    jc_sync();                                            // the previous readers of blk / vt are done
+#pragma unroll
+    for (int v = 0; v < 4; ++v) blk[(4 * v + lr) * JC_LD + lc] = A[v];
+    jc_sync();
+    double r[16];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const jc_d2 t = *reinterpret_cast<const jc_d2*>(&blk[lc * JC_LD + 2 * q]);
+        r[2 * q] = (2 * q <= lc) ? t.x : 0.0;
+        r[2 * q + 1] = (2 * q + 1 <= lc) ? t.y : 0.0;
+    }
+    // right-looking: after pivot j every later column takes its update at once - 15 - j INDEPENDENT DPP FMAs (lane i:
+    // A[i][q] -= L[i][j] L[q][j], L[q][j] = lane q's r[j]) instead of a chain of j dependent ones per pivot
+    // (a column of L leaves for LDS the moment it is final and a column of W' is born at its own pivot: 16 doubles alive
+    // between them, not 32)
+    double mydinv = 0.0;
+    double w[16];                                         // row lc of W' = D L^-1 (W'[i][:] = e_i - sum_k L[i][k] W[k][:])
+    jc_sync();                                            // every lane has read its row of blk
+    jc_for<0, 16>([&](auto jcn) {
+        constexpr int j = decltype(jcn)::value;
+        const double d = readlane_f64(r[j], j);
+        if (!(d > 0.0)) bad = true;
+        // v_rsq_f64 + ONE Newton step (3e-16 on 1 / sqrt, as rollout_one.hip) and sqrt = d / sqrt: six dependent operations on
+        // the serial spine of the tile instead of the twelve of sqrt_rsqrt_fast
+        double inv = __builtin_amdgcn_rsq(d);
+        inv = fma(inv, fma(-0.5 * d * inv, inv, 0.5), inv);
+        const double sd = d * inv;
+        const double lj = (lc > j) ? r[j] * inv : 0.0;    // L[i][j] below the diagonal, zero elsewhere
+        r[j] = (lc == j) ? sd : lj;
+        mydinv = (lc == j) ? inv : mydinv;
+        const double mj = lj * inv;                       // L[i][j] / L[j][j]: the multiplier of W'[j][:] for the rows below j
+        w[j] = (lc == j) ? 1.0 : 0.0;
+        if (lr == 0) blk[lc * JC_LD + j] = r[j];          // L_kk[lc][j] (zero above the diagonal)
+        // (r[j] and mj are VALU results of this step, w[] of the previous one: the first DPP read of each group carries the wait)
+        jc_for<j + 1, 16>([&](auto qc) {
+            constexpr int q = decltype(qc)::value;
+            jc_fnma_bcast<q, q == j + 1>(r[q], r[j], lj);
+        });
+        jc_for<0, j + 1>([&](auto cc) {
+            constexpr int c = decltype(cc)::value;
+            jc_fnma_self<j, c == 0>(w[c], mj);
+        });
+    });
+    if (lr == 0) {                                        // W = D^-1 W', row-major (above the diagonal: zero)
+#pragma unroll
+        for (int q = 0; q < 8; ++q)
+            *reinterpret_cast<jc_d2*>(&vt[lc * JC_LD + 2 * q]) = jc_d2{w[2 * q] * mydinv, w[2 * q + 1] * mydinv};
+    }
+    jc_sync();
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+        const int rr = 4 * v + lr;
+        V[v] = vt[lc * JC_LD + rr];                       // V[rr][lc] = W[lc][rr] (zero below the diagonal)
+        R[v] = blk[lc * JC_LD + rr];   // R_kk[rr][lc] = L_kk[lc][rr] (zero below the diagonal)
+    }
+    mydinv_out = mydinv;
+}
+
 #ifndef GPMPC_JC_OCC8
 #define GPMPC_JC_OCC8 1                        // waves per SIMD of the eight-tile instance (2: 256 registers, ~45 of them spilled: no faster)
 #endif
@@ -177,65 +239,12 @@ __global__ __launch_bounds__(64, (NTL == 8) ? GPMPC_JC_OCC8 : 2) void joint_chol
             });
             JCPH(1);
             // ---- the diagonal tile in "lane = row" form (every DPP row of 16 lanes holds a copy and does the same work) ----------
-            jc_sync();                                            // the previous readers of blk / vt are done
-#pragma unroll
-            for (int v = 0; v < 4; ++v) blk[(4 * v + lr) * JC_LD + lc] = acc[k][v];
-            jc_sync();
-            double r[16];
-#pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                const jc_d2 t = *reinterpret_cast<const jc_d2*>(&blk[lc * JC_LD + 2 * q]);
-                r[2 * q] = (2 * q <= lc) ? t.x : 0.0;
-                r[2 * q + 1] = (2 * q + 1 <= lc) ? t.y : 0.0;
-            }
-            // right-looking: after pivot j every later column takes its update at once - 15 - j INDEPENDENT DPP FMAs (lane i:
-            // A[i][q] -= L[i][j] L[q][j], L[q][j] = lane q's r[j]) instead of a chain of j dependent ones per pivot
-            // (a column of L leaves for LDS the moment it is final and a column of W' is born at its own pivot: 16 doubles alive
-            // between them, not 32)
-            double mydinv = 0.0;
-            double w[16];                                         // row lc of W' = D L^-1 (W'[i][:] = e_i - sum_k L[i][k] W[k][:])
-            jc_sync();                                            // every lane has read its row of blk
-            jc_for<0, 16>([&](auto jcn) {
-                constexpr int j = decltype(jcn)::value;
-                const double d = readlane_f64(r[j], j);
-                if (!(d > 0.0)) bad = true;
-                // v_rsq_f64 + ONE Newton step (3e-16 on 1 / sqrt, as rollout_one.hip) and sqrt = d / sqrt: six dependent operations on
-                // the serial spine of the tile instead of the twelve of sqrt_rsqrt_fast
-                double inv = __builtin_amdgcn_rsq(d);
-                inv = fma(inv, fma(-0.5 * d * inv, inv, 0.5), inv);
-                const double sd = d * inv;
-                const double lj = (lc > j) ? r[j] * inv : 0.0;    // L[i][j] below the diagonal, zero elsewhere
-                r[j] = (lc == j) ? sd : lj;
-                mydinv = (lc == j) ? inv : mydinv;
-                const double mj = lj * inv;                       // L[i][j] / L[j][j]: the multiplier of W'[j][:] for the rows below j
-                w[j] = (lc == j) ? 1.0 : 0.0;
-                if (lr == 0) blk[lc * JC_LD + j] = r[j];          // L_kk[lc][j] (zero above the diagonal)
-                // (r[j] and mj are VALU results of this step, w[] of the previous one: the first DPP read of each group carries the wait)
-                jc_for<j + 1, 16>([&](auto qc) {
-                    constexpr int q = decltype(qc)::value;
-                    jc_fnma_bcast<q, q == j + 1>(r[q], r[j], lj);
-                });
-                jc_for<0, j + 1>([&](auto cc) {
-                    constexpr int c = decltype(cc)::value;
-                    jc_fnma_self<j, c == 0>(w[c], mj);
-                });
-            });
-            if (lr == 0) {                                        // W = D^-1 W', row-major (above the diagonal: zero)
-#pragma unroll
-                for (int q = 0; q < 8; ++q)
-                    *reinterpret_cast<jc_d2*>(&vt[lc * JC_LD + 2 * q]) = jc_d2{w[2 * q] * mydinv, w[2 * q + 1] * mydinv};
-            }
+            double mydinv;
+            jc_d4 V;
+            jc_diag_tile(blk, vt, acc[k], lr, lc, bad, mydinv, U[jc_idx(k, k, NTL)], V);
             // (1 / diag: an unconditional store as well; its slot sits behind the rows of the cache entry)
             __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(jc_u2, mydinv), Fr,
                                                   (lr == 0 && 16 * k + lc < n) ? (unsigned)(((long)a.fc_cap * CS + n_c + 16 * k + lc) * 8) : 0x7ffff000u, 0, 0);
-            jc_sync();
-            jc_d4 V;
-#pragma unroll
-            for (int v = 0; v < 4; ++v) {
-                const int rr = 4 * v + lr;
-                V[v] = vt[lc * JC_LD + rr];                       // V[rr][lc] = W[lc][rr] (zero below the diagonal)
-                U[jc_idx(k, k, NTL)][v] = blk[lc * JC_LD + rr];   // R_kk[rr][lc] = L_kk[lc][rr] (zero below the diagonal)
-            }
             JCPH(2);
             // ---- the rest of the row on the matrix pipe; the next row's A tiles are requested behind it ------------------------
             jc_for<k + 1, NTL>([&](auto jcn) {
@@ -291,6 +300,205 @@ int joint_chol_mfma_launch(const JointArgs& a, hipStream_t st) {
     else if (ntl <= 4) hipLaunchKernelGGL(joint_chol_mfma_kernel<4>, g, b, 0, st, a);
     else if (ntl <= 6) hipLaunchKernelGGL(joint_chol_mfma_kernel<6>, g, b, 0, st, a);
     else hipLaunchKernelGGL(joint_chol_mfma_kernel<8>, g, b, 0, st, a);
+    GPMPC_HIP_CHECK(hipGetLastError());
+    return GPMPC_OK;
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// joint_tail_mfma_kernel: the TAIL of a joint draw - the root of the posterior covariance with gpytorch's jitter-on-failure chain
+// (reference src/agent.py:641), y = mean + R z, variance floor, variance-is-zero rule and beta clip (:646-708) - one
+// WAVE per chain on the same tile machinery.  joint_kernel's TAIL phase walked S with one label row per thread and 16-column blocks
+// behind workgroup barriers: ~130 us per launch at the configs[4] shard for an attempt that fails around pivot 50 (the car as
+// shipped), ~120 us of the pendulum's 300 us draw for its one-and-a-half factorisations.
+//   * an attempt is the left-looking tile Cholesky of joint_chol_mfma_kernel on S + jit I, abandoned at the first diagonal tile with a
+//     non-positive pivot; a retry whose jitter would not change one diagonal entry of the columns walked is counted, not run (as
+//     joint_kernel does: the shipped car's 1e-20 .. 1e-18 against variances of 1e-4 .. 1);
+//   * R never leaves the registers: column k of R (tiles R_pk, p <= k) is final at the end of step k and contributes
+//     (R^T z)[16 k + c] = sum_p sum_r R_pk[r][c] z[16 p + r] right there (four values per lane and tile, two cross-row exchanges per column).
+// S may have only its lower triangle valid (joint_kernel's layout) or both (joint_test_mfma_kernel's): element (r, c) is read at
+// min(r, c) * mT + max(r, c) - in the column-major lower storage that IS the valid copy.
+template <int NTL>
+__global__ __launch_bounds__(64, (NTL >= 6) ? 1 : 2) void joint_tail_mfma_kernel(const JointArgs a) {
+    constexpr int NTT = NTL * (NTL + 1) / 2;
+    constexpr int TS = 16 * JC_LD;
+    constexpr int T = 3;
+    __shared__ __attribute__((aligned(16))) double blk[TS];
+    __shared__ __attribute__((aligned(16))) double vt[TS];
+    __shared__ double zs[NTL * 16];                               // base samples
+    __shared__ double ys[NTL * 16];                               // R^T z
+    const GpParams& gp = a.gp;
+    const int lane = threadIdx.x, lr = lane >> 4, lc = lane & 15;
+    const int m = a.m, n = m * gp.T;
+    const long chain = a.chain0 + blockIdx.x;
+    const double* Sm = a.Sall + chain * (long)n * n;
+    const __amdgpu_buffer_rsrc_t Sr = __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(Sm), 0, n * n * 8, 0x00020000);
+    for (int t = lane; t < NTL * 16; t += 64) zs[t] = (t < n) ? a.z[chain * (long)n + t] : 0.0;
+    // tile (k, j), register v, this lane: element (16 k + 4 v + lr, 16 j + lc) + jit on the diagonal; the identity beyond n
+    auto load_tile = [&](auto kc, auto jcn, double jit) -> jc_d4 {
+        constexpr int k = decltype(kc)::value, j = decltype(jcn)::value;
+        jc_d4 t;
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            const int r = 16 * k + 4 * v + lr, c = 16 * j + lc;
+            // (off-diagonal tiles: r < c always; diagonal tiles: the lane's entry may lie below the diagonal - its mirror image is read)
+            const int lo = (k == j) ? min(r, c) : r, hi = (k == j) ? max(r, c) : c;
+            t[v] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(Sr, (unsigned)((lo * n + hi) * 8), 0, 0));
+        }
+        if constexpr (j >= NTL - 2) {
+            const bool cin = 16 * j + lc < n;
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                const bool rin = (k >= NTL - 2) ? (16 * k + 4 * v + lr < n) : true;
+                double val = (cin && rin) ? t[v] : 0.0;
+                if constexpr (k == j) val = (4 * v + lr == lc && !cin) ? 1.0 : val;
+                t[v] = val;
+            }
+        }
+        if constexpr (k == j) {
+#pragma unroll
+            for (int v = 0; v < 4; ++v) t[v] += (4 * v + lr == lc && 16 * k + lc < n) ? jit : 0.0;
+        }
+        return t;
+    };
+    int level = 0, info_acc = 0;
+    bool rooted = false;
+    double jit_total = 0.0;
+    jc_sync();
+#pragma unroll 1
+    while (!rooted) {
+        // ---- one attempt ------------------------------------------------------------------------------------------------------------
+        jc_d4 U[NTT];
+        bool failed = false;                                      // uniform
+        int c_fail = 0;
+        // (an early-exit chain: step k + 1 stands INSIDE the success branch of step k - with the steps side by side under `if (!failed)`
+        // every tile is alive across every join and the kernel spills a third of its registers)
+        auto step = [&](auto self, auto kc) -> void {
+            constexpr int k = decltype(kc)::value;
+            jc_d4 acc[NTL];
+            jc_for<k, NTL>([&](auto jcn) { acc[decltype(jcn)::value] = load_tile(kc, jcn, jit_total); });
+            jc_d4 Xn[k > 0 ? k : 1];
+            jc_for<0, k>([&](auto pc) {
+                constexpr int p = decltype(pc)::value;
+                Xn[p] = -U[jc_idx(p, k, NTL)];
+                acc[k] = jc_nat(Xn[p], U[jc_idx(p, k, NTL)], acc[k]);
+            });
+            jc_for<k + 1, NTL>([&](auto jcn) {
+                constexpr int j = decltype(jcn)::value;
+                jc_for<0, k>([&](auto pc) {
+                    constexpr int p = decltype(pc)::value;
+                    acc[j] = jc_nat(Xn[p], U[jc_idx(p, j, NTL)], acc[j]);
+                });
+            });
+            bool bad = false;
+            double mydinv;
+            jc_d4 V;
+            jc_diag_tile(blk, vt, acc[k], lr, lc, bad, mydinv, U[jc_idx(k, k, NTL)], V);
+            if (__builtin_amdgcn_ballot_w64(bad && (16 * k + lc < n)) != 0) {     // (uniform)
+                failed = true;
+                c_fail = min(16 * (k + 1), n);
+                return;
+            }
+            jc_for<k + 1, NTL>([&](auto jcn) {
+                constexpr int j = decltype(jcn)::value;
+                const jc_d4 zero = {0.0, 0.0, 0.0, 0.0};
+                U[jc_idx(k, j, NTL)] = jc_nat(V, acc[j], zero);
+            });
+            // column k of R is final: (R^T z)[16 k + lc] = sum_p sum_v sum_lr R_pk[4 v + lr][lc] z[16 p + 4 v + lr]
+            double sacc = 0.0;
+            jc_for<0, k + 1>([&](auto pc) {
+                constexpr int p = decltype(pc)::value;
+#pragma unroll
+                for (int v = 0; v < 4; ++v) sacc = fma(U[jc_idx(p, k, NTL)][v], zs[16 * p + 4 * v + lr], sacc);
+            });
+            sacc += __shfl_xor(sacc, 16, 64);
+            sacc += __shfl_xor(sacc, 32, 64);
+            if (lr == 0) ys[16 * k + lc] = sacc;
+            if constexpr (k + 1 < NTL) self(self, std::integral_constant<int, k + 1>{});
+        };
+        step(step, std::integral_constant<int, 0>{});
+        if (!failed) {
+            rooted = true;
+        } else {
+            // a retry whose jitter does not change ONE diagonal entry of the columns walked repeats the failed attempt operation for
+            // operation: it is counted, not run (total jitter after retry i is jitter * 10^i, accumulated incrementally like the library)
+            bool identical = true;
+            while (identical) {
+                if (level == 3) break;
+                const double jn = gp.jitter * ((level == 0) ? 1.0 : (level == 1) ? 10.0 : 100.0);
+                const double jp = (level == 0) ? 0.0 : gp.jitter * ((level == 1) ? 1.0 : 10.0);
+                const double jit_next = jit_total + (jn - jp);
+                bool same = true;
+                for (int t1 = lane; t1 < c_fail; t1 += 64) {
+                    const double d = Sm[(long)t1 * n + t1];
+                    same = same && ((d + jit_next) == (d + jit_total));
+                }
+                identical = __builtin_amdgcn_ballot_w64(!same) == 0;
+                jit_total = jit_next;
+                ++level;
+            }
+            if (identical && level == 3) break;
+        }
+    }
+    info_acc |= (level << 1);
+    if (!rooted) {
+        info_acc |= GPMPC_INFO_ROOT_FAIL;
+        if (lane == 0) atomicOr(a.any_fail, 1);
+    }
+    jc_sync();
+    // ---- sample + post-processing (reference src/agent.py:641-708): one lane per test point --------------------------------------------
+    for (int j = lane; j < m; j += 64) {
+        double vv[T], mm[T], yy[T];
+        bool all_zero = (a.var_zero_thr >= 0.0);
+#pragma unroll
+        for (int b = 0; b < T; ++b) {
+            const int tau = j * T + b;
+            double v = Sm[(long)tau * n + tau];
+            if (v < gp.var_floor) {
+                v = gp.var_floor;
+                info_acc |= GPMPC_INFO_VAR_CLAMPED;
+            }
+            vv[b] = v;
+            mm[b] = a.mean[chain * (long)n + tau];
+            all_zero = all_zero && (v <= a.var_zero_thr);
+            yy[b] = rooted ? ys[tau] + mm[b] : __builtin_nan("");
+        }
+#pragma unroll
+        for (int b = 0; b < T; ++b) {
+            double yb = all_zero ? mm[b] : yy[b];
+            if (a.apply_clip) {
+                const double sd = a.beta * sqrt(vv[b]);
+                yb = fmin(fmax(yb, mm[b] - sd), mm[b] + sd);
+            }
+            const long off = chain * (long)n + j * T + b;
+            a.var[off] = vv[b];
+            a.y[off] = yb;
+        }
+    }
+    if (a.covar) {                                                // (debug / tests) the covariance, both triangles from the valid one
+        double* Cv = a.covar + chain * (long)n * n;
+        for (int e = lane; e < n * n; e += 64) {
+            const int t2 = e / n, t1 = e - t2 * n;
+            Cv[(long)t1 * n + t2] = Sm[(long)min(t1, t2) * n + max(t1, t2)];
+        }
+    }
+    // (the lanes' bits: OR over the wave)
+    for (int off = 32; off >= 1; off >>= 1) info_acc |= __shfl_xor(info_acc, off, 64);
+    if (lane == 0) a.info[chain] = (a.info_in ? a.info[chain] : 0) | info_acc;
+}
+
+bool joint_tail_mfma_eligible(int mT, int T) { return T == 3 && mT >= 2 && mT <= 128; }
+
+int joint_tail_mfma_launch(const JointArgs& a, hipStream_t st) {
+    const int n = a.m * a.gp.T;
+    if (!joint_tail_mfma_eligible(n, a.gp.T)) return fail(GPMPC_E_UNSUPPORTED, "joint_tail_mfma_kernel: T = 3, 2..128 test slots");
+    const long nch = a.chain1 - a.chain0;
+    const dim3 g((unsigned)nch), b(64);
+    const int ntl = (n + 15) / 16;
+    if (ntl <= 2) hipLaunchKernelGGL(joint_tail_mfma_kernel<2>, g, b, 0, st, a);
+    else if (ntl <= 4) hipLaunchKernelGGL(joint_tail_mfma_kernel<4>, g, b, 0, st, a);
+    else if (ntl <= 6) hipLaunchKernelGGL(joint_tail_mfma_kernel<6>, g, b, 0, st, a);
+    else hipLaunchKernelGGL(joint_tail_mfma_kernel<8>, g, b, 0, st, a);
     GPMPC_HIP_CHECK(hipGetLastError());
     return GPMPC_OK;
 }
