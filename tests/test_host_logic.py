@@ -118,6 +118,12 @@ def test_argument_validation_without_a_gpu():
     rc = lib.gpmpc_rollout(ok, env, 1, 1, _lib.MODE_RECONDITIONED, 3, -1.0, 2.5, 4, 5, 1, 0, 1, 1, 0, 1, None, None, 1,
                            None, 0, None)
     assert rc == -1 and b"car_residual needs" in lib.gpmpc_last_error_string()
+    # the entry points of rounds 6 (ABI 8 / 9) check their arguments on the host as well
+    assert lib.gpmpc_joint_sample_pending(ok, None, None, 4, 0, None, None, None, 0, 5, None, None, -1.0, 2.5, 1, None, None, None, None,
+                                          None, 0, None, None, 0, None, None, 0, 0, _lib.PENDING_USE | _lib.PENDING_WRITE) == -1
+    assert b"NULL pointer" in lib.gpmpc_last_error_string() and lib.gpmpc_joint_pending_written() == 0
+    assert lib.gpmpc_build_x_hat(2, 1, 4, 5, None, None, 0, None, None) == -1 and b"gpmpc_build_x_hat" in lib.gpmpc_last_error_string()
+    assert lib.gpmpc_assemble_jacobians_plin(ok, env, 4, 5, None, None, None, None, None, None, None, None, None, None, None, None) != 0
 
 
 def test_product_path_fails_loudly_without_hip_device():
