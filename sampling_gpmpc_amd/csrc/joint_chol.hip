@@ -57,21 +57,18 @@ __device__ __forceinline__ jc_d4 jc_nat(const jc_d4& X, const jc_d4& Y, jc_d4 C)
     return C;
 }
 // acc -= m * src@lane J of the DPP row (src is read through DPP: it must not have been written in the two instructions before)
-template <int J, bool NOP = false>
+// (EVERY statement carries its own two wait states: the register a DPP read names must not have been written by the VALU in the two
+// instructions before, and hipcc is free to put a copy of an operand right in front of an asm statement - it did, at the last pivot of
+// the eight-tile instance; tools/check_dpp_hazard.py, a CPU test, scans this file's ISA for exactly that)
+template <int J, bool NOP = true>
 __device__ __forceinline__ void jc_fnma_bcast(double& acc, double src, double m) {
-    if constexpr (NOP)      // the first DPP read behind the VALU instructions that wrote the step's sources: two wait states
-        asm("s_nop 1\n\tv_fmac_f64_dpp %0, %1, -%2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(src), "v"(m), "n"(J));
-    else
-        asm("v_fmac_f64_dpp %0, %1, -%2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(src), "v"(m), "n"(J));
+    asm("s_nop 1\n\tv_fmac_f64_dpp %0, %1, -%2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(src), "v"(m), "n"(J));
 }
 
 // acc -= m * acc@lane J of the DPP row (accumulator and broadcast source are the SAME register: as two asm operands hipcc copies it)
-template <int J, bool NOP = false>
+template <int J, bool NOP = true>
 __device__ __forceinline__ void jc_fnma_self(double& acc, double m) {
-    if constexpr (NOP)
-        asm("s_nop 1\n\tv_fmac_f64_dpp %0, %0, -%1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(m), "n"(J));
-    else
-        asm("v_fmac_f64_dpp %0, %0, -%1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(m), "n"(J));
+    asm("s_nop 1\n\tv_fmac_f64_dpp %0, %0, -%1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(m), "n"(J));
 }
 
 // GPMPC_PHASE_TIMERS: cycles of chain 0's wave per phase (loads | updates | diagonal tile | panel | stores), tools/debug/chol_phases.py

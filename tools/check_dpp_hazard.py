@@ -31,7 +31,7 @@ import tempfile
 
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(REPO, "sampling_gpmpc_amd", "csrc")
-SOURCES = ["rollout_indep.hip", "rollout_tiles.hip", "rollout_one.hip"]
+SOURCES = ["rollout_indep.hip", "rollout_tiles.hip", "rollout_one.hip", "joint_chol.hip"]
 EXTRA = {"rollout_one.hip": ["-mllvm", "-disable-machine-licm"]}        # as csrc/build.py compiles it
 
 
@@ -56,12 +56,16 @@ def regs(tok):
 TOK = r"-?[va]\[\d+:\d+\]|-?[va]\d+"
 MFMA_WS_RELAXED = 6         # rollout_one.hip only (its solve statements are scheduled on the mfma64_fill.hip measurement)
 RELAXED_FILES = ("rollout_one",)
+# joint_chol.hip issues its MFMAs through the compiler builtin (hipcc's own hazard recogniser pads them) and its DPP broadcasts from
+# inline asm: rule D1 only
+DPP_ONLY_FILES = ("joint_chol", "jc")
 
 
 def check(path, mfma_ws=None):
     if mfma_ws is None:     # STRICT by default: an MFMA is one wait state like any instruction; relaxed only for the named files
         mfma_ws = MFMA_WS_RELAXED if os.path.basename(path).startswith(RELAXED_FILES) else 1
     counts = {"dpp": 0, "mfma": 0}
+    dpp_only = os.path.basename(path).startswith(DPP_ONLY_FILES)
     problems, kernel = [], None
     window = []          # preceding instructions, newest last: (wait states, wait states for M2-M4, kind, set of ('v'|'a', n) written)
     for ln, raw in enumerate(open(path), 1):
@@ -94,7 +98,9 @@ def check(path, mfma_ws=None):
             counts["dpp"] += 1
             if len(tagged) > 1:
                 scan(tagged[1], "D1", 2, ("valu",))
-        if is_mfma:
+        if is_mfma and dpp_only:
+            counts["mfma"] += 1
+        elif is_mfma:
             counts["mfma"] += 1
             srcs = tagged[1:]
             for i, rd in enumerate(srcs):
@@ -103,7 +109,7 @@ def check(path, mfma_ws=None):
         else:
             reads = set().union(*tagged[(1 if (op.startswith("v_") or op.startswith("ds_read") or op.startswith("buffer_load")
                                                or op.startswith("global_load") or op.startswith("scratch_load")) else 0):]) if tagged else set()
-            if reads:
+            if reads and not dpp_only:
                 scan(reads, "M4", 6, ("mfma",))
         if op == "s_nop":
             m = re.search(r"s_nop\s+(\d+)", code)
