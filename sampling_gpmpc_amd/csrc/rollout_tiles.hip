@@ -55,12 +55,15 @@ __device__ double g_tiles_dbg[64 * 64];
 
 // GPMPC_TILES_PHASES: per-phase s_memtime totals of wave 0 (lane 0) in g_tiles_dbg[63 * 64 + phase] (tools/debug/tiles_phases.py)
 #ifdef GPMPC_TILES_PHASES
-#define TPH_DECL long long tph_[8] = {0, 0, 0, 0, 0, 0, 0, 0}; long long tpht_ = __builtin_readcyclecounter()
-#define TPH(i) do { const long long n_ = __builtin_readcyclecounter(); tph_[i] += n_ - tpht_; tpht_ = n_; } while (0)
-#define TPH_STORE do { if (blockIdx.x == 0 && threadIdx.x == 0) for (int i_ = 0; i_ < 8; ++i_) g_tiles_dbg[63 * 64 + i_] = (double)tph_[i_]; } while (0)
+#define TPH_DECL long long tph_[8] = {0, 0, 0, 0, 0, 0, 0, 0}; long long tpht_ = __builtin_readcyclecounter(); long long tps_[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; long long tpst_ = tpht_
+#define TPH(i) do { const long long n_ = __builtin_readcyclecounter(); tph_[i] += n_ - tpht_; tpht_ = n_; tpst_ = n_; } while (0)
+// sub-phases (slots 8 .. 23 of the record): cycles since the last TPH / TPS mark
+#define TPS(i) do { const long long n_ = __builtin_readcyclecounter(); tps_[i] += n_ - tpst_; tpst_ = n_; } while (0)
+#define TPH_STORE do { if (blockIdx.x == 0 && threadIdx.x == 0) { for (int i_ = 0; i_ < 8; ++i_) g_tiles_dbg[63 * 64 + i_] = (double)tph_[i_]; for (int i_ = 0; i_ < 16; ++i_) g_tiles_dbg[63 * 64 + 8 + i_] = (double)tps_[i_]; } } while (0)
 #else
 #define TPH_DECL
 #define TPH(i)
+#define TPS(i)
 #define TPH_STORE
 #endif
 
@@ -395,6 +398,19 @@ __global__ __launch_bounds__(64, 1) void rollout_tiles_kernel(const RolloutArgs 
     int info_acc = 0;
     int n_pts = 0;                                                // appended points; n_h = 3 n_pts label rows
 
+    // the feedback law's constants once, not one scalar round trip per step and use (they sit in the kernel-argument segment)
+    double fbK[NU][NX], fbg[NX];
+#pragma unroll
+    for (int i = 0; i < NU; ++i)
+#pragma unroll
+        for (int j = 0; j < NX; ++j) fbK[i][j] = a.env.K[i][j];
+#pragma unroll
+    for (int j = 0; j < NX; ++j) fbg[j] = a.env.x_goal[j];
+    const bool use_fb = a.env.use_feedback != 0;
+    const double env_dt = a.env.dt;
+    double uf_next[NU];
+#pragma unroll
+    for (int i = 0; i < NU; ++i) uf_next[i] = a.u_ff[i];         // (step 0's input; a conditioning-only pass uses the seed's point)
     TPH_DECL;
 #pragma unroll 1
     for (int tt = -n_pre; tt < H; ++tt) {
@@ -412,15 +428,20 @@ __global__ __launch_bounds__(64, 1) void rollout_tiles_kernel(const RolloutArgs 
             for (int d = 0; d < NX; ++d) x[d] = xP[d].get();
 #pragma unroll
             for (int i = 0; i < NU; ++i) {
-                const double uf = a.u_ff[t * NU + i];
-                if (a.env.use_feedback) {
+                const double uf = uf_next[i];                     // requested a step ago (a scalar round trip per step otherwise)
+                if (use_fb) {
                     double acc = 0.0;
 #pragma unroll
-                    for (int j = 0; j < NX; ++j) acc += (a.env.x_goal[j] - x[j]) * a.env.K[i][j];
+                    for (int j = 0; j < NX; ++j) acc += (fbg[j] - x[j]) * fbK[i][j];
                     u[i] = -acc + uf;
                 } else {
                     u[i] = uf;
                 }
+            }
+            {
+                const int tn1 = (tt + 1 < 0) ? 0 : min(tt + 1, H - 1);   // the next step's input: requested now, used a step later
+#pragma unroll
+                for (int i = 0; i < NU; ++i) uf_next[i] = a.u_ff[tn1 * NU + i];
             }
             xi[0] = x[(ENV == GPMPC_ENV_PENDULUM1D) ? 0 : (NX > 2 ? 2 : 0)];
             xi[1] = u[0];
@@ -444,6 +465,7 @@ __global__ __launch_bounds__(64, 1) void rollout_tiles_kernel(const RolloutArgs 
             }
         }
 
+        TPS(0);                                                   // A1: state, feedback law, GP input, trajectory stores
         // ---- phase A: the real block at the test point (grid root) ---------------------------------------------------
         double P0 = 0.0, P1 = 0.0;                                // lanes < N0: PA0', PA1'; lanes N0 .. N0+N1-1: PB0', PB1'
         double E0[NE], E1[NE];
@@ -481,6 +503,7 @@ __global__ __launch_bounds__(64, 1) void rollout_tiles_kernel(const RolloutArgs 
                 SX[2 * L::XH + L::YH + (l - N0)] = P1;
             }
             tiles_sync_lds();
+            TPS(1);                                               // A2: unpark, exponential, axis products, record to LDS
 #pragma unroll
             for (int q = 0; q < NE; ++q) {
                 const double pa0 = SX[ea_[q]], pa1 = SX[L::XH + ea_[q]];
@@ -495,6 +518,7 @@ __global__ __launch_bounds__(64, 1) void rollout_tiles_kernel(const RolloutArgs 
                 dst[ycol] = wEe[q];
             }
             tiles_sync_lds();
+            TPS(2);                                               // A3: grid entries, pseudo-tiles to LDS
             double Sq[2] = {0.0, 0.0};
             double rt[NRT];
 #pragma unroll
@@ -503,6 +527,7 @@ __global__ __launch_bounds__(64, 1) void rollout_tiles_kernel(const RolloutArgs 
             const double Sa = Sq[0], Sb = Sq[1];
             Sr = Sa + Sb;
             tiles_sync_lds();                                     // SCR is reused by phase B
+            TPS(3);                                               // A4: the real block's Gram on the matrix pipe
         }
 
         TPH(0);
@@ -553,6 +578,7 @@ __global__ __launch_bounds__(64, 1) void rollout_tiles_kernel(const RolloutArgs 
 #pragma unroll
                         for (int b = 0; b < T; ++b) out[aa][b] = kk * fma(Aa[aa], Bb[b], (aa == b) ? cd[aa] : 0.0);
                 }
+                TPS(4);                                           // B1: kernel entries against the test point (one exponential)
                 // minus the real-data correction  v_r(point, task a) . v_r(test point, task b)  in Kronecker form
                 {
                     double PAj[2][N0], PBj[2][N1];
@@ -594,6 +620,7 @@ __global__ __launch_bounds__(64, 1) void rollout_tiles_kernel(const RolloutArgs 
                     tl_outer<N0>(c0, c1, c2, P0, P1, xa, xb);
                     out[2][0] -= c0, out[2][1] -= c1, out[2][2] -= c2;
                 }
+                TPS(5);                                           // B2: the Kronecker correction (records from LDS, DPP products)
                 const double2_v y01 = *reinterpret_cast<const double2_v*>(YT + jr * 4);
                 const double y2 = YT[jr * 4 + 2];
                 const double yt[T] = {y01.x, y01.y, y2};
@@ -612,6 +639,7 @@ __global__ __launch_bounds__(64, 1) void rollout_tiles_kernel(const RolloutArgs 
                     if constexpr (tg < NT) V[tg] = SCRm[(4 * w + kq) * 4 + jq];
                 });
                 tiles_sync_lds();
+                TPS(6);                                           // B3 / C: through the lane-map converter into tile registers
             }
         });
 
@@ -910,13 +938,26 @@ __global__ __launch_bounds__(64, 1) void rollout_tiles_kernel(const RolloutArgs 
                 }
             }
             tiles_sync_lds();
+            TPS(7);                                               // H1: the point's record, labels, point, C to LDS
             // MFMA side.  Lane (kq, jq) of tile pair (Rt, Pt) is the entry row gi = 4 Rt + jq, column gk = 4 Pt + kq of L.
             // New rows are n_h .. n_h+2; their entry against an OLD column is v of that column = V[Pt] in this very lane.
             const int base = n_h;
-            auto entry = [&](int Rt, int Pt, double vown, double old) -> double {
+            // (the entries of C and 1 / diag this lane will want are read HERE, in front of the store chain below: their LDS latency -
+            // seven dependent round trips where the diagonal tiles use them - passes under the stores)
+            auto c_read = [&](int Rt, int Pt) -> double {
                 const int gi = 4 * Rt + jq, gk = 4 * Pt + kq;
                 const int ci = min(max(gi - base, 0), 2), ck = min(max(gk - base, 0), 2);
-                const double cval = SXm[64 + 3 * ci + ck];
+                return SXm[64 + 3 * ci + ck];
+            };
+            auto d_read = [&](int Rt, bool rowwise) -> double {
+                const int g = 4 * Rt + (rowwise ? kq : jq);
+                return SXm[73 + min(max(g - base, 0), 2)];
+            };
+            const int tn_ = n_h >> 2;
+            const double cv_tt = c_read(tn_, tn_), cv_ut = c_read(tn_ + 1, tn_), cv_uu = c_read(tn_ + 1, tn_ + 1);
+            const double dr_t = d_read(tn_, true), dc_t = d_read(tn_, false), dr_u = d_read(tn_ + 1, true), dc_u = d_read(tn_ + 1, false);
+            auto entry = [&](int Rt, int Pt, double vown, double old, double cval) -> double {
+                const int gi = 4 * Rt + jq, gk = 4 * Pt + kq;
                 double val = (gk <= gi) ? cval : 0.0;             // both new
                 const bool dead = vo_new && gi > base;            // (only read for rows base .. base + 2)
                 val = (gk < base) ? (dead ? 0.0 : vown) : val;    // new row, old column
@@ -935,25 +976,24 @@ __global__ __launch_bounds__(64, 1) void rollout_tiles_kernel(const RolloutArgs 
                     constexpr int p = decltype(pcn)::value;
                     if constexpr (p < NT) {
                         if (p < tn) {
-                            if (isnew) {
-                                const unsigned e = rowtile + p;
-                                tile_store(lane16 + (e >> 1) * 1024u + (e & 1u) * 8u, 0, deadrow ? 0.0 : -V[p]);
-                            }
+                            // (unconditional: a lane that holds no new row names an offset beyond the descriptor's end - the store is
+                            // dropped without traffic and without an exec-mask region per tile)
+                            const unsigned e = rowtile + p;
+                            tile_store(isnew ? lane16 + (e >> 1) * 1024u + (e & 1u) * 8u : 0x7ffff000u, 0, deadrow ? 0.0 : -V[p]);
                             self(self, std::integral_constant<int, p + 1>{});
                         }
                     }
                 };
                 store_from(store_from, std::integral_constant<int, 0>{});
             }
+            TPS(8);                                               // H2: the new rows' tiles against the complete old tile rows (stores)
             // the tile pairs that involve tile tn itself (old rows of the incomplete tile) and the new tile tn+1
             // (a search for V[tn] over the register array turns it into a scratch array: hipcc makes a table lookup of it)
             const double Vtn = ((n_h & 3) != 0) ? Vlast : 0.0;    // tile row tn exists only if it is incomplete
             const bool wraps = i0 >= 2;                           // rows n_h .. n_h+2 reach into tile tn+1
             // diagonal tile tn: U = L^T (natural), its row / column scalings
-            auto diag_scal = [&](int Rt, double oldv, bool rowwise) -> double {
+            auto diag_scal = [&](int Rt, double oldv, bool rowwise, double cv_) -> double {
                 const int g = 4 * Rt + (rowwise ? kq : jq);
-                const int c = min(max(g - base, 0), 2);
-                const double cv_ = SXm[73 + c];
                 double v = (g >= base + 3) ? 1.0 : cv_;
                 v = (g < base) ? oldv : v;
                 return v;
@@ -973,8 +1013,8 @@ __global__ __launch_bounds__(64, 1) void rollout_tiles_kernel(const RolloutArgs 
                 const double dcur = dcP.get();
                 const double drow_old = mfma_zero_v(dcur, ones);  // [k][i] = 1 / d_k
                 const double dcol_old = mfma_zero_v(ones, dcur);  // [k][i] = 1 / d_i
-                const double U = entry(tn, tn, Vtn, ucP.get());
-                const double drow = diag_scal(tn, drow_old, true), dcol = diag_scal(tn, dcol_old, false);
+                const double U = entry(tn, tn, Vtn, ucP.get(), cv_tt);
+                const double drow = diag_scal(tn, drow_old, true, dr_t), dcol = diag_scal(tn, dcol_old, false, dc_t);
                 const double Gt = inverse_tile(U, drow, dcol);
                 TDBG(26, U);
                 TDBG(27, drow);
@@ -983,11 +1023,11 @@ __global__ __launch_bounds__(64, 1) void rollout_tiles_kernel(const RolloutArgs 
                 tile_store(lane16, tri(tn) + tn, Gt);
                 double Unext = U, dnext = (kq == jq) ? drow : 0.0;
                 if (wraps) {
-                    const double X = entry(tn + 1, tn, Vtn, 0.0);
+                    const double X = entry(tn + 1, tn, Vtn, 0.0, cv_ut);
                     const bool newrow1 = jq <= i0 - 2;            // rows of tile tn+1 that exist now
                     if (newrow1) tile_store(lane16, tri(tn + 1) + tn, -X);
-                    const double U1 = entry(tn + 1, tn + 1, 0.0, 0.0);
-                    const double drow1 = diag_scal(tn + 1, 1.0, true), dcol1 = diag_scal(tn + 1, 1.0, false);
+                    const double U1 = entry(tn + 1, tn + 1, 0.0, 0.0, cv_uu);
+                    const double drow1 = diag_scal(tn + 1, 1.0, true, dr_u), dcol1 = diag_scal(tn + 1, 1.0, false, dc_u);
                     const double G1 = inverse_tile(U1, drow1, dcol1);
                     TDBG(30, U1);
                     TDBG(31, drow1);
@@ -1007,6 +1047,7 @@ __global__ __launch_bounds__(64, 1) void rollout_tiles_kernel(const RolloutArgs 
                 ucP.put(Unext);
                 dcP.put(dnext);
             }
+            TPS(9);                                               // H3: the incomplete diagonal tile(s): entries, inverses, stores
             // a tile row that became complete moves into its AGPRs
             if (i0 >= 1 && tn < NRA) {                            // (uniform) a resident row completed: its stores first -
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this lane re-reads only its own slots
@@ -1026,6 +1067,7 @@ __global__ __launch_bounds__(64, 1) void rollout_tiles_kernel(const RolloutArgs 
                 });
             }
             n_pts += 1;
+            TPS(10);                                              // H4: a completed tile row back into its AGPRs
         }
 
         TPH(5);
@@ -1035,7 +1077,7 @@ __global__ __launch_bounds__(64, 1) void rollout_tiles_kernel(const RolloutArgs 
 #pragma unroll
             for (int d = 0; d < NX; ++d) x[d] = xP[d].get();
             if (ENV == GPMPC_ENV_PENDULUM1D) {
-                const double x0n = x[0] + x[1] * a.env.dt;
+                const double x0n = x[0] + x[1] * env_dt;
                 x[1] = x[1] + y[0];
                 x[0] = x0n;
             } else {
@@ -1046,7 +1088,7 @@ __global__ __launch_bounds__(64, 1) void rollout_tiles_kernel(const RolloutArgs 
                 x[0] = x[0] + vv * g0;
                 x[1] = x[1] + vv * g1;
                 x[I2] = x[I2] + vv * g2;
-                x[I3] = x[I3] + uP.get() * a.env.dt;
+                x[I3] = x[I3] + uP.get() * env_dt;
             }
 #pragma unroll
             for (int d = 0; d < NX; ++d) xP[d].put(x[d]);

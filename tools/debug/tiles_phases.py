@@ -18,3 +18,8 @@ tot = ph.sum()
 for n, v in zip(names, ph):
     print(f"  {n:28s} {v / H:10.0f} cycles/step  {100 * v / max(tot, 1):5.1f} %")
 print(f"  total {tot / H:.0f} cycles/step, {tot:.0f} per rollout")
+sub = np.array(buf)[63 * 64 + 8: 63 * 64 + 24]
+snames = ["A1 state / feedback / input", "A2 exp + axis products", "A3 grid entries -> LDS", "A4 real-block Gram (MFMA)", "B1 kernel entries", "B2 Kronecker correction",
+          "B3/C lane-map conversion", "H1 record / labels / C -> LDS", "H2 new rows' tile stores", "H3 diagonal tiles", "H4 row reload into AGPRs"]
+for n, v in zip(snames, sub):
+    print(f"      {n:32s} {v / H:10.0f} cycles/step")
