@@ -260,3 +260,42 @@ def test_pending_rows_of_the_factor_cache(sg, pname, Ns, Hh, monkeypatch):
             assert e < tol_m, f"call {i}: {name} with pending rows is {e:.1e} from the recomputed rows"
         ey = float(np.abs(a[3] - b[3]).max() / np.abs(b[3]).max())
         assert ey < tol_y, f"call {i}: samples {ey:.1e}"
+
+
+def test_closed_loop_sequence_is_deterministic_at_full_width(sg):
+    """The closed loop's OWN sequence at the configs[4] shard (Ns = 1024, H = 40, two MPC steps x four SQP iterations, dispatcher's choice
+    of path, pending rows on): two fresh Agents with the same base samples give bit-equal means, variances and Jacobians at every call -
+    joint_chol_mfma_kernel (in place on the pending block), the test-mode launch that writes the pending rows, joint_tail_mfma_kernel and
+    the TOP + BOTTOM pair all run at full width here (the repeat-determinism test above rewinds the cache, which drops the pending rows)."""
+    from tests.helpers import closed_loop_params
+    lib = sg._lib.load()
+    Ns, iters = 1024, 4
+    p = closed_loop_params("params_car_residual", Ns, H, 2, iters)
+    p["common"]["use_cuda"] = True
+    p["agent"]["base_sample_generator"] = "counter"
+    x0 = np.array(p["env"]["start"], dtype=np.float64)[:4]
+    runs = []
+    for rep in range(2):
+        agent = sg.Agent(p, sg.make_env(p))
+        u_h, x_h, rec = _u_ff(), np.tile(x0, (H, Ns)), []
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            for step in range(2):
+                agent.mpc_iteration(step)
+                for k in range(iters):
+                    agent.train_hallucinated_dynGP(k)
+                    gv, yg, _ = agent.dyn_fg_jacobians(agent.get_batch_x_hat(x_h, u_h), k)
+                    post = agent.model_i_call
+                    rec.append((post.mean.clone(), post.variance.clone(), gv.copy(), yg.copy(), bool(post.used_pending),
+                                int(lib.gpmpc_joint_last_path())))
+                    assert np.isfinite(gv).all() and not (post.last_info & sg._lib.INFO_TRAIN_CHOL_FAIL).any()
+                    mean_next = gv[:, :, :, 0].mean(axis=0).T
+                    x_h = np.tile(np.vstack([x0[None, :], mean_next[:-1]]), (1, Ns))
+        runs.append(rec)
+        del agent
+    assert [r[4] for r in runs[0]] == [False, False, True, True, True, False, True, True]
+    assert [r[5] for r in runs[0]] == [sg._lib.JOINT_VALU] + [sg._lib.JOINT_MFMA] * 7
+    for i, (a, b) in enumerate(zip(*runs)):
+        assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]), f"call {i}: mean / variance differ between two runs"
+        np.testing.assert_array_equal(a[2], b[2])
+        np.testing.assert_array_equal(a[3], b[3])
