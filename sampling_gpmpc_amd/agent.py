@@ -308,7 +308,9 @@ class Agent(object):
         # a draw that failed leaves NaN labels behind (negative 1 x 1 variance, an eigensolver that did not converge, a root that
         # failed with the eigh root switched off): the observed-slot scan has to see them - gpytorch's mask policy drops such slots
         call = self.model_i_call
-        if call is not None and (int(getattr(call, "last_bits", 0)) & (_lib.INFO_NEG_1x1 | _lib.INFO_EIGH_NOCONV | _lib.INFO_ROOT_FAIL)):
+        bits = int(getattr(call, "last_bits", 0)) if call is not None else 0
+        root_nan = (bits & _lib.INFO_ROOT_FAIL) and not (bits & _lib.INFO_ROOT_EIGH)   # ROOT_FAIL | ROOT_EIGH = the batch was redrawn
+        if root_nan or (bits & (_lib.INFO_NEG_1x1 | _lib.INFO_EIGH_NOCONV)):            # with the eigh root: finite labels (the car as shipped)
             self._hall_all_observed = False
 
     def get_batch_x_hat_u_diff(self, x_h, u_h):

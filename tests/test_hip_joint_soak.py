@@ -284,6 +284,9 @@ def test_closed_loop_sequence_is_deterministic_at_full_width(sg):
                 agent.mpc_iteration(step)
                 for k in range(iters):
                     agent.train_hallucinated_dynGP(k)
+                    if agent.model_i.n_h:   # the Agent skips the observed-slot scan when every label came out of a finite draw (the eigh
+                        from sampling_gpmpc_amd.gp_model import _observed_slots    # redraw of the car included): the scan has to agree
+                        assert torch.equal(agent.model_i.h_slots, _observed_slots(agent.model_i.hall_Y)) and (k == 0 or agent._hall_all_observed)
                     gv, yg, _ = agent.dyn_fg_jacobians(agent.get_batch_x_hat(x_h, u_h), k)
                     post = agent.model_i_call
                     rec.append((post.mean.clone(), post.variance.clone(), gv.copy(), yg.copy(), bool(post.used_pending),
