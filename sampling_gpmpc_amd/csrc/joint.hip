@@ -1020,6 +1020,7 @@ static int joint_mfma_from() {
 }
 static int g_tail_kernel_force = -1;      // gpmpc_debug_joint_tail_kernel: -1 default (on), 0 / 1 forced
 static int g_chol_kernel_force = -1;      // gpmpc_debug_joint_chol_kernel: -1 default (on), 0 / 1 forced (tests, A/B timing)
+static int g_real_kernel_force = -1;      // gpmpc_debug_joint_real_kernel: -1 default (on), 0 / 1 forced (tests, A/B timing)
 static int g_eigh_narrow_force = -1;      // gpmpc_debug_eigh_narrow: -1 heuristic, 0 / 1 forced (tests)
 static int g_joint_path_pin = 0;          // gpmpc_joint_pin_path: 0 auto, 1 VALU path, 2 matrix-pipe path where instantiated
 static int g_joint_last_path = 0;
@@ -1114,6 +1115,13 @@ int gpmpc_debug_joint_tail_kernel(int mode) {
 int gpmpc_debug_joint_chol_kernel(int mode) {
     const int prev = g_chol_kernel_force;
     g_chol_kernel_force = mode < 0 ? -1 : (mode ? 1 : 0);
+    return prev;
+}
+// tests / A-B timing: joint_real_mfma_kernel (columns conditioned on the real data alone: the factor extension with nothing cached, the
+// draw without hallucinated slots) off (0) / on (1), -1 = default (on; GPMPC_JOINT_REAL_KERNEL=0 turns it off); returns the previous value
+int gpmpc_debug_joint_real_kernel(int mode) {
+    const int prev = g_real_kernel_force;
+    g_real_kernel_force = mode < 0 ? -1 : (mode ? 1 : 0);
     return prev;
 }
 // tests: force the two-launch form of the eigendecomposition root off (0) / on (1), -1 = the rank heuristic; returns the previous value
@@ -1339,6 +1347,10 @@ int gpmpc_joint_sample_pending(const gpmpc_gp_desc_t* gp, const void* plan, cons
         const bool pend_use = (pending & GPMPC_PENDING_USE) && own && b.n_c > 0 && gp->T == 3 && joint_chol_mfma_eligible(n_new);
         const bool pend_write = (pending & GPMPC_PENDING_WRITE) && own && !split && gp->T == 3 && n_ho + mT <= a.fc_cap &&
                                 joint_chol_mfma_eligible(mT);
+        static const char* renv = getenv("GPMPC_JOINT_REAL_KERNEL");
+        const int rforce = g_real_kernel_force >= 0 ? g_real_kernel_force : (renv ? atoi(renv) : 1);
+        const bool real_first = rforce != 0 && b.n_c == 0 && n_new == n_ho && joint_real_mfma_eligible(a.gp.n_r, a.gp.N_r, n_ho, n_h, gp->T, gp->D) &&
+                                joint_chol_mfma_eligible(n_new) && !(fenv && atoi(fenv) == 0);
         const long step = split ? w.xt_slots : (own ? nchains : w.tc_slots);
         for (long c0 = 0; c0 < nchains; c0 += step) {
             b.chain0 = c0;
@@ -1353,6 +1365,16 @@ int gpmpc_joint_sample_pending(const gpmpc_gp_desc_t* gp, const void* plan, cons
                 if (int rc = joint_chol_mfma_launch(b, st)) return rc;
                 b.pend_use = 0;
                 GPMPC_HIP_CHECK(hipGetLastError());
+                b.info_in = 1;
+            } else if (n_new > 0 && real_first) {
+                // nothing cached - the second SQP iteration of an MPC step, right behind the reset - so the new slots only meet the real
+                // columns: one wave per chain forms X^T and the Schur complement in the cache (what a draw with pending rows leaves
+                // there), joint_chol_mfma_kernel factorises it in place (0.41 + 0.18 -> 0.1 + 0.18 ms at the configs[4] shard)
+                b.mfma_mode = JOINT_MFMA_FACTOR;
+                if (int rc = joint_real_mfma_launch(b, st)) return rc;
+                b.pend_use = 1;
+                if (int rc = joint_chol_mfma_launch(b, st)) return rc;
+                b.pend_use = 0;
                 b.info_in = 1;
             } else if (n_new > 0) {
                 if (mfma_factor) {
@@ -1400,7 +1422,17 @@ int gpmpc_joint_sample_pending(const gpmpc_gp_desc_t* gp, const void* plan, cons
         // hallucinated row cached: 13.3 ms against 11.2 - the test rows' stream is the critical path of this kernel either way.)
         g_joint_last_path = 1;
         const int nrow = n_ho + 1 + mT - a.n_c;        // rows that are computed (the cached ones have no thread)
-        if (tail_kernel) {                             // head (factor rows, test rows, mean, S) here, the tail one wave per chain
+        static const char* renv = getenv("GPMPC_JOINT_REAL_KERNEL");
+        const int rforce = g_real_kernel_force >= 0 ? g_real_kernel_force : (renv ? atoi(renv) : 1);
+        if (n_ho == 0 && tail_kernel && rforce != 0 && g_joint_path_pin != 1 && joint_real_mfma_eligible(a.gp.n_r, a.gp.N_r, mT, m, gp->T, gp->D)) {
+            // no hallucinated slot (the first SQP iteration of the first MPC step): the test columns only meet the real data, whose
+            // inverse factor all chains of an output share - X = L_rr^-1 K_r*, mean and S one wave per chain on the matrix pipe
+            g_joint_last_path = 2;
+            a.mfma_mode = JOINT_MFMA_TEST;
+            if (int rc = joint_real_mfma_launch(a, st)) return rc;
+            a.info_in = 1;
+            if (int rc = joint_tail_mfma_launch(a, st)) return rc;
+        } else if (tail_kernel) {                             // head (factor rows, test rows, mean, S) here, the tail one wave per chain
             a.phase = JOINT_PHASE_HEAD;
             a.abandon_root = 0;
             launch(a, nrow);

@@ -98,4 +98,10 @@ int joint_chol_mfma_launch(const JointArgs& a, hipStream_t st);
 bool joint_tail_mfma_eligible(int mT, int T);
 int joint_tail_mfma_launch(const JointArgs& a, hipStream_t st);
 
+// columns conditioned on the real data alone (joint_real_mfma_kernel): a.mfma_mode = JOINT_MFMA_FACTOR - the n_ho new hallucinated slots with
+// nothing cached: X^T and the Schur complement before the noise into the cache, as a draw with GPMPC_PENDING_WRITE leaves them -, or
+// JOINT_MFMA_TEST - a draw without hallucinated slots: mean into a.mean, S into a.Sall, info[chain] = 0
+bool joint_real_mfma_eligible(int n_r, int N_r, int ncols, int P, int T, int D);      // P: points behind the columns (m / n_h)
+int joint_real_mfma_launch(const JointArgs& a, hipStream_t st);
+
 }  // namespace gpmpc

@@ -500,6 +500,269 @@ int joint_tail_mfma_launch(const JointArgs& a, hipStream_t st) {
     return GPMPC_OK;
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// joint_real_mfma_kernel: columns conditioned on the REAL data alone, one WAVE per chain on the same tile machinery.  Two uses:
+//   * JOINT_MFMA_FACTOR - the second SQP iteration of every MPC step: the hallucinated set was reset (reference src/agent.py:261-272),
+//     the n_ho slots of the first iteration's points are all new and only meet the real columns.  X = L_rr^-1 K_r,new is their block of
+//     the factor against the real columns (X^T into the cache rows 0 .. n_ho - 1) and S = K_nn - X^T X their Schur complement before the
+//     likelihood noise (into the rows' diagonal block): exactly what a draw with GPMPC_PENDING_WRITE leaves behind, so the factor
+//     extension is this launch + joint_chol_mfma_kernel in its pending form.  (joint_test_mfma_kernel's factor mode did that in 0.41
+//     ms at the configs[4] shard: eight waves and 158 KB of LDS per chain, one chain per CU, for a substitution over three slot tiles.)
+//   * JOINT_MFMA_TEST - a draw with NO hallucinated slot (the first SQP iteration of the first MPC step; reference src/agent.py:629-641
+//     on the real-data model): mean = X^T w_r and S = K** - X^T X (both triangles, into a.Sall) for the test slots; the tail follows.
+// L_rr^-1 is the plan's (shared by all chains of an output): the A operand of X_qj = sum_{q2 <= q} Linv_{q q2} K_{q2 j} is a tile of
+// LinvT as it lies in memory (nat(X, Y) = X^T Y), the kernel entries are formed in the D layout they are consumed in.
+// dynamic LDS: the RBF values of every (column point, column point) and (real point, column point) pair - one exponential per pair
+// of POINTS, formed in a pass of its own; the tiles' entries (nine per pair of full points) take theirs from here
+template <int NTL, int NQ>
+__global__ __launch_bounds__(64, 1) void joint_real_mfma_kernel(const JointArgs a) {
+    constexpr int D = 2, T = 3, NC = NTL * 16, NR = NQ * 16;
+    extern __shared__ __attribute__((aligned(16))) double jr_dyn[];
+    __shared__ __attribute__((aligned(16))) double cx[NC][D];     // column slots: input point | one-hot of the tasks 1, 2 | point index
+    __shared__ __attribute__((aligned(16))) double cb[NC][2];
+    __shared__ int cp[NC];
+    __shared__ __attribute__((aligned(16))) double rx[NR][D];     // real slots: the same, and w_r
+    __shared__ __attribute__((aligned(16))) double ra[NR][4];     // a0 a1 a2 (all zero beyond n_r: the entry is zero) | w_r
+    __shared__ int rp[NR];
+    const GpParams& gp = a.gp;
+    const int lane = threadIdx.x, lr = lane >> 4, lc = lane & 15;
+    const bool test = a.mfma_mode == JOINT_MFMA_TEST;
+    const int n_r = gp.n_r, Tr = gp.real_has_grad ? T : 1, CS = a.fc_cs;
+    const int n = test ? a.m * T : a.n_ho;                        // columns
+    const int P = test ? a.m : a.n_h, R = gp.N_r;                 // column points, real points
+    double* knn = jr_dyn;                                         // [P][P]
+    double* krn = knn + P * P;                                    // [R][P]
+    const long chain = a.chain0 + blockIdx.x;
+    const long s = chain / gp.g_ny;
+    const int o = (int)(chain - s * gp.g_ny);
+    const double il0 = gp.inv_l2[o][0], il1 = gp.inv_l2[o][1], os = gp.os[o];
+    const double* LinvT = plan_LinvT(a.plan, gp, o);
+    const double* w_r = plan_w(a.plan, gp, o);
+    const double* pts = (test ? a.X_s : a.X_h) + chain * (long)P * D;
+#ifdef GPMPC_PHASE_TIMERS
+    long long jph[5] = {0, 0, 0, 0, 0};
+    long long jt = __builtin_readcyclecounter();
+#endif
+    // tiles of LinvT: LT(q2, q)[r][c] = Linv[16 q + c][16 q2 + r], q2 <= q (zero beyond n_r); requested first: they arrive under the pair pass
+    jc_d4 LT[NQ * (NQ + 1) / 2];
+    jc_for<0, NQ>([&](auto q2c) {
+        constexpr int q2 = decltype(q2c)::value;
+        jc_for<q2, NQ>([&](auto qc) {
+            constexpr int q = decltype(qc)::value;
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                const int r = 16 * q2 + 4 * v + lr, c = 16 * q + lc;
+                const double val = LinvT[(long)min(r, n_r - 1) * n_r + min(c, n_r - 1)];
+                LT[jc_idx(q2, q, NQ)][v] = (r < n_r && c < n_r) ? val : 0.0;
+            }
+        });
+    });
+    for (int c = lane; c < NC; c += 64) {
+        const int cc = min(c, n - 1);
+        const int sl = test ? cc : a.h_slots[cc];
+        const int pt = sl / T, tk = sl - pt * T;
+        cx[c][0] = pts[pt * D];
+        cx[c][1] = pts[pt * D + 1];
+        cb[c][0] = (tk == 1) ? 1.0 : 0.0;
+        cb[c][1] = (tk == 2) ? 1.0 : 0.0;
+        cp[c] = pt;
+    }
+    for (int i = lane; i < NR; i += 64) {
+        const int ii = min(i, n_r - 1), pi = ii / Tr, tk = ii - pi * Tr;
+        const bool in = i < n_r;
+        rx[i][0] = a.X_r[pi * D];
+        rx[i][1] = a.X_r[pi * D + 1];
+        ra[i][0] = (in && tk == 0) ? 1.0 : 0.0;
+        ra[i][1] = (in && tk == 1) ? 1.0 : 0.0;
+        ra[i][2] = (in && tk == 2) ? 1.0 : 0.0;
+        ra[i][3] = in ? w_r[i] : 0.0;
+        rp[i] = pi;
+    }
+    // ---- one exponential per pair of points (the points themselves through LDS: [P] column points | [R] real points) ---------------------
+    {
+        jc_d2* ppt = reinterpret_cast<jc_d2*>(knn + (((P + R) * P + 1) & ~1));      // 16-byte aligned
+        for (int i = lane; i < P + R; i += 64) ppt[i] = (i < P) ? jc_d2{pts[i * D], pts[i * D + 1]} : jc_d2{a.X_r[(i - P) * D], a.X_r[(i - P) * D + 1]};
+        jc_sync();
+        const float invP = 1.0f / (float)P;
+        const int tot = (P + R) * P;                              // knn and krn are one table of P + R rows
+        // four exponentials in lockstep (expn_neg: a lone wave's dependent FP64 chain costs ~8 cycles per operation, four interleaved ~4)
+        for (int e0 = 0; e0 < tot; e0 += 256) {
+            double arg[4], ev[4];
+            int ee[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int e = min(e0 + 64 * u + lane, tot - 1);
+                int i = (int)(((float)e + 0.5f) * invP);
+                i = (i * P > e) ? i - 1 : (((i + 1) * P <= e) ? i + 1 : i);
+                const jc_d2 xa = ppt[i], xb = ppt[e - i * P];
+                const double r0 = xa.x - xb.x, r1 = xa.y - xb.y;
+                arg[u] = -0.5 * (r0 * r0 * il0 + r1 * r1 * il1);
+                ee[u] = e;
+            }
+            expn_neg<4>(arg, ev);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) knn[ee[u]] = os * ev[u];   // (clamped duplicates write the same value)
+        }
+    }
+    JCPH(0);
+    // cov(task a of x, task b of x') from the pair's RBF value k (tasks as one-hot weights, no selects):
+    //   fa = a0 - a1 q0 - a2 q1, fb = b0 + b1 q0 + b2 q1, entry = k (fa fb + a1 b1 / l0^2 + a2 b2 / l1^2), q = (x - x') / l^2
+    auto entry = [&](double k, double x0, double x1, double a0, double a1, double a2, double y0, double y1, double b0, double b1,
+                     double b2) -> double {
+        const double q0 = (x0 - y0) * il0, q1 = (x1 - y1) * il1;
+        const double fa = fma(-a1, q0, fma(-a2, q1, a0));
+        const double fb = fma(b1, q0, fma(b2, q1, b0));
+        const double cd = fma(a1 * il0, b1, a2 * il1 * b2);
+        return k * fma(fa, fb, cd);
+    };
+    jc_sync();
+    JCPH(1);
+    double* fc = a.fcache ? a.fcache + (chain - a.fc_chain_base) * a.fc_stride : nullptr;
+    // every store below is unconditional: a lane with nothing to store names an offset beyond its descriptor's end (dropped without
+    // traffic) - a store under an `if` is a branch, and the entries of the next tile no longer schedule under this tile's products
+    double* Sm = test ? a.Sall + chain * (long)n * n : fc + n_r;  // S: leading dimension n / CS
+    const int ldS = test ? n : CS;
+    const __amdgpu_buffer_rsrc_t Srs = __builtin_amdgcn_make_buffer_rsrc(Sm, 0, ((n - 1) * ldS + n) * 8, 0x00020000);
+    double* Xb = test ? a.mean + chain * (long)n : fc;            // the mean / the cache rows' real columns
+    const __amdgpu_buffer_rsrc_t Xrs = __builtin_amdgcn_make_buffer_rsrc(Xb, 0, (test ? n : (n - 1) * CS + n_r) * 8, 0x00020000);
+    // ---- X = L_rr^-1 K_r,cols ------------------------------------------------------------------------------------------------------------
+    jc_d4 X[NQ][NTL];
+    jc_for<0, NQ>([&](auto qc) {
+        jc_for<0, NTL>([&](auto jcn) { X[decltype(qc)::value][decltype(jcn)::value] = jc_d4{0.0, 0.0, 0.0, 0.0}; });
+    });
+    jc_for<0, NQ>([&](auto q2c) {
+        constexpr int q2 = decltype(q2c)::value;
+        double x0[4], x1[4], a0[4], a1[4], a2[4];
+        int kro[4];
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            const int i = 16 * q2 + 4 * v + lr;
+            const jc_d2 xx = *reinterpret_cast<const jc_d2*>(&rx[i][0]);
+            const jc_d4 aa = *reinterpret_cast<const jc_d4*>(&ra[i][0]);
+            x0[v] = xx.x, x1[v] = xx.y, a0[v] = aa.x, a1[v] = aa.y, a2[v] = aa.z;
+            kro[v] = rp[i] * P;
+        }
+        jc_for<0, NTL>([&](auto jcn) {
+            constexpr int j = decltype(jcn)::value;
+            const jc_d2 yy = *reinterpret_cast<const jc_d2*>(&cx[16 * j + lc][0]);
+            const jc_d2 bb = *reinterpret_cast<const jc_d2*>(&cb[16 * j + lc][0]);
+            const double b0 = 1.0 - bb.x - bb.y;
+            const int pc = cp[16 * j + lc];
+            jc_d4 Kt;
+#pragma unroll
+            for (int v = 0; v < 4; ++v) Kt[v] = entry(krn[kro[v] + pc], x0[v], x1[v], a0[v], a1[v], a2[v], yy.x, yy.y, b0, bb.x, bb.y);
+            jc_for<q2, NQ>([&](auto qc) {
+                constexpr int q = decltype(qc)::value;
+                X[q][j] = jc_nat(LT[jc_idx(q2, q, NQ)], Kt, X[q][j]);
+            });
+        });
+    });
+    JCPH(2);
+    jc_for<0, NTL>([&](auto jcn) {
+        constexpr int j = decltype(jcn)::value;
+        const int c = 16 * j + lc;
+        if (!test) {                                              // (uniform) X^T: cache row c, real columns
+            jc_for<0, NQ>([&](auto qc) {
+                constexpr int q = decltype(qc)::value;
+                // (the components by name: __builtin_bit_cast of `X[q][j][v]`, a vector ELEMENT, compiled to component 0 for every v)
+                const double xs[4] = {X[q][j].x, X[q][j].y, X[q][j].z, X[q][j].w};
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    const int i = 16 * q + 4 * v + lr;
+                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(jc_u2, xs[v]), Xrs,
+                                                          (i < n_r && c < n) ? (unsigned)((c * CS + i) * 8) : 0x7ffff000u, 0, 0);
+                }
+            });
+        } else {                                                  // mean = X^T w_r
+            double part = 0.0;
+            jc_for<0, NQ>([&](auto qc) {
+                constexpr int q = decltype(qc)::value;
+#pragma unroll
+                for (int v = 0; v < 4; ++v) part = fma(X[q][j][v], ra[16 * q + 4 * v + lr][3], part);
+            });
+            part += __shfl_xor(part, 16, 64);
+            part += __shfl_xor(part, 32, 64);
+            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(jc_u2, part), Xrs, (lr == 0 && c < n) ? (unsigned)(c * 8) : 0x7ffff000u, 0, 0);
+        }
+    });
+    JCPH(3);
+    // ---- S = K_cc - X^T X, upper tiles (the diagonal ones whole) -------------------------------------------------------------------------
+    jc_for<0, NTL>([&](auto kc) {
+        constexpr int k = decltype(kc)::value;
+        double x0[4], x1[4], a0[4], a1[4], a2[4];
+        int kro[4];
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            const int rr = 16 * k + 4 * v + lr;
+            const jc_d2 xx = *reinterpret_cast<const jc_d2*>(&cx[rr][0]);
+            const jc_d2 aa = *reinterpret_cast<const jc_d2*>(&cb[rr][0]);
+            x0[v] = xx.x, x1[v] = xx.y, a1[v] = aa.x, a2[v] = aa.y, a0[v] = 1.0 - aa.x - aa.y;
+            kro[v] = cp[rr] * P;
+        }
+        jc_for<k, NTL>([&](auto jcn) {
+            constexpr int j = decltype(jcn)::value;
+            const jc_d2 yy = *reinterpret_cast<const jc_d2*>(&cx[16 * j + lc][0]);
+            const jc_d2 bb = *reinterpret_cast<const jc_d2*>(&cb[16 * j + lc][0]);
+            const double b0 = 1.0 - bb.x - bb.y;
+            const int pc = cp[16 * j + lc];
+            jc_d4 acc;
+#pragma unroll
+            for (int v = 0; v < 4; ++v) acc[v] = -entry(knn[kro[v] + pc], x0[v], x1[v], a0[v], a1[v], a2[v], yy.x, yy.y, b0, bb.x, bb.y);
+            jc_for<0, NQ>([&](auto qc) {
+                constexpr int q = decltype(qc)::value;
+                acc = jc_nat(X[q][k], X[q][j], acc);
+            });
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                const int rr = 16 * k + 4 * v + lr, c = 16 * j + lc;
+                const bool ok = rr < n && c < n;
+                const jc_u2 val = __builtin_bit_cast(jc_u2, -acc[v]);
+                __builtin_amdgcn_raw_buffer_store_b64(val, Srs, ok ? (unsigned)((rr * ldS + c) * 8) : 0x7ffff000u, 0, 0);
+                if constexpr (k != j)                             // joint_eigh_kernel reads whole columns: the mirror image (test use)
+                    __builtin_amdgcn_raw_buffer_store_b64(val, Srs, (ok && test) ? (unsigned)((c * ldS + rr) * 8) : 0x7ffff000u, 0, 0);
+            }
+        });
+    });
+    JCPH(4);
+#ifdef GPMPC_PHASE_TIMERS
+    if (chain == a.chain0 && lane == 0)
+        for (int i = 0; i < 5; ++i) g_jc_phase[i] = jph[i];      // (read right behind this launch: tools/debug/real_phases.py)
+#endif
+    if (test && lane == 0) a.info[chain] = 0;
+}
+
+// dynamic LDS of joint_real_mfma_kernel: the pair tables of P column points against themselves and against the N_r real points | the points
+static size_t joint_real_lds_bytes(int P, int N_r) { return ((size_t)P * P + (size_t)N_r * P + 1 + 2 * (size_t)(P + N_r)) * sizeof(double); }
+
+// P: the points the columns' slots are spread over (test use: m; factor use: n_h).  Four waves per CU: 36 KB of pair tables each
+bool joint_real_mfma_eligible(int n_r, int N_r, int ncols, int P, int T, int D) {
+    return T == 3 && D == 2 && n_r >= 1 && n_r <= 64 && ncols >= 2 && ncols <= 128 && P >= 1 && joint_real_lds_bytes(P, N_r) <= 36 * 1024;
+}
+
+int joint_real_mfma_launch(const JointArgs& a, hipStream_t st) {
+    const int n = (a.mfma_mode == JOINT_MFMA_TEST) ? a.m * a.gp.T : a.n_ho;
+    const int P = (a.mfma_mode == JOINT_MFMA_TEST) ? a.m : a.n_h;
+    if (!joint_real_mfma_eligible(a.gp.n_r, a.gp.N_r, n, P, a.gp.T, a.gp.D) || (a.mfma_mode != JOINT_MFMA_TEST && a.mfma_mode != JOINT_MFMA_FACTOR))
+        return fail(GPMPC_E_UNSUPPORTED, "joint_real_mfma_kernel: T = 3, D = 2, <= 64 real slots, 2..128 columns, pair tables <= 36 KB");
+    const size_t lds = joint_real_lds_bytes(P, a.gp.N_r);
+    const long nch = a.chain1 - a.chain0;
+    const dim3 g((unsigned)nch), b(64);
+    const int ntl = (n + 15) / 16;
+#define GPMPC_REAL_LAUNCH(NQ_)                                                                     \
+    do {                                                                                           \
+        if (ntl <= 2) hipLaunchKernelGGL((joint_real_mfma_kernel<2, NQ_>), g, b, lds, st, a);        \
+        else if (ntl <= 4) hipLaunchKernelGGL((joint_real_mfma_kernel<4, NQ_>), g, b, lds, st, a);   \
+        else if (ntl <= 6) hipLaunchKernelGGL((joint_real_mfma_kernel<6, NQ_>), g, b, lds, st, a);   \
+        else hipLaunchKernelGGL((joint_real_mfma_kernel<8, NQ_>), g, b, lds, st, a);                 \
+    } while (0)
+    if (a.gp.n_r <= 48) GPMPC_REAL_LAUNCH(3);
+    else GPMPC_REAL_LAUNCH(4);
+#undef GPMPC_REAL_LAUNCH
+    GPMPC_HIP_CHECK(hipGetLastError());
+    return GPMPC_OK;
+}
+
 }  // namespace gpmpc
 
 extern "C" int gpmpc_debug_read_joint_chol_phases(long long* out /*[host] 8*/) {

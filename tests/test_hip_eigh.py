@@ -185,7 +185,7 @@ def test_config5_shard_as_shipped(sg):
             gp_val, y_grad, u_grad = agent.dyn_fg_jacobians(agent.get_batch_x_hat(x_h, u_h), k)
             # the kernel path the dispatcher takes at the shipped shape: the matrix pipe from the second SQP iteration on
             # (120 hallucinated slots >= GPMPC_JOINT_MFMA_FROM); a dispatcher change that silently drops it fails here
-            assert raw.gpmpc_joint_last_path() == (sg._lib.JOINT_MFMA if k >= 1 else sg._lib.JOINT_VALU), k
+            assert raw.gpmpc_joint_last_path() == sg._lib.JOINT_MFMA, k     # (k = 0: no hallucinated slot, joint_real_mfma_kernel)
             sv, sy, su = small.dyn_fg_jacobians(small.get_batch_x_hat(xs, u_h), k)
             mv, my, _ = mid.dyn_fg_jacobians(mid.get_batch_x_hat(xm, u_h), k)
             np.testing.assert_array_equal(gp_val[m0:m0 + msub], mv)
@@ -367,7 +367,7 @@ def test_joint_draws_of_the_closed_loop_against_reference_run(sg, suffix):
     raw = sg._lib.load()
 
     def check(step, k, post):
-        assert raw.gpmpc_joint_last_path() == (sg._lib.JOINT_MFMA if (k >= 1 or step >= 1) else sg._lib.JOINT_VALU)
+        assert raw.gpmpc_joint_last_path() == sg._lib.JOINT_MFMA
         assert (post.last_info & sg._lib.INFO_ROOT_EIGH).all()
 
     with warnings.catch_warnings():
