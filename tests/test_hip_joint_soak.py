@@ -262,6 +262,56 @@ def test_pending_rows_of_the_factor_cache(sg, pname, Ns, Hh, monkeypatch):
         assert ey < tol_y, f"call {i}: samples {ey:.1e}"
 
 
+@pytest.mark.parametrize("pname,Ns,Hh", [("params_car_residual", 96, 40), ("params_car_residual", 8, 13), ("params_pendulum1D_samples", 40, 30),
+                                         ("params_pendulum1D_samples", 5, 7)])
+def test_real_data_kernel_against_the_launches_it_replaces(sg, pname, Ns, Hh):
+    """joint_real_mfma_kernel (columns conditioned on the real data alone, one wave per chain): its TEST use - the draw without hallucinated
+    slots, k = 0 of the first MPC step - against joint_kernel's head, and its FACTOR use - the factor extension with nothing cached, k = 1 -
+    against joint_test_mfma_kernel's factor mode (matrix-pipe path pinned so that every shape takes it): same Agent sequence with the kernel
+    on and off (gpmpc_debug_joint_real_kernel), mean / variance to rounding, samples to the tolerance of the configuration's root.  Odd
+    point counts (H = 13, 7) put the pair tables' point block on an odd offset."""
+    from tests.helpers import closed_loop_params
+    lib = sg._lib.load()
+    p = closed_loop_params(pname, Ns, Hh, 1, 3)
+    p["common"]["use_cuda"] = True
+    p["agent"]["base_sample_generator"] = "counter"
+    x0 = np.array(p["env"]["start"], dtype=np.float64)
+    runs = {}
+    lib.gpmpc_joint_pin_path(sg._lib.JOINT_MFMA)
+    try:
+        for mode in (1, 0):
+            lib.gpmpc_debug_joint_real_kernel(mode)
+            agent = sg.Agent(p, sg.make_env(p))
+            x0a = x0[: agent.nx]
+            u_h, x_h = 0.1 * np.ones((Hh, agent.nu)), np.tile(x0a, (Hh, Ns)) + 0.01 * np.arange(Hh)[:, None]
+            rec = []
+            agent.mpc_iteration(0)
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                for k in range(2):
+                    agent.train_hallucinated_dynGP(k)
+                    gv, _, _ = agent.dyn_fg_jacobians(agent.get_batch_x_hat(x_h, u_h), k)
+                    post = agent.model_i_call
+                    assert not (post.last_info & sg._lib.INFO_TRAIN_CHOL_FAIL).any()
+                    rec.append((post.mean.clone(), post.variance.clone(), gv.copy(), int(lib.gpmpc_joint_last_path())))
+            runs[mode] = rec
+            del agent
+    finally:
+        lib.gpmpc_debug_joint_real_kernel(-1)
+        lib.gpmpc_joint_pin_path(sg._lib.JOINT_AUTO)
+    # k = 0 without the kernel is joint_kernel's head (the VALU path: nothing else is instantiated for an empty hallucinated set)
+    assert [r[3] for r in runs[1]] == [sg._lib.JOINT_MFMA] * 2 and runs[0][0][3] == sg._lib.JOINT_VALU
+    # (the real block through the plan's explicit L_rr^-1 here, by substitution in the launches replaced: 1e-9 of the largest variance on the
+    # car, whose posterior variances are 1e-4 of the prior's - the bar between the VALU and the matrix-pipe path above is 1e-8 as well)
+    tol_y, tol_m = (1e-8, 1e-10) if "pendulum" in pname else (1e-4, 1e-8)
+    for k, (a, b) in enumerate(zip(runs[1], runs[0])):
+        for j, name in ((0, "mean"), (1, "variance")):
+            e = float(((a[j] - b[j]).abs() / b[j].abs().max()).max())
+            assert e < tol_m, f"k = {k}: {name} with joint_real_mfma_kernel is {e:.1e} from the launch it replaces"
+        ey = float(np.abs(a[2] - b[2]).max() / np.abs(b[2]).max())
+        assert ey < tol_y, f"k = {k}: samples {ey:.1e}"
+
+
 def test_closed_loop_sequence_is_deterministic_at_full_width(sg):
     """The closed loop's OWN sequence at the configs[4] shard (Ns = 1024, H = 40, two MPC steps x four SQP iterations, dispatcher's choice
     of path, pending rows on): two fresh Agents with the same base samples give bit-equal means, variances and Jacobians at every call -
