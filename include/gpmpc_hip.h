@@ -320,7 +320,10 @@ int    gpmpc_joint_pending_written(void);    /* 1: the last gpmpc_joint_sample[_
  * FP64 matrix pipe with the whole test block in registers, the tail draws - instantiated for n_r <= 64 real slots,
  * n_r + n_ho <= 416 conditioning slots (<= 544 with the test rows in two launches; that form needs the caller's factor cache) and
  * m*T + 1 <= 128; taken from 100 hallucinated slots on
- * (GPMPC_JOINT_MFMA_FROM).  Results of the two paths agree to rounding, not bit for bit: a caller that compares launches bit
+ * (GPMPC_JOINT_MFMA_FROM).  Round 6: a draw WITHOUT hallucinated slots (T = 3, <= 64 real slots, m*T <= 128) also reports
+ * GPMPC_JOINT_MFMA unless the VALU path is pinned - joint_real_mfma_kernel forms X = L_rr^-1 K_r*, the mean and S one wave per
+ * chain against the plan's shared inverse factor (GPMPC_JOINT_REAL_KERNEL=0: joint_kernel's head as before); the same kernel
+ * is the matrix-pipe path's factor extension while nothing is cached.  Results of the two paths agree to rounding, not bit for bit: a caller that compares launches bit
  * for bit (cache on / off, sample shards against the whole batch) pins the path.  gpmpc_joint_pin_path(GPMPC_JOINT_AUTO) releases
  * the pin; a pinned GPMPC_JOINT_MFMA falls back to the VALU path for sizes it is not instantiated for.
  */
