@@ -541,7 +541,7 @@ __global__ __launch_bounds__(64, 1) void joint_real_mfma_kernel(const JointArgs 
     const double* w_r = plan_w(a.plan, gp, o);
     const double* pts = (test ? a.X_s : a.X_h) + chain * (long)P * D;
 #ifdef GPMPC_PHASE_TIMERS
-    long long jph[5] = {0, 0, 0, 0, 0};
+    long long jph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     long long jt = __builtin_readcyclecounter();
 #endif
     // tiles of LinvT: LT(q2, q)[r][c] = Linv[16 q + c][16 q2 + r], q2 <= q (zero beyond n_r); requested first: they arrive under the pair pass
@@ -579,11 +579,13 @@ __global__ __launch_bounds__(64, 1) void joint_real_mfma_kernel(const JointArgs 
         ra[i][3] = in ? w_r[i] : 0.0;
         rp[i] = pi;
     }
+    JCPH(5);
     // ---- one exponential per pair of points (the points themselves through LDS: [P] column points | [R] real points) ---------------------
     {
         jc_d2* ppt = reinterpret_cast<jc_d2*>(knn + (((P + R) * P + 1) & ~1));      // 16-byte aligned
         for (int i = lane; i < P + R; i += 64) ppt[i] = (i < P) ? jc_d2{pts[i * D], pts[i * D + 1]} : jc_d2{a.X_r[(i - P) * D], a.X_r[(i - P) * D + 1]};
         jc_sync();
+        JCPH(6);
         const float invP = 1.0f / (float)P;
         const int tot = (P + R) * P;                              // knn and krn are one table of P + R rows
         // four exponentials in lockstep (expn_neg: a lone wave's dependent FP64 chain costs ~8 cycles per operation, four interleaved ~4)
@@ -727,7 +729,7 @@ __global__ __launch_bounds__(64, 1) void joint_real_mfma_kernel(const JointArgs 
     JCPH(4);
 #ifdef GPMPC_PHASE_TIMERS
     if (chain == a.chain0 && lane == 0)
-        for (int i = 0; i < 5; ++i) g_jc_phase[i] = jph[i];      // (read right behind this launch: tools/debug/real_phases.py)
+        for (int i = 0; i < 8; ++i) g_jc_phase[i] = jph[i];      // (read right behind this launch: tools/debug/real_phases.py)
 #endif
     if (test && lane == 0) a.info[chain] = 0;
 }

@@ -22,6 +22,6 @@ with warnings.catch_warnings():
         agent.dyn_fg_jacobians(agent.get_batch_x_hat(x_h, u_h), 0)
         torch.cuda.synchronize()
         raw.gpmpc_debug_read_joint_chol_phases(out)
-        v = list(out)[:5]
-        print(f"descriptors + pair tables {v[0]} | LinvT tiles {v[1]} | X (entries + products) {v[2]} | mean / X^T stores {v[3]} | S (entries, products, stores) {v[4]} | "
-              f"total {sum(v)} cycles", flush=True)
+        v = list(out)[:8]
+        print(f"[LinvT requests + descriptors {v[5]} | points to LDS {v[6]} | pair pass {v[0]}] descriptors + pair tables {v[5] + v[6] + v[0]} | LinvT tiles {v[1]} | X (entries + products) {v[2]} | mean / X^T stores {v[3]} | S (entries, products, stores) {v[4]} | "
+              f"total {sum(v[:8])} cycles", flush=True)
