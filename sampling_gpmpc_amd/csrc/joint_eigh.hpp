@@ -677,7 +677,10 @@ __global__ __launch_bounds__(64, WPE) void joint_eigh_kernel(const EighArgs a) {
                 eigh_gram<true, (WPE == GPMPC_EIGH_NARROW_WPE ? 2 : 4)>(Lm, n, r, rp, G);
                 EPH(1);
                 const int h = rp / 2, nsl = (h / 2) * h;
-                if (nsl <= 128 || WPE == GPMPC_EIGH_NARROW_WPE) gtot = eigh_jacobi_lds<2>(G, rp, rlog, e_cs, conv, sweeps);     // (the narrow launch: ranks <= 32, nsl <= 128)
+                // (ranks <= 16 - the closed loop's points - have at most 28 off-diagonal blocks: ONE per lane; with two the second is a dummy
+                // on the pad slot whose reads, rotation and writes are a fifth of a round's instructions, and the kernel is VALU bound)
+                if (nsl <= 64) gtot = eigh_jacobi_lds<1>(G, rp, rlog, e_cs, conv, sweeps);
+                else if (nsl <= 128 || WPE == GPMPC_EIGH_NARROW_WPE) gtot = eigh_jacobi_lds<2>(G, rp, rlog, e_cs, conv, sweeps);     // (the narrow launch: ranks <= 32, nsl <= 128)
                 else if (nsl <= 256) gtot = eigh_jacobi_lds<4>(G, rp, rlog, e_cs, conv, sweeps);
                 else if (nsl <= 384) gtot = eigh_jacobi_lds<6>(G, rp, rlog, e_cs, conv, sweeps);
                 else gtot = eigh_jacobi_lds<EIGH_MAXIT>(G, rp, rlog, e_cs, conv, sweeps);
