@@ -1311,6 +1311,11 @@ int gpmpc_joint_sample_pending(const gpmpc_gp_desc_t* gp, const void* plan, cons
     static const char* tenv = getenv("GPMPC_JOINT_TAIL_KERNEL");
     const int tforce = g_tail_kernel_force >= 0 ? g_tail_kernel_force : (tenv ? atoi(tenv) : 1);
     const bool tail_kernel = tforce != 0 && joint_tail_mfma_eligible(mT, gp->T);
+    // joint_tail_mfma_kernel abandons too (one flag read at the head of an attempt): it pays as soon as the launch has a second round of
+    // waves (one wave per chain and SIMD at six tiles and more, two below); GPMPC_JOINT_ABANDON=0 / 1 forces it off / on
+    static const char* taenv = getenv("GPMPC_JOINT_ABANDON");
+    const int tail_abandon = (root_mode == GPMPC_ROOT_AUTO && mT > 1 &&
+                              (taenv ? atoi(taenv) != 0 : nchains > (mT > 80 ? 1024 : 2048))) ? 1 : 0;
     const bool split = !joint_use_mfma(a.gp.n_r, n_ho, m, gp->T) && joint_use_mfma_split(a.gp.n_r, n_ho, m, gp->T) &&
                        a.fcache && n_ho <= a.fc_cap && (a.fc_cap % 2) == 0;
     if (joint_use_mfma(a.gp.n_r, n_ho, m, gp->T) || split) {
@@ -1408,6 +1413,7 @@ int gpmpc_joint_sample_pending(const gpmpc_gp_desc_t* gp, const void* plan, cons
             if (int rc = joint_mfma_launch(b, st)) return rc;
             b.pend_write = 0;
             if (tail_kernel) {
+                b.abandon_root = tail_abandon;
                 if (int rc = joint_tail_mfma_launch(b, st)) return rc;
             } else {
                 b.phase = JOINT_PHASE_TAIL;
@@ -1431,6 +1437,7 @@ int gpmpc_joint_sample_pending(const gpmpc_gp_desc_t* gp, const void* plan, cons
             a.mfma_mode = JOINT_MFMA_TEST;
             if (int rc = joint_real_mfma_launch(a, st)) return rc;
             a.info_in = 1;
+            a.abandon_root = tail_abandon;
             if (int rc = joint_tail_mfma_launch(a, st)) return rc;
         } else if (tail_kernel) {                             // head (factor rows, test rows, mean, S) here, the tail one wave per chain
             a.phase = JOINT_PHASE_HEAD;
@@ -1438,6 +1445,7 @@ int gpmpc_joint_sample_pending(const gpmpc_gp_desc_t* gp, const void* plan, cons
             launch(a, nrow);
             GPMPC_HIP_CHECK(hipGetLastError());
             a.info_in = 1;
+            a.abandon_root = tail_abandon;
             if (int rc = joint_tail_mfma_launch(a, st)) return rc;
         } else {
             a.abandon_root = abandon_for(nrow);

@@ -359,11 +359,20 @@ __global__ __launch_bounds__(64, (NTL >= 6) ? 1 : 2) void joint_tail_mfma_kernel
         return t;
     };
     int level = 0, info_acc = 0;
-    bool rooted = false;
+    bool rooted = false, abandoned = false;
     double jit_total = 0.0;
     jc_sync();
 #pragma unroll 1
     while (!rooted) {
+        // abandon_root (GPMPC_ROOT_AUTO): once ANY chain of the batch has failed every retry the eigendecomposition root redraws the WHOLE
+        // batch (A.7 step 4) - a chain that sees the flag at the head of an attempt skips it (its sample and info word are the eigh kernel's
+        // either way; the variance / clip part below still runs).  On the shipped car every chain fails: the launch's first round of waves
+        // raises the flag, the other rounds skip their attempts.
+        if (a.abandon_root && __builtin_amdgcn_readfirstlane(*(volatile int*)a.any_fail) != 0) {
+            abandoned = true;
+            level = 3;                                            // what the batch reports after the redraw
+            break;
+        }
         // ---- one attempt ------------------------------------------------------------------------------------------------------------
         jc_d4 U[NTT];
         bool failed = false;                                      // uniform
@@ -440,7 +449,7 @@ __global__ __launch_bounds__(64, (NTL >= 6) ? 1 : 2) void joint_tail_mfma_kernel
     info_acc |= (level << 1);
     if (!rooted) {
         info_acc |= GPMPC_INFO_ROOT_FAIL;
-        if (lane == 0) atomicOr(a.any_fail, 1);
+        if (lane == 0 && !abandoned) atomicOr(a.any_fail, 1);
     }
     jc_sync();
     // ---- sample + post-processing (reference src/agent.py:641-708): one lane per test point --------------------------------------------
