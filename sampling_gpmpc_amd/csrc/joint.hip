@@ -1239,6 +1239,10 @@ int gpmpc_joint_sample_pending(const gpmpc_gp_desc_t* gp, const void* plan, cons
     if (ws_bytes < (size_t)w.total * sizeof(double))
         return fail(GPMPC_E_WORKSPACE, "gpmpc_joint_sample: workspace too small");
     a.Sall = (double*)ws + w.s_off;
+    a.Sv = a.Sall;
+    a.Sv_ld = (int)mT;
+    a.Sv_cs = (long)mT * mT;
+    a.Sv_chain_base = 0;
     a.any_fail = (int*)((double*)ws + w.f_off);
     if (factor_cache) {
         // an EVEN row count and a 16-byte aligned base: the matrix-pipe path moves cache rows in 16-byte units, and with an odd
@@ -1316,6 +1320,7 @@ int gpmpc_joint_sample_pending(const gpmpc_gp_desc_t* gp, const void* plan, cons
     static const char* taenv = getenv("GPMPC_JOINT_ABANDON");
     const int tail_abandon = (root_mode == GPMPC_ROOT_AUTO && mT > 1 &&
                               (taenv ? atoi(taenv) != 0 : nchains > (mT > 80 ? 1024 : 2048))) ? 1 : 0;
+    JointArgs sv_args = a;                             // whose Sv* the eigh launch reads (redirected only with the caller's own cache: one batch)
     const bool split = !joint_use_mfma(a.gp.n_r, n_ho, m, gp->T) && joint_use_mfma_split(a.gp.n_r, n_ho, m, gp->T) &&
                        a.fcache && n_ho <= a.fc_cap && (a.fc_cap % 2) == 0;
     if (joint_use_mfma(a.gp.n_r, n_ho, m, gp->T) || split) {
@@ -1409,6 +1414,13 @@ int gpmpc_joint_sample_pending(const gpmpc_gp_desc_t* gp, const void* plan, cons
             } else {
                 b.mfma_mode = JOINT_MFMA_TEST;
                 b.pend_write = pend_write ? 1 : 0;
+                if (pend_write && tail_kernel) {       // S once: the pending block IS the covariance buffer of this draw's tail and eigh root
+                    b.Sv = b.fcache + (long)n_ho * b.fc_cs + a.gp.n_r + n_ho;
+                    b.Sv_ld = b.fc_cs;
+                    b.Sv_cs = b.fc_stride;
+                    b.Sv_chain_base = b.fc_chain_base;
+                    sv_args = b;
+                }
             }
             if (int rc = joint_mfma_launch(b, st)) return rc;
             b.pend_write = 0;
@@ -1468,7 +1480,9 @@ int gpmpc_joint_sample_pending(const gpmpc_gp_desc_t* gp, const void* plan, cons
         e.var = var;
         e.y = y;
         e.info = (int*)info;
-        e.Sall = a.Sall;
+        e.Sall = sv_args.Sv;
+        e.S_ld = sv_args.Sv_ld;
+        e.S_cs = sv_args.Sv_cs;
         e.any_fail = a.any_fail;
         e.force = (root_mode == GPMPC_ROOT_EIGH);
         e.ws = (double*)ws + w.e_off;

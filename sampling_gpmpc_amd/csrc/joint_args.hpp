@@ -50,6 +50,13 @@ struct JointArgs {
     long ws_chain_stride;   // doubles
     int ld;                 // rows of M (padded)
     double* Sall;           // [chains][mT*mT] posterior covariance, column-major, both triangles written
+    // where the READERS of the test rows' covariance (joint_tail_mfma_kernel, joint_eigh_kernel) find it, and where joint_test_mfma_kernel's
+    // test mode writes it: chain c at Sv + (c - Sv_chain_base) * Sv_cs, element (r, c2) at r * Sv_ld + c2.  Default: Sall, mT, mT * mT, 0.  With
+    // pending rows written (pend_write) it is the diagonal block of the cache rows the next call's new slots will occupy - S is written
+    // ONCE (115 KB per chain at the configs[4] shard) instead of into Sall and into the cache
+    double* Sv;
+    long Sv_cs, Sv_chain_base;
+    int Sv_ld;
     int* any_fail;          // set when a chain's jitter chain failed (read by joint_eigh_kernel)
     // factor cache (caller-owned, persists between calls): per chain the hallucinated rows of the factor, row-major
     // [rows_cap][fc_cs] (columns: real slots, then hallucinated slots; the diagonal blocks as block_factor left them) and

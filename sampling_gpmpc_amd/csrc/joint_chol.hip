@@ -328,8 +328,10 @@ __global__ __launch_bounds__(64, (NTL >= 6) ? 1 : 2) void joint_tail_mfma_kernel
     const int lane = threadIdx.x, lr = lane >> 4, lc = lane & 15;
     const int m = a.m, n = m * gp.T;
     const long chain = a.chain0 + blockIdx.x;
-    const double* Sm = a.Sall + chain * (long)n * n;
-    const __amdgpu_buffer_rsrc_t Sr = __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(Sm), 0, n * n * 8, 0x00020000);
+    // the covariance through its view (JointArgs::Sv*): the chain's S buffer, or the pending block of the factor cache (leading dimension CS)
+    const int ld = a.Sv_ld;
+    const double* Sm = a.Sv + (chain - a.Sv_chain_base) * a.Sv_cs;
+    const __amdgpu_buffer_rsrc_t Sr = __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(Sm), 0, ((n - 1) * ld + n) * 8, 0x00020000);
     for (int t = lane; t < NTL * 16; t += 64) zs[t] = (t < n) ? a.z[chain * (long)n + t] : 0.0;
     // tile (k, j), register v, this lane: element (16 k + 4 v + lr, 16 j + lc) + jit on the diagonal; the identity beyond n
     auto load_tile = [&](auto kc, auto jcn, double jit) -> jc_d4 {
@@ -340,7 +342,7 @@ __global__ __launch_bounds__(64, (NTL >= 6) ? 1 : 2) void joint_tail_mfma_kernel
             const int r = 16 * k + 4 * v + lr, c = 16 * j + lc;
             // (off-diagonal tiles: r < c always; diagonal tiles: the lane's entry may lie below the diagonal - its mirror image is read)
             const int lo = (k == j) ? min(r, c) : r, hi = (k == j) ? max(r, c) : c;
-            t[v] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(Sr, (unsigned)((lo * n + hi) * 8), 0, 0));
+            t[v] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(Sr, (unsigned)((lo * ld + hi) * 8), 0, 0));
         }
         if constexpr (j >= NTL - 2) {
             const bool cin = 16 * j + lc < n;
@@ -436,7 +438,7 @@ __global__ __launch_bounds__(64, (NTL >= 6) ? 1 : 2) void joint_tail_mfma_kernel
                 const double jit_next = jit_total + (jn - jp);
                 bool same = true;
                 for (int t1 = lane; t1 < c_fail; t1 += 64) {
-                    const double d = Sm[(long)t1 * n + t1];
+                    const double d = Sm[(long)t1 * ld + t1];
                     same = same && ((d + jit_next) == (d + jit_total));
                 }
                 identical = __builtin_amdgcn_ballot_w64(!same) == 0;
@@ -459,7 +461,7 @@ __global__ __launch_bounds__(64, (NTL >= 6) ? 1 : 2) void joint_tail_mfma_kernel
 #pragma unroll
         for (int b = 0; b < T; ++b) {
             const int tau = j * T + b;
-            double v = Sm[(long)tau * n + tau];
+            double v = Sm[(long)tau * ld + tau];
             if (v < gp.var_floor) {
                 v = gp.var_floor;
                 info_acc |= GPMPC_INFO_VAR_CLAMPED;
@@ -485,7 +487,7 @@ __global__ __launch_bounds__(64, (NTL >= 6) ? 1 : 2) void joint_tail_mfma_kernel
         double* Cv = a.covar + chain * (long)n * n;
         for (int e = lane; e < n * n; e += 64) {
             const int t2 = e / n, t1 = e - t2 * n;
-            Cv[(long)t1 * n + t2] = Sm[(long)min(t1, t2) * n + max(t1, t2)];
+            Cv[(long)t1 * n + t2] = Sm[(long)min(t1, t2) * ld + max(t1, t2)];
         }
     }
     // (the lanes' bits: OR over the wave)

@@ -44,7 +44,9 @@ struct EighArgs {
     const double* var;
     double* y;
     int* info;
-    const double* Sall;      // [chains][n*n]  column-major, both triangles valid (joint_kernel mirrors the lower one)
+    const double* Sall;      // chain c at Sall + c * S_cs, element (r, c2) at r * S_ld + c2, both triangles valid (default: S_ld = n, S_cs = n * n; with
+    int S_ld;                //   pending rows written it is the diagonal block of the factor-cache rows: S_ld = the cache's row stride)
+    long S_cs;
     const int* any_fail;     // device flag set by joint_kernel when a chain's jitter chain failed
     int force;
     double* ws;              // per slot: L [n*n] | 2 x packed G [np*(np+1)/2] | rotation log [EIGH_MAX_SWEEPS/2 * np*np]
@@ -461,7 +463,8 @@ __global__ __launch_bounds__(64, WPE) void joint_eigh_kernel(const EighArgs a) {
     for (long item = blockIdx.x; item < nwork; item += gridDim.x) {
         const long chain = (a.pass == EIGH_PASS_DEFERRED) ? (long)a.defer_list[item] : item;
         const int o = (int)(chain % gp.g_ny);
-        const double* Sm = a.Sall + chain * (long)n * n;
+        const double* Sm = a.Sall + chain * a.S_cs;
+        const int ldS = a.S_ld;
         double kmax = gp.os[o];
         if (T > 1) {
 #pragma unroll
@@ -488,7 +491,7 @@ __global__ __launch_bounds__(64, WPE) void joint_eigh_kernel(const EighArgs a) {
 #pragma unroll
         for (int i = 0; i < RPL; ++i) {
             const int t = lane + 64 * i;
-            d[i] = (t < n) ? Sm[(long)t * n + t] : 0.0;
+            d[i] = (t < n) ? Sm[(long)t * ldS + t] : 0.0;
             pivoted[i] = !(t < n);
         }
         int r = 0;
@@ -539,7 +542,7 @@ __global__ __launch_bounds__(64, WPE) void joint_eigh_kernel(const EighArgs a) {
 #pragma unroll
                 for (int c = 0; c < EIGH_PB; ++c) {
                     const int p = cand[c];
-                    acc[i][c] = (c < nc) ? Sm[(long)p * n + t] : 0.0;     // joint_kernel mirrors S: a column is contiguous
+                    acc[i][c] = (c < nc) ? Sm[(long)p * ldS + t] : 0.0;   // joint_kernel mirrors S: a column is contiguous
                 }
             }
             // minus the previous columns: chunks of 32 columns, the candidates' rows of L staged in LDS ([column][cand])

@@ -743,8 +743,11 @@ __global__ __launch_bounds__(JM_THREADS) void joint_test_mfma_kernel(const Joint
     // products (A operand: its own tile, in place in its registers; B operands: the published tiles).  (Rounds 1-4 of this kernel
     // ran three passes of two accumulators - every tile published three times, two MFMAs per LDS round trip: 208 k cycles per chain.)
     // test mode: K = K** and the label column / row of G is -mean; factor mode: K = K_nn + noise (the Schur complement)
-    const int ldS = fmode ? ncols : mT;
-    double* Sm = a.Sall + chain * (long)mT * mT;
+    const int ldS = fmode ? ncols : mT;           // the matrix's size ...
+    // ... and where it goes: factor mode - the chain's S buffer, leading dimension ncols (joint_chol_mfma_kernel's input); the test modes - the
+    // covariance view (JointArgs::Sv*: the S buffer, or - pending rows - the diagonal block of the cache rows the next call's new slots take)
+    const int ldO = fmode ? ncols : a.Sv_ld;
+    double* Sm = fmode ? a.Sall + chain * (long)mT * mT : a.Sv + (chain - a.Sv_chain_base) * a.Sv_cs;
     double* mean = a.mean + chain * (long)mT;
     // -K_cc tile (I, J) straight into the accumulators' registers: register v, lane (kk, jj) = -K_cc(row 16 I + 4 v + kk, column 16 J + jj)
     // (test mode: K**; factor mode: K_nn + noise).  One exponential per ENTRY here - 20 per lane against 1.6 per thread when the
@@ -778,7 +781,7 @@ __global__ __launch_bounds__(JM_THREADS) void joint_test_mfma_kernel(const Joint
 #pragma unroll
         for (int v = 0; v < 4; ++v) {                         // (unconditional loads, clamped)
             const int t1 = 16 * I + 4 * v + (lane >> 4);
-            ls[v] = Sm[(long)min(t1, ldS - 1) * ldS + min(t2, ldS - 1)];
+            ls[v] = Sm[(long)min(t1, ldS - 1) * ldO + min(t2, ldS - 1)];
             lm[v] = mean[min((t1 == mT) ? t2 : t1, mT - 1)];
         }
 #pragma unroll
@@ -799,8 +802,10 @@ __global__ __launch_bounds__(JM_THREADS) void joint_test_mfma_kernel(const Joint
     const unsigned ring_gb = (unsigned)(size_t)(__attribute__((address_space(3))) double*)ring;
     const unsigned stash_gb = (unsigned)(size_t)(__attribute__((address_space(3))) double*)linv + (unsigned)wv * (JM_STASH * 2048u);
     double* tbuf = ring + wv * 272;               // [16][17] per wave, inside the exchange buffer: used between two barriers of its own
-    // pend_write: S also goes into the diagonal block of the cache rows the next call's new slots will occupy (both triangles)
+    // pend_write: S also goes into the diagonal block of the cache rows the next call's new slots will occupy (both triangles) - unless
+    // the covariance view already IS that block (the dispatcher points Sv there when joint_tail_mfma_kernel follows)
     double* pblk = fc + (long)a.n_ho * CS + n_r + a.n_ho;
+    const bool pend2 = a.pend_write && pblk != Sm;
     auto tile_out = [&](int I, int J, int d, const jm_d4& sn) {
         // the tile and its mirror image, both as 128-byte row segments: the mirror through a per-wave LDS transpose
         const int jj = lane & 15, kk = lane >> 4;
@@ -813,8 +818,8 @@ __global__ __launch_bounds__(JM_THREADS) void joint_test_mfma_kernel(const Joint
             const int t1 = 16 * I + 4 * v + kk;
             const double val = sv[v];
             if (t1 < ldS && t2 < ldS) {
-                if (d > 0 || t1 >= t2) Sm[(long)t1 * ldS + t2] = val;      // diagonal tiles: the lower part here, its mirror below
-                if (a.pend_write && (d > 0 || t1 >= t2)) pblk[(long)t1 * CS + t2] = val;
+                if (d > 0 || t1 >= t2) Sm[(long)t1 * ldO + t2] = val;      // diagonal tiles: the lower part here, its mirror below
+                if (pend2 && (d > 0 || t1 >= t2)) pblk[(long)t1 * CS + t2] = val;
             } else if (!fmode && t1 == mT && t2 < mT) {
                 mean[t2] = -val;                                            // the label row
             }
@@ -824,8 +829,8 @@ __global__ __launch_bounds__(JM_THREADS) void joint_test_mfma_kernel(const Joint
             const int r2 = 16 * J + 4 * v + kk, c2 = 16 * I + jj;           // entry (r2, c2) of S = entry (c2, r2) of the tile
             const double val = tbuf[jj * 17 + 4 * v + kk];
             if (r2 < ldS && c2 < ldS) {
-                if (d > 0 || c2 > r2) Sm[(long)r2 * ldS + c2] = val;
-                if (a.pend_write && (d > 0 || c2 > r2)) pblk[(long)r2 * CS + c2] = val;
+                if (d > 0 || c2 > r2) Sm[(long)r2 * ldO + c2] = val;
+                if (pend2 && (d > 0 || c2 > r2)) pblk[(long)r2 * CS + c2] = val;
             } else if (!fmode && r2 == mT && c2 < mT && d > 0) {
                 mean[c2] = -val;                                            // the label column of an off-diagonal tile
             }
