@@ -522,8 +522,9 @@ int joint_tail_mfma_launch(const JointArgs& a, hipStream_t st) {
 //     ms at the configs[4] shard: eight waves and 158 KB of LDS per chain, one chain per CU, for a substitution over three slot tiles.)
 //   * JOINT_MFMA_TEST - a draw with NO hallucinated slot (the first SQP iteration of the first MPC step; reference src/agent.py:629-641
 //     on the real-data model): mean = X^T w_r and S = K** - X^T X (both triangles, into a.Sall) for the test slots; the tail follows.
-// L_rr^-1 is the plan's (shared by all chains of an output): the A operand of X_qj = sum_{q2 <= q} Linv_{q q2} K_{q2 j} is a tile of
-// LinvT as it lies in memory (nat(X, Y) = X^T Y), the kernel entries are formed in the D layout they are consumed in.
+// The real block's factor is the plan's (shared by all chains of an output): blocked substitution over its 16 x 16 tiles - the A operands
+// are tiles of L and of the plan's inverse as they lie in memory (nat(X, Y) = X^T Y) -, the kernel entries are formed in the D layout they
+// are consumed in.
 // dynamic LDS: the RBF values of every (column point, column point) and (real point, column point) pair - one exponential per pair
 // of POINTS, formed in a pass of its own; the tiles' entries (nine per pair of full points) take theirs from here
 template <int NTL, int NQ>
@@ -555,7 +556,12 @@ __global__ __launch_bounds__(64, 1) void joint_real_mfma_kernel(const JointArgs 
     long long jph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     long long jt = __builtin_readcyclecounter();
 #endif
-    // tiles of LinvT: LT(q2, q)[r][c] = Linv[16 q + c][16 q2 + r], q2 <= q (zero beyond n_r); requested first: they arrive under the pair pass
+    // The real block by BLOCKED SUBSTITUTION, as joint_test_mfma_kernel does it (a product with the whole explicit inverse loses
+    // cond(L_rr) eps where the substitution loses cond(diagonal tile) eps: 1e-9 against 1e-12 of the largest variance on the shipped car):
+    //   X_q = Linv_qq (K_q - sum_{p < q} L_qp X_p),   Linv_qq = the diagonal tile of the plan's inverse (= the inverse of L's diagonal tile).
+    // A operands, D layout, nat(A, B) = A^T B:  LT(q, q)[r][c] = Linv[16 q + c][16 q + r];  LT(p, q)[r][c] = - L[16 q + c][16 p + r], p < q
+    // (zero beyond n_r); requested first: they arrive under the pair pass
+    const double* Lrr = plan_L(a.plan, gp, o);
     jc_d4 LT[NQ * (NQ + 1) / 2];
     jc_for<0, NQ>([&](auto q2c) {
         constexpr int q2 = decltype(q2c)::value;
@@ -564,7 +570,8 @@ __global__ __launch_bounds__(64, 1) void joint_real_mfma_kernel(const JointArgs 
 #pragma unroll
             for (int v = 0; v < 4; ++v) {
                 const int r = 16 * q2 + 4 * v + lr, c = 16 * q + lc;
-                const double val = LinvT[(long)min(r, n_r - 1) * n_r + min(c, n_r - 1)];
+                const long rc = min(r, n_r - 1), cc = min(c, n_r - 1);
+                const double val = (q == q2) ? LinvT[rc * n_r + cc] : -Lrr[cc * n_r + rc];
                 LT[jc_idx(q2, q, NQ)][v] = (r < n_r && c < n_r) ? val : 0.0;
             }
         });
@@ -665,9 +672,12 @@ __global__ __launch_bounds__(64, 1) void joint_real_mfma_kernel(const JointArgs 
             jc_d4 Kt;
 #pragma unroll
             for (int v = 0; v < 4; ++v) Kt[v] = entry(krn[kro[v] + pc], x0[v], x1[v], a0[v], a1[v], a2[v], yy.x, yy.y, b0, bb.x, bb.y);
-            jc_for<q2, NQ>([&](auto qc) {
+            // X[q2][j] holds - sum_{p < q2} L_{q2 p} X_p: the tile row is final, then it leaves its share in the rows below
+            const jc_d4 zero = {0.0, 0.0, 0.0, 0.0};
+            X[q2][j] = jc_nat(LT[jc_idx(q2, q2, NQ)], Kt + X[q2][j], zero);
+            jc_for<q2 + 1, NQ>([&](auto qc) {
                 constexpr int q = decltype(qc)::value;
-                X[q][j] = jc_nat(LT[jc_idx(q2, q, NQ)], Kt, X[q][j]);
+                X[q][j] = jc_nat(LT[jc_idx(q2, q, NQ)], X[q2][j], X[q][j]);
             });
         });
     });
