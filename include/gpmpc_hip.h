@@ -255,7 +255,7 @@ int    gpmpc_rollout_seeded(const gpmpc_gp_desc_t* gp, const gpmpc_env_desc_t* e
  *           moves rows in 16-byte units).
  *           Bit-identity: with the joint path PINNED (gpmpc_joint_pin_path(GPMPC_JOINT_VALU) or ..._MFMA) results are
  *           bit-identical with and without the cache.  Under GPMPC_JOINT_AUTO the dispatcher takes the matrix-pipe path
- *           from GPMPC_JOINT_MFMA_FROM (100) observed hallucinated slots on, and chains that HAVE cache room take its
+ *           from GPMPC_JOINT_MFMA_FROM (100; 48 for wide test blocks) observed hallucinated slots on, and chains that HAVE cache room take its
  *           factor extension while chains beyond the cache budget compute their rows on the VALU: a sample's low-order
  *           bits then depend on which side of the budget it sits (1e-13 on a Cholesky root, up to 1e-5 on the
  *           eigendecomposition root of params_car_residual.yaml).  Pin the path wherever
@@ -319,8 +319,8 @@ int    gpmpc_joint_pending_written(void);    /* 1: the last gpmpc_joint_sample[_
  * joint_kernel factorises the Schur complement, joint_test_mfma_kernel forms V^T = L^-1 K_o*, the mean and S = K** - V^T V on the
  * FP64 matrix pipe with the whole test block in registers, the tail draws - instantiated for n_r <= 64 real slots,
  * n_r + n_ho <= 416 conditioning slots (<= 544 with the test rows in two launches; that form needs the caller's factor cache) and
- * m*T + 1 <= 128; taken from 100 hallucinated slots on
- * (GPMPC_JOINT_MFMA_FROM).  Round 6: a draw WITHOUT hallucinated slots (T = 3, <= 64 real slots, m*T <= 128) also reports
+ * m*T + 1 <= 128; taken from 100 hallucinated slots on, from 48 when m*T >= 84
+ * (GPMPC_JOINT_MFMA_FROM, when set, is the whole rule).  Round 6: a draw WITHOUT hallucinated slots (T = 3, <= 64 real slots, m*T <= 128) also reports
  * GPMPC_JOINT_MFMA unless the VALU path is pinned - joint_real_mfma_kernel forms X = L_rr^-1 K_r*, the mean and S one wave per
  * chain against the plan's shared inverse factor (GPMPC_JOINT_REAL_KERNEL=0: joint_kernel's head as before); the same kernel
  * is the matrix-pipe path's factor extension while nothing is cached.  Results of the two paths agree to rounding, not bit for bit: a caller that compares launches bit

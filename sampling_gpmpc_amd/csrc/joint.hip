@@ -1024,21 +1024,28 @@ static int g_real_kernel_force = -1;      // gpmpc_debug_joint_real_kernel: -1 d
 static int g_eigh_narrow_force = -1;      // gpmpc_debug_eigh_narrow: -1 heuristic, 0 / 1 forced (tests)
 static int g_joint_path_pin = 0;          // gpmpc_joint_pin_path: 0 auto, 1 VALU path, 2 matrix-pipe path where instantiated
 static int g_joint_last_path = 0;
-static bool joint_mfma_wanted(int n_ho) {
+static bool joint_mfma_wanted(int n_ho, int mT) {
     if (g_joint_path_pin == 1) return false;
     if (g_joint_path_pin == 2) return true;
     const int from = joint_mfma_from();
-    return from > 0 && n_ho >= from;
+    if (from > 0 && n_ho >= from) return true;
+    // Round 6 (the factor rows with nothing cached by joint_real_mfma_kernel, the Cholesky and the tail one wave per chain, S written once): with
+    // a WIDE test block the matrix pipe also wins below 100 slots - Ns = 1024, scattered points, VALU / matrix pipe in ms: pendulum H = 30 at
+    // 90 slots 0.547 / 0.458 (its closed loop's second SQP iteration: 0.489 -> 0.405), car H = 30 at 90 slots 2.44 / 2.30; with a narrow one it
+    // does not (car H = 20 at 60 / 120 slots 1.44 / 1.61 and 1.89 / 2.33; pendulum H = 15 at 90 slots 0.38 / 0.52: the fixed per-chain parts
+    // of joint_test_mfma_kernel do not shrink with the columns).  GPMPC_JOINT_MFMA_FROM, when set, is the whole rule.
+    static const char* env = getenv("GPMPC_JOINT_MFMA_FROM");
+    return !env && n_ho >= 48 && mT >= 84;
 }
 static bool joint_use_mfma(int n_r, int n_ho, int m, int T) {
-    return n_ho >= 1 && joint_mfma_eligible(n_r, n_ho, m * T + 1, T) && joint_mfma_wanted(n_ho);
+    return n_ho >= 1 && joint_mfma_eligible(n_r, n_ho, m * T + 1, T) && joint_mfma_wanted(n_ho, m * T);
 }
 // conditioning sets beyond one launch of joint_test_mfma_kernel (the 45 + 480 slots of the k = 0 draw of MPC steps >= 1 at
 // configs[4]): the test rows in two launches (JOINT_MFMA_TEST_TOP / _BOTTOM); needs a caller-owned factor cache with every row
 static bool joint_use_mfma_split(int n_r, int n_ho, int m, int T) {
     static const char* env = getenv("GPMPC_JOINT_MFMA_SPLIT");         // 0: such draws stay on the vector pipe (A/B timing)
     if (env && atoi(env) == 0) return false;
-    return joint_mfma_split_eligible(n_r, n_ho, m * T + 1, T) && joint_mfma_wanted(n_ho);
+    return joint_mfma_split_eligible(n_r, n_ho, m * T + 1, T) && joint_mfma_wanted(n_ho, m * T);
 }
 
 static long eigh_grid(long nchains) {
